@@ -1,0 +1,153 @@
+/* tarl_hip.h — C ABI of libtarl_hip.so: hand-written HIP kernels (gfx950 / MI355X) for TARL-simulator's MPNN + PPO
+ * routing hot path.
+ *
+ * The reference (OliBus801/TARL-simulator) is pure Python and has no FFI of its own; the path sits behind Python
+ * classes. Each entry point below names the reference interface it replaces (file:line in the
+ * reference tree). The host-side mirror of those classes (tarl-simulator_amd/src/...) binds this library with
+ * ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - Every data pointer is a DEVICE pointer unless the name ends in `_host`. Buffers are caller-owned (torch
+ *    allocations); the library borrows them for the duration of the call and never allocates per call.
+ *  - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and the host is never synchronised
+ *    (except tarl_plan_create, which uploads the static plan with blocking copies).
+ *  - Return value: 0 = ok, negative = tarl_status error; tarl_last_error() returns a thread-local message.
+ *  - Batched state: B independent environments over ONE static graph. x is fp32 [B][R][ldx] with
+ *    ldx >= F = 3*Nmax+7 (row stride in floats) and x_bstride (env stride in floats); column map as in
+ *    src/feature_helpers.py:38-54. agent_features is fp32 [B][A][9] (src/feature_helpers.py:59-71).
+ *  - Randomness is an input: pass explicit noise tensors for parity, or NULL to draw Philox4x32-10 on device from
+ *    (seed, counter).
+ */
+#ifndef TARL_HIP_H
+#define TARL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TARL_ABI_VERSION 1
+
+typedef enum {
+  TARL_OK = 0,
+  TARL_ERR_INVALID = -1,   /* bad argument (null pointer, negative size, index out of range) */
+  TARL_ERR_HIP = -2,       /* a HIP runtime call failed */
+  TARL_ERR_NOMEM = -3,
+  TARL_ERR_UNSUPPORTED = -4
+} tarl_status;
+
+typedef struct tarl_plan tarl_plan; /* opaque static per-graph plan */
+typedef void* tarl_stream;          /* hipStream_t */
+
+int tarl_abi_version(void);
+const char* tarl_last_error(void);
+
+/* ---- static plan ---------------------------------------------------------------------------------------------
+ * Replaces the per-step sort/argsort/unique of GraphDistribution.__init__ (src/reinforcement_learning.py:21-35)
+ * and PyG's per-call gather indices (src/direction_mpnn.py:230, src/response_mpnn.py:40): int32 CSC (in-edges by
+ * destination, ascending original edge id) and CSR (out-edges by source) built once.
+ * edge_index_host: int64 [2][E] on the HOST. src_order_host (nullable): permutation of 0..E-1 that sorts
+ * edge_index[0]; NULL = stable order (the reference's pinned CPU behaviour). */
+int tarl_plan_create(const int64_t* edge_index_host, int64_t num_edges, int64_t num_nodes,
+                     const int64_t* src_order_host, tarl_plan** out);
+void tarl_plan_destroy(tarl_plan* plan);
+/* info[0..5] = num_nodes, num_edges, num_groups (distinct sources), max_in_degree, max_out_degree, src_sorted */
+int tarl_plan_info(const tarl_plan* plan, int64_t* info6_host);
+
+/* ---- traffic-flow step ---------------------------------------------------------------------------------------
+ * tarl_direction_step == DirectionMPNN.forward: message + aggregate + update (src/direction_mpnn.py:44-196,210-236).
+ *   edge_attr [E]; log_edge_attr [E] = log(edge_attr + 1e-12) and log_eps = log(1e-12), both evaluated by the host
+ *   (so the Gumbel scores are bit-identical to the reference's fp32 ones); congestion_constant [R] or NULL
+ *   (then recomputed from x as src/simulation_core_model.py:55-67 does); gumbel [B][E] or NULL (device Philox);
+ *   delta_travel_time [B][E] or NULL (side output, src/direction_mpnn.py:94-96); chosen [B][R] scratch/out.
+ *   x is updated in place (every row, also when nothing was chosen). */
+int tarl_direction_step(const tarl_plan* plan, float* x, int64_t B, int64_t x_bstride, int64_t ldx, int32_t Nmax,
+                        int64_t num_roads, const float* edge_attr, const float* log_edge_attr, float log_eps,
+                        const float* congestion_constant, float time, const float* gumbel, uint64_t seed,
+                        uint64_t counter, float* delta_travel_time, float* chosen, tarl_stream stream);
+
+/* tarl_response_step == ResponseMPNN.forward: message + max-aggregate + update (src/response_mpnn.py:25-127).
+ *   popped [B][R] uint8 out (the update mask appended to update_history, :125); any_popped: int32[1] or NULL,
+ *   set to 1 iff any row of any environment popped (the `.any()` of :106, kept on device). */
+int tarl_response_step(const tarl_plan* plan, float* x, int64_t B, int64_t x_bstride, int64_t ldx, int32_t Nmax,
+                       int64_t num_roads, uint8_t* popped, int32_t* any_popped, tarl_stream stream);
+
+/* tarl_core_step == SimulationCoreModel.forward (src/simulation_core_model.py:41-83): both rounds, same outputs as
+ * the two calls above, fused into fewer launches. */
+int tarl_core_step(const tarl_plan* plan, float* x, int64_t B, int64_t x_bstride, int64_t ldx, int32_t Nmax,
+                   int64_t num_roads, const float* edge_attr, const float* log_edge_attr, float log_eps,
+                   const float* congestion_constant, float time, const float* gumbel, uint64_t seed, uint64_t counter,
+                   float* delta_travel_time, float* chosen, uint8_t* popped, int32_t* any_popped, tarl_stream stream);
+
+/* ---- environment step around the core (src/reinforcement_learning.py:222-309, src/agents/base.py:244-403) -------
+ * tarl_apply_action: x[b, src(e), SELECTED_ROAD] = dst(e) for every edge with action[b][e] != 0 (:223-231).
+ *   Exactly one of action_onehot (int64 [B][E], the reference's action format) / choice (int32 [B][N]: chosen edge id
+ *   per source node, -1 = none) must be non-NULL. */
+int tarl_apply_action(const tarl_plan* plan, float* x, int64_t B, int64_t x_bstride, int64_t ldx, int32_t Nmax,
+                      const int64_t* action_onehot, const int32_t* choice, tarl_stream stream);
+
+/* tarl_withdraw_step == Agents.withdraw_agent_from_network (src/agents/base.py:348-403) over all num_nodes rows;
+ *   adjacency = the plan's edge set (replaces the dense N x N bool matrix). withdrawn [B][num_nodes] uint8 or NULL. */
+int tarl_withdraw_step(const tarl_plan* plan, float* x, int64_t B, int64_t x_bstride, int64_t ldx, int32_t Nmax,
+                       int64_t num_nodes, float* agent_features, int64_t num_agents, int64_t a_bstride, float time,
+                       uint8_t* withdrawn, tarl_stream stream);
+
+/* tarl_insert_step == Agents.insert_agent_into_network (src/agents/base.py:247-331), stable (agent-id) order within
+ *   a road. congestion_constant [num_nodes] or NULL (then time_congestion = 0, as :312-313).
+ *   ready_scratch: int32 [B][2 * num_agents]. Also emits, when non-NULL, reward [B] = -sum_rows NUMBER_OF_AGENT
+ *   (src/reinforcement_learning.py:266-267) and counts [B][num_nodes] (the NUMBER_OF_AGENT column, the critic input). */
+int tarl_insert_step(float* x, int64_t B, int64_t x_bstride, int64_t ldx, int32_t Nmax, int64_t num_nodes,
+                     float* agent_features, int64_t num_agents, int64_t a_bstride, const float* congestion_constant,
+                     float time, int32_t* ready_scratch, float* reward, float* counts, tarl_stream stream);
+
+/* tarl_reset_state == TransportationSimulator.reset + Agents.reset (src/transportation_simulator.py:353-358,
+ *   src/agents/base.py:496-503): zero FIFO blocks and NUMBER_OF_AGENT, clear ON_WAY / DONE. agent_features nullable. */
+int tarl_reset_state(float* x, int64_t B, int64_t x_bstride, int64_t ldx, int32_t Nmax, int64_t num_nodes,
+                     float* agent_features, int64_t num_agents, int64_t a_bstride, tarl_stream stream);
+
+/* ---- GraphDistribution (src/reinforcement_learning.py:15-96) ---------------------------------------------------
+ * tarl_graphdist_softmax: proba = scatter_softmax(logits / temperature, src) (:25); logits/proba [B][E] in original
+ *   edge order. */
+int tarl_graphdist_softmax(const tarl_plan* plan, const float* logits, int64_t B, float temperature, float* proba,
+                           tarl_stream stream);
+/* tarl_graphdist_sample (:62-80 with the cumsum of :38-42): per source node the first out-edge (plan order) with
+ *   u < cum, cum = fp32(fp32(base + s) - fp32(base)) with base/s accumulated in double like torch's CPU cumsum.
+ *   uniform [B][num_groups] or NULL (Philox). Outputs (each nullable): action_onehot int64 [B][E]; choice int32 [B][N]
+ *   (edge id or -1). group_sums: double scratch [B][num_groups + 1]. */
+int tarl_graphdist_sample(const tarl_plan* plan, const float* proba, int64_t B, const float* uniform, uint64_t seed,
+                          uint64_t counter, double* group_sums, int64_t* action_onehot, int32_t* choice,
+                          tarl_stream stream);
+/* tarl_graphdist_mode (:45-55): one-hot (fp32, like zeros_like(proba)) of the per-node argmax, first maximum wins. */
+int tarl_graphdist_mode(const tarl_plan* plan, const float* proba, int64_t B, float* mode_onehot, int32_t* choice,
+                        tarl_stream stream);
+/* tarl_graphdist_logprob_entropy_fwd (:82-96): log_prob [B] = sum_e a_e log(p_e + 1e-8), -inf when the action is not
+ *   exactly one edge per source node; entropy [B] = -sum_e p_e log(p_e + 1e-8). Action given as one-hot or choice.
+ *   Outputs nullable. One workgroup per batch row, fixed reduction order. */
+int tarl_graphdist_logprob_entropy_fwd(const tarl_plan* plan, const float* proba, int64_t B,
+                                       const int64_t* action_onehot, const int32_t* choice, float* log_prob,
+                                       float* entropy, tarl_stream stream);
+/* backward of (log_prob, entropy) w.r.t. logits through the segment softmax: grad_logits [B][E] (overwritten).
+ *   grad_log_prob / grad_entropy [B] nullable (= 0). log_prob_fwd [B] nullable: rows whose forward log_prob is -inf
+ *   get zero log-prob gradient (the reference assigns -inf through a mask, :91). */
+int tarl_graphdist_logprob_entropy_bwd(const tarl_plan* plan, const float* proba, int64_t B, float temperature,
+                                       const int64_t* action_onehot, const int32_t* choice,
+                                       const float* grad_log_prob, const float* grad_entropy,
+                                       const float* log_prob_fwd, float* grad_logits, tarl_stream stream);
+
+/* ---- policy / critic (src/agents/mpnn_agent.py) ------------------------------------------------------------------
+ * tarl_policy_edge_logits_fwd: live MPNNPolicyNet.forward (:175-178,215-217):
+ *   logits[b][e] = emb[(int) road_index[b][dst(e)]]; road_index points at the ROAD_INDEX observation column with
+ *   element strides (ri_bstride, ri_nstride); emb [num_embeddings]. */
+int tarl_policy_edge_logits_fwd(const tarl_plan* plan, const float* road_index, int64_t ri_bstride,
+                                int64_t ri_nstride, int64_t B, const float* emb, int64_t num_embeddings,
+                                float* logits, tarl_stream stream);
+/* backward: grad_emb [num_embeddings] += sum_b sum_{e: dst(e)=n} grad_logits[b][e] (one fp32 atomic per (b, n)). */
+int tarl_policy_edge_logits_bwd(const tarl_plan* plan, const float* road_index, int64_t ri_bstride,
+                                int64_t ri_nstride, int64_t B, const float* grad_logits, float* grad_emb,
+                                int64_t num_embeddings, tarl_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TARL_HIP_H */

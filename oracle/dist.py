@@ -21,7 +21,9 @@ def segment_softmax(logits: torch.Tensor, index: torch.Tensor, n: int) -> torch.
 class GraphDist:
     """``GraphDistribution.__init__`` (``:17-55``)."""
 
-    def __init__(self, logits: torch.Tensor, edge_index: torch.Tensor, temperature: float = 1.0):
+    def __init__(self, logits: torch.Tensor, edge_index: torch.Tensor, temperature: float = 1.0, proba=None):
+        """``proba`` (test hook): use these probabilities instead of the softmax of ``logits`` so that the integer
+        part (cumsum / sample) can be checked on bit-identical fp inputs."""
         src = edge_index[0]
         self.edge_index = edge_index
         self.groups, self.index = torch.sort(src, stable=True)  # reference: unstable call, stable on CPU in practice
@@ -29,7 +31,7 @@ class GraphDist:
         self.nodes = torch.unique(self.groups)
         self.nb_nodes = self.nodes.numel()
         n_all = int(src.max()) + 1
-        self.proba = segment_softmax(logits / temperature, src, n_all)
+        self.proba = segment_softmax(logits / temperature, src, n_all) if proba is None else proba
         self.proba_sort = self.proba[..., self.index]
         self.log_proba_sort = torch.log(self.proba_sort + 1e-8)
         g = self.groups

@@ -1,0 +1,298 @@
+// dist.hip — GraphDistribution: one categorical per source node over its out-edges, on the static CSR plan.
+//
+// Reference semantics restated: src/reinforcement_learning.py:15-96 (+ torch-scatter 2.1.2 scatter_softmax /
+// scatter_max, torch CPU cumsum). The per-step sort/argsort/unique/cumsum/boundary masks of the reference are all
+// static topology and live in the plan; what remains per call is segment arithmetic.
+#include <math.h>
+
+#include "tarl_common.h"
+
+#define DIST_BLOCK 256
+#define ENV_BLOCK 1024
+#define LOG_EPS_P 1e-8f  // log(p + 1e-8), src/reinforcement_learning.py:27
+
+// ---- segment softmax ---------------------------------------------------------------------------------------------
+// proba = exp(l/T - max_g) / sum_g, the group sum accumulated sequentially in plan order (scatter_softmax, no epsilon).
+__global__ __launch_bounds__(DIST_BLOCK) void k_softmax(const int32_t* __restrict__ out_ptr,
+                                                        const int32_t* __restrict__ out_eid,
+                                                        const float* __restrict__ logits, int64_t B, int64_t N,
+                                                        int64_t E, float temperature, float* __restrict__ proba) {
+  const int64_t gid = (int64_t)blockIdx.x * DIST_BLOCK + threadIdx.x;
+  if (gid >= B * N) return;
+  const int64_t b = gid / N;
+  const int32_t i = (int32_t)(gid - b * N);
+  const int32_t k0 = out_ptr[i], k1 = out_ptr[i + 1];
+  if (k0 == k1) return;
+  const float* lb = logits + b * E;
+  float* pb = proba + b * E;
+  float mx = -INFINITY;
+  for (int32_t k = k0; k < k1; ++k) mx = fmaxf(mx, lb[out_eid[k]] / temperature);
+  float sum = 0.0f;
+  for (int32_t k = k0; k < k1; ++k) sum = sum + expf(lb[out_eid[k]] / temperature - mx);
+  for (int32_t k = k0; k < k1; ++k) {
+    const int32_t e = out_eid[k];
+    pb[e] = expf(lb[e] / temperature - mx) / sum;
+  }
+}
+
+// ---- sample ---------------------------------------------------------------------------------------------------------
+// One workgroup per environment. Phase A: per-group sums in double + exclusive scan over the groups (the reference's
+// *global* cumsum over the sorted edges: torch's CPU cumsum accumulates fp32 inputs in double and rounds every output
+// to fp32). Phase B: per group, cum_k = fp32(fp32(base + s_k) - fp32(base)), pick the first k with u < cum_k.
+__global__ __launch_bounds__(ENV_BLOCK) void k_sample(const int32_t* __restrict__ out_ptr,
+                                                      const int32_t* __restrict__ out_eid,
+                                                      const int32_t* __restrict__ node_of_group,
+                                                      const float* __restrict__ proba, int64_t N, int64_t E, int64_t G,
+                                                      const float* __restrict__ uniform, uint64_t seed,
+                                                      uint64_t counter, double* __restrict__ base_all,
+                                                      int64_t* __restrict__ onehot, int32_t* __restrict__ choice) {
+  __shared__ double s_wave[ENV_BLOCK / 64];
+  const int64_t b = blockIdx.x;
+  const float* pb = proba + b * E;
+  double* base = base_all + b * (G + 1);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+
+  double running = 0.0;
+  for (int64_t g0 = 0; g0 < G; g0 += ENV_BLOCK) {
+    const int64_t g = g0 + tid;
+    double s = 0.0;
+    if (g < G) {
+      const int32_t i = node_of_group[g];
+      const int32_t k1 = out_ptr[i + 1];
+      for (int32_t k = out_ptr[i]; k < k1; ++k) s += (double)pb[out_eid[k]];
+    }
+    // inclusive scan inside the wave, then across waves
+    double inc = s;
+    for (int off = 1; off < 64; off <<= 1) {
+      const double v = __shfl_up(inc, off);
+      if (lane >= off) inc += v;
+    }
+    if (lane == 63) s_wave[wid] = inc;
+    __syncthreads();
+    double wbase = 0.0, tot = 0.0;
+    for (int w = 0; w < ENV_BLOCK / 64; ++w) {
+      const double v = s_wave[w];
+      if (w < wid) wbase += v;
+      tot += v;
+    }
+    double exc = __shfl_up(inc, 1);  // exclusive prefix inside the wave
+    if (lane == 0) exc = 0.0;
+    if (g < G) base[g] = running + wbase + exc;
+    running += tot;
+    __syncthreads();
+  }
+  // every thread reads only the base it wrote itself (same g) => no extra fence needed
+  for (int64_t g0 = 0; g0 < G; g0 += ENV_BLOCK) {
+    const int64_t g = g0 + tid;
+    if (g >= G) break;
+    const int32_t i = node_of_group[g];
+    const double bg = base[g];
+    const float bg32 = (float)bg;
+    const float u = uniform ? uniform[b * G + g] : philox_uniform(seed, counter, (uint64_t)(b * G + g));
+    double run = bg;
+    int32_t pick = -1;
+    const int32_t k1 = out_ptr[i + 1];
+    for (int32_t k = out_ptr[i]; k < k1; ++k) {
+      const int32_t e = out_eid[k];
+      run += (double)pb[e];
+      const float cum = (float)run - bg32;
+      const bool hit = (pick < 0) && (u < cum);
+      if (hit) pick = e;
+      if (onehot) onehot[b * E + e] = hit ? 1 : 0;
+    }
+    if (choice) choice[b * N + i] = pick;
+  }
+}
+
+__global__ __launch_bounds__(DIST_BLOCK) void k_fill_choice(int32_t* __restrict__ choice, int64_t n) {
+  const int64_t gid = (int64_t)blockIdx.x * DIST_BLOCK + threadIdx.x;
+  if (gid < n) choice[gid] = -1;
+}
+
+// ---- mode: per-node argmax, first maximum in ORIGINAL edge order wins (scatter_max on CPU) ---------------------------
+__global__ __launch_bounds__(DIST_BLOCK) void k_mode(const int32_t* __restrict__ out_ptr,
+                                                     const int32_t* __restrict__ out_eid,
+                                                     const float* __restrict__ proba, int64_t B, int64_t N, int64_t E,
+                                                     float* __restrict__ onehot, int32_t* __restrict__ choice) {
+  const int64_t gid = (int64_t)blockIdx.x * DIST_BLOCK + threadIdx.x;
+  if (gid >= B * N) return;
+  const int64_t b = gid / N;
+  const int32_t i = (int32_t)(gid - b * N);
+  const float* pb = proba + b * E;
+  const int32_t k0 = out_ptr[i], k1 = out_ptr[i + 1];
+  float best = -INFINITY;
+  int32_t best_e = -1;
+  for (int32_t k = k0; k < k1; ++k) {
+    const int32_t e = out_eid[k];
+    const float p = pb[e];
+    if (best_e < 0 || p > best || (p == best && e < best_e)) {
+      best = p;
+      best_e = e;
+    }
+  }
+  if (onehot)
+    for (int32_t k = k0; k < k1; ++k) onehot[b * E + out_eid[k]] = (out_eid[k] == best_e) ? 1.0f : 0.0f;
+  if (choice) choice[gid] = best_e;
+}
+
+// ---- log_prob / entropy forward -------------------------------------------------------------------------------------
+// One workgroup per batch row; fixed reduction tree => deterministic.
+__device__ __forceinline__ float block_sum(float v, float* s_red) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  __syncthreads();
+  if (lane == 0) s_red[wid] = v;
+  __syncthreads();
+  float tot = 0.0f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += s_red[w];
+  return tot;
+}
+
+__global__ __launch_bounds__(ENV_BLOCK) void k_logprob_entropy_fwd(const int32_t* __restrict__ out_ptr,
+                                                                   const int32_t* __restrict__ out_eid,
+                                                                   const float* __restrict__ proba, int64_t N,
+                                                                   int64_t E, const int64_t* __restrict__ onehot,
+                                                                   const int32_t* __restrict__ choice,
+                                                                   float* __restrict__ log_prob,
+                                                                   float* __restrict__ entropy) {
+  __shared__ float s_red[ENV_BLOCK / 64];
+  const int64_t b = blockIdx.x;
+  const float* pb = proba + b * E;
+  float lp = 0.0f, ent = 0.0f, bad = 0.0f;
+  for (int64_t i = threadIdx.x; i < N; i += ENV_BLOCK) {
+    const int32_t k0 = out_ptr[i], k1 = out_ptr[i + 1];
+    if (k0 == k1) continue;
+    long long asum = 0;
+    const int32_t ce = choice ? choice[b * N + i] : -1;
+    for (int32_t k = k0; k < k1; ++k) {
+      const int32_t e = out_eid[k];
+      const float p = pb[e];
+      const float lg = logf(p + LOG_EPS_P);
+      ent -= p * lg;
+      const long long a = onehot ? (long long)onehot[b * E + e] : (e == ce ? 1 : 0);
+      asum += a;
+      lp += (float)a * lg;
+    }
+    if (asum != 1) bad = 1.0f;
+  }
+  const float lp_t = block_sum(lp, s_red);
+  const float ent_t = block_sum(ent, s_red);
+  const float bad_t = block_sum(bad, s_red);
+  if (threadIdx.x == 0) {
+    if (log_prob) log_prob[b] = bad_t > 0.0f ? -INFINITY : lp_t;
+    if (entropy) entropy[b] = ent_t;
+  }
+}
+
+// ---- backward through the segment softmax ----------------------------------------------------------------------------
+// L = gl*LP + ge*H with LP = sum a log(p+eps), H = -sum p log(p+eps), p = softmax(l/T) per group:
+//   q_k = gl * a_k/(p_k+eps) + ge * (-log(p_k+eps) - p_k/(p_k+eps)),  dL/dl_j = p_j (q_j - sum_k p_k q_k) / T.
+__global__ __launch_bounds__(DIST_BLOCK) void k_logprob_entropy_bwd(const int32_t* __restrict__ out_ptr,
+                                                                    const int32_t* __restrict__ out_eid,
+                                                                    const float* __restrict__ proba, int64_t B,
+                                                                    int64_t N, int64_t E, float temperature,
+                                                                    const int64_t* __restrict__ onehot,
+                                                                    const int32_t* __restrict__ choice,
+                                                                    const float* __restrict__ g_lp,
+                                                                    const float* __restrict__ g_ent,
+                                                                    const float* __restrict__ lp_fwd,
+                                                                    float* __restrict__ grad) {
+  const int64_t gid = (int64_t)blockIdx.x * DIST_BLOCK + threadIdx.x;
+  if (gid >= B * N) return;
+  const int64_t b = gid / N;
+  const int32_t i = (int32_t)(gid - b * N);
+  const int32_t k0 = out_ptr[i], k1 = out_ptr[i + 1];
+  if (k0 == k1) return;
+  const float* pb = proba + b * E;
+  float gl = g_lp ? g_lp[b] : 0.0f;
+  if (lp_fwd && isinf(lp_fwd[b])) gl = 0.0f;  // masked assignment of -inf in the reference: no gradient
+  const float ge = g_ent ? g_ent[b] : 0.0f;
+  const int32_t ce = choice ? choice[gid] : -1;
+  float dot = 0.0f;
+  for (int32_t k = k0; k < k1; ++k) {
+    const int32_t e = out_eid[k];
+    const float p = pb[e];
+    const float a = onehot ? (float)onehot[b * E + e] : (e == ce ? 1.0f : 0.0f);
+    const float q = gl * a / (p + LOG_EPS_P) + ge * (-logf(p + LOG_EPS_P) - p / (p + LOG_EPS_P));
+    dot += p * q;
+  }
+  for (int32_t k = k0; k < k1; ++k) {
+    const int32_t e = out_eid[k];
+    const float p = pb[e];
+    const float a = onehot ? (float)onehot[b * E + e] : (e == ce ? 1.0f : 0.0f);
+    const float q = gl * a / (p + LOG_EPS_P) + ge * (-logf(p + LOG_EPS_P) - p / (p + LOG_EPS_P));
+    grad[b * E + e] = p * (q - dot) / temperature;
+  }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------
+extern "C" int tarl_graphdist_softmax(const tarl_plan* plan, const float* logits, int64_t B, float temperature,
+                                      float* proba, tarl_stream stream) {
+  TARL_REQUIRE(plan && logits && proba, "null argument");
+  TARL_REQUIRE(B >= 1, "B must be positive");
+  if (plan->N == 0 || plan->E == 0) return TARL_OK;
+  hipLaunchKernelGGL(k_softmax, dim3((unsigned)ceil_div(B * plan->N, DIST_BLOCK)), dim3(DIST_BLOCK), 0,
+                     (hipStream_t)stream, plan->out_ptr, plan->out_eid, logits, B, plan->N, plan->E, temperature,
+                     proba);
+  TARL_LAUNCH_CHECK();
+  return TARL_OK;
+}
+
+extern "C" int tarl_graphdist_sample(const tarl_plan* plan, const float* proba, int64_t B, const float* uniform,
+                                     uint64_t seed, uint64_t counter, double* group_sums, int64_t* onehot,
+                                     int32_t* choice, tarl_stream stream) {
+  TARL_REQUIRE(plan && proba && group_sums, "null argument");
+  TARL_REQUIRE(B >= 1 && B < ((int64_t)1 << 31), "bad B");
+  if (plan->E == 0) return TARL_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (choice && plan->G != plan->N) {  // nodes without out-edges keep -1
+    hipLaunchKernelGGL(k_fill_choice, dim3((unsigned)ceil_div(B * plan->N, DIST_BLOCK)), dim3(DIST_BLOCK), 0, s,
+                       choice, B * plan->N);
+    TARL_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_sample, dim3((unsigned)B), dim3(ENV_BLOCK), 0, s, plan->out_ptr, plan->out_eid,
+                     plan->node_of_group, proba, plan->N, plan->E, plan->G, uniform, seed, counter, group_sums, onehot,
+                     choice);
+  TARL_LAUNCH_CHECK();
+  return TARL_OK;
+}
+
+extern "C" int tarl_graphdist_mode(const tarl_plan* plan, const float* proba, int64_t B, float* onehot,
+                                   int32_t* choice, tarl_stream stream) {
+  TARL_REQUIRE(plan && proba, "null argument");
+  TARL_REQUIRE(B >= 1, "B must be positive");
+  if (plan->N == 0) return TARL_OK;
+  hipLaunchKernelGGL(k_mode, dim3((unsigned)ceil_div(B * plan->N, DIST_BLOCK)), dim3(DIST_BLOCK), 0,
+                     (hipStream_t)stream, plan->out_ptr, plan->out_eid, proba, B, plan->N, plan->E, onehot, choice);
+  TARL_LAUNCH_CHECK();
+  return TARL_OK;
+}
+
+extern "C" int tarl_graphdist_logprob_entropy_fwd(const tarl_plan* plan, const float* proba, int64_t B,
+                                                  const int64_t* onehot, const int32_t* choice, float* log_prob,
+                                                  float* entropy, tarl_stream stream) {
+  TARL_REQUIRE(plan && proba, "null argument");
+  TARL_REQUIRE(B >= 1 && B < ((int64_t)1 << 31), "bad B");
+  TARL_REQUIRE(log_prob == nullptr || ((onehot != nullptr) != (choice != nullptr)),
+               "log_prob needs exactly one of action_onehot / choice");
+  hipLaunchKernelGGL(k_logprob_entropy_fwd, dim3((unsigned)B), dim3(ENV_BLOCK), 0, (hipStream_t)stream, plan->out_ptr,
+                     plan->out_eid, proba, plan->N, plan->E, onehot, choice, log_prob, entropy);
+  TARL_LAUNCH_CHECK();
+  return TARL_OK;
+}
+
+extern "C" int tarl_graphdist_logprob_entropy_bwd(const tarl_plan* plan, const float* proba, int64_t B,
+                                                  float temperature, const int64_t* onehot, const int32_t* choice,
+                                                  const float* grad_log_prob, const float* grad_entropy,
+                                                  const float* log_prob_fwd, float* grad_logits, tarl_stream stream) {
+  TARL_REQUIRE(plan && proba && grad_logits, "null argument");
+  TARL_REQUIRE(B >= 1, "B must be positive");
+  TARL_REQUIRE(grad_log_prob == nullptr || ((onehot != nullptr) != (choice != nullptr)),
+               "grad_log_prob needs exactly one of action_onehot / choice");
+  if (plan->N == 0 || plan->E == 0) return TARL_OK;
+  hipLaunchKernelGGL(k_logprob_entropy_bwd, dim3((unsigned)ceil_div(B * plan->N, DIST_BLOCK)), dim3(DIST_BLOCK), 0,
+                     (hipStream_t)stream, plan->out_ptr, plan->out_eid, proba, B, plan->N, plan->E, temperature, onehot,
+                     choice, grad_log_prob, grad_entropy, log_prob_fwd, grad_logits);
+  TARL_LAUNCH_CHECK();
+  return TARL_OK;
+}

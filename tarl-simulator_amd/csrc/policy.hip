@@ -1,0 +1,67 @@
+// policy.hip — the live MPNNPolicyNet forward: logits[e] = W_emb[road_index(dst(e))]
+// (src/agents/mpnn_agent.py:175-178,215-217). The Dijkstra prior, travel time and norm computed after it in the
+// reference (:181-190) are discarded there and therefore not evaluated here. An index outside
+// [0, num_embeddings) (ROAD_INDEX = -1 on SRC/DEST pseudo-nodes raises IndexError in the reference) yields
+// logit 0 and receives no gradient.
+#include "tarl_common.h"
+
+#define POL_BLOCK 256
+
+__global__ __launch_bounds__(POL_BLOCK) void k_edge_logits_fwd(const int32_t* __restrict__ dst,
+                                                               const float* __restrict__ road_index,
+                                                               int64_t ri_bstride, int64_t ri_nstride, int64_t B,
+                                                               int64_t E, const float* __restrict__ emb, int64_t M,
+                                                               float* __restrict__ logits) {
+  const int64_t gid = (int64_t)blockIdx.x * POL_BLOCK + threadIdx.x;
+  if (gid >= B * E) return;
+  const int64_t b = gid / E;
+  const int32_t e = (int32_t)(gid - b * E);
+  const long long idx = (long long)road_index[b * ri_bstride + (int64_t)dst[e] * ri_nstride];
+  logits[gid] = (idx >= 0 && idx < M) ? emb[idx] : 0.0f;
+}
+
+// one thread per (batch row, node n): sum the gradients of n's in-edges (ascending edge id), one atomic per (b, n)
+__global__ __launch_bounds__(POL_BLOCK) void k_edge_logits_bwd(const int32_t* __restrict__ in_ptr,
+                                                               const int32_t* __restrict__ in_eid,
+                                                               const float* __restrict__ road_index,
+                                                               int64_t ri_bstride, int64_t ri_nstride, int64_t B,
+                                                               int64_t N, int64_t E,
+                                                               const float* __restrict__ grad_logits,
+                                                               float* __restrict__ grad_emb, int64_t M) {
+  const int64_t gid = (int64_t)blockIdx.x * POL_BLOCK + threadIdx.x;
+  if (gid >= B * N) return;
+  const int64_t b = gid / N;
+  const int32_t n = (int32_t)(gid - b * N);
+  const int32_t k0 = in_ptr[n], k1 = in_ptr[n + 1];
+  if (k0 == k1) return;
+  const long long idx = (long long)road_index[b * ri_bstride + (int64_t)n * ri_nstride];
+  if (idx < 0 || idx >= M) return;
+  float s = 0.0f;
+  for (int32_t k = k0; k < k1; ++k) s += grad_logits[b * E + in_eid[k]];
+  atomicAdd(&grad_emb[idx], s);
+}
+
+extern "C" int tarl_policy_edge_logits_fwd(const tarl_plan* plan, const float* road_index, int64_t ri_bstride,
+                                           int64_t ri_nstride, int64_t B, const float* emb, int64_t M, float* logits,
+                                           tarl_stream stream) {
+  TARL_REQUIRE(plan && road_index && emb && logits, "null argument");
+  TARL_REQUIRE(B >= 1 && M >= 1, "bad sizes");
+  if (plan->E == 0) return TARL_OK;
+  hipLaunchKernelGGL(k_edge_logits_fwd, dim3((unsigned)ceil_div(B * plan->E, POL_BLOCK)), dim3(POL_BLOCK), 0,
+                     (hipStream_t)stream, plan->dst, road_index, ri_bstride, ri_nstride, B, plan->E, emb, M, logits);
+  TARL_LAUNCH_CHECK();
+  return TARL_OK;
+}
+
+extern "C" int tarl_policy_edge_logits_bwd(const tarl_plan* plan, const float* road_index, int64_t ri_bstride,
+                                           int64_t ri_nstride, int64_t B, const float* grad_logits, float* grad_emb,
+                                           int64_t M, tarl_stream stream) {
+  TARL_REQUIRE(plan && road_index && grad_logits && grad_emb, "null argument");
+  TARL_REQUIRE(B >= 1 && M >= 1, "bad sizes");
+  if (plan->E == 0 || plan->N == 0) return TARL_OK;
+  hipLaunchKernelGGL(k_edge_logits_bwd, dim3((unsigned)ceil_div(B * plan->N, POL_BLOCK)), dim3(POL_BLOCK), 0,
+                     (hipStream_t)stream, plan->in_ptr, plan->in_eid, road_index, ri_bstride, ri_nstride, B, plan->N,
+                     plan->E, grad_logits, grad_emb, M);
+  TARL_LAUNCH_CHECK();
+  return TARL_OK;
+}

@@ -1,0 +1,89 @@
+"""ctypes binding of libtarl_hip.so (C ABI: include/tarl_hip.h).
+
+There is NO fallback: if the shared library is missing or lacks a symbol, ``load()`` raises. Build it with
+``python __graft_entry__.py build`` (or ``make -C tarl-simulator_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtarl_hip.so")
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_i32 = C.c_int32
+_u64 = C.c_uint64
+_f32 = C.c_float
+
+# name -> (restype, argtypes); must list every symbol include/tarl_hip.h declares (tests/test_abi.py checks it)
+_STATE = [_p, _i64, _i64, _i64, _i32]  # x, B, x_bstride, ldx, Nmax
+SIGNATURES = {
+    "tarl_abi_version": (C.c_int, []),
+    "tarl_last_error": (C.c_char_p, []),
+    "tarl_plan_create": (C.c_int, [_p, _i64, _i64, _p, C.POINTER(_p)]),
+    "tarl_plan_destroy": (None, [_p]),
+    "tarl_plan_info": (C.c_int, [_p, C.POINTER(_i64)]),
+    "tarl_direction_step": (C.c_int, [_p] + _STATE + [_i64, _p, _p, _f32, _p, _f32, _p, _u64, _u64, _p, _p, _p]),
+    "tarl_response_step": (C.c_int, [_p] + _STATE + [_i64, _p, _p, _p]),
+    "tarl_core_step": (C.c_int, [_p] + _STATE + [_i64, _p, _p, _f32, _p, _f32, _p, _u64, _u64, _p, _p, _p, _p, _p]),
+    "tarl_apply_action": (C.c_int, [_p] + _STATE + [_p, _p, _p]),
+    "tarl_withdraw_step": (C.c_int, [_p] + _STATE + [_i64, _p, _i64, _i64, _f32, _p, _p]),
+    "tarl_insert_step": (C.c_int, _STATE + [_i64, _p, _i64, _i64, _p, _f32, _p, _p, _p, _p]),
+    "tarl_reset_state": (C.c_int, _STATE + [_i64, _p, _i64, _i64, _p]),
+    "tarl_graphdist_softmax": (C.c_int, [_p, _p, _i64, _f32, _p, _p]),
+    "tarl_graphdist_sample": (C.c_int, [_p, _p, _i64, _p, _u64, _u64, _p, _p, _p, _p]),
+    "tarl_graphdist_mode": (C.c_int, [_p, _p, _i64, _p, _p, _p]),
+    "tarl_graphdist_logprob_entropy_fwd": (C.c_int, [_p, _p, _i64, _p, _p, _p, _p, _p]),
+    "tarl_graphdist_logprob_entropy_bwd": (C.c_int, [_p, _p, _i64, _f32, _p, _p, _p, _p, _p, _p, _p]),
+    "tarl_policy_edge_logits_fwd": (C.c_int, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _p]),
+    "tarl_policy_edge_logits_bwd": (C.c_int, [_p, _p, _i64, _i64, _i64, _p, _p, _i64, _p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class TarlError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libtarl_hip.so once; raise (never fall back) when it or one of its symbols is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise TarlError(f"{LIB_PATH} not found: the HIP extension is not built "
+                            "(run `python __graft_entry__.py build`); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as exc:
+                raise TarlError(f"{LIB_PATH} does not export {name}; rebuild the extension") from exc
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().tarl_last_error()
+        raise TarlError(f"libtarl_hip error {rc}: {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device (or host) address of a tensor, ``None`` -> NULL."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,319 @@
+"""Thin, validated wrappers over the C ABI (include/tarl_hip.h). Tensors in, tensors out; no compute happens in Python
+and there is no fallback: every function enqueues hand-written HIP kernels on torch's current stream.
+
+Batched state convention: ``x`` is fp32 ``(R, F)`` or ``(B, R, F)`` (last dim contiguous, arbitrary row / env
+strides), mutated in place like the reference does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+
+import torch
+
+from . import lib as _lib
+
+EPS_GUMBEL = 1e-12   # src/direction_mpnn.py:136
+
+
+def _check_dev(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise _lib.TarlError(f"{name} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+
+
+def _contig(t: torch.Tensor, dtype, name: str):
+    _check_dev(t, dtype, name)
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
+def _state(x: torch.Tensor, Nmax: int):
+    """-> (B, rows, x_bstride, ldx)."""
+    _check_dev(x, torch.float32, "x")
+    if x.dim() not in (2, 3) or x.stride(-1) != 1 or x.size(-1) < 3 * Nmax + 7:
+        raise ValueError(f"x must be (R,F) or (B,R,F) with F >= 3*Nmax+7 and a contiguous last dim, got {tuple(x.shape)}")
+    if x.dim() == 2:
+        return 1, x.size(0), x.size(0) * x.stride(0), x.stride(0)
+    return x.size(0), x.size(1), x.stride(0), x.stride(1)
+
+
+def _agents(a: torch.Tensor, B: int):
+    """-> (A, a_bstride)."""
+    _check_dev(a, torch.float32, "agent_features")
+    if a.size(-1) != 9 or a.stride(-1) != 1 or a.stride(-2) != 9:
+        raise ValueError("agent_features must be (A,9) or (B,A,9) with contiguous rows")
+    if a.dim() == 2:
+        if B != 1:
+            raise ValueError("batched state needs batched agent_features (B,A,9)")
+        return a.size(0), a.size(0) * 9
+    if a.size(0) != B:
+        raise ValueError("agent_features batch does not match x")
+    return a.size(1), a.stride(0)
+
+
+class Plan:
+    """Static per-graph plan (``tarl_plan_create``): int32 CSC/CSR built once on the host and kept on the device."""
+
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, src_order: torch.Tensor | None = None):
+        L = _lib.load()
+        ei = edge_index.detach().to("cpu", torch.int64).contiguous()
+        if ei.dim() != 2 or ei.size(0) != 2:
+            raise ValueError("edge_index must be (2, E)")
+        so = None if src_order is None else src_order.detach().to("cpu", torch.int64).contiguous()
+        handle = C.c_void_p()
+        _lib.check(L.tarl_plan_create(ei.data_ptr(), ei.size(1), int(num_nodes), _lib.ptr(so), C.byref(handle)))
+        self._h = handle
+        self._finalizer = weakref.finalize(self, L.tarl_plan_destroy, handle)
+        info = (C.c_int64 * 6)()
+        _lib.check(L.tarl_plan_info(handle, info))
+        self.num_nodes, self.num_edges, self.num_groups, self.max_in, self.max_out, src_sorted = [int(v) for v in info]
+        self.src_sorted = bool(src_sorted)
+        self.device = torch.device("cuda", torch.cuda.current_device())
+
+    @property
+    def handle(self):
+        return self._h
+
+
+_LOG_EPS = None
+
+
+def log_eps() -> float:
+    """fp32 ``log(0 + 1e-12)`` evaluated by torch on the CPU, as the reference does (src/direction_mpnn.py:138)."""
+    global _LOG_EPS
+    if _LOG_EPS is None:
+        _LOG_EPS = float(torch.log(torch.zeros(1, dtype=torch.float32) + EPS_GUMBEL)[0])
+    return _LOG_EPS
+
+
+class EdgeConst:
+    """Per-graph edge constants on the device: ``edge_attr`` (E,) and ``log(edge_attr + 1e-12)`` evaluated on the CPU
+    with torch so that the Gumbel-max scores are bit-identical to the reference's."""
+
+    def __init__(self, edge_attr: torch.Tensor, device):
+        ea = edge_attr.detach().to("cpu", torch.float32).reshape(-1).contiguous()
+        self.edge_attr = ea.to(device)
+        self.log_edge_attr = torch.log(ea + EPS_GUMBEL).to(device)
+        self.log_eps = log_eps()
+
+
+def gumbel_from_uniform_cpu(u: torch.Tensor) -> torch.Tensor:
+    """``-log(-log(u))`` evaluated on the CPU (parity runs feed the reference's own noise, src/direction_mpnn.py:137)."""
+    u = u.detach().to("cpu", torch.float32)
+    return -torch.log(-torch.log(u))
+
+
+def direction_step(plan: Plan, x, Nmax, ec: EdgeConst, t, *, congestion_constant=None, gumbel=None, seed=0, counter=0,
+                   want_dtt=True, chosen=None):
+    """DirectionMPNN.forward on B environments. Returns (delta_travel_time (B,E) or None, chosen (B,R))."""
+    L = _lib.load()
+    B, R, bs, ldx = _state(x, Nmax)
+    E = plan.num_edges
+    if chosen is None:
+        chosen = torch.empty((B, R), dtype=torch.float32, device=x.device)
+    dtt = torch.empty((B, E), dtype=torch.float32, device=x.device) if want_dtt else None
+    if gumbel is not None:
+        _contig(gumbel, torch.float32, "gumbel")
+        if gumbel.numel() != B * E:
+            raise ValueError("gumbel must hold B*E values")
+    if congestion_constant is not None:
+        _contig(congestion_constant, torch.float32, "congestion_constant")
+        if congestion_constant.numel() < R:
+            raise ValueError("congestion_constant shorter than num_roads")
+    _lib.check(L.tarl_direction_step(plan.handle, x.data_ptr(), B, bs, ldx, Nmax, R, ec.edge_attr.data_ptr(),
+                                     ec.log_edge_attr.data_ptr(), ec.log_eps, _lib.ptr(congestion_constant), float(t),
+                                     _lib.ptr(gumbel), int(seed), int(counter), _lib.ptr(dtt), chosen.data_ptr(),
+                                     _lib.current_stream()))
+    return dtt, chosen
+
+
+def response_step(plan: Plan, x, Nmax, *, popped=None, any_flag=None):
+    """ResponseMPNN.forward on B environments. Returns popped (B,R) uint8; ``any_flag`` int32[1] set on device."""
+    L = _lib.load()
+    B, R, bs, ldx = _state(x, Nmax)
+    if popped is None:
+        popped = torch.empty((B, R), dtype=torch.uint8, device=x.device)
+    _lib.check(L.tarl_response_step(plan.handle, x.data_ptr(), B, bs, ldx, Nmax, R, popped.data_ptr(),
+                                    _lib.ptr(any_flag), _lib.current_stream()))
+    return popped
+
+
+def core_step(plan: Plan, x, Nmax, ec: EdgeConst, t, *, congestion_constant=None, gumbel=None, seed=0, counter=0,
+              want_dtt=True, chosen=None, popped=None, any_flag=None):
+    """SimulationCoreModel.forward (both rounds). Returns (dtt or None, popped)."""
+    L = _lib.load()
+    B, R, bs, ldx = _state(x, Nmax)
+    E = plan.num_edges
+    if chosen is None:
+        chosen = torch.empty((B, R), dtype=torch.float32, device=x.device)
+    if popped is None:
+        popped = torch.empty((B, R), dtype=torch.uint8, device=x.device)
+    dtt = torch.empty((B, E), dtype=torch.float32, device=x.device) if want_dtt else None
+    if gumbel is not None:
+        _contig(gumbel, torch.float32, "gumbel")
+    _lib.check(L.tarl_core_step(plan.handle, x.data_ptr(), B, bs, ldx, Nmax, R, ec.edge_attr.data_ptr(),
+                                ec.log_edge_attr.data_ptr(), ec.log_eps, _lib.ptr(congestion_constant), float(t),
+                                _lib.ptr(gumbel), int(seed), int(counter), _lib.ptr(dtt), chosen.data_ptr(),
+                                popped.data_ptr(), _lib.ptr(any_flag), _lib.current_stream()))
+    return dtt, popped
+
+
+def apply_action(plan: Plan, x, Nmax, *, action_onehot=None, choice=None):
+    L = _lib.load()
+    B, N, bs, ldx = _state(x, Nmax)
+    if N != plan.num_nodes:
+        raise ValueError("x rows must equal the plan's node count")
+    if action_onehot is not None:
+        _contig(action_onehot, torch.int64, "action")
+    if choice is not None:
+        _contig(choice, torch.int32, "choice")
+    _lib.check(L.tarl_apply_action(plan.handle, x.data_ptr(), B, bs, ldx, Nmax, _lib.ptr(action_onehot),
+                                   _lib.ptr(choice), _lib.current_stream()))
+
+
+def withdraw_step(plan: Plan, x, Nmax, agent_features, t, *, withdrawn=None, want_mask=True):
+    L = _lib.load()
+    B, N, bs, ldx = _state(x, Nmax)
+    A, abs_ = _agents(agent_features, B)
+    if withdrawn is None and want_mask:
+        withdrawn = torch.empty((B, N), dtype=torch.uint8, device=x.device)
+    _lib.check(L.tarl_withdraw_step(plan.handle, x.data_ptr(), B, bs, ldx, Nmax, N, agent_features.data_ptr(), A, abs_,
+                                    float(t), _lib.ptr(withdrawn), _lib.current_stream()))
+    return withdrawn
+
+
+def insert_step(x, Nmax, agent_features, t, *, congestion_constant=None, scratch=None, reward=None, counts=None):
+    L = _lib.load()
+    B, N, bs, ldx = _state(x, Nmax)
+    A, abs_ = _agents(agent_features, B)
+    if scratch is None:
+        scratch = torch.empty((B, 2 * A), dtype=torch.int32, device=x.device)
+    _lib.check(L.tarl_insert_step(x.data_ptr(), B, bs, ldx, Nmax, N, agent_features.data_ptr(), A, abs_,
+                                  _lib.ptr(congestion_constant), float(t), scratch.data_ptr(), _lib.ptr(reward),
+                                  _lib.ptr(counts), _lib.current_stream()))
+
+
+def reset_state(x, Nmax, agent_features=None):
+    L = _lib.load()
+    B, N, bs, ldx = _state(x, Nmax)
+    A, abs_ = (0, 0) if agent_features is None else _agents(agent_features, B)
+    _lib.check(L.tarl_reset_state(x.data_ptr(), B, bs, ldx, Nmax, N, _lib.ptr(agent_features), A, abs_,
+                                  _lib.current_stream()))
+
+
+# ---- GraphDistribution ------------------------------------------------------------------------------------------------
+def _rows(t: torch.Tensor, E: int, name: str):
+    if t.size(-1) != E:
+        raise ValueError(f"{name} last dim must be E={E}")
+    return t.numel() // E
+
+
+def graphdist_softmax(plan: Plan, logits, temperature=1.0):
+    L = _lib.load()
+    _contig(logits, torch.float32, "logits")
+    B = _rows(logits, plan.num_edges, "logits")
+    proba = torch.empty_like(logits)
+    _lib.check(L.tarl_graphdist_softmax(plan.handle, logits.data_ptr(), B, float(temperature), proba.data_ptr(),
+                                        _lib.current_stream()))
+    return proba
+
+
+def graphdist_sample(plan: Plan, proba, *, uniform=None, seed=0, counter=0, want_onehot=True, want_choice=False):
+    L = _lib.load()
+    _contig(proba, torch.float32, "proba")
+    E, G, N = plan.num_edges, plan.num_groups, plan.num_nodes
+    B = _rows(proba, E, "proba")
+    if uniform is not None:
+        _contig(uniform, torch.float32, "uniform")
+        if uniform.numel() != B * G:
+            raise ValueError("uniform must hold B*num_groups values")
+    sums = torch.empty((B, G + 1), dtype=torch.float64, device=proba.device)
+    onehot = torch.empty(proba.shape, dtype=torch.int64, device=proba.device) if want_onehot else None
+    choice = torch.empty(proba.shape[:-1] + (N,), dtype=torch.int32, device=proba.device) if want_choice else None
+    _lib.check(L.tarl_graphdist_sample(plan.handle, proba.data_ptr(), B, _lib.ptr(uniform), int(seed), int(counter),
+                                       sums.data_ptr(), _lib.ptr(onehot), _lib.ptr(choice), _lib.current_stream()))
+    return onehot, choice
+
+
+def graphdist_mode(plan: Plan, proba, *, want_choice=False):
+    L = _lib.load()
+    _contig(proba, torch.float32, "proba")
+    B = _rows(proba, plan.num_edges, "proba")
+    onehot = torch.zeros_like(proba)
+    choice = (torch.empty(proba.shape[:-1] + (plan.num_nodes,), dtype=torch.int32, device=proba.device)
+              if want_choice else None)
+    _lib.check(L.tarl_graphdist_mode(plan.handle, proba.data_ptr(), B, onehot.data_ptr(), _lib.ptr(choice),
+                                     _lib.current_stream()))
+    return onehot, choice
+
+
+def graphdist_logprob_entropy(plan: Plan, proba, *, action_onehot=None, choice=None, want_logprob=True,
+                              want_entropy=True):
+    L = _lib.load()
+    _contig(proba, torch.float32, "proba")
+    B = _rows(proba, plan.num_edges, "proba")
+    shape = proba.shape[:-1]
+    if action_onehot is not None:
+        _contig(action_onehot, torch.int64, "action")
+    if choice is not None:
+        _contig(choice, torch.int32, "choice")
+    lp = torch.empty(shape, dtype=torch.float32, device=proba.device) if want_logprob else None
+    ent = torch.empty(shape, dtype=torch.float32, device=proba.device) if want_entropy else None
+    _lib.check(L.tarl_graphdist_logprob_entropy_fwd(plan.handle, proba.data_ptr(), B, _lib.ptr(action_onehot),
+                                                    _lib.ptr(choice), _lib.ptr(lp), _lib.ptr(ent),
+                                                    _lib.current_stream()))
+    return lp, ent
+
+
+def graphdist_logprob_entropy_bwd(plan: Plan, proba, temperature, *, action_onehot=None, choice=None,
+                                  grad_log_prob=None, grad_entropy=None, log_prob_fwd=None):
+    L = _lib.load()
+    _contig(proba, torch.float32, "proba")
+    B = _rows(proba, plan.num_edges, "proba")
+    for name, t in (("grad_log_prob", grad_log_prob), ("grad_entropy", grad_entropy), ("log_prob_fwd", log_prob_fwd)):
+        if t is not None:
+            _contig(t, torch.float32, name)
+    grad = torch.zeros_like(proba)
+    _lib.check(L.tarl_graphdist_logprob_entropy_bwd(plan.handle, proba.data_ptr(), B, float(temperature),
+                                                    _lib.ptr(action_onehot), _lib.ptr(choice),
+                                                    _lib.ptr(grad_log_prob), _lib.ptr(grad_entropy),
+                                                    _lib.ptr(log_prob_fwd), grad.data_ptr(), _lib.current_stream()))
+    return grad
+
+
+# ---- policy -----------------------------------------------------------------------------------------------------------
+def _road_index_view(node_features: torch.Tensor, plan: Plan):
+    """node_features (..., N, C>=7): the ROAD_INDEX observation column (ObservationFeatureHelpers.ROAD_INDEX = 6)."""
+    _check_dev(node_features, torch.float32, "node_features")
+    if node_features.dim() == 2:
+        nf = node_features.unsqueeze(0)
+    else:
+        nf = node_features.reshape(-1, node_features.size(-2), node_features.size(-1))
+    if nf.size(1) != plan.num_nodes or nf.size(2) < 7:
+        raise ValueError("node_features must be (..., N, >=7)")
+    col = nf[:, :, 6]
+    return col, nf.size(0), col.stride(0), col.stride(1)
+
+
+def policy_edge_logits(plan: Plan, node_features, emb):
+    L = _lib.load()
+    _contig(emb, torch.float32, "emb")
+    col, B, bs, ns = _road_index_view(node_features, plan)
+    shape = (plan.num_edges,) if node_features.dim() == 2 else tuple(node_features.shape[:-2]) + (plan.num_edges,)
+    logits = torch.empty(shape, dtype=torch.float32, device=emb.device)
+    _lib.check(L.tarl_policy_edge_logits_fwd(plan.handle, col.data_ptr(), bs, ns, B, emb.data_ptr(), emb.numel(),
+                                             logits.data_ptr(), _lib.current_stream()))
+    return logits
+
+
+def policy_edge_logits_bwd(plan: Plan, node_features, grad_logits, num_embeddings):
+    L = _lib.load()
+    _contig(grad_logits, torch.float32, "grad_logits")
+    col, B, bs, ns = _road_index_view(node_features, plan)
+    grad_emb = torch.zeros(num_embeddings, dtype=torch.float32, device=grad_logits.device)
+    _lib.check(L.tarl_policy_edge_logits_bwd(plan.handle, col.data_ptr(), bs, ns, B, grad_logits.data_ptr(),
+                                             grad_emb.data_ptr(), num_embeddings, _lib.current_stream()))
+    return grad_emb

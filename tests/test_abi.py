@@ -1,0 +1,55 @@
+"""CPU: the C-ABI library loads and exports every symbol include/tarl_hip.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "tarl_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tarl_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from tarl_hip import lib
+    assert os.path.exists(lib.LIB_PATH), "build the extension first: python __graft_entry__.py build"
+    so = ctypes.CDLL(lib.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 19
+    for n in names:
+        assert hasattr(so, n), f"{n} declared in include/tarl_hip.h but not exported"
+    # the ctypes table binds exactly the declared entry points
+    assert sorted(lib.SIGNATURES) == names
+    L = lib.load()
+    assert L.tarl_abi_version() == 1
+
+
+def test_plan_create_rejects_bad_input_without_gpu_compute():
+    """Argument validation happens on the host before any HIP call."""
+    import torch
+    from tarl_hip import lib
+    L = lib.load()
+    ei = torch.tensor([[0, 1], [1, 5]], dtype=torch.int64)   # node 5 out of range for 3 nodes
+    h = ctypes.c_void_p()
+    rc = L.tarl_plan_create(ei.data_ptr(), 2, 3, None, ctypes.byref(h))
+    assert rc == -1 and b"out of range" in L.tarl_last_error()
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from tarl_hip import lib
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    import pytest
+    with pytest.raises(lib.TarlError):
+        lib.load()
+
+
+def test_cpu_tensor_is_refused():
+    """No CPU fallback: a host tensor handed to an op raises instead of being computed elsewhere."""
+    import pytest
+    import torch
+    from tarl_hip import lib, ops
+    with pytest.raises(lib.TarlError):
+        ops._check_dev(torch.zeros(4), torch.float32, "x")
