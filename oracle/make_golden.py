@@ -84,10 +84,13 @@ def draws(seed, n):
 # ----------------------------------------------------------------------------------------------------------------
 def gen_core_steps():
     """DirectionMPNN / ResponseMPNN / SimulationCoreModel on random mid-simulation states (a2-a8)."""
-    for tag, (W, H, het, with_const) in {"core_hom": (2, 3, False, True), "core_het": (3, 2, True, True),
-                                         "core_noconst": (2, 2, True, False)}.items():
+    # NOTE: states in which gridlock relief over-fills a FIFO (count reaches Nmax) are outside the reference's defined
+    # domain: its unconditional slot writes then overwrite MAX_NUMBER_OF_AGENT / NUMBER_OF_AGENT and it raises
+    # IndexError one or two steps later (observed here on an 8x8 torus). No fixture can pin that corner.
+    for tag, (W, H, het, with_const, sseed) in {"core_hom": (2, 3, False, True, 5), "core_het": (3, 2, True, True, 5),
+                                                "core_noconst": (2, 2, True, False, 5)}.items():
         net = synth.torus_network(W, H, heterogeneous=het, seed=11)
-        x = synth.random_state(net, seed=5, t=100.0)
+        x = synth.random_state(net, seed=sseed, t=100.0)
         E = net.edge_index.size(1)
         g = Data(x=x.clone(), edge_index=net.edge_index, edge_attr=net.edge_attr,
                  edge_index_routes=net.edge_index, edge_attr_routes=net.edge_attr, num_roads=net.num_roads)
@@ -122,6 +125,7 @@ def gen_core_steps():
             rec[f"pop{s}"] = hist[-1][1].clone() if len(hist) > hist_before else torch.zeros(net.num_roads, dtype=torch.bool)
             rec[f"t{s}"] = t
         rec["steps"] = steps
+        rec["max_count"] = float(g.x[:, 3 * net.Nmax + 1].max())
         save(tag, **rec)
 
 

@@ -103,13 +103,14 @@ def direction_update(x, chosen, t, Nmax, congestion_constant=None):
     R = x.size(0)
     rows = torch.arange(R)
     q = x[:, c.N].to(torch.int64)
-    n0 = x[:, c.N].clone()
+    n0 = x[:, c.N]                       # a live VIEW, exactly as the reference's ``start_counts`` (``:173``)
     x[rows, q] = chosen
     x[rows, Nmax + q] = float(t)
-    if congestion_constant is None:
-        _, congestion_constant = congestion_constants(x, Nmax)
-    t_cong = congestion_constant / (x[:, c.MAXN] + 10 - n0)
-    tt = torch.maximum(x[:, c.FF], t_cong)
+    if congestion_constant is None:      # ``:178-183`` — evaluated inside update, after the first two writes
+        critical = x[rows, c.MAXFLOW] * x[rows, c.FF] / 3600
+        congestion_constant = x[rows, c.FF] * (x[rows, c.MAXN] + 10 - critical)
+    t_cong = congestion_constant / (x[rows, c.MAXN] + 10 - n0)
+    tt = torch.maximum(x[rows, c.FF], t_cong)
     x[rows, 2 * Nmax + q] = t + tt
     is_agent = chosen != 0
     x[is_agent, c.N] = n0[is_agent] + 1
@@ -118,8 +119,6 @@ def direction_update(x, chosen, t, Nmax, congestion_constant=None):
 
 def direction_step(x, edge_index, edge_attr, t, Nmax, *, gumbel=None, uniform=None, congestion_constant=None):
     """DirectionMPNN.forward == propagate (src/direction_mpnn.py:210-236). Returns (x, delta_travel_time)."""
-    if congestion_constant is None:  # SimulationCoreModel computes it before the round (pre-update state)
-        _, congestion_constant = congestion_constants(x, Nmax)
     agent_id, prob, dtt = direction_message(x, edge_index, edge_attr, t, Nmax)
     chosen = direction_aggregate(agent_id, prob, edge_index[1], x.size(0), gumbel=gumbel, uniform=uniform)
     direction_update(x, chosen, t, Nmax, congestion_constant)
@@ -158,6 +157,8 @@ def response_step(x, edge_index, Nmax):
 def core_step(x, edge_index, edge_attr, t, Nmax, *, gumbel=None, uniform=None, congestion_constant=None):
     """SimulationCoreModel.forward on the road rows (src/simulation_core_model.py:41-83).
     Returns (x, delta_travel_time, popped)."""
+    if congestion_constant is None:  # ``:55-67``: computed from the pre-round state when the graph lacks the attributes
+        _, congestion_constant = congestion_constants(x, Nmax)
     _, dtt = direction_step(x, edge_index, edge_attr, t, Nmax, gumbel=gumbel, uniform=uniform,
                             congestion_constant=congestion_constant)
     _, popped = response_step(x, edge_index, Nmax)

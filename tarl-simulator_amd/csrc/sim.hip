@@ -99,26 +99,29 @@ __global__ __launch_bounds__(SIM_BLOCK) void k_direction_update(float* __restric
   const int32_t i = (int32_t)(gid - b * R);
   float* xi = x + b * L.bstride + (int64_t)i * L.ldx;
   const int Nmax = L.Nmax;
-  const float n0 = xi[L.col_n()];
+  const int F = L.F();
+  const float who = chosen[gid];
+  // The reference performs three unconditional indexed writes at columns q, Nmax+q, 2Nmax+q with q = int(count) and
+  // reads the counter through a live view. When a gridlock-relief move has over-filled a FIFO (q >= Nmax) those
+  // writes land in the neighbouring blocks / scalar columns; reproduced here write by write, re-reading the row in
+  // between exactly as the sequence of torch ops does. (A column >= F raises IndexError there; skipped here.)
+  const int q = (int)xi[L.col_n()];  // .to(int64) truncates
+  if (q >= 0 && q < F) xi[q] = who;
+  if (q >= 0 && Nmax + q < F) xi[Nmax + q] = t;
   const float maxn = xi[L.col_maxn()];
   const float ff = xi[L.col_ff()];
+  const float n0 = xi[L.col_n()];
   float c;
   if (cong) {
     c = cong[i];
-  } else {  // src/simulation_core_model.py:55-67
+  } else {  // src/direction_mpnn.py:178-183 (same expression as src/simulation_core_model.py:55-67)
     const float critical = xi[L.col_maxflow()] * ff / 3600.0f;
     c = ff * (maxn + 10.0f - critical);
   }
   const float t_cong = c / (maxn + 10.0f - n0);
   const float tt = (t_cong != t_cong) ? t_cong : fmaxf(ff, t_cong);  // torch.maximum propagates NaN
-  const float who = chosen[gid];
-  const int q = (int)n0;  // .to(int64) truncates
-  if (q >= 0 && q < Nmax) {  // outside [0, Nmax) the reference scribbles over other blocks or raises; not reproduced
-    xi[q] = who;
-    xi[Nmax + q] = t;
-    xi[2 * Nmax + q] = t + tt;
-  }
-  if (who != 0.0f) xi[L.col_n()] = n0 + 1.0f;
+  if (q >= 0 && 2 * Nmax + q < F) xi[2 * Nmax + q] = t + tt;
+  if (who != 0.0f) xi[L.col_n()] = xi[L.col_n()] + 1.0f;
 }
 
 // ---- Response: message + max-aggregate (src-centric gather; S6-S8) -------------------------------------------------

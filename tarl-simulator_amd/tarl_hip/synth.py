@@ -111,7 +111,7 @@ def random_state(net: SynthNetwork, *, seed: int = 0, t: float = 100.0, fill: fl
                     torch.where(u > 0.85, maxn - torch.randint(0, 4, (R,), generator=g),
                                 (torch.rand(R, generator=g) * fill * 2 * maxn.float()).to(torch.int64)))
     n = n.clamp(min=0)
-    n = torch.minimum(n, maxn)
+    n = torch.minimum(n, maxn - 1)   # a FIFO at MAX that receives a gridlock-relief move leaves the reference's domain
     total = int(n.sum().item())
     pool = num_agents if num_agents is not None else max(total, 1)
     ids = (torch.randperm(max(pool, total), generator=g)[:total] + 1).float()
