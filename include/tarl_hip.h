@@ -147,6 +147,47 @@ int tarl_policy_edge_logits_bwd(const tarl_plan* plan, const float* road_index, 
                                 int64_t ri_nstride, int64_t B, const float* grad_logits, float* grad_emb,
                                 int64_t num_embeddings, tarl_stream stream);
 
+/* tarl_critic_mlp_fwd == MPNNValueNetSimple.forward (:428-450): value = W3 relu(W2 relu(W1 [counts, time] + b1) + b2) + b3
+ *   with the reference's state-dict layout: w1 [64][N+1] (last input column = time), w2 [64][64], w3 [64] (= [1][64]).
+ *   counts [M][ldc] = the NUMBER_OF_AGENT observation column per node (row stride ldc >= N); time_rows[m / rows_per_time]
+ *   is row m's clock (rows_per_time = B for a time-major [T][B] rollout buffer, 1 for per-row times).
+ *   value [M]; h1_out / h2_out [M][64] nullable (post-ReLU activations kept for the backward). fp32 MFMA
+ *   (v_mfma_f32_32x32x2_f32, exact fp32 products), hidden tile kept in LDS. */
+int tarl_critic_mlp_fwd(const float* counts, int64_t ldc, int64_t M, int64_t N, const float* time_rows,
+                        int64_t rows_per_time, const float* w1, const float* b1, const float* w2, const float* b2,
+                        const float* w3, const float* b3, float* value, float* h1_out, float* h2_out,
+                        tarl_stream stream);
+/* backward for minibatch-sized M: ACCUMULATES (+=) into gw1 [64][N+1], gb1 [64], gw2 [64][64], gb2 [64], gw3 [64],
+ *   gb3 [1]; scratch: fp32 [2][M][64]. */
+int tarl_critic_mlp_bwd(const float* counts, int64_t ldc, int64_t M, int64_t N, const float* time_rows,
+                        int64_t rows_per_time, const float* w1, const float* w2, const float* w3, const float* h1,
+                        const float* h2, const float* grad_value, float* scratch, float* gw1, float* gb1, float* gw2,
+                        float* gb2, float* gw3, float* gb3, tarl_stream stream);
+
+/* ---- PPO update (src/rl/ppo_trainer.py:35-37,129-145; torchrl 0.5.0 GAE / ClipPPOLoss formulas) ---------
+ * tarl_gae: GAE(gamma, lmbda) over time-major [T][B] tensors; next_value[t] = V(next obs of frame t) (for an unbroken
+ *   rollout pass value + B of a [T+1][B] buffer); done / terminated uint8 nullable (= all false).
+ *   advantage (un-normalised) and value_target = advantage + value are written. */
+int tarl_gae(const float* reward, const float* value, const float* next_value, const uint8_t* done,
+             const uint8_t* terminated, int64_t T, int64_t B, float gamma, float lmbda, float* advantage,
+             float* value_target, tarl_stream stream);
+/* average_gae=True: stats = {sum, sum of squares, count} in double (partial: double scratch [512]); all-reduce stats
+ *   across ranks if the statistic must be global, then tarl_advantage_normalize applies
+ *   A <- (A - mean) / max(std_unbiased, 1e-6). */
+int tarl_advantage_stats(const float* advantage, int64_t n, double* partial, double* stats3, tarl_stream stream);
+int tarl_advantage_normalize(float* advantage, int64_t n, const double* stats3, tarl_stream stream);
+/* tarl_ppo_loss == ClipPPOLoss(clip_epsilon) forward + gradient seeds in one launch. out6 = {loss_objective,
+ *   loss_critic, loss_entropy, clip_fraction, kl_approx, ESS}; grad_* [M] nullable: d(loss_objective + loss_critic +
+ *   loss_entropy) / d(log_prob_new | entropy | value), multiplied by grad_scale (1/world_size for averaged DP grads). */
+int tarl_ppo_loss(const float* log_prob_new, const float* log_prob_old, const float* advantage, const float* value,
+                  const float* value_target, const float* entropy, int64_t M, float clip_epsilon, float entropy_coef,
+                  float critic_coef, float grad_scale, float* out6, float* grad_log_prob, float* grad_entropy,
+                  float* grad_value, tarl_stream stream);
+/* tarl_adam_step == torch.optim.Adam single-tensor update (src/rl/ppo_trainer.py:37,144) on a flat fp32 buffer;
+ *   step is 1-based; grad is multiplied by grad_scale first. */
+int tarl_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,
+                   double lr, double beta1, double beta2, double eps, float grad_scale, tarl_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,7 +50,7 @@ def clip_ppo_loss(log_prob_new, log_prob_old, advantage, value, value_target, en
 
 def adam_step(param, grad, m, v, step, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
     """torch.optim.Adam defaults (src/rl/ppo_trainer.py:37), single-tensor form; ``step`` is 1-based. In place."""
-    m.mul_(beta1).add_(grad, alpha=1 - beta1)
+    m.lerp_(grad, 1 - beta1)
     v.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
     bc1 = 1 - beta1 ** step
     bc2 = 1 - beta2 ** step

@@ -1,0 +1,253 @@
+// critic.hip — MPNNValueNetSimple: value = MLP(cat(NUMBER_OF_AGENT per node, time)), (N+1) -> 64 -> 64 -> 1 with ReLU
+// (src/agents/mpnn_agent.py:420-450). The only GEMM-shaped work on the path, hence the only MFMA user.
+//
+// Forward: one fused kernel. A workgroup owns 128 rows; each of its 4 waves accumulates a 32 x 64 slab of the first
+// layer with v_mfma_f32_32x32x2_f32 (exact fp32 products, k-ordered fma chain: no reduced-precision path is taken, the
+// parity contract is 1e-4 on values), staging X and W1 tiles k-major in LDS (padded: conflict-free ds_read_b32 for the
+// MFMA operand pattern "lane -> row, half-wave -> k"). The 128 x 64 hidden tile never leaves the CU: layer 2 is a
+// second MFMA pass out of LDS, layer 3 a 64-long dot product per row.
+// The per-row `time` feature is the last input column in the reference; here it is a rank-1 update after the K loop,
+// which keeps the big operand (counts, row stride = N) 16-byte friendly and shared with the rollout buffer.
+#include "tarl_common.h"
+
+#define CR_H 64        // hidden width (fixed by the reference architecture)
+#define CR_BM 128      // rows per workgroup
+#define CR_BK 32       // K chunk
+#define CR_THREADS 256
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct CriticParams {
+  const float* w1;  // [64][N+1]
+  const float* b1;  // [64]
+  const float* w2;  // [64][64]
+  const float* b2;  // [64]
+  const float* w3;  // [64]
+  const float* b3;  // [1]
+};
+
+// C/D layout of the 32x32 f32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+__device__ __forceinline__ int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+__global__ __launch_bounds__(CR_THREADS) void k_critic_fwd(const float* __restrict__ counts, int64_t ldc, int64_t M,
+                                                           int64_t N, const float* __restrict__ time_rows,
+                                                           int64_t rows_per_time, CriticParams P,
+                                                           float* __restrict__ value, float* __restrict__ h1_out,
+                                                           float* __restrict__ h2_out) {
+  // one array for all LDS (phases reuse it): Xs [32][129] + Ws [32][65]  |  Hs [64][129] + W2s [64][65]
+  __shared__ float lds[CR_H * (CR_BM + 1) + CR_H * (CR_H + 1)];
+  float* Xs = lds;                          // [k][row], row stride 129
+  float* Ws = lds + CR_BK * (CR_BM + 1);    // [k][j],  stride 65
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t row0 = (int64_t)blockIdx.x * CR_BM;
+  const int64_t ldw = N + 1;
+
+  f32x16 acc0 = {0}, acc1 = {0};
+  for (int64_t k0 = 0; k0 < N; k0 += CR_BK) {
+    // stage X tile: 128 rows x 32 k  (lanes along k => 128-B coalesced segments)
+#pragma unroll
+    for (int it = 0; it < (CR_BM * CR_BK) / CR_THREADS; ++it) {
+      const int idx = it * CR_THREADS + tid;
+      const int r = idx >> 5, k = idx & 31;
+      const int64_t gr = row0 + r, gk = k0 + k;
+      Xs[k * (CR_BM + 1) + r] = (gr < M && gk < N) ? counts[gr * ldc + gk] : 0.0f;
+    }
+#pragma unroll
+    for (int it = 0; it < (CR_H * CR_BK) / CR_THREADS; ++it) {
+      const int idx = it * CR_THREADS + tid;
+      const int j = idx >> 5, k = idx & 31;
+      const int64_t gk = k0 + k;
+      Ws[k * (CR_H + 1) + j] = (gk < N) ? P.w1[(int64_t)j * ldw + gk] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < CR_BK; kk += 2) {
+      const int k = kk + (lane >> 5);
+      const float a = Xs[k * (CR_BM + 1) + wave * 32 + (lane & 31)];
+      const float b0 = Ws[k * (CR_H + 1) + (lane & 31)];
+      const float b1 = Ws[k * (CR_H + 1) + 32 + (lane & 31)];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // epilogue of layer 1: + time * W1[:, N] + b1, ReLU; park h1 k-major in LDS for the second MFMA pass
+  float* Hs = lds;                           // [j][row], stride 129
+  float* W2s = lds + CR_H * (CR_BM + 1);     // [k][j],  stride 65   (W2s[k][j] = w2[j][k])
+  {
+    const int j0 = lane & 31;
+    const float wt0 = P.w1[(int64_t)j0 * ldw + N], wt1 = P.w1[(int64_t)(j0 + 32) * ldw + N];
+    const float bb0 = P.b1[j0], bb1 = P.b1[j0 + 32];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int lr = wave * 32 + mfma_row(r, lane);
+      const int64_t gr = row0 + lr;
+      const float tm = (gr < M) ? time_rows[gr / rows_per_time] : 0.0f;
+      float v0 = acc0[r] + tm * wt0 + bb0;
+      float v1 = acc1[r] + tm * wt1 + bb1;
+      v0 = v0 > 0.0f ? v0 : 0.0f;
+      v1 = v1 > 0.0f ? v1 : 0.0f;
+      Hs[j0 * (CR_BM + 1) + lr] = v0;
+      Hs[(j0 + 32) * (CR_BM + 1) + lr] = v1;
+      if (h1_out && gr < M) {
+        h1_out[gr * CR_H + j0] = v0;
+        h1_out[gr * CR_H + j0 + 32] = v1;
+      }
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < (CR_H * CR_H) / CR_THREADS; ++it) {
+    const int idx = it * CR_THREADS + tid;
+    const int j = idx >> 6, k = idx & 63;
+    W2s[k * (CR_H + 1) + j] = P.w2[j * CR_H + k];
+  }
+  __syncthreads();
+  f32x16 c0 = {0}, c1 = {0};
+#pragma unroll
+  for (int kk = 0; kk < CR_H; kk += 2) {
+    const int k = kk + (lane >> 5);
+    const float a = Hs[k * (CR_BM + 1) + wave * 32 + (lane & 31)];
+    const float b0 = W2s[k * (CR_H + 1) + (lane & 31)];
+    const float b1 = W2s[k * (CR_H + 1) + 32 + (lane & 31)];
+    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, c1, 0, 0, 0);
+  }
+  __syncthreads();  // everyone is done reading Hs / W2s
+  {
+    const int j0 = lane & 31;
+    const float bb0 = P.b2[j0], bb1 = P.b2[j0 + 32];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int lr = wave * 32 + mfma_row(r, lane);
+      const int64_t gr = row0 + lr;
+      float v0 = c0[r] + bb0, v1 = c1[r] + bb1;
+      v0 = v0 > 0.0f ? v0 : 0.0f;
+      v1 = v1 > 0.0f ? v1 : 0.0f;
+      Hs[j0 * (CR_BM + 1) + lr] = v0;
+      Hs[(j0 + 32) * (CR_BM + 1) + lr] = v1;
+      if (h2_out && gr < M) {
+        h2_out[gr * CR_H + j0] = v0;
+        h2_out[gr * CR_H + j0 + 32] = v1;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < CR_BM) {
+    const int64_t gr = row0 + tid;
+    if (gr < M) {
+      float s = 0.0f;
+#pragma unroll 8
+      for (int j = 0; j < CR_H; ++j) s += Hs[j * (CR_BM + 1) + tid] * P.w3[j];
+      value[gr] = s + P.b3[0];
+    }
+  }
+}
+
+// ---- backward (minibatch-sized M) ------------------------------------------------------------------------------------
+// stage 1: one workgroup per row m: dh2, dh1 (masked by the ReLUs) -> scratch; stage 2: weight gradients as plain
+// reductions over m (deterministic order), dW1 over a (j, k) grid with k-coalesced reads of the counts.
+__global__ __launch_bounds__(CR_H) void k_critic_bwd_rows(int64_t M, const float* __restrict__ dv,
+                                                          const float* __restrict__ h1, const float* __restrict__ h2,
+                                                          CriticParams P, float* __restrict__ dh1,
+                                                          float* __restrict__ dh2) {
+  __shared__ float s_dh2[CR_H];
+  const int64_t m = blockIdx.x;
+  const int j = threadIdx.x;
+  const float g = dv[m];
+  const float d2 = (h2[m * CR_H + j] > 0.0f) ? g * P.w3[j] : 0.0f;
+  s_dh2[j] = d2;
+  dh2[m * CR_H + j] = d2;
+  __syncthreads();
+  float s = 0.0f;
+  for (int i = 0; i < CR_H; ++i) s += s_dh2[i] * P.w2[i * CR_H + j];  // dh1[j] = sum_i dh2[i] * w2[i][j]
+  dh1[m * CR_H + j] = (h1[m * CR_H + j] > 0.0f) ? s : 0.0f;
+}
+
+__global__ __launch_bounds__(CR_THREADS) void k_critic_bwd_small(int64_t M, const float* __restrict__ dv,
+                                                                 const float* __restrict__ h1,
+                                                                 const float* __restrict__ h2,
+                                                                 const float* __restrict__ dh1,
+                                                                 const float* __restrict__ dh2,
+                                                                 const float* __restrict__ time_rows,
+                                                                 int64_t rows_per_time, int64_t N,
+                                                                 float* __restrict__ gw1, float* __restrict__ gb1,
+                                                                 float* __restrict__ gw2, float* __restrict__ gb2,
+                                                                 float* __restrict__ gw3, float* __restrict__ gb3) {
+  // grid: 64*64 threads for gw2 (+ the small vectors handled by the first threads)
+  const int idx = blockIdx.x * CR_THREADS + threadIdx.x;
+  if (idx < CR_H * CR_H) {
+    const int j = idx >> 6, k = idx & 63;
+    float s = 0.0f;
+    for (int64_t m = 0; m < M; ++m) s += dh2[m * CR_H + j] * h1[m * CR_H + k];
+    gw2[idx] += s;
+  }
+  if (idx < CR_H) {
+    float sb2 = 0.0f, sb1 = 0.0f, sw3 = 0.0f, swt = 0.0f;
+    for (int64_t m = 0; m < M; ++m) {
+      sb2 += dh2[m * CR_H + idx];
+      sb1 += dh1[m * CR_H + idx];
+      sw3 += dv[m] * h2[m * CR_H + idx];
+      swt += dh1[m * CR_H + idx] * time_rows[m / rows_per_time];
+    }
+    gb2[idx] += sb2;
+    gb1[idx] += sb1;
+    gw3[idx] += sw3;
+    gw1[(int64_t)idx * (N + 1) + N] += swt;  // the time column of W1
+  }
+  if (idx == 0) {
+    float s = 0.0f;
+    for (int64_t m = 0; m < M; ++m) s += dv[m];
+    gb3[0] += s;
+  }
+}
+
+__global__ __launch_bounds__(CR_THREADS) void k_critic_bwd_w1(int64_t M, int64_t N, const float* __restrict__ counts,
+                                                              int64_t ldc, const float* __restrict__ dh1,
+                                                              float* __restrict__ gw1) {
+  const int64_t k = (int64_t)blockIdx.x * CR_THREADS + threadIdx.x;
+  const int j = blockIdx.y;
+  if (k >= N) return;
+  float s = 0.0f;
+  for (int64_t m = 0; m < M; ++m) s += dh1[m * CR_H + j] * counts[m * ldc + k];
+  gw1[(int64_t)j * (N + 1) + k] += s;
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------
+extern "C" int tarl_critic_mlp_fwd(const float* counts, int64_t ldc, int64_t M, int64_t N, const float* time_rows,
+                                   int64_t rows_per_time, const float* w1, const float* b1, const float* w2,
+                                   const float* b2, const float* w3, const float* b3, float* value, float* h1_out,
+                                   float* h2_out, tarl_stream stream) {
+  TARL_REQUIRE(counts && time_rows && w1 && b1 && w2 && b2 && w3 && b3 && value, "null argument");
+  TARL_REQUIRE(M >= 1 && N >= 1 && ldc >= N && rows_per_time >= 1, "bad sizes");
+  TARL_REQUIRE(ceil_div(M, CR_BM) < ((int64_t)1 << 31), "too many rows");
+  const CriticParams P{w1, b1, w2, b2, w3, b3};
+  hipLaunchKernelGGL(k_critic_fwd, dim3((unsigned)ceil_div(M, CR_BM)), dim3(CR_THREADS), 0, (hipStream_t)stream, counts,
+                     ldc, M, N, time_rows, rows_per_time, P, value, h1_out, h2_out);
+  TARL_LAUNCH_CHECK();
+  return TARL_OK;
+}
+
+extern "C" int tarl_critic_mlp_bwd(const float* counts, int64_t ldc, int64_t M, int64_t N, const float* time_rows,
+                                   int64_t rows_per_time, const float* w1, const float* w2, const float* w3,
+                                   const float* h1, const float* h2, const float* grad_value, float* scratch,
+                                   float* gw1, float* gb1, float* gw2, float* gb2, float* gw3, float* gb3,
+                                   tarl_stream stream) {
+  TARL_REQUIRE(counts && time_rows && w1 && w2 && w3 && h1 && h2 && grad_value && scratch, "null argument");
+  TARL_REQUIRE(gw1 && gb1 && gw2 && gb2 && gw3 && gb3, "null gradient buffer");
+  TARL_REQUIRE(M >= 1 && N >= 1 && ldc >= N && rows_per_time >= 1, "bad sizes");
+  TARL_REQUIRE(M < ((int64_t)1 << 31), "too many rows");
+  const CriticParams P{w1, nullptr, w2, nullptr, w3, nullptr};
+  float* dh1 = scratch;
+  float* dh2 = scratch + M * CR_H;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_critic_bwd_rows, dim3((unsigned)M), dim3(CR_H), 0, s, M, grad_value, h1, h2, P, dh1, dh2);
+  TARL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_critic_bwd_small, dim3((CR_H * CR_H) / CR_THREADS), dim3(CR_THREADS), 0, s, M, grad_value, h1, h2,
+                     dh1, dh2, time_rows, rows_per_time, N, gw1, gb1, gw2, gb2, gw3, gb3);
+  TARL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_critic_bwd_w1, dim3((unsigned)ceil_div(N, CR_THREADS), CR_H), dim3(CR_THREADS), 0, s, M, N,
+                     counts, ldc, dh1, gw1);
+  TARL_LAUNCH_CHECK();
+  return TARL_OK;
+}

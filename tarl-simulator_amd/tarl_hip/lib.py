@@ -17,6 +17,7 @@ _i64 = C.c_int64
 _i32 = C.c_int32
 _u64 = C.c_uint64
 _f32 = C.c_float
+_f64 = C.c_double
 
 # name -> (restype, argtypes); must list every symbol include/tarl_hip.h declares (tests/test_abi.py checks it)
 _STATE = [_p, _i64, _i64, _i64, _i32]  # x, B, x_bstride, ldx, Nmax
@@ -40,6 +41,13 @@ SIGNATURES = {
     "tarl_graphdist_logprob_entropy_bwd": (C.c_int, [_p, _p, _i64, _f32, _p, _p, _p, _p, _p, _p, _p]),
     "tarl_policy_edge_logits_fwd": (C.c_int, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _p]),
     "tarl_policy_edge_logits_bwd": (C.c_int, [_p, _p, _i64, _i64, _i64, _p, _p, _i64, _p]),
+    "tarl_critic_mlp_fwd": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64] + [_p] * 6 + [_p, _p, _p, _p]),
+    "tarl_critic_mlp_bwd": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64] + [_p] * 3 + [_p, _p, _p, _p] + [_p] * 6 + [_p]),
+    "tarl_gae": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _f32, _f32, _p, _p, _p]),
+    "tarl_advantage_stats": (C.c_int, [_p, _i64, _p, _p, _p]),
+    "tarl_advantage_normalize": (C.c_int, [_p, _i64, _p, _p]),
+    "tarl_ppo_loss": (C.c_int, [_p] * 6 + [_i64, _f32, _f32, _f32, _f32, _p, _p, _p, _p, _p]),
+    "tarl_adam_step": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _f64, _f64, _f64, _f64, _f32, _p]),
 }
 
 _lib = None

@@ -317,3 +317,106 @@ def policy_edge_logits_bwd(plan: Plan, node_features, grad_logits, num_embedding
     _lib.check(L.tarl_policy_edge_logits_bwd(plan.handle, col.data_ptr(), bs, ns, B, grad_logits.data_ptr(),
                                              grad_emb.data_ptr(), num_embeddings, _lib.current_stream()))
     return grad_emb
+
+
+# ---- critic -----------------------------------------------------------------------------------------------------------
+class CriticWeights:
+    """Flat views of the reference's ``final_mlp.{0,2,4}.{weight,bias}`` tensors (device, fp32, contiguous)."""
+
+    def __init__(self, w1, b1, w2, b2, w3, b3):
+        self.w1, self.b1, self.w2, self.b2, self.w3, self.b3 = (_contig(t, torch.float32, n) for t, n in
+                                                               ((w1, "w1"), (b1, "b1"), (w2, "w2"), (b2, "b2"),
+                                                                (w3, "w3"), (b3, "b3")))
+        if self.w1.size(0) != 64 or self.w2.shape != (64, 64) or self.w3.numel() != 64:
+            raise ValueError("critic must be (N+1)->64->64->1")
+        self.N = self.w1.size(1) - 1
+
+
+def critic_forward(cw: CriticWeights, counts, time_rows, rows_per_time=1, *, keep_hidden=False):
+    """counts (M, N) fp32 with contiguous last dim (row stride free); time_rows (ceil(M / rows_per_time),)."""
+    L = _lib.load()
+    _check_dev(counts, torch.float32, "counts")
+    if counts.dim() != 2 or counts.stride(1) != 1 or counts.size(1) != cw.N:
+        raise ValueError(f"counts must be (M, {cw.N}) with a contiguous last dim")
+    _contig(time_rows, torch.float32, "time_rows")
+    M = counts.size(0)
+    if time_rows.numel() * rows_per_time < M:
+        raise ValueError("time_rows too short")
+    value = torch.empty(M, dtype=torch.float32, device=counts.device)
+    h1 = torch.empty((M, 64), dtype=torch.float32, device=counts.device) if keep_hidden else None
+    h2 = torch.empty((M, 64), dtype=torch.float32, device=counts.device) if keep_hidden else None
+    _lib.check(L.tarl_critic_mlp_fwd(counts.data_ptr(), counts.stride(0), M, cw.N, time_rows.data_ptr(), rows_per_time,
+                                     cw.w1.data_ptr(), cw.b1.data_ptr(), cw.w2.data_ptr(), cw.b2.data_ptr(),
+                                     cw.w3.data_ptr(), cw.b3.data_ptr(), value.data_ptr(), _lib.ptr(h1), _lib.ptr(h2),
+                                     _lib.current_stream()))
+    return value, h1, h2
+
+
+def critic_backward(cw: CriticWeights, counts, time_rows, rows_per_time, h1, h2, grad_value, grads):
+    """Accumulates into ``grads`` = (gw1, gb1, gw2, gb2, gw3, gb3), tensors shaped like the weights."""
+    L = _lib.load()
+    M = counts.size(0)
+    _contig(grad_value, torch.float32, "grad_value")
+    scratch = torch.empty((2, M, 64), dtype=torch.float32, device=counts.device)
+    gw1, gb1, gw2, gb2, gw3, gb3 = (_contig(g, torch.float32, "grad") for g in grads)
+    _lib.check(L.tarl_critic_mlp_bwd(counts.data_ptr(), counts.stride(0), M, cw.N, time_rows.data_ptr(), rows_per_time,
+                                     cw.w1.data_ptr(), cw.w2.data_ptr(), cw.w3.data_ptr(), h1.data_ptr(), h2.data_ptr(),
+                                     grad_value.data_ptr(), scratch.data_ptr(), gw1.data_ptr(), gb1.data_ptr(),
+                                     gw2.data_ptr(), gb2.data_ptr(), gw3.data_ptr(), gb3.data_ptr(),
+                                     _lib.current_stream()))
+
+
+# ---- PPO --------------------------------------------------------------------------------------------------------------
+def gae(reward, value, next_value, *, done=None, terminated=None, gamma=0.99, lmbda=0.95):
+    """Time-major (T, B) fp32 tensors -> (advantage, value_target), un-normalised."""
+    L = _lib.load()
+    for n, t in (("reward", reward), ("value", value), ("next_value", next_value)):
+        _contig(t, torch.float32, n)
+    T, B = reward.shape
+    adv, tgt = torch.empty_like(reward), torch.empty_like(reward)
+    _lib.check(L.tarl_gae(reward.data_ptr(), value.data_ptr(), next_value.data_ptr(), _lib.ptr(done),
+                          _lib.ptr(terminated), T, B, float(gamma), float(lmbda), adv.data_ptr(), tgt.data_ptr(),
+                          _lib.current_stream()))
+    return adv, tgt
+
+
+def advantage_stats(adv):
+    L = _lib.load()
+    _contig(adv, torch.float32, "advantage")
+    partial = torch.empty(512, dtype=torch.float64, device=adv.device)
+    stats = torch.empty(3, dtype=torch.float64, device=adv.device)
+    _lib.check(L.tarl_advantage_stats(adv.data_ptr(), adv.numel(), partial.data_ptr(), stats.data_ptr(),
+                                      _lib.current_stream()))
+    return stats
+
+
+def advantage_normalize_(adv, stats):
+    L = _lib.load()
+    _lib.check(L.tarl_advantage_normalize(adv.data_ptr(), adv.numel(), stats.data_ptr(), _lib.current_stream()))
+    return adv
+
+
+def ppo_loss(lp_new, lp_old, adv, value, target, entropy, *, clip_epsilon=0.2, entropy_coef=0.01, critic_coef=1.0,
+             grad_scale=1.0, want_grads=True):
+    """-> (out6, g_lp, g_ent, g_val); out6 = loss_objective, loss_critic, loss_entropy, clip_fraction, kl_approx, ESS."""
+    L = _lib.load()
+    ts = [_contig(t.reshape(-1), torch.float32, "ppo input") for t in (lp_new, lp_old, adv, value, target, entropy)]
+    M = ts[0].numel()
+    if any(t.numel() != M for t in ts):
+        raise ValueError("ppo_loss inputs must have the same number of elements")
+    out = torch.empty(6, dtype=torch.float32, device=ts[0].device)
+    gs = [torch.empty(M, dtype=torch.float32, device=ts[0].device) if want_grads else None for _ in range(3)]
+    _lib.check(L.tarl_ppo_loss(*(t.data_ptr() for t in ts), M, float(clip_epsilon), float(entropy_coef),
+                               float(critic_coef), float(grad_scale), out.data_ptr(), *(_lib.ptr(g) for g in gs),
+                               _lib.current_stream()))
+    return out, gs[0], gs[1], gs[2]
+
+
+def adam_step_(param, grad, exp_avg, exp_avg_sq, step, *, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    L = _lib.load()
+    for n, t in (("param", param), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
+        _contig(t, torch.float32, n)
+    _lib.check(L.tarl_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                param.numel(), int(step), float(lr), float(beta1), float(beta2), float(eps),
+                                float(grad_scale), _lib.current_stream()))
+    return param
