@@ -188,6 +188,13 @@ int tarl_ppo_loss(const float* log_prob_new, const float* log_prob_old, const fl
 int tarl_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,
                    double lr, double beta1, double beta2, double eps, float grad_scale, tarl_stream stream);
 
+/* ---- measurement hook (bench.py roofline leg; nothing comparable in the reference) ------------------------------------
+ * tarl_prof_enable(n > 0) brackets the next n launches of the Direction message+aggregate kernel with HIP events on
+ * their launch stream; tarl_prof_enable(0) turns it off. tarl_prof_collect synchronises those events and returns the
+ * summed kernel time (ms) and the number of timed launches. */
+int tarl_prof_enable(int64_t max_launches);
+int tarl_prof_collect(double* total_ms_host, int64_t* launches_host);
+
 #ifdef __cplusplus
 }
 #endif

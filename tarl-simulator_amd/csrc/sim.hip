@@ -173,6 +173,50 @@ __global__ __launch_bounds__(SIM_BLOCK) void k_response_update(float* __restrict
   xi[L.col_n()] = xi[L.col_n()] - 1.0f;
 }
 
+// ---- live kernel timing (bench.py's roofline leg) -------------------------------------------------------------------
+// When enabled, every launch of the Direction gather kernel (the message-passing scatter kernel the roofline is quoted
+// on) is bracketed by a pair of HIP events on the launch stream. Events come from a pre-created pool (no allocation in
+// the launch path); tarl_prof_collect() synchronises them after the timed region and returns the summed duration.
+#include <vector>
+static bool g_prof_on = false;
+static std::vector<hipEvent_t> g_prof_events;  // pairs: start, stop
+static size_t g_prof_used = 0;
+
+extern "C" int tarl_prof_enable(int64_t max_launches) {
+  for (hipEvent_t e : g_prof_events) (void)hipEventDestroy(e);
+  g_prof_events.clear();
+  g_prof_used = 0;
+  g_prof_on = max_launches > 0;
+  for (int64_t i = 0; i < 2 * max_launches; ++i) {
+    hipEvent_t e;
+    TARL_CHECK_HIP(hipEventCreate(&e));
+    g_prof_events.push_back(e);
+  }
+  return TARL_OK;
+}
+
+extern "C" int tarl_prof_collect(double* total_ms, int64_t* launches) {
+  TARL_REQUIRE(total_ms && launches, "null argument");
+  double tot = 0.0;
+  for (size_t i = 0; i + 1 < g_prof_used; i += 2) {
+    TARL_CHECK_HIP(hipEventSynchronize(g_prof_events[i + 1]));
+    float ms = 0.0f;
+    TARL_CHECK_HIP(hipEventElapsedTime(&ms, g_prof_events[i], g_prof_events[i + 1]));
+    tot += ms;
+  }
+  *total_ms = tot;
+  *launches = (int64_t)(g_prof_used / 2);
+  g_prof_used = 0;
+  return TARL_OK;
+}
+
+static inline hipEvent_t prof_event(hipStream_t s) {
+  if (!g_prof_on || g_prof_used >= g_prof_events.size()) return nullptr;
+  hipEvent_t e = g_prof_events[g_prof_used++];
+  (void)hipEventRecord(e, s);
+  return e;
+}
+
 // ---- host side -----------------------------------------------------------------------------------------------------
 static int check_state(const tarl_plan* plan, const float* x, int64_t B, int64_t bstride, int64_t ldx, int32_t Nmax,
                        int64_t R) {
@@ -199,9 +243,11 @@ extern "C" int tarl_direction_step(const tarl_plan* plan, float* x, int64_t B, i
   const Layout L{Nmax, ldx, x_bstride};
   const unsigned grid = (unsigned)ceil_div(B * R, SIM_BLOCK);
   hipStream_t s = (hipStream_t)stream;
+  const bool timed = prof_event(s) != nullptr;
   hipLaunchKernelGGL(k_direction_gather, dim3(grid), dim3(SIM_BLOCK), 0, s, view(plan), x, L, B, R, edge_attr,
                      log_edge_attr, log_eps, time, gumbel, seed, counter, dtt, chosen);
   TARL_LAUNCH_CHECK();
+  if (timed) (void)prof_event(s);
   hipLaunchKernelGGL(k_direction_update, dim3(grid), dim3(SIM_BLOCK), 0, s, x, L, B, R, cong, time, chosen);
   TARL_LAUNCH_CHECK();
   return TARL_OK;

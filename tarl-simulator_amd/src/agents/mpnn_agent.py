@@ -1,0 +1,129 @@
+"""MPNNPolicyNet / MPNNValueNetSimple — the learned actor and critic (reference: src/agents/mpnn_agent.py).
+
+Same constructors, ``forward`` signatures and state-dict keys (``nodes_embedding.weight``, ``edge_mlp.{0,2,4}.*``,
+``edge_mlp_test.{0,2}.*``, ``final_mlp.{0,2,4}.*``). Live actor: logits[e] = W_emb[ROAD_INDEX(dst(e))]
+(``tarl_policy_edge_logits_fwd/bwd``); live critic: MLP(cat(NUMBER_OF_AGENT per node, time)) on fp32 MFMA
+(``tarl_critic_mlp_fwd/bwd``). What the reference computes and discards after the logits (Dijkstra prior, travel
+time, norm — :181-190) is not evaluated; the all-pairs Dijkstra matrix of its constructor is built lazily on request.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .._compat import MessagePassingBase, cached_plan, require_cuda
+from ..feature_helpers import ObservationFeatureHelpers
+from .base import Agents
+
+
+class _EdgeLogits(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emb_weight, node_features, plan):
+        from tarl_hip import ops
+        ctx.plan, ctx.nf, ctx.shape = plan, node_features, emb_weight.shape
+        return ops.policy_edge_logits(plan, node_features, emb_weight.detach().reshape(-1).contiguous())
+
+    @staticmethod
+    def backward(ctx, grad_logits):
+        from tarl_hip import ops
+        g = ops.policy_edge_logits_bwd(ctx.plan, ctx.nf, grad_logits.contiguous(), int(torch.Size(ctx.shape).numel()))
+        return g.view(ctx.shape), None, None
+
+
+class MPNNPolicyNet(MessagePassingBase, Agents):
+    h = ObservationFeatureHelpers()
+
+    def __init__(self, edge_index, num_nodes, free_flow_time_travel, device):
+        Agents.__init__(self, device=device)
+        MessagePassingBase.__init__(self, aggr="mean", flow="target_to_source")
+        self.edge_index = edge_index
+        self.num_nodes = num_nodes
+        self.num_edges = edge_index.size(1)
+        self.dim_node_features = 16
+        self.dim_edge_features = 1
+        self._free_flow = free_flow_time_travel
+        self._dist_matrix = None
+        self.nodes_embedding = nn.Embedding(num_nodes, 1)
+        self.edge_mlp_test = nn.Sequential(nn.Linear(2 * self.dim_node_features, 16), nn.ReLU(), nn.Linear(16, 1))
+        self.edge_mlp = nn.Sequential(nn.Linear(2 * self.dim_node_features + self.dim_edge_features, 64), nn.ReLU(),
+                                      nn.Linear(64, 32), nn.ReLU(), nn.Linear(32, 1))
+        for seq in (self.edge_mlp, self.edge_mlp_test):       # dormant heads: U(-0.1, 0.1) weights, zero bias
+            for m in seq:
+                if isinstance(m, nn.Linear):
+                    nn.init.uniform_(m.weight, -0.1, 0.1)
+                    nn.init.constant_(m.bias, 0)
+        self.to(device)
+
+    @property
+    def dist_matrix(self):
+        """All-pairs free-flow shortest-path matrix, built on first access (the reference builds it eagerly with
+        networkx in the constructor although the live forward never reads it)."""
+        if self._dist_matrix is None:
+            self.refresh_dijkstra(self.edge_index, self._free_flow)
+        return self._dist_matrix
+
+    def refresh_dijkstra(self, edge_index: torch.Tensor, free_flow_travel: torch.Tensor):
+        import scipy.sparse as sp
+        from scipy.sparse.csgraph import dijkstra
+        assert free_flow_travel.size(0) == edge_index.size(1) and edge_index.size(0) == 2
+        ei = edge_index.cpu().numpy()
+        g = sp.csr_matrix((free_flow_travel.detach().cpu().numpy().astype("float64"), (ei[0], ei[1])),
+                          shape=(self.num_nodes, self.num_nodes))
+        self._dist_matrix = torch.tensor(dijkstra(g, directed=True), dtype=torch.float32, device=self.device)
+
+    def forward(self, node_features: torch.Tensor, edge_features: torch.Tensor, agent_index: torch.Tensor):
+        """node_features (N,7) or (B,N,7) -> logits (E,) or (B,E)."""
+        require_cuda(node_features, "node_features")
+        plan = cached_plan(self.edge_index, self.num_nodes)
+        return _EdgeLogits.apply(self.nodes_embedding.weight, node_features, plan)
+
+    def update_edges(self, x, edge_index, edge_attr=None):
+        plan = cached_plan(edge_index, x.size(0))
+        return _EdgeLogits.apply(self.nodes_embedding.weight, x[:, :7], plan).view(-1, 1)
+
+
+class _CriticMLP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, counts, time_rows, w1, b1, w2, b2, w3, b3):
+        from tarl_hip import ops
+        cw = ops.CriticWeights(w1.detach().contiguous(), b1.detach().contiguous(), w2.detach().contiguous(),
+                               b2.detach().contiguous(), w3.detach().reshape(-1).contiguous(), b3.detach().contiguous())
+        value, h1, h2 = ops.critic_forward(cw, counts, time_rows, 1, keep_hidden=True)
+        ctx.cw, ctx.saved = cw, (counts, time_rows, h1, h2)
+        ctx.w3_shape = w3.shape
+        return value
+
+    @staticmethod
+    def backward(ctx, grad_value):
+        from tarl_hip import ops
+        counts, time_rows, h1, h2 = ctx.saved
+        cw = ctx.cw
+        grads = [torch.zeros_like(t) for t in (cw.w1, cw.b1, cw.w2, cw.b2, cw.w3, cw.b3)]
+        ops.critic_backward(cw, counts, time_rows, 1, h1, h2, grad_value.contiguous(), grads)
+        return None, None, grads[0], grads[1], grads[2], grads[3], grads[4].view(ctx.w3_shape), grads[5]
+
+
+class MPNNValueNetSimple(MessagePassingBase, Agents):
+    """Critic actually used by the runner: ``final_mlp`` = Linear(N+1,64)-ReLU-Linear(64,64)-ReLU-Linear(64,1)."""
+
+    def __init__(self, edge_index, num_nodes, device):
+        Agents.__init__(self, device=device)
+        MessagePassingBase.__init__(self, aggr="mean", flow="target_to_source")
+        self.edge_index = edge_index
+        self.num_nodes = num_nodes
+        self.num_edges = edge_index.size(1)
+        self.dim_nodes_features = 16
+        self.dim_edges_features = 1
+        self.final_mlp = nn.Sequential(nn.Linear(num_nodes + 1, 64), nn.ReLU(), nn.Linear(64, 64), nn.ReLU(),
+                                       nn.Linear(64, 1))
+        self.to(device)
+
+    def forward(self, node_features, edge_features, agent_index, time):
+        """node_features (...,N,7), time (...,1) -> (...,1)."""
+        require_cuda(node_features, "node_features")
+        lead = node_features.shape[:-2]
+        counts = node_features[..., 1].reshape(-1, self.num_nodes).contiguous()
+        time_rows = time.reshape(-1).to(torch.float32).contiguous()
+        l0, l2, l4 = self.final_mlp[0], self.final_mlp[2], self.final_mlp[4]
+        v = _CriticMLP.apply(counts, time_rows, l0.weight, l0.bias, l2.weight, l2.bias, l4.weight, l4.bias)
+        return v.view(*lead, 1)

@@ -1,0 +1,107 @@
+"""TransportationSimulator — the graph container the env and the runner talk to (reference:
+src/transportation_simulator.py). In scope here: the graph layout contract (``graph.x``, ``edge_index``,
+``edge_index_routes``, ``edge_attr*``, ``num_roads``, ``congestion_constant``), ``load_network`` for synthetic
+scenarios and for the reference's ``save/<scenario>/network.pt`` cache, ``config_parameters / configure_core /
+set_time / reset / state / run``. MATSim XML ingestion, plots and CSV metrics are out of scope.
+"""
+from __future__ import annotations
+
+import os
+import time
+
+import torch
+
+from ._compat import Data
+from .agents.base import Agents
+from .feature_helpers import FeatureHelpers
+from .simulation_core_model import SimulationCoreModel
+
+
+class TransportationSimulator:
+    def __init__(self, device: str, torch_compile: bool = False):
+        self.model_core = None
+        self.agent = Agents(device)
+        self.device = device
+        self.torch_compile = torch_compile
+        self.graph = None
+        self.time = 0
+        self.inserting_time = self.core_time = self.withdraw_time = self.choice_time = 0
+        self.timestep = 1
+        self.leg_histogram_values = []
+        self.road_optimality_values = []
+        self.on_way_before = 0
+        self.done_before = 0
+
+    # -- network ------------------------------------------------------------------------------------------------------
+    def load_network(self, scenario: str) -> None:
+        from tarl_hip import synth
+        spec = synth.parse_scenario(scenario)
+        if spec is not None:
+            W, H = synth.torus_for_edges(spec["edges"])
+            net = synth.torus_network(W, H)
+            self.graph = Data(x=net.x, edge_index=net.edge_index, edge_attr=net.edge_attr,
+                              edge_index_routes=net.edge_index, edge_attr_routes=net.edge_attr,
+                              num_roads=net.num_roads, critical_number=net.critical_number,
+                              congestion_constant=net.congestion_constant)
+            self.Nmax = net.Nmax
+        else:
+            path = os.path.join("save", scenario, "network.pt")
+            d = torch.load(path, weights_only=False)
+            self.graph, self.Nmax = d["graph"], d["Nmax"]
+        for k in list(vars(self.graph)) if hasattr(self.graph, "__dict__") else []:
+            v = getattr(self.graph, k)
+            if torch.is_tensor(v) and k != "adj_matrix":      # the dense N x N adjacency is never needed here
+                setattr(self.graph, k, v.to(self.device))
+        self.h = FeatureHelpers(Nmax=self.Nmax)
+
+    def save_network(self, file_path: str) -> None:
+        os.makedirs(os.path.dirname(file_path), exist_ok=True)
+        torch.save({"graph": self.graph, "Nmax": self.Nmax}, file_path)
+
+    def configure_core(self):
+        self.model_core = SimulationCoreModel(self.Nmax, self.device, self.time, torch_compile=self.torch_compile)
+
+    def config_parameters(self, timestep_size: float = 1, start_time: int = 0):
+        self.timestep = timestep_size
+        self.time = start_time
+        self.configure_core()
+
+    def set_time(self, time):
+        self.time = time
+        self.agent.set_time(time)
+        self.model_core.set_time(time)
+
+    # -- classical step (insert -> withdraw -> choice -> core), as ``run()`` of the reference ------------------------------
+    def run(self):
+        h = self.h
+        b = time.time()
+        self.graph.x = self.agent.insert_agent_into_network(self.graph, h)
+        e = time.time(); self.inserting_time += e - b; b = e
+        self.graph.x = self.agent.withdraw_agent_from_network(self.graph, h)
+        e = time.time(); self.withdraw_time += e - b; b = e
+        self.graph = self.agent.choice(self.graph, h)
+        e = time.time(); self.choice_time += e - b; b = e
+        self.graph = self.model_core(self.graph)
+        self.core_time += time.time() - b
+        self.set_time(self.time + self.timestep)
+        self._log_step()
+
+    def _log_step(self):
+        """Per-step records kept on the device (the reference syncs and copies to the host every step)."""
+        on_way = torch.sum(self.agent.agent_features[:, self.agent.ON_WAY])
+        done = torch.sum(self.agent.agent_features[:, self.agent.DONE])
+        self.leg_histogram_values.append([on_way - self.on_way_before + done - self.done_before,
+                                          done - self.done_before, on_way, self.time])
+        self.on_way_before, self.done_before = on_way, done
+        self.road_optimality_values.append(
+            (self.time, self.model_core.direction_mpnn.road_optimality_data["delta_travel_time"]))
+
+    def reset(self):
+        from tarl_hip import ops
+        ops.reset_state(self.graph.x, self.Nmax)
+
+    def state(self):
+        h = self.h
+        x = self.graph.x[:, h.MAX_NUMBER_OF_AGENT:]
+        agent_index = self.graph.x[:, h.HEAD_FIFO].to(torch.int64)
+        return x, self.graph.edge_attr, self.graph.edge_index, agent_index

@@ -1,0 +1,60 @@
+"""Data-parallel helpers over torch.distributed (backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+The hot path shards by *rollouts*: every rank owns its own environments and minibatch; the only exchange per optimiser
+step is ONE all-reduce of the flat fp32 gradient buffer, plus a 3-double all-reduce of the advantage statistics so that
+``average_gae`` normalises with the global mean / std. Parameters stay replicated (identical Adam on
+every rank)."""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def init_from_env(backend=None):
+    """Initialise from RANK / WORLD_SIZE / MASTER_* (torchrun). Returns (rank, world_size, local_rank)."""
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if ws > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=ws)
+    return rank, ws, local
+
+
+def allreduce_sum_(t: torch.Tensor):
+    """In-place sum over ranks (no-op for a single process)."""
+    if world()[1] > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def allreduce_max_float(v: float, device) -> float:
+    if world()[1] == 1:
+        return v
+    t = torch.tensor([v], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def broadcast_(t: torch.Tensor, src=0):
+    if world()[1] > 1:
+        dist.broadcast(t, src=src)
+    return t
+
+
+def barrier():
+    if world()[1] > 1:
+        dist.barrier()

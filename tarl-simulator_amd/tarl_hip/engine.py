@@ -1,0 +1,88 @@
+"""SimEngine — B independent environments of the traffic simulator over ONE static road graph, all state resident on one
+GPU, stepped by the HIP kernels with no host synchronisation.
+
+One step == ``SimulatorEnv._step`` of the reference (src/reinforcement_learning.py:222-309): apply the routing action,
+DirectionMPNN + ResponseMPNN, withdraw, insert, reward, advance the clock. The reference has a single environment
+(``batch_size=[]``); the batch dimension is this build's way of giving the message-passing kernels enough edges per
+launch — every environment follows exactly the reference's semantics.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+EPISODE_START = 6 * 3600 - 60   # SimulatorEnv._reset: set_time(3600 * 6 - 60)
+EPISODE_END = 7 * 3600          # done = time > 7 * 3600
+
+
+class SimEngine:
+    def __init__(self, x, edge_index, edge_attr, Nmax, agent_features, *, congestion_constant=None, num_envs=None,
+                 device="cuda", timestep=1, seed=0, plan=None):
+        """``x`` (N,F) or (B,N,F); ``agent_features`` (A,9) or (B,A,9). 2-D inputs are replicated ``num_envs`` times;
+        3-D inputs are used in place (views are kept, so a caller-owned tensor keeps tracking the state)."""
+        dev = torch.device(device)
+        self.Nmax = int(Nmax)
+
+        def batched(t, B):
+            if t.dim() == 3:                        # caller-owned batch: used in place
+                return t if t.is_cuda else t.to(dev, torch.float32)
+            if B == 1 and t.is_cuda:                # single environment: a view, the caller's tensor tracks the state
+                return t.unsqueeze(0)
+            return t.to(dev, torch.float32).unsqueeze(0).repeat(B, 1, 1).contiguous()
+
+        B = x.size(0) if x.dim() == 3 else int(num_envs or 1)
+        self.x = batched(x, B)
+        self.B, self.N, self.F = self.x.shape
+        self.agents = batched(agent_features, self.B)
+        self.A = self.agents.size(1)
+        self.device = self.x.device
+        self.edge_index = edge_index.to("cpu", torch.int64)
+        self.E = self.edge_index.size(1)
+        self.plan = plan if plan is not None else ops.Plan(self.edge_index, self.N)
+        self.ec = ops.EdgeConst(edge_attr, self.device)
+        self.cc = None if congestion_constant is None else congestion_constant.to(self.device, torch.float32).contiguous()
+        self.timestep = int(timestep)
+        self.time = EPISODE_START
+        self.seed = int(seed)
+        self.noise_counter = 0
+        # per-step scratch (allocated once; the library never allocates)
+        self.chosen = torch.empty((self.B, self.N), dtype=torch.float32, device=self.device)
+        self.popped = torch.empty((self.B, self.N), dtype=torch.uint8, device=self.device)
+        self.ins_scratch = torch.empty((self.B, 2 * self.A), dtype=torch.int32, device=self.device)
+        self.reward = torch.zeros(self.B, dtype=torch.float32, device=self.device)
+        self.counts = torch.zeros((self.B, self.N), dtype=torch.float32, device=self.device)
+        self.dtt = None
+
+    # -- observation -------------------------------------------------------------------------------------------------
+    @property
+    def node_features(self):
+        """(B, N, 7) view: the observation columns x[:, 3*Nmax:] (TransportationSimulator.state)."""
+        return self.x[:, :, 3 * self.Nmax:]
+
+    def refresh_counts(self):
+        self.counts.copy_(self.x[:, :, 3 * self.Nmax + 1])
+        return self.counts
+
+    # -- control -----------------------------------------------------------------------------------------------------
+    def reset(self):
+        """SimulatorEnv._reset: zero FIFOs / counters, clear ON_WAY / DONE, clock = 6 h - 60 s."""
+        ops.reset_state(self.x, self.Nmax, self.agents)
+        self.time = EPISODE_START
+        self.counts.zero_()
+        self.reward.zero_()
+
+    def step(self, *, choice=None, action_onehot=None, gumbel=None, want_dtt=False):
+        """One env step for all B environments. Noise: explicit ``gumbel`` (B,E) or device Philox keyed by
+        (seed, noise_counter). Returns (reward (B,), done: bool). ``self.counts`` holds the new per-node counts."""
+        t = float(self.time)
+        ops.apply_action(self.plan, self.x, self.Nmax, action_onehot=action_onehot, choice=choice)
+        self.noise_counter += 1
+        self.dtt, _ = ops.core_step(self.plan, self.x, self.Nmax, self.ec, t, congestion_constant=self.cc, gumbel=gumbel,
+                                    seed=self.seed, counter=self.noise_counter, want_dtt=want_dtt, chosen=self.chosen,
+                                    popped=self.popped)
+        ops.withdraw_step(self.plan, self.x, self.Nmax, self.agents, t, want_mask=False)
+        ops.insert_step(self.x, self.Nmax, self.agents, t, congestion_constant=self.cc, scratch=self.ins_scratch,
+                        reward=self.reward, counts=self.counts)
+        self.time += self.timestep           # the reference's equality test compares a view with itself
+        return self.reward, self.time > EPISODE_END

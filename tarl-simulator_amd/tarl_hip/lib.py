@@ -48,6 +48,8 @@ SIGNATURES = {
     "tarl_advantage_normalize": (C.c_int, [_p, _i64, _p, _p]),
     "tarl_ppo_loss": (C.c_int, [_p] * 6 + [_i64, _f32, _f32, _f32, _f32, _p, _p, _p, _p, _p]),
     "tarl_adam_step": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _f64, _f64, _f64, _f64, _f32, _p]),
+    "tarl_prof_enable": (C.c_int, [_i64]),
+    "tarl_prof_collect": (C.c_int, [C.POINTER(_f64), C.POINTER(_i64)]),
 }
 
 _lib = None

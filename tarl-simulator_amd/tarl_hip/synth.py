@@ -141,3 +141,11 @@ def torus_for_edges(num_edges: int) -> tuple[int, int]:
     while v % w:
         w -= 1
     return w, v // w
+
+
+def parse_scenario(name: str):
+    """``synthetic-<edges>-<agents>[-<seed>]`` -> dict, anything else -> None."""
+    parts = str(name).split("-")
+    if len(parts) < 3 or parts[0] != "synthetic":
+        return None
+    return {"edges": int(parts[1]), "agents": int(parts[2]), "seed": int(parts[3]) if len(parts) > 3 else 0}

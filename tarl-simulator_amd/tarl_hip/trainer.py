@@ -1,0 +1,150 @@
+"""VecPPOTrainer — the reference's ``ppo_train`` loop (src/rl/ppo_trainer.py:21-39,129-145) on B vectorised
+environments per GPU, every arithmetic step a HIP kernel behind the C ABI:
+
+  HOT LOOP A (T frames): policy logits -> GraphDistribution softmax / sample / log_prob -> env step
+  HOT LOOP B (num_epochs): critic over all frames (MFMA) -> GAE -> advantage normalisation (global statistics) ->
+                           minibatch of ``sub_batch_size`` frames -> clipped PPO loss fwd+bwd -> one gradient
+                           all-reduce (RCCL) -> fused Adam.
+
+Semantics kept from the reference: ONE collector batch per call (``total_frames == frames_per_batch``), the
+environment is reset at the start of the batch (``reset_at_each_iter=True``), GAE is recomputed every epoch with the
+current critic, one minibatch + one Adam step per epoch, loss = objective + critic + entropy, no gradient clipping.
+Multi-GPU: one process per GPU, each with its own environments and minibatch; gradients are averaged.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import dist_utils, ops
+from .flatparams import FlatParams
+
+
+class VecPPOTrainer:
+    def __init__(self, engine, emb_param, critic_params, *, rollout_steps, num_epochs=1, sub_batch_size=32, lr=1e-3,
+                 gamma=0.99, lmbda=0.95, clip_epsilon=0.2, entropy_coef=0.01, critic_coef=1.0, temperature=1.0,
+                 extra_params=(), seed=0):
+        """``emb_param``: nn.Parameter (num_nodes, 1) — MPNNPolicyNet.nodes_embedding.weight;
+        ``critic_params``: [w1 (64,N+1), b1, w2 (64,64), b2, w3 (1,64), b3] — MPNNValueNetSimple.final_mlp.{0,2,4};
+        ``extra_params``: further actor/critic parameters that never receive gradient on the live path (the dormant
+        edge MLPs) — they sit in the flat buffer so that the optimiser covers ``loss_module.parameters()`` like the
+        reference's does."""
+        self.eng = engine
+        self.T = int(rollout_steps)
+        self.num_epochs = int(num_epochs)
+        self.M = int(sub_batch_size)
+        self.lr, self.gamma, self.lmbda = lr, gamma, lmbda
+        self.clip_epsilon, self.entropy_coef, self.critic_coef, self.temperature = clip_epsilon, entropy_coef, critic_coef, temperature
+        self.rank, self.world = dist_utils.world()
+        self.emb_param = emb_param
+        self.critic_params = list(critic_params)
+        self.flat = FlatParams([emb_param] + self.critic_params + list(extra_params), device=engine.device)
+        # replicas start identical: rank 0's initial weights win
+        dist_utils.broadcast_(self.flat.flat, src=0)
+        B, N, dev = engine.B, engine.N, engine.device
+        self.counts = torch.zeros((self.T + 1, B, N), dtype=torch.float32, device=dev)
+        self.choice = torch.zeros((self.T, B, N), dtype=torch.int32, device=dev)
+        self.logp = torch.zeros((self.T, B), dtype=torch.float32, device=dev)
+        self.reward = torch.zeros((self.T, B), dtype=torch.float32, device=dev)
+        self.times = torch.zeros(self.T + 1, dtype=torch.float32, device=dev)
+        self.values = torch.zeros((self.T + 1, B), dtype=torch.float32, device=dev)
+        self.gen = torch.Generator(device=dev)
+        self.gen.manual_seed(int(seed) + 7919 * self.rank)
+        self.seed = int(seed) + self.rank
+        self.sample_counter = 0
+        self.last = {}
+
+    # -- views of the live parameters -----------------------------------------------------------------------------------
+    def _emb(self):
+        return self.emb_param.data.reshape(-1)
+
+    def _critic(self):
+        w1, b1, w2, b2, w3, b3 = (p.data for p in self.critic_params)
+        return ops.CriticWeights(w1, b1, w2, b2, w3.reshape(-1), b3)
+
+    # -- HOT LOOP A -------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def collect(self):
+        """T frames for all B environments (SyncDataCollector with reset_at_each_iter=True, ExplorationType.RANDOM)."""
+        eng = self.eng
+        eng.reset()
+        emb = self._emb()
+        host_times = []
+        for t in range(self.T):
+            self.counts[t].copy_(eng.counts)
+            host_times.append(float(eng.time))
+            logits = ops.policy_edge_logits(eng.plan, eng.node_features, emb)
+            proba = ops.graphdist_softmax(eng.plan, logits, self.temperature)
+            self.sample_counter += 1
+            _, choice = ops.graphdist_sample(eng.plan, proba, seed=self.seed ^ 0x5DEECE66D, counter=self.sample_counter,
+                                             want_onehot=False, want_choice=True)
+            lp, _ = ops.graphdist_logprob_entropy(eng.plan, proba, choice=choice, want_entropy=False)
+            self.choice[t].copy_(choice)
+            self.logp[t].copy_(lp)
+            reward, _done = eng.step(choice=choice)
+            self.reward[t].copy_(reward)
+        self.counts[self.T].copy_(eng.counts)
+        host_times.append(float(eng.time))
+        self.times.copy_(torch.tensor(host_times, dtype=torch.float32))
+        return self.T * eng.B
+
+    # -- HOT LOOP B -------------------------------------------------------------------------------------------------------
+    def advantages(self):
+        """GAE(gamma, lmbda, average_gae=True) with the current critic over all (T+1)*B observations."""
+        eng = self.eng
+        T, B, N = self.T, eng.B, eng.N
+        cw = self._critic()
+        v, _, _ = ops.critic_forward(cw, self.counts.view((T + 1) * B, N), self.times, rows_per_time=B)
+        self.values = v.view(T + 1, B)
+        adv, target = ops.gae(self.reward, self.values[:T], self.values[1:], gamma=self.gamma, lmbda=self.lmbda)
+        stats = ops.advantage_stats(adv)
+        dist_utils.allreduce_sum_(stats)          # global mean / std over all ranks' frames
+        ops.advantage_normalize_(adv, stats)
+        return adv, target
+
+    def minibatch_step(self, adv, target):
+        eng = self.eng
+        T, B, N, E = self.T, eng.B, eng.N, eng.E
+        M = min(self.M, T * B)
+        idx = torch.randperm(T * B, generator=self.gen, device=eng.device)[:M]
+        counts_mb = self.counts[:T].view(T * B, N).index_select(0, idx)
+        choice_mb = self.choice.view(T * B, N).index_select(0, idx)
+        lp_old = self.logp.view(-1).index_select(0, idx)
+        adv_mb = adv.view(-1).index_select(0, idx)
+        tgt_mb = target.view(-1).index_select(0, idx)
+        time_mb = self.times[:T].index_select(0, torch.div(idx, B, rounding_mode="floor"))
+        # actor forward (the live policy reads only the static ROAD_INDEX column: broadcast one observation over M rows)
+        nf = eng.node_features[:1].expand(M, N, 7)
+        logits = ops.policy_edge_logits(eng.plan, nf, self._emb())
+        proba = ops.graphdist_softmax(eng.plan, logits, self.temperature)
+        lp_new, ent = ops.graphdist_logprob_entropy(eng.plan, proba, choice=choice_mb)
+        cw = self._critic()
+        value, h1, h2 = ops.critic_forward(cw, counts_mb, time_mb, 1, keep_hidden=True)
+        scale = 1.0 / self.world
+        out, g_lp, g_ent, g_val = ops.ppo_loss(lp_new, lp_old, adv_mb, value, tgt_mb, ent,
+                                               clip_epsilon=self.clip_epsilon, entropy_coef=self.entropy_coef,
+                                               critic_coef=self.critic_coef, grad_scale=scale)
+        # backward
+        self.flat.zero_grad()
+        g_logits = ops.graphdist_logprob_entropy_bwd(eng.plan, proba, self.temperature, choice=choice_mb,
+                                                     grad_log_prob=g_lp, grad_entropy=g_ent, log_prob_fwd=lp_new)
+        g_emb = ops.policy_edge_logits_bwd(eng.plan, nf, g_logits, self.emb_param.numel())
+        self.flat.grad_view(self.emb_param).add_(g_emb.view_as(self.emb_param))
+        gw = [self.flat.grad_view(p) for p in self.critic_params]
+        ops.critic_backward(cw, counts_mb, time_mb, 1, h1, h2, g_val,
+                            (gw[0], gw[1], gw[2], gw[3], gw[4].view(-1), gw[5]))
+        self.flat.allreduce_grads()               # ONE all-reduce of the fused gradient buffer (RCCL over xGMI)
+        self.flat.adam_step(lr=self.lr)
+        return out
+
+    def update(self):
+        out = None
+        for _ in range(self.num_epochs):
+            adv, target = self.advantages()
+            out = self.minibatch_step(adv, target)
+        self.last = {"losses": out}
+        return out
+
+    def train_iteration(self):
+        frames = self.collect()
+        self.update()
+        return frames

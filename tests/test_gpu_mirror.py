@@ -1,0 +1,239 @@
+"""GPU: the drop-in mirror classes (same names / signatures as the reference's) reproduce the reference's own outputs
+(golden vectors) when driven exactly the way the reference's tests and runner drive them."""
+import math
+
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+
+
+def dev(t):
+    return t.cuda()
+
+
+def test_direction_response_modules_golden():
+    from src.direction_mpnn import DirectionMPNN
+    from src.response_mpnn import ResponseMPNN
+    g = load_golden("core_het")
+    Nmax = g["Nmax"]
+    d, r = DirectionMPNN(Nmax=Nmax), ResponseMPNN(Nmax=Nmax)
+    x, ei, ea, cc = dev(g["x0"].clone()), dev(g["edge_index"]), dev(g["edge_attr"]), dev(g["congestion_constant"])
+    n_pop_steps = 0
+    for s in range(g["steps"]):
+        d.set_time(g[f"t{s}"]); r.set_time(g[f"t{s}"])
+        d.inject_uniform(g[f"u{s}"])
+        out = d(x, ei, ea, critical_number=None, congestion_constant=cc)
+        assert out is x and out.shape == g["x0"].shape                 # in place, shape preserved
+        assert torch.equal(x.cpu(), g[f"xd{s}"])
+        assert torch.equal(d.road_optimality_data["delta_travel_time"].cpu(), g[f"dtt{s}"])
+        out2 = r(x, ei, ea)
+        assert out2 is x and torch.equal(x.cpu(), g[f"xr{s}"])
+        n_pop_steps += int(g[f"pop{s}"].any())
+    hist = r.update_history                                           # only steps with >= 1 pop are recorded
+    assert len(hist) == n_pop_steps
+    k = 0
+    for s in range(g["steps"]):
+        if g[f"pop{s}"].any():
+            assert hist[k][0] == g[f"t{s}"] and torch.equal(hist[k][1].cpu(), g[f"pop{s}"])
+            k += 1
+
+
+def test_core_model_braess_like_reference_test():
+    """tests/simulation_core_model_test.py + response_mpnn_test.py of the reference on its Braess fixture."""
+    from src._compat import Data
+    from src.simulation_core_model import SimulationCoreModel
+    g = load_golden("braess")
+    ei, ea = dev(g["edge_index"]), dev(g["edge_attr"])
+    graph = Data(x=dev(g["x0"].clone()), edge_index=ei, edge_attr=ea, edge_index_routes=ei, edge_attr_routes=ea,
+                 num_roads=3)
+    core = SimulationCoreModel(Nmax=100, device="cuda", time=0)
+    assert isinstance(core, torch.nn.Module)
+    core.direction_mpnn.inject_uniform(g["u0"])
+    out = core(graph)
+    assert torch.is_tensor(out.x) and out.x.shape == g["x0"].shape
+    assert torch.equal(out.x.cpu(), g["x1"]) and len(core.response_mpnn.update_history) == 0
+
+
+def test_agents_like_reference_test():
+    """tests/agents_test.py of the reference (insert / withdraw / capacity limit) through the mirror's Agents."""
+    from src._compat import Data
+    from src.agents.base import Agents
+    from src.feature_helpers import FeatureHelpers
+    g = load_golden("agents_tiny")
+    h = FeatureHelpers(Nmax=5)
+    ei = torch.tensor([[1, 0], [0, 0]]).cuda()
+
+    def graph():
+        return Data(x=dev(g["x0"].clone()), edge_index=ei, edge_index_routes=torch.empty((2, 0), dtype=torch.long),
+                    edge_attr_routes=torch.empty((0, 1)), num_roads=1)
+    ag = Agents("cuda")
+    ag.agent_features = dev(g["agents0"].clone())
+    assert len(ag) == 9
+    gr = graph()
+    ag.time = 0
+    gr.x = ag.insert_agent_into_network(gr, h)
+    assert gr.x[0, h.NUMBER_OF_AGENT] == 2 and torch.all(ag.agent_features[:2, ag.ON_WAY] == 1)
+    gr.x = ag.withdraw_agent_from_network(gr, h)
+    assert gr.x[0, h.NUMBER_OF_AGENT] == 2
+    ag.time = 10
+    gr.x = ag.withdraw_agent_from_network(gr, h)
+    assert gr.x[0, h.NUMBER_OF_AGENT] == 0 and torch.all(ag.agent_features[:2, ag.DONE] == 1)
+    assert torch.equal(gr.x.cpu(), g["x_w10"]) and torch.equal(ag.agent_features.cpu(), g["agents_w10"])
+    assert len(ag.withdraw_history) == 2 and bool(ag.withdraw_history[1][1][0])
+    ag2 = Agents("cuda")
+    ag2.agent_features = dev(g["cap_agents0"].clone())
+    g2 = graph()
+    ag2.time = 0
+    g2.x = ag2.insert_agent_into_network(g2, h)
+    assert g2.x[0, h.NUMBER_OF_AGENT] == 2
+    assert torch.all(ag2.agent_features[:2, ag2.ON_WAY] == 1) and torch.all(ag2.agent_features[2:, ag2.ON_WAY] == 0)
+
+
+@pytest.mark.parametrize("name", ["dist_small", "dist_mid"])
+def test_graph_distribution_golden(name):
+    from src.reinforcement_learning import GraphDistribution
+    g = load_golden(name)
+    ei = dev(g["edge_index"])
+    d = GraphDistribution(dev(g["logits"]), ei)
+    assert isinstance(d, torch.distributions.Distribution) and d.nb_nodes == g["nb_nodes"]
+    assert torch.allclose(d.proba.cpu(), g["proba"], atol=1e-6, rtol=1e-5)
+    assert torch.equal(d.mode.cpu(), g["mode"]) and torch.equal(d.deterministic_sample.cpu(), g["mode"])
+    for k in range(4):
+        d.inject_uniform(g[f"u{k}"])
+        a = d.sample()
+        assert a.dtype == torch.int64 and torch.equal(a.cpu(), g[f"a{k}"])
+        assert abs(d.log_prob(a).item() - float(g[f"lp{k}"])) < 1e-4
+    assert abs(d.entropy().item() - float(g["entropy"])) < 1e-4
+    assert d.log_prob(dev(g["bad"])).item() == -math.inf
+    lb = dev(g["logits_b"]).requires_grad_(True)
+    db = GraphDistribution(lb, ei)
+    lp, ent = db.log_prob(dev(g["acts_b"])), db.entropy()
+    assert torch.allclose(lp.cpu(), g["lp_b"], atol=1e-4) and torch.allclose(ent.cpu(), g["ent_b"], atol=1e-4)
+    (lp * dev(g["w_b"])).sum().backward()
+    assert torch.allclose(lb.grad.cpu(), g["grad_lp_b"], atol=1e-4)
+    lb.grad = None
+    (GraphDistribution(lb, ei).entropy() * dev(g["w_b"])).sum().backward()
+    assert torch.allclose(lb.grad.cpu(), g["grad_ent_b"], atol=1e-4)
+
+
+def test_policy_and_value_nets_golden():
+    from src.agents.mpnn_agent import MPNNPolicyNet, MPNNValueNetSimple
+    g = load_golden("nets")
+    ei = dev(g["edge_index"])
+    N = g["node_features"].size(0)
+    pol = MPNNPolicyNet(ei, N, torch.ones(ei.size(1)), device="cuda")
+    val = MPNNValueNetSimple(ei, N, device="cuda")
+    pol.load_state_dict({k: g["pol__" + k.replace(".", "__")] for k in pol.state_dict()})
+    val.load_state_dict({k: g["val__" + k.replace(".", "__")] for k in val.state_dict()})
+    nf, nfb = dev(g["node_features"]), dev(g["node_features_b"])
+    ea, ai = dev(g["edge_attr"]), dev(g["agent_index"])
+    logits = pol(nf, ea, ai)
+    assert logits.shape == (ei.size(1),) and torch.equal(logits.detach().cpu(), g["logits"])
+    lb = pol(nfb, ea.expand(2, -1, -1), ai.expand(2, -1))
+    assert torch.equal(lb.detach().cpu(), g["logits_b"])
+    v = val(nf, ea, ai, dev(g["time"]))
+    assert v.shape == (1,) and abs(v.item() - g["value"].item()) <= 1e-4 * max(1, abs(g["value"].item()))
+    vb = val(nfb, ea.expand(2, -1, -1), ai.expand(2, -1), dev(g["time_b"]))
+    assert vb.shape == (2, 1) and torch.allclose(vb.detach().cpu(), g["value_b"], rtol=1e-4, atol=1e-4)
+    # autograd flows into the module parameters through the HIP backward kernels
+    (lb.sum() + vb.sum()).backward()
+    assert pol.nodes_embedding.weight.grad.abs().sum() > 0 and val.final_mlp[0].weight.grad.abs().sum() > 0
+    assert pol.edge_mlp[0].weight.grad is None
+
+
+def _make_env(g, monkeypatch):
+    """SimulatorEnv on the golden fixture's synthetic network: the scenario loader is replaced exactly like the
+    reference's tests/rl_metrics_test.py:10-13 does."""
+    from src._compat import Data
+    from src.feature_helpers import FeatureHelpers
+    from src.reinforcement_learning import SimulatorEnv
+    from src.transportation_simulator import TransportationSimulator
+
+    def fake_load(self, scenario):
+        ei, ea = dev(g["edge_index"]), dev(g["edge_attr"])
+        self.graph = Data(x=dev(g["x_init"].clone()), edge_index=ei, edge_attr=ea, edge_index_routes=ei,
+                          edge_attr_routes=ea, num_roads=g["x_init"].size(0),
+                          congestion_constant=dev(g["congestion_constant"]))
+        self.Nmax = g["Nmax"]
+        self.h = FeatureHelpers(Nmax=self.Nmax)
+    monkeypatch.setattr(TransportationSimulator, "load_network", fake_load)
+    return SimulatorEnv(device="cuda", timestep_size=1, start_time=0, scenario="golden")
+
+
+def test_simulator_env_rollout_golden(monkeypatch):
+    """SimulatorEnv._reset / _step + GraphDistribution driven like the reference's collector, 90 frames."""
+    from src._compat import TensorDict
+    from src.agents.base import Agents
+    from src.reinforcement_learning import GraphDistribution
+    g = load_golden("env_hom")
+    env = _make_env(g, monkeypatch)
+    ag = Agents("cuda")
+    ag.agent_features = dev(g["agents0"].clone())
+    env.simulator.agent = ag
+    td = env._reset()
+    assert set(td.keys()) >= {"node_features", "edge_features", "agent_index", "time", "done", "terminated"}
+    assert td["node_features"].shape == (env.num_node, 7) and td["agent_index"].dtype == torch.int64
+    assert torch.equal(td["node_features"].cpu(), g["obs0_node"]) and env.simulator.time == g["time0"]
+    ei = env.simulator.graph.edge_index
+    emb = dev(g["w_emb"])
+    for s in range(g["T"]):
+        logits = emb[td["node_features"][:, 6].long()][ei[1]]          # the live policy expression
+        d = GraphDistribution(logits, ei)
+        d.inject_uniform(g["u_sample"][s])
+        a = d.sample()
+        assert torch.equal(a.cpu(), g["action"][s])
+        env.simulator.model_core.direction_mpnn.inject_uniform(g["u_dir"][s])
+        td = env._step(TensorDict({"action": a}, batch_size=[]))
+        assert torch.equal(env.simulator.graph.x.cpu(), g["x"][s]), f"state differs at step {s}"
+        assert torch.equal(ag.agent_features.cpu(), g["agents"][s])
+        assert torch.equal(td["reward"].cpu(), g["reward"][s]) and env.simulator.time == int(g["time"][s])
+    assert len(env.simulator.model_core.response_mpnn.update_history) == g["n_pop_events"]
+    assert len(env.simulator.leg_histogram_values) == g["T"] and len(env.simulator.road_optimality_values) == g["T"]
+    assert float(ag.agent_features[:, ag.DONE].sum()) == g["done_total"]
+
+
+def test_ppo_train_and_runner_end_to_end(tmp_path, monkeypatch, capsys):
+    """main.py --algo mpnn+ppo --mode train on a synthetic scenario (BASELINE config 3 shape, shortened): weights move,
+    the checkpoint has the reference's keys, eval runs; then --algo mpnn --mode eval --steps."""
+    import importlib
+    import sys
+    from conftest import PKG
+    sys.path.insert(0, PKG)
+    monkeypatch.chdir(tmp_path)
+    main = importlib.import_module("main").main
+    from src.runner import Runner
+    created = []
+    orig_setup = Runner.setup
+
+    def spy_setup(self):
+        orig_setup(self)
+        created.append(self)
+    monkeypatch.setattr(Runner, "setup", spy_setup)
+    main(["--algo", "mpnn+ppo", "--mode", "train", "--scenario", "synthetic-1024-1024", "--rollout-steps", "48",
+          "--epochs", "3", "--steps", "20", "--num-envs", "3", "--output-dir", str(tmp_path / "run"), "--seed", "1"])
+    r = created[-1]
+    out = capsys.readouterr().out
+    assert "Simulation Summary" in out
+    ckpt = torch.load(tmp_path / "run" / "policy.pt")
+    assert any(k.endswith("nodes_embedding.weight") for k in ckpt) and any("edge_mlp.0.weight" in k for k in ckpt)
+    import json
+    logs = [json.loads(l) for l in open(tmp_path / "run" / "train_log.jsonl")]
+    assert logs and all(math.isfinite(v) for v in logs[-1].values())
+    torch.manual_seed(1)
+    from src.agents.mpnn_agent import MPNNPolicyNet
+    fresh = MPNNPolicyNet(r.policy_net.edge_index, r.policy_net.num_nodes, None, device="cuda")
+    assert not torch.equal(fresh.nodes_embedding.weight, r.policy_net.nodes_embedding.weight)   # the actor trained
+    assert torch.equal(fresh.edge_mlp[0].weight, r.policy_net.edge_mlp[0].weight)               # dormant head untouched
+    main(["--algo", "mpnn", "--mode", "eval", "--scenario", "synthetic-1024-256", "--steps", "30"])
+    assert "Simulation Summary" in capsys.readouterr().out
+    main(["--algo", "random", "--mode", "eval", "--scenario", "synthetic-1024-256", "--steps", "15",
+          "--start-end-time", "21540", "21600"])
+    assert "Simulation Summary" in capsys.readouterr().out
