@@ -91,25 +91,35 @@ def cpu_baseline(args, net):
     config size on the host CPU; bounded by --cpu-seconds."""
     from oracle import sim, dist, nets
     from tarl_hip import synth
-    torch.set_num_threads(os.cpu_count() or 1)
     N, Nmax, E = net.num_roads, net.Nmax, net.edge_index.size(1)
-    x = net.x.clone()
-    ag = synth.population(args.agents, N, seed=args.seed)
     adj = net.dense_adjacency()
     w = torch.randn(N)
-    t, steps = 21540, 0
-    t0 = time.perf_counter()
-    while True:
-        d = dist.GraphDist(nets.policy_logits(sim.observe(x, Nmax)[0], net.edge_index, w), net.edge_index)
-        a = d.sample()
-        d.log_prob(a)
-        sim.env_step(x, ag, net.edge_index, net.edge_attr, adj, a, t, Nmax,
-                     congestion_constant=net.congestion_constant)
-        t += 1
-        steps += 1
-        el = time.perf_counter() - t0
-        if el >= args.cpu_seconds or steps >= 4096:
-            break
+
+    def rollout(x, ag, t, budget_s, max_steps):
+        steps, t0 = 0, time.perf_counter()
+        while True:
+            d = dist.GraphDist(nets.policy_logits(sim.observe(x, Nmax)[0], net.edge_index, w), net.edge_index)
+            a = d.sample()
+            d.log_prob(a)
+            sim.env_step(x, ag, net.edge_index, net.edge_attr, adj, a, t, Nmax,
+                         congestion_constant=net.congestion_constant)
+            t += 1
+            steps += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s or steps >= max_steps:
+                return steps, el
+
+    # the oracle's ops are small: more threads can be slower. Probe a few thread counts, keep the fastest.
+    ncpu = os.cpu_count() or 1
+    best_nt, best_rate = 1, 0.0
+    for nt in sorted({1, min(8, ncpu), min(16, ncpu)}):
+        torch.set_num_threads(nt)
+        rollout(net.x.clone(), synth.population(args.agents, N, seed=args.seed), 21540, 0.3, 2)       # warm up
+        st, el = rollout(net.x.clone(), synth.population(args.agents, N, seed=args.seed), 21540, 1.0, 64)
+        if st / el > best_rate:
+            best_nt, best_rate = nt, st / el
+    torch.set_num_threads(best_nt)
+    steps, el = rollout(net.x.clone(), synth.population(args.agents, N, seed=args.seed), 21540, args.cpu_seconds, 8192)
     return {"value": steps / el, "unit": "env-steps/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{steps} env steps of 1 environment (oracle rollout: policy logits, GraphDistribution sample + "
                       f"log_prob, env step) on the {E}-edge / {args.agents}-agent workload, {el:.1f} s, torch CPU"}
