@@ -188,6 +188,43 @@ int tarl_ppo_loss(const float* log_prob_new, const float* log_prob_old, const fl
 int tarl_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,
                    double lr, double beta1, double beta2, double eps, float grad_scale, tarl_stream stream);
 
+/* ---- fused rollout frame (vectorised fast path; same results as the entry points above, 4 launches per frame) ----------
+ * Caller-owned side buffers that mirror x / agent_features (all device memory, 16-byte aligned):
+ *   rec0 [B][N][4] = {head_id, head_dep, n, sel}      rec1 [B][N][4] = {tail_id, head_arr, -, -}
+ *   post [B][N][4] = {n', head', tail', chosen} (state after the Direction update, written by the gather kernel)
+ *   st0  [N][4]    = {MAX_NUMBER_OF_AGENT, FREE_FLOW_TIME_TRAVEL, ROAD_INDEX, congestion_constant} (static, shared)
+ *   a_origin / a_dest int32 [B][A], a_dep fp32 [B][A], a_status uint8 [B][A] (0 waiting, 1 on the way, 2 done).
+ * tarl_fused_pack rebuilds them from x / agent_features (call after construction, reset, or any external write to x).
+ * x and agent_features stay authoritative and bit-identical to the unfused path after every call. */
+typedef struct tarl_fused {
+  float* rec0;
+  float* rec1;
+  float* post;
+  float* st0;
+  int32_t* a_origin;
+  int32_t* a_dest;
+  float* a_dep;
+  uint8_t* a_status;
+} tarl_fused;
+
+int tarl_fused_pack(const tarl_plan* plan, const tarl_fused* f, const float* x, int64_t B, int64_t x_bstride,
+                    int64_t ldx, int32_t Nmax, const float* congestion_constant, const float* agent_features,
+                    int64_t num_agents, int64_t a_bstride, tarl_stream stream);
+/* == MPNNPolicyNet.forward (live path) + GraphDistribution(logits).sample()/log_prob()/entropy() + the choice phase of
+ *   SimulatorEnv._step, one launch: choice int32 [B][N] (nullable), log_prob / entropy [B] (nullable); writes
+ *   SELECTED_ROAD into x and rec0. uniform [B][num_groups] or NULL (Philox); group_sums: double [B][num_groups+1]. */
+int tarl_fused_policy_step(const tarl_plan* plan, const tarl_fused* f, float* x, int64_t B, int64_t x_bstride,
+                           int64_t ldx, int32_t Nmax, const float* emb, int64_t num_embeddings, float temperature,
+                           const float* uniform, uint64_t seed, uint64_t counter, double* group_sums, int32_t* choice,
+                           float* log_prob, float* entropy, tarl_stream stream);
+/* == tarl_core_step + tarl_withdraw_step + tarl_insert_step in three launches (gather on the hot records; one row
+ *   pass over x; insert + reward + counts). use_cong = 0 reproduces a graph without congestion_constant in insert. */
+int tarl_fused_env_step(const tarl_plan* plan, const tarl_fused* f, float* x, int64_t B, int64_t x_bstride, int64_t ldx,
+                        int32_t Nmax, float* agent_features, int64_t num_agents, int64_t a_bstride,
+                        const float* edge_attr, const float* log_edge_attr, float log_eps, int use_cong, float time,
+                        const float* gumbel, uint64_t seed, uint64_t counter, float* delta_travel_time, uint8_t* popped,
+                        uint8_t* withdrawn, int32_t* ins_scratch, float* reward, float* counts, tarl_stream stream);
+
 /* ---- measurement hook (bench.py roofline leg; nothing comparable in the reference) ------------------------------------
  * tarl_prof_enable(n > 0) brackets the next n launches of the Direction message+aggregate kernel with HIP events on
  * their launch stream; tarl_prof_enable(0) turns it off. tarl_prof_collect synchronises those events and returns the

@@ -18,7 +18,7 @@ EPISODE_END = 7 * 3600          # done = time > 7 * 3600
 
 class SimEngine:
     def __init__(self, x, edge_index, edge_attr, Nmax, agent_features, *, congestion_constant=None, num_envs=None,
-                 device="cuda", timestep=1, seed=0, plan=None):
+                 device="cuda", timestep=1, seed=0, plan=None, fused=True):
         """``x`` (N,F) or (B,N,F); ``agent_features`` (A,9) or (B,A,9). 2-D inputs are replicated ``num_envs`` times;
         3-D inputs are used in place (views are kept, so a caller-owned tensor keeps tracking the state)."""
         dev = torch.device(device)
@@ -53,6 +53,17 @@ class SimEngine:
         self.reward = torch.zeros(self.B, dtype=torch.float32, device=self.device)
         self.counts = torch.zeros((self.B, self.N), dtype=torch.float32, device=self.device)
         self.dtt = None
+        # fused fast path (csrc/fused.hip): packed hot records + agent SoA mirroring x / agents
+        self.fs = ops.FusedState(self.B, self.N, self.A, self.device) if fused else None
+        self.sums = torch.empty((self.B, self.plan.num_groups + 1), dtype=torch.float64, device=self.device)
+        self.sample_counter = 0
+        if self.fs is not None:
+            self.resync()
+
+    def resync(self):
+        """Rebuild the fused side buffers from ``x`` / ``agents`` (after construction, reset, or external writes)."""
+        if self.fs is not None:
+            ops.fused_pack(self.plan, self.fs, self.x, self.Nmax, self.agents, self.cc)
 
     # -- observation -------------------------------------------------------------------------------------------------
     @property
@@ -71,6 +82,7 @@ class SimEngine:
         self.time = EPISODE_START
         self.counts.zero_()
         self.reward.zero_()
+        self.resync()
 
     def step(self, *, choice=None, action_onehot=None, gumbel=None, want_dtt=False):
         """One env step for all B environments. Noise: explicit ``gumbel`` (B,E) or device Philox keyed by
@@ -86,3 +98,22 @@ class SimEngine:
                         reward=self.reward, counts=self.counts)
         self.time += self.timestep           # the reference's equality test compares a view with itself
         return self.reward, self.time > EPISODE_END
+
+    # -- fused fast path: 1 + 3 launches per frame, outputs written straight into caller buffers ---------------------------
+    def policy_step_fused(self, emb, temperature=1.0, *, choice=None, log_prob=None, entropy=None, uniform=None):
+        """Live policy logits -> softmax -> sample -> log_prob -> choice phase for all B environments (one launch)."""
+        self.sample_counter += 1
+        ops.fused_policy_step(self.plan, self.fs, self.x, self.Nmax, emb, temperature, uniform=uniform,
+                              seed=self.seed ^ 0x5DEECE66D, counter=self.sample_counter, sums=self.sums, choice=choice,
+                              log_prob=log_prob, entropy=entropy)
+
+    def step_fused(self, *, reward=None, counts=None, gumbel=None, dtt=None, popped=None, withdrawn=None):
+        """Core + withdraw + insert (three launches). Returns done (bool)."""
+        self.noise_counter += 1
+        ops.fused_env_step(self.plan, self.fs, self.x, self.Nmax, self.agents, self.ec, float(self.time),
+                           use_cong=self.cc is not None, gumbel=gumbel, seed=self.seed, counter=self.noise_counter,
+                           dtt=dtt, popped=popped, withdrawn=withdrawn, scratch=self.ins_scratch,
+                           reward=self.reward if reward is None else reward,
+                           counts=self.counts if counts is None else counts)
+        self.time += self.timestep
+        return self.time > EPISODE_END

@@ -48,9 +48,20 @@ SIGNATURES = {
     "tarl_advantage_normalize": (C.c_int, [_p, _i64, _p, _p]),
     "tarl_ppo_loss": (C.c_int, [_p] * 6 + [_i64, _f32, _f32, _f32, _f32, _p, _p, _p, _p, _p]),
     "tarl_adam_step": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _f64, _f64, _f64, _f64, _f32, _p]),
+    "tarl_fused_pack": (C.c_int, [_p, _p] + _STATE + [_p, _p, _i64, _i64, _p]),
+    "tarl_fused_policy_step": (C.c_int, [_p, _p] + _STATE + [_p, _i64, _f32, _p, _u64, _u64, _p, _p, _p, _p, _p]),
+    "tarl_fused_env_step": (C.c_int, [_p, _p] + _STATE + [_p, _i64, _i64, _p, _p, _f32, C.c_int, _f32, _p, _u64, _u64,
+                                                         _p, _p, _p, _p, _p, _p, _p]),
     "tarl_prof_enable": (C.c_int, [_i64]),
     "tarl_prof_collect": (C.c_int, [C.POINTER(_f64), C.POINTER(_i64)]),
 }
+
+
+
+class FusedStruct(C.Structure):
+    """``tarl_fused`` of include/tarl_hip.h."""
+    _fields_ = [(n, C.c_void_p) for n in ("rec0", "rec1", "post", "st0", "a_origin", "a_dest", "a_dep", "a_status")]
+
 
 _lib = None
 _lock = threading.Lock()

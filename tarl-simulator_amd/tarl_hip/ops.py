@@ -420,3 +420,73 @@ def adam_step_(param, grad, exp_avg, exp_avg_sq, step, *, lr=1e-3, beta1=0.9, be
                                 param.numel(), int(step), float(lr), float(beta1), float(beta2), float(eps),
                                 float(grad_scale), _lib.current_stream()))
     return param
+
+
+# ---- fused rollout frame ----------------------------------------------------------------------------------------------
+class FusedState:
+    """Side buffers of the fused path (``tarl_fused`` in include/tarl_hip.h): packed hot / post / static node records and
+    the agent SoA. They mirror ``x`` / ``agent_features``; call :func:`fused_pack` after any external write to those."""
+
+    def __init__(self, B: int, N: int, A: int, device):
+        f32 = dict(dtype=torch.float32, device=device)
+        self.rec0 = torch.zeros((B, N, 4), **f32)
+        self.rec1 = torch.zeros((B, N, 4), **f32)
+        self.post = torch.zeros((B, N, 4), **f32)
+        self.st0 = torch.zeros((N, 4), **f32)
+        self.a_origin = torch.zeros((B, A), dtype=torch.int32, device=device)
+        self.a_dest = torch.zeros((B, A), dtype=torch.int32, device=device)
+        self.a_dep = torch.zeros((B, A), **f32)
+        self.a_status = torch.zeros((B, A), dtype=torch.uint8, device=device)
+        self.struct = _lib.FusedStruct(*(t.data_ptr() for t in (self.rec0, self.rec1, self.post, self.st0,
+                                                                self.a_origin, self.a_dest, self.a_dep, self.a_status)))
+        self.B, self.N, self.A = B, N, A
+
+    @property
+    def ref(self):
+        return C.byref(self.struct)
+
+
+def fused_pack(plan: Plan, fs: FusedState, x, Nmax, agent_features, congestion_constant=None):
+    L = _lib.load()
+    B, N, bs, ldx = _state(x, Nmax)
+    A, abs_ = _agents(agent_features, B)
+    _lib.check(L.tarl_fused_pack(plan.handle, fs.ref, x.data_ptr(), B, bs, ldx, Nmax, _lib.ptr(congestion_constant),
+                                 agent_features.data_ptr(), A, abs_, _lib.current_stream()))
+
+
+def fused_policy_step(plan: Plan, fs: FusedState, x, Nmax, emb, temperature=1.0, *, uniform=None, seed=0, counter=0,
+                      sums=None, choice=None, log_prob=None, entropy=None):
+    """Live policy + GraphDistribution sample/log_prob/entropy + choice phase in one launch; outputs are written into
+    the tensors passed in (e.g. slices of the rollout buffers)."""
+    L = _lib.load()
+    B, N, bs, ldx = _state(x, Nmax)
+    _contig(emb, torch.float32, "emb")
+    if sums is None:
+        sums = torch.empty((B, plan.num_groups + 1), dtype=torch.float64, device=x.device)
+    for n, t, dt in (("choice", choice, torch.int32), ("log_prob", log_prob, torch.float32),
+                     ("entropy", entropy, torch.float32), ("uniform", uniform, torch.float32)):
+        if t is not None:
+            _contig(t, dt, n)
+    _lib.check(L.tarl_fused_policy_step(plan.handle, fs.ref, x.data_ptr(), B, bs, ldx, Nmax, emb.data_ptr(), emb.numel(),
+                                        float(temperature), _lib.ptr(uniform), int(seed), int(counter), sums.data_ptr(),
+                                        _lib.ptr(choice), _lib.ptr(log_prob), _lib.ptr(entropy), _lib.current_stream()))
+    return sums
+
+
+def fused_env_step(plan: Plan, fs: FusedState, x, Nmax, agent_features, ec: EdgeConst, t, *, use_cong=True, gumbel=None,
+                   seed=0, counter=0, dtt=None, popped=None, withdrawn=None, scratch=None, reward=None, counts=None):
+    L = _lib.load()
+    B, N, bs, ldx = _state(x, Nmax)
+    A, abs_ = _agents(agent_features, B)
+    if scratch is None:
+        scratch = torch.empty((B, 2 * A), dtype=torch.int32, device=x.device)
+    for n, tt, dt in (("gumbel", gumbel, torch.float32), ("dtt", dtt, torch.float32), ("reward", reward, torch.float32),
+                      ("counts", counts, torch.float32), ("popped", popped, torch.uint8),
+                      ("withdrawn", withdrawn, torch.uint8)):
+        if tt is not None:
+            _contig(tt, dt, n)
+    _lib.check(L.tarl_fused_env_step(plan.handle, fs.ref, x.data_ptr(), B, bs, ldx, Nmax, agent_features.data_ptr(), A,
+                                     abs_, ec.edge_attr.data_ptr(), ec.log_edge_attr.data_ptr(), ec.log_eps,
+                                     1 if use_cong else 0, float(t), _lib.ptr(gumbel), int(seed), int(counter),
+                                     _lib.ptr(dtt), _lib.ptr(popped), _lib.ptr(withdrawn), scratch.data_ptr(),
+                                     _lib.ptr(reward), _lib.ptr(counts), _lib.current_stream()))
