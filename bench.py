@@ -172,7 +172,7 @@ def main():
                        "envs_per_gpu": B, "env_steps_per_step": B * T, "parallelism": f"dp{world} (rollouts sharded, "
                        "one gradient all-reduce per optimiser step)"},
             "msgpass_edges_per_sec": value * E,
-            "roofline": {"bound": "hbm", "kernel": "k_direction_gather (DirectionMPNN message+aggregate)",
+            "roofline": {"bound": "hbm", "kernel": "k_fused_direction (DirectionMPNN message+aggregate on the packed hot records)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": avg_s * 1e6, "launches_timed": k_n.value},

@@ -210,13 +210,22 @@ typedef struct tarl_fused {
 int tarl_fused_pack(const tarl_plan* plan, const tarl_fused* f, const float* x, int64_t B, int64_t x_bstride,
                     int64_t ldx, int32_t Nmax, const float* congestion_constant, const float* agent_features,
                     int64_t num_agents, int64_t a_bstride, tarl_stream stream);
-/* == MPNNPolicyNet.forward (live path) + GraphDistribution(logits).sample()/log_prob()/entropy() + the choice phase of
- *   SimulatorEnv._step, one launch: choice int32 [B][N] (nullable), log_prob / entropy [B] (nullable); writes
- *   SELECTED_ROAD into x and rec0. uniform [B][num_groups] or NULL (Philox); group_sums: double [B][num_groups+1]. */
-int tarl_fused_policy_step(const tarl_plan* plan, const tarl_fused* f, float* x, int64_t B, int64_t x_bstride,
-                           int64_t ldx, int32_t Nmax, const float* emb, int64_t num_embeddings, float temperature,
-                           const float* uniform, uint64_t seed, uint64_t counter, double* group_sums, int32_t* choice,
-                           float* log_prob, float* entropy, tarl_stream stream);
+/* The live policy (MPNNPolicyNet.forward: logits = emb[ROAD_INDEX(dst)]) does not read the dynamic state, so
+ * GraphDistribution's probabilities are the same for every environment and frame between two optimiser steps.
+ * tarl_fused_policy_prepare evaluates them once per parameter update — same arithmetic and reduction trees as
+ * tarl_policy_edge_logits_fwd + tarl_graphdist_softmax + the cumsum of tarl_graphdist_sample +
+ * tarl_graphdist_logprob_entropy_fwd — into per-edge tables in plan (CSR) order: thresholds [E] (fp32 inverse-CDF
+ * thresholds), log_probs [E] (log(p + 1e-8)), entropy1 [1]; group_base: double scratch [num_groups + 1].
+ * tarl_fused_policy_step == GraphDistribution.sample() + log_prob() (+ entropy) + the choice phase of
+ * SimulatorEnv._step for B environments in one launch: choice int32 [B][N] (nullable), log_prob / entropy [B]
+ * (nullable); uniform [B][num_groups] or NULL (Philox). SELECTED_ROAD goes to rec0 and reaches x in the row pass of
+ * the same frame (tarl_fused_env_step). */
+int tarl_fused_policy_prepare(const tarl_plan* plan, const tarl_fused* f, const float* emb, int64_t num_embeddings,
+                              float temperature, double* group_base, float* thresholds, float* log_probs,
+                              float* entropy1, tarl_stream stream);
+int tarl_fused_policy_step(const tarl_plan* plan, const tarl_fused* f, int64_t B, const float* thresholds,
+                           const float* log_probs, const float* entropy1, const float* uniform, uint64_t seed,
+                           uint64_t counter, int32_t* choice, float* log_prob, float* entropy, tarl_stream stream);
 /* == tarl_core_step + tarl_withdraw_step + tarl_insert_step in three launches (gather on the hot records; one row
  *   pass over x; insert + reward + counts). use_cong = 0 reproduces a graph without congestion_constant in insert. */
 int tarl_fused_env_step(const tarl_plan* plan, const tarl_fused* f, float* x, int64_t B, int64_t x_bstride, int64_t ldx,

@@ -23,6 +23,7 @@
 #define FB 256
 #define ENVB 1024
 #define LOG_EPS_P 1e-8f
+#define INS_CAP 2048   // LDS candidate list of the insert kernel (entries)
 
 struct FusedBufs {
   float4* rec0;         // [B][N] {head_id, head_dep, n, sel}
@@ -95,22 +96,21 @@ __device__ __forceinline__ float live_logit(const float* __restrict__ emb, int64
   return (idx >= 0 && idx < M) ? emb[idx] : 0.0f;
 }
 
-__global__ __launch_bounds__(ENVB) void k_fused_policy(const int32_t* __restrict__ out_ptr,
-                                                       const int32_t* __restrict__ out_dst,
-                                                       const int32_t* __restrict__ out_eid,
-                                                       const int32_t* __restrict__ node_of_group, int64_t N, int64_t G,
-                                                       const float* __restrict__ emb, int64_t M, float temperature,
-                                                       const float* __restrict__ uniform, uint64_t seed,
-                                                       uint64_t counter, double* __restrict__ base_all, FusedBufs fb,
-                                                       float* __restrict__ x, Layout L, int32_t* __restrict__ choice,
-                                                       float* __restrict__ log_prob, float* __restrict__ entropy) {
+// The live policy's logits depend only on (emb, static ROAD_INDEX of the target road): they are identical for every
+// environment and every frame between two optimiser steps. k_policy_tables therefore evaluates, ONCE per parameter
+// update and with exactly the arithmetic / reduction trees of k_softmax + k_sample + k_logprob_entropy_fwd, the per-edge
+// tables (CSR order): thr[k] = fp32 inverse-CDF threshold, lg[k] = log(p + 1e-8), plus the entropy; k_fused_choice then
+// only draws one uniform per (environment, node), walks <= deg thresholds and reduces the log-prob (same tree).
+__global__ __launch_bounds__(ENVB) void k_policy_tables(const int32_t* __restrict__ out_ptr,
+                                                        const int32_t* __restrict__ out_dst,
+                                                        const int32_t* __restrict__ node_of_group, int64_t N, int64_t G,
+                                                        const float* __restrict__ emb, int64_t M, float temperature,
+                                                        const float4* __restrict__ st0, double* __restrict__ base,
+                                                        float* __restrict__ thr, float* __restrict__ lgt,
+                                                        float* __restrict__ entropy_out) {
   __shared__ double s_wave[ENVB / 64];
   __shared__ float s_red[ENVB / 64];
-  const int64_t b = blockIdx.x;
-  double* base = base_all + b * (G + 1);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-
-  // phase A: group sums of p in double + exclusive scan over the groups (global cumsum of the reference)
   double running = 0.0;
   for (int64_t g0 = 0; g0 < G; g0 += ENVB) {
     const int64_t g = g0 + tid;
@@ -119,11 +119,10 @@ __global__ __launch_bounds__(ENVB) void k_fused_policy(const int32_t* __restrict
       const int32_t i = node_of_group[g];
       const int32_t k0 = out_ptr[i], k1 = out_ptr[i + 1];
       float mx = -INFINITY;
-      for (int32_t k = k0; k < k1; ++k) mx = fmaxf(mx, live_logit(emb, M, fb.st0, out_dst[k]) / temperature);
+      for (int32_t k = k0; k < k1; ++k) mx = fmaxf(mx, live_logit(emb, M, st0, out_dst[k]) / temperature);
       float sum = 0.0f;
-      for (int32_t k = k0; k < k1; ++k) sum = sum + expf(live_logit(emb, M, fb.st0, out_dst[k]) / temperature - mx);
-      for (int32_t k = k0; k < k1; ++k)
-        s += (double)(expf(live_logit(emb, M, fb.st0, out_dst[k]) / temperature - mx) / sum);
+      for (int32_t k = k0; k < k1; ++k) sum = sum + expf(live_logit(emb, M, st0, out_dst[k]) / temperature - mx);
+      for (int32_t k = k0; k < k1; ++k) s += (double)(expf(live_logit(emb, M, st0, out_dst[k]) / temperature - mx) / sum);
     }
     double inc = s;
     for (int off = 1; off < 64; off <<= 1) {
@@ -144,22 +143,16 @@ __global__ __launch_bounds__(ENVB) void k_fused_policy(const int32_t* __restrict
     running += tot;
     __syncthreads();
   }
-  // phase B: per node sample / log-prob / entropy / choice. Node order and strides match k_logprob_entropy_fwd.
-  float lp = 0.0f, ent = 0.0f;
+  float ent = 0.0f;
   for (int64_t i = tid; i < N; i += ENVB) {
     const int32_t k0 = out_ptr[i], k1 = out_ptr[i + 1];
-    if (k0 == k1) {
-      if (choice) choice[b * N + i] = -1;
-      continue;
-    }
-    // group rank of node i: nodes with out-edges are numbered in ascending id
+    if (k0 == k1) continue;
     float mx = -INFINITY;
-    for (int32_t k = k0; k < k1; ++k) mx = fmaxf(mx, live_logit(emb, M, fb.st0, out_dst[k]) / temperature);
+    for (int32_t k = k0; k < k1; ++k) mx = fmaxf(mx, live_logit(emb, M, st0, out_dst[k]) / temperature);
     float sum = 0.0f;
-    for (int32_t k = k0; k < k1; ++k) sum = sum + expf(live_logit(emb, M, fb.st0, out_dst[k]) / temperature - mx);
-    // recover g from the scan layout: base is indexed by group; with G == N the group id is the node id
+    for (int32_t k = k0; k < k1; ++k) sum = sum + expf(live_logit(emb, M, st0, out_dst[k]) / temperature - mx);
     int64_t g = i;
-    if (G != N) {  // binary search node_of_group
+    if (G != N) {
       int64_t lo = 0, hi = G - 1;
       while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
@@ -169,37 +162,63 @@ __global__ __launch_bounds__(ENVB) void k_fused_policy(const int32_t* __restrict
     }
     const double bg = base[g];
     const float bg32 = (float)bg;
-    const float u = uniform ? uniform[b * G + g] : philox_uniform(seed, counter, (uint64_t)(b * G + g));
     double run = bg;
-    int32_t pick = -1, pick_dst = -1;
-    float lg_pick = 0.0f;
     for (int32_t k = k0; k < k1; ++k) {
-      const float p = expf(live_logit(emb, M, fb.st0, out_dst[k]) / temperature - mx) / sum;
+      const float p = expf(live_logit(emb, M, st0, out_dst[k]) / temperature - mx) / sum;
       const float lg = logf(p + LOG_EPS_P);
       ent -= p * lg;
       run += (double)p;
-      const float cum = (float)run - bg32;
-      if (pick < 0 && u < cum) {
-        pick = out_eid[k];
-        pick_dst = out_dst[k];
-        lg_pick = lg;
+      thr[k] = (float)run - bg32;
+      lgt[k] = lg;
+    }
+  }
+  const float ent_t = fb_block_sum(ent, s_red);
+  if (tid == 0) entropy_out[0] = ent_t;
+}
+
+__global__ __launch_bounds__(ENVB) void k_fused_choice(const int32_t* __restrict__ out_ptr,
+                                                       const int32_t* __restrict__ out_dst,
+                                                       const int32_t* __restrict__ out_eid,
+                                                       const int32_t* __restrict__ group_of_node, int64_t N, int64_t G,
+                                                       const float* __restrict__ thr, const float* __restrict__ lgt,
+                                                       const float* __restrict__ entropy_in,
+                                                       const float* __restrict__ uniform, uint64_t seed,
+                                                       uint64_t counter, FusedBufs fb, int32_t* __restrict__ choice,
+                                                       float* __restrict__ log_prob, float* __restrict__ entropy) {
+  __shared__ float s_red[ENVB / 64];
+  const int64_t b = blockIdx.x;
+  const int tid = threadIdx.x;
+  float lp = 0.0f;
+  bool bad = false;
+  for (int64_t i = tid; i < N; i += ENVB) {
+    const int32_t k0 = out_ptr[i], k1 = out_ptr[i + 1];
+    if (k0 == k1) {
+      if (choice) choice[b * N + i] = -1;
+      continue;
+    }
+    const int64_t g = group_of_node[i];
+    const float u = uniform ? uniform[b * G + g] : philox_uniform(seed, counter, (uint64_t)(b * G + g));
+    int32_t pick = -1;
+    for (int32_t k = k0; k < k1; ++k) {
+      if (u < thr[k]) {
+        pick = k;
+        break;
       }
     }
     if (pick >= 0) {
-      lp += lg_pick;
-      fb.rec0[b * N + i].w = (float)pick_dst;
-      x[b * L.bstride + i * L.ldx + L.col_sel()] = (float)pick_dst;
+      lp += lgt[pick];
+      fb.rec0[b * N + i].w = (float)out_dst[pick];   // SELECTED_ROAD; x gets it in the row pass of the same frame
+      if (choice) choice[b * N + i] = out_eid[pick];
+    } else {
+      bad = true;
+      if (choice) choice[b * N + i] = -1;
     }
-    if (choice) choice[b * N + i] = pick;
-    if (pick < 0) lp = -INFINITY;  // a node that selected nothing makes the action infeasible (log_prob = -inf)
   }
-  // infeasibility must dominate the sum: reduce a flag separately so that -inf + finite ordering cannot produce NaN
-  const float bad = fb_block_sum(isinf(lp) ? 1.0f : 0.0f, s_red);
-  const float lp_t = fb_block_sum(isinf(lp) ? 0.0f : lp, s_red);
-  const float ent_t = fb_block_sum(ent, s_red);
+  const float bad_t = fb_block_sum(bad ? 1.0f : 0.0f, s_red);
+  const float lp_t = fb_block_sum(lp, s_red);
   if (tid == 0) {
-    if (log_prob) log_prob[b] = bad > 0.0f ? -INFINITY : lp_t;
-    if (entropy) entropy[b] = ent_t;
+    if (log_prob) log_prob[b] = bad_t > 0.0f ? -INFINITY : lp_t;
+    if (entropy) entropy[b] = entropy_in[0];
   }
 }
 
@@ -375,6 +394,7 @@ __global__ __launch_bounds__(FB) void k_fused_rows(const int32_t* __restrict__ o
     tail_id = (qn >= 1 && qn <= Nmax) ? xi[qn - 1] : 0.0f;
   }
   if (n != n0) xi[L.col_n()] = n;
+  xi[L.col_sel()] = r0.w;  // the choice phase of this frame (k_fused_choice keeps it in the hot record)
   fb.rec0[gid] = make_float4(head_id, head_dep, n, r0.w);
   fb.rec1[gid] = make_float4(tail_id, head_arr, 0.0f, 0.0f);
 }
@@ -397,7 +417,8 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(float* __restrict__ x, La
                                                        float* __restrict__ reward, float* __restrict__ counts) {
   __shared__ int32_t s_wave[ENVB / 64];
   __shared__ float s_red[ENVB / 64];
-  __shared__ int32_t s_total;
+  __shared__ int32_t s_cnt;
+  __shared__ int32_t s_un_agent[INS_CAP], s_un_road[INS_CAP];
   const int64_t b = blockIdx.x;
   float* xb = x + b * L.bstride;
   float* agb = ag + b * a_bstride;
@@ -406,34 +427,65 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(float* __restrict__ x, La
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int Nmax = L.Nmax;
 
-  int32_t basec = 0;
-  for (int64_t a0 = 0; a0 < A; a0 += ENVB) {
-    const int64_t a = a0 + tid;
-    bool cnd = false;
-    int32_t road = 0, cap = 0;
-    if (a < A && fb.a_status[b * A + a] == 0 && fb.a_dep[b * A + a] <= t)
-      cnd = fused_target(fb, b, N, fb.a_origin[b * A + a], &road, &cap);
-    const unsigned long long bal = __ballot(cnd);
-    const int lane_off = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) s_wave[wid] = __popcll(bal);
+  // phase 1: candidates (ready agent whose target road has room). Candidates are rare (a handful per frame), so they
+  // are appended unordered to an LDS list with an atomic counter and then ranked by agent id (deterministic: the
+  // reference admits agents in stable agent-id order). A backlog larger than the LDS list falls back to the ordered
+  // ballot compaction into the global scratch.
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  for (int64_t a = tid; a < A; a += ENVB) {
+    if (fb.a_status[b * A + a] == 0 && fb.a_dep[b * A + a] <= t) {
+      int32_t road = 0, cap = 0;
+      if (fused_target(fb, b, N, fb.a_origin[b * A + a], &road, &cap)) {
+        const int32_t pos = atomicAdd(&s_cnt, 1);
+        if (pos < INS_CAP) {
+          s_un_agent[pos] = (int32_t)a;
+          s_un_road[pos] = road;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  int32_t Lc = s_cnt;
+  if (Lc <= INS_CAP) {
+    for (int32_t idx = tid; idx < Lc; idx += ENVB) {
+      const int32_t a = s_un_agent[idx];
+      int32_t pos = 0;
+      for (int32_t k = 0; k < Lc; ++k) pos += (s_un_agent[k] < a) ? 1 : 0;
+      cand_agent[pos] = a;
+      cand_road[pos] = s_un_road[idx];
+    }
+    __threadfence_block();
     __syncthreads();
-    int32_t wbase = 0, tot = 0;
-    for (int w = 0; w < ENVB / 64; ++w) {
-      const int32_t v = s_wave[w];
-      if (w < wid) wbase += v;
-      tot += v;
+  } else {
+    int32_t basec = 0;
+    for (int64_t a0 = 0; a0 < A; a0 += ENVB) {
+      const int64_t a = a0 + tid;
+      bool cnd = false;
+      int32_t road = 0, cap = 0;
+      if (a < A && fb.a_status[b * A + a] == 0 && fb.a_dep[b * A + a] <= t)
+        cnd = fused_target(fb, b, N, fb.a_origin[b * A + a], &road, &cap);
+      const unsigned long long bal = __ballot(cnd);
+      const int lane_off = __popcll(bal & ((1ull << lane) - 1ull));
+      if (lane == 0) s_wave[wid] = __popcll(bal);
+      __syncthreads();
+      int32_t wbase = 0, tot = 0;
+      for (int w = 0; w < ENVB / 64; ++w) {
+        const int32_t v = s_wave[w];
+        if (w < wid) wbase += v;
+        tot += v;
+      }
+      if (cnd) {
+        cand_agent[basec + wbase + lane_off] = (int32_t)a;
+        cand_road[basec + wbase + lane_off] = road;
+      }
+      basec += tot;
+      __syncthreads();
     }
-    if (cnd) {
-      cand_agent[basec + wbase + lane_off] = (int32_t)a;
-      cand_road[basec + wbase + lane_off] = road;
-    }
-    basec += tot;
+    Lc = basec;
+    __threadfence_block();
     __syncthreads();
   }
-  if (tid == 0) s_total = basec;
-  __threadfence_block();
-  __syncthreads();
-  const int32_t Lc = s_total;
 
   for (int32_t idx = tid; idx < Lc; idx += ENVB) {
     const int32_t r = cand_road[idx];
@@ -504,6 +556,8 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(float* __restrict__ x, La
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
+hipEvent_t tarl_prof_event(hipStream_t s);  // sim.hip: live timing of the message-passing gather kernel
+
 static FusedBufs to_bufs(const tarl_fused* f) {
   return FusedBufs{(float4*)f->rec0, (float4*)f->rec1, (float4*)f->post, (const float4*)f->st0,
                    f->a_origin,      f->a_dest,        f->a_dep,         f->a_status};
@@ -543,20 +597,29 @@ extern "C" int tarl_fused_pack(const tarl_plan* plan, const tarl_fused* f, const
   return TARL_OK;
 }
 
-extern "C" int tarl_fused_policy_step(const tarl_plan* plan, const tarl_fused* f, float* x, int64_t B, int64_t x_bstride,
-                                      int64_t ldx, int32_t Nmax, const float* emb, int64_t num_embeddings,
-                                      float temperature, const float* uniform, uint64_t seed, uint64_t counter,
-                                      double* group_sums, int32_t* choice, float* log_prob, float* entropy,
-                                      tarl_stream stream) {
-  int rc = check_fused(plan, f, x, B, x_bstride, ldx, Nmax);
-  if (rc) return rc;
-  TARL_REQUIRE(emb && group_sums && num_embeddings >= 1, "null argument");
-  TARL_REQUIRE(B < ((int64_t)1 << 31), "too many environments");
+extern "C" int tarl_fused_policy_prepare(const tarl_plan* plan, const tarl_fused* f, const float* emb,
+                                         int64_t num_embeddings, float temperature, double* group_base,
+                                         float* thresholds, float* log_probs, float* entropy1, tarl_stream stream) {
+  TARL_REQUIRE(plan && f && f->st0 && emb && group_base && thresholds && log_probs && entropy1, "null argument");
+  TARL_REQUIRE(num_embeddings >= 1, "bad sizes");
   if (plan->N == 0) return TARL_OK;
-  const Layout L{Nmax, ldx, x_bstride};
-  hipLaunchKernelGGL(k_fused_policy, dim3((unsigned)B), dim3(ENVB), 0, (hipStream_t)stream, plan->out_ptr, plan->out_dst,
-                     plan->out_eid, plan->node_of_group, plan->N, plan->G, emb, num_embeddings, temperature, uniform,
-                     seed, counter, group_sums, to_bufs(f), x, L, choice, log_prob, entropy);
+  hipLaunchKernelGGL(k_policy_tables, dim3(1), dim3(ENVB), 0, (hipStream_t)stream, plan->out_ptr, plan->out_dst,
+                     plan->node_of_group, plan->N, plan->G, emb, num_embeddings, temperature, (const float4*)f->st0,
+                     group_base, thresholds, log_probs, entropy1);
+  TARL_LAUNCH_CHECK();
+  return TARL_OK;
+}
+
+extern "C" int tarl_fused_policy_step(const tarl_plan* plan, const tarl_fused* f, int64_t B, const float* thresholds,
+                                      const float* log_probs, const float* entropy1, const float* uniform,
+                                      uint64_t seed, uint64_t counter, int32_t* choice, float* log_prob, float* entropy,
+                                      tarl_stream stream) {
+  TARL_REQUIRE(plan && f && f->rec0 && thresholds && log_probs && entropy1, "null argument");
+  TARL_REQUIRE(B >= 1 && B < ((int64_t)1 << 31), "bad B");
+  if (plan->N == 0) return TARL_OK;
+  hipLaunchKernelGGL(k_fused_choice, dim3((unsigned)B), dim3(ENVB), 0, (hipStream_t)stream, plan->out_ptr, plan->out_dst,
+                     plan->out_eid, plan->group_of_node, plan->N, plan->G, thresholds, log_probs, entropy1, uniform, seed,
+                     counter, to_bufs(f), choice, log_prob, entropy);
   TARL_LAUNCH_CHECK();
   return TARL_OK;
 }
@@ -579,9 +642,11 @@ extern "C" int tarl_fused_env_step(const tarl_plan* plan, const tarl_fused* f, f
   const FusedBufs fb = to_bufs(f);
   hipStream_t s = (hipStream_t)stream;
   const unsigned grid = (unsigned)ceil_div(B * plan->N, FB);
+  const bool timed = tarl_prof_event(s) != nullptr;
   hipLaunchKernelGGL(k_fused_direction, dim3(grid), dim3(FB), 0, s, plan->in_ptr, plan->in_src, plan->in_eid, plan->E, B,
                      plan->N, fb, edge_attr, log_edge_attr, log_eps, time, gumbel, seed, counter, delta_travel_time);
   TARL_LAUNCH_CHECK();
+  if (timed) (void)tarl_prof_event(s);
   hipLaunchKernelGGL(k_fused_rows, dim3(grid), dim3(FB), 0, s, plan->out_ptr, plan->out_dst, x, L, B, plan->N, fb,
                      agent_features, A, a_bstride, time, popped, withdrawn);
   TARL_LAUNCH_CHECK();

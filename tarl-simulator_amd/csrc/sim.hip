@@ -210,7 +210,9 @@ extern "C" int tarl_prof_collect(double* total_ms, int64_t* launches) {
   return TARL_OK;
 }
 
-static inline hipEvent_t prof_event(hipStream_t s) {
+hipEvent_t tarl_prof_event(hipStream_t s);  // shared with fused.hip
+static inline hipEvent_t prof_event(hipStream_t s) { return tarl_prof_event(s); }
+hipEvent_t tarl_prof_event(hipStream_t s) {
   if (!g_prof_on || g_prof_used >= g_prof_events.size()) return nullptr;
   hipEvent_t e = g_prof_events[g_prof_used++];
   (void)hipEventRecord(e, s);

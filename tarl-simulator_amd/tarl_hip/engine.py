@@ -55,7 +55,6 @@ class SimEngine:
         self.dtt = None
         # fused fast path (csrc/fused.hip): packed hot records + agent SoA mirroring x / agents
         self.fs = ops.FusedState(self.B, self.N, self.A, self.device) if fused else None
-        self.sums = torch.empty((self.B, self.plan.num_groups + 1), dtype=torch.float64, device=self.device)
         self.sample_counter = 0
         if self.fs is not None:
             self.resync()
@@ -100,12 +99,15 @@ class SimEngine:
         return self.reward, self.time > EPISODE_END
 
     # -- fused fast path: 1 + 3 launches per frame, outputs written straight into caller buffers ---------------------------
-    def policy_step_fused(self, emb, temperature=1.0, *, choice=None, log_prob=None, entropy=None, uniform=None):
-        """Live policy logits -> softmax -> sample -> log_prob -> choice phase for all B environments (one launch)."""
+    def prepare_policy(self, emb, temperature=1.0):
+        """Evaluate the live policy's distribution tables; call once per parameter update."""
+        self.tables = ops.fused_policy_prepare(self.plan, self.fs, emb, temperature, getattr(self, "tables", None))
+
+    def policy_step_fused(self, *, choice=None, log_prob=None, entropy=None, uniform=None):
+        """GraphDistribution sample -> log_prob -> choice phase for all B environments (one launch)."""
         self.sample_counter += 1
-        ops.fused_policy_step(self.plan, self.fs, self.x, self.Nmax, emb, temperature, uniform=uniform,
-                              seed=self.seed ^ 0x5DEECE66D, counter=self.sample_counter, sums=self.sums, choice=choice,
-                              log_prob=log_prob, entropy=entropy)
+        ops.fused_policy_step(self.plan, self.fs, self.tables, uniform=uniform, seed=self.seed ^ 0x5DEECE66D,
+                              counter=self.sample_counter, choice=choice, log_prob=log_prob, entropy=entropy)
 
     def step_fused(self, *, reward=None, counts=None, gumbel=None, dtt=None, popped=None, withdrawn=None):
         """Core + withdraw + insert (three launches). Returns done (bool)."""

@@ -454,23 +454,41 @@ def fused_pack(plan: Plan, fs: FusedState, x, Nmax, agent_features, congestion_c
                                  agent_features.data_ptr(), A, abs_, _lib.current_stream()))
 
 
-def fused_policy_step(plan: Plan, fs: FusedState, x, Nmax, emb, temperature=1.0, *, uniform=None, seed=0, counter=0,
-                      sums=None, choice=None, log_prob=None, entropy=None):
-    """Live policy + GraphDistribution sample/log_prob/entropy + choice phase in one launch; outputs are written into
-    the tensors passed in (e.g. slices of the rollout buffers)."""
+class PolicyTables:
+    """Per-edge tables of the live policy's GraphDistribution (plan order), valid until the embedding changes."""
+
+    def __init__(self, plan: Plan, device):
+        self.thresholds = torch.empty(plan.num_edges, dtype=torch.float32, device=device)
+        self.log_probs = torch.empty(plan.num_edges, dtype=torch.float32, device=device)
+        self.entropy = torch.empty(1, dtype=torch.float32, device=device)
+        self.base = torch.empty(plan.num_groups + 1, dtype=torch.float64, device=device)
+
+
+def fused_policy_prepare(plan: Plan, fs: FusedState, emb, temperature=1.0, tables: PolicyTables | None = None):
     L = _lib.load()
-    B, N, bs, ldx = _state(x, Nmax)
     _contig(emb, torch.float32, "emb")
-    if sums is None:
-        sums = torch.empty((B, plan.num_groups + 1), dtype=torch.float64, device=x.device)
+    if tables is None:
+        tables = PolicyTables(plan, emb.device)
+    _lib.check(L.tarl_fused_policy_prepare(plan.handle, fs.ref, emb.data_ptr(), emb.numel(), float(temperature),
+                                           tables.base.data_ptr(), tables.thresholds.data_ptr(),
+                                           tables.log_probs.data_ptr(), tables.entropy.data_ptr(),
+                                           _lib.current_stream()))
+    return tables
+
+
+def fused_policy_step(plan: Plan, fs: FusedState, tables: PolicyTables, *, uniform=None, seed=0, counter=0, choice=None,
+                      log_prob=None, entropy=None):
+    """GraphDistribution sample + log_prob (+ entropy) + choice phase for all B environments in one launch; outputs are
+    written into the tensors passed in (e.g. slices of the rollout buffers)."""
+    L = _lib.load()
     for n, t, dt in (("choice", choice, torch.int32), ("log_prob", log_prob, torch.float32),
                      ("entropy", entropy, torch.float32), ("uniform", uniform, torch.float32)):
         if t is not None:
             _contig(t, dt, n)
-    _lib.check(L.tarl_fused_policy_step(plan.handle, fs.ref, x.data_ptr(), B, bs, ldx, Nmax, emb.data_ptr(), emb.numel(),
-                                        float(temperature), _lib.ptr(uniform), int(seed), int(counter), sums.data_ptr(),
-                                        _lib.ptr(choice), _lib.ptr(log_prob), _lib.ptr(entropy), _lib.current_stream()))
-    return sums
+    _lib.check(L.tarl_fused_policy_step(plan.handle, fs.ref, fs.B, tables.thresholds.data_ptr(),
+                                        tables.log_probs.data_ptr(), tables.entropy.data_ptr(), _lib.ptr(uniform),
+                                        int(seed), int(counter), _lib.ptr(choice), _lib.ptr(log_prob),
+                                        _lib.ptr(entropy), _lib.current_stream()))
 
 
 def fused_env_step(plan: Plan, fs: FusedState, x, Nmax, agent_features, ec: EdgeConst, t, *, use_cong=True, gumbel=None,

@@ -72,9 +72,10 @@ class VecPPOTrainer:
         if eng.fs is not None:
             # fused path: 4 launches per frame, every output lands directly in the rollout buffers (no copies)
             self.counts[0].zero_()
+            eng.prepare_policy(emb, self.temperature)      # once per parameter update, not per frame
             for t in range(self.T):
                 host_times.append(float(eng.time))
-                eng.policy_step_fused(emb, self.temperature, choice=self.choice[t], log_prob=self.logp[t])
+                eng.policy_step_fused(choice=self.choice[t], log_prob=self.logp[t])
                 eng.step_fused(reward=self.reward[t], counts=self.counts[t + 1])
             host_times.append(float(eng.time))
             self.times.copy_(torch.tensor(host_times, dtype=torch.float32))

@@ -45,6 +45,7 @@ def test_fused_equals_unfused_frame_by_frame(ops, W, H, het, B, A, frames, with_
     fs = ops.FusedState(B, N, A + 1, "cuda")
     ops.fused_pack(plan, fs, x2, Nmax, a2, cc)
     emb = torch.randn(N, generator=torch.Generator().manual_seed(1)).cuda()
+    tables = ops.fused_policy_prepare(plan, fs, emb, 0.9)
     gen = torch.Generator().manual_seed(2)
     r1, c1 = torch.empty(B, device="cuda"), torch.empty((B, N), device="cuda")
     r2, c2 = torch.empty(B, device="cuda"), torch.empty((B, N), device="cuda")
@@ -68,7 +69,7 @@ def test_fused_equals_unfused_frame_by_frame(ops, W, H, het, B, A, frames, with_
         wd1 = ops.withdraw_step(plan, x1, Nmax, a1, t)
         ops.insert_step(x1, Nmax, a1, t, congestion_constant=cc, reward=r1, counts=c1)
         # fused chain
-        ops.fused_policy_step(plan, fs, x2, Nmax, emb, 0.9, uniform=u_s, choice=ch2, log_prob=lp2, entropy=en2)
+        ops.fused_policy_step(plan, fs, tables, uniform=u_s, choice=ch2, log_prob=lp2, entropy=en2)
         ops.fused_env_step(plan, fs, x2, Nmax, a2, ec, t, use_cong=with_cc, gumbel=gum, dtt=dtt2, popped=pop2,
                            withdrawn=wd2, reward=r2, counts=c2)
         assert torch.equal(ch1, ch2) and torch.equal(lp1, lp2) and torch.equal(en1, en2), f"policy frame {s}"
@@ -96,13 +97,13 @@ def test_fused_golden_rollout(ops):
     ops.reset_state(x, Nmax, ag)
     fs = ops.FusedState(1, N, A, "cuda")
     ops.fused_pack(plan, fs, x, Nmax, ag, cc)
-    emb = dev(g["w_emb"])
+    tables = ops.fused_policy_prepare(plan, fs, dev(g["w_emb"]))
     choice = torch.empty((1, N), dtype=torch.int32, device="cuda")
     lp, reward = torch.empty(1, device="cuda"), torch.empty(1, device="cuda")
     t = g["time0"]
     for s in range(g["T"]):
-        ops.fused_policy_step(plan, fs, x, Nmax, emb, 1.0, uniform=dev(g["u_sample"][s]).view(1, -1).contiguous(),
-                              choice=choice, log_prob=lp)
+        ops.fused_policy_step(plan, fs, tables, uniform=dev(g["u_sample"][s]).view(1, -1).contiguous(), choice=choice,
+                              log_prob=lp)
         onehot = torch.zeros(ei.size(1), dtype=torch.int64)
         onehot[choice.cpu().view(-1).long()] = 1
         assert torch.equal(onehot, g["action"][s]), f"action differs at frame {s}"
@@ -127,6 +128,7 @@ def test_fused_full_size_equals_unfused(ops):
     e1, e2 = mk(False), mk(True)
     emb = torch.randn(N, generator=torch.Generator().manual_seed(3)).cuda()
     e1.reset(); e2.reset()
+    e2.prepare_policy(emb)
     ch2 = torch.empty((B, N), dtype=torch.int32, device="cuda")
     lp2 = torch.empty(B, device="cuda")
     for s in range(50):
@@ -136,7 +138,7 @@ def test_fused_full_size_equals_unfused(ops):
                                       want_choice=True)
         lp1, _ = ops.graphdist_logprob_entropy(e1.plan, p, choice=ch1, want_entropy=False)
         e1.step(choice=ch1)
-        e2.policy_step_fused(emb, choice=ch2, log_prob=lp2)
+        e2.policy_step_fused(choice=ch2, log_prob=lp2)
         e2.step_fused()
         assert torch.equal(ch1, ch2) and torch.equal(lp1, lp2), f"frame {s}"
         assert torch.equal(e1.x, e2.x) and torch.equal(e1.agents, e2.agents), f"frame {s}"
