@@ -193,14 +193,20 @@ int tarl_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
  *   rec0 [B][N][4] = {head_id, head_dep, n, sel}      rec1 [B][N][4] = {tail_id, head_arr, -, -}
  *   post [B][N][4] = {n', head', tail', chosen} (state after the Direction update, written by the gather kernel)
  *   st0  [N][4]    = {MAX_NUMBER_OF_AGENT, FREE_FLOW_TIME_TRAVEL, ROAD_INDEX, congestion_constant} (static, shared)
+ *   slots [B][N][ld_slots]: slot-interleaved FIFO store, slot s at floats 3s..3s+2 = {agent id, arrival, departure};
+ *                  ld_slots >= 3*Nmax (pad to a multiple of 16 floats)
  *   a_origin / a_dest int32 [B][A], a_dep fp32 [B][A], a_status uint8 [B][A] (0 waiting, 1 on the way, 2 done).
- * tarl_fused_pack rebuilds them from x / agent_features (call after construction, reset, or any external write to x).
- * x and agent_features stay authoritative and bit-identical to the unfused path after every call. */
+ * tarl_fused_pack imports x / agent_features (call after construction, reset, or any external write to x); between
+ * pack and export the packed state is authoritative for the FIFO columns, NUMBER_OF_AGENT and SELECTED_ROAD;
+ * tarl_fused_export writes them back into x in the reference's column layout, bit-identical to the unfused path.
+ * agent_features is updated in place by every call. */
 typedef struct tarl_fused {
   float* rec0;
   float* rec1;
   float* post;
   float* st0;
+  float* slots;
+  int64_t ld_slots;
   int32_t* a_origin;
   int32_t* a_dest;
   float* a_dep;
@@ -226,13 +232,16 @@ int tarl_fused_policy_prepare(const tarl_plan* plan, const tarl_fused* f, const 
 int tarl_fused_policy_step(const tarl_plan* plan, const tarl_fused* f, int64_t B, const float* thresholds,
                            const float* log_probs, const float* entropy1, const float* uniform, uint64_t seed,
                            uint64_t counter, int32_t* choice, float* log_prob, float* entropy, tarl_stream stream);
+int tarl_fused_export(const tarl_plan* plan, const tarl_fused* f, float* x, int64_t B, int64_t x_bstride, int64_t ldx,
+                      int32_t Nmax, tarl_stream stream);
 /* == tarl_core_step + tarl_withdraw_step + tarl_insert_step in three launches (gather on the hot records; one row
- *   pass over x; insert + reward + counts). use_cong = 0 reproduces a graph without congestion_constant in insert. */
-int tarl_fused_env_step(const tarl_plan* plan, const tarl_fused* f, float* x, int64_t B, int64_t x_bstride, int64_t ldx,
-                        int32_t Nmax, float* agent_features, int64_t num_agents, int64_t a_bstride,
-                        const float* edge_attr, const float* log_edge_attr, float log_eps, int use_cong, float time,
-                        const float* gumbel, uint64_t seed, uint64_t counter, float* delta_travel_time, uint8_t* popped,
-                        uint8_t* withdrawn, int32_t* ins_scratch, float* reward, float* counts, tarl_stream stream);
+ *   pass over the slot store; insert + reward + counts). use_cong = 0 reproduces a graph without congestion_constant
+ *   in insert. All outputs after ins_scratch are nullable. */
+int tarl_fused_env_step(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, float* agent_features,
+                        int64_t num_agents, int64_t a_bstride, const float* edge_attr, const float* log_edge_attr,
+                        float log_eps, int use_cong, float time, const float* gumbel, uint64_t seed, uint64_t counter,
+                        float* delta_travel_time, uint8_t* popped, uint8_t* withdrawn, int32_t* ins_scratch,
+                        float* reward, float* counts, tarl_stream stream);
 
 /* ---- measurement hook (bench.py roofline leg; nothing comparable in the reference) ------------------------------------
  * tarl_prof_enable(n > 0) brackets the next n launches of the Direction message+aggregate kernel with HIP events on

@@ -10,8 +10,13 @@
 //   * ONE row pass applies Direction update + Response pop + withdraw to x and refreshes the hot record;
 //   * the live policy (logits = emb[road_index(dst)]), segment softmax, inverse-CDF sample, log-prob and the choice
 //     phase are one launch; agent bookkeeping scans a 1-byte status + 4-byte departure SoA instead of 36-B AoS rows.
-// x and agent_features remain authoritative and bit-identical to what the unfused kernels (and the reference) produce
-// after every frame; tests/test_gpu_fused.py checks that frame by frame.
+//   * the FIFO contents live in a slot-interleaved store  slots[b][i][s] = {id, arrival, departure}  (row stride padded
+//     to 64 B) instead of the reference's three column blocks: the Direction update's unconditional per-row write is then
+//     ONE 12-byte store instead of three dwords in three different DRAM sectors (+ counter), and `n` / `sel` live only
+//     in the hot record. tarl_fused_export rebuilds the reference's x layout on demand.
+// The packed state is authoritative between tarl_fused_pack and tarl_fused_export; the exported x and agent_features are
+// bit-identical to what the unfused kernels (and the reference) produce after every frame; tests/test_gpu_fused.py
+// checks that frame by frame.
 //
 // Domain: pure road graph (plan nodes == rows of x, ROAD_INDEX(i) == i is NOT assumed: the static record carries it).
 // Counts that reach Nmax (outside the reference's defined domain) are not supported by this path.
@@ -30,6 +35,8 @@ struct FusedBufs {
   float4* rec1;         // [B][N] {tail_id, head_arr, 0, 0}
   float4* post;         // [B][N] {n', head', tail', chosen}
   const float4* st0;    // [N]    {maxn, ff, road_index, cong}
+  float* slots;         // [B][N][lds] slot-interleaved FIFO store: slot s at floats 3s..3s+2 = {id, arrival, departure}
+  int64_t lds;          // row stride of slots in floats (>= 3*Nmax, multiple of 16)
   int32_t* a_origin;    // [B][A]
   int32_t* a_dest;      // [B][A]
   float* a_dep;         // [B][A]
@@ -51,6 +58,12 @@ __global__ __launch_bounds__(FB) void k_pack_nodes(const float* __restrict__ x, 
   fb.rec0[gid] = make_float4(xi[0], xi[2 * Nmax], n, xi[L.col_sel()]);
   fb.rec1[gid] = make_float4(tail, xi[Nmax], 0.0f, 0.0f);
   fb.post[gid] = make_float4(n, xi[0], tail, 0.0f);
+  float* sl = fb.slots + gid * fb.lds;
+  for (int sidx = 0; sidx < Nmax; ++sidx) {
+    sl[3 * sidx + 0] = xi[sidx];
+    sl[3 * sidx + 1] = xi[Nmax + sidx];
+    sl[3 * sidx + 2] = xi[2 * Nmax + sidx];
+  }
   if (b == 0 && st0_out) {
     const float maxn = xi[L.col_maxn()], ff = xi[L.col_ff()];
     float c;
@@ -207,7 +220,9 @@ __global__ __launch_bounds__(ENVB) void k_fused_choice(const int32_t* __restrict
     }
     if (pick >= 0) {
       lp += lgt[pick];
-      fb.rec0[b * N + i].w = (float)out_dst[pick];   // SELECTED_ROAD; x gets it in the row pass of the same frame
+      float4 r = fb.rec0[b * N + i];                  // SELECTED_ROAD lives in the hot record (whole-record store:
+      r.w = (float)out_dst[pick];                     // no partial-sector writes); x gets it at export
+      fb.rec0[b * N + i] = r;
       if (choice) choice[b * N + i] = out_eid[pick];
     } else {
       bad = true;
@@ -280,16 +295,15 @@ __global__ __launch_bounds__(FB) void k_fused_direction(const int32_t* __restric
 
 // ---- the row pass: Direction update + Response pop + withdraw on x, then refresh the hot record -------------------------
 __global__ __launch_bounds__(FB) void k_fused_rows(const int32_t* __restrict__ out_ptr,
-                                                   const int32_t* __restrict__ out_dst, float* __restrict__ x, Layout L,
-                                                   int64_t B, int64_t N, FusedBufs fb, float* __restrict__ ag, int64_t A,
-                                                   int64_t a_bstride, float t, uint8_t* __restrict__ popped_out,
+                                                   const int32_t* __restrict__ out_dst, int Nmax, int64_t B, int64_t N,
+                                                   FusedBufs fb, float* __restrict__ ag, int64_t A, int64_t a_bstride,
+                                                   float t, uint8_t* __restrict__ popped_out,
                                                    uint8_t* __restrict__ withdrawn_out) {
   const int64_t gid = (int64_t)blockIdx.x * FB + threadIdx.x;
   if (gid >= B * N) return;
   const int64_t b = gid / N;
   const int32_t i = (int32_t)(gid - b * N);
-  const int Nmax = L.Nmax;
-  float* xi = x + b * L.bstride + (int64_t)i * L.ldx;
+  float* sl = fb.slots + gid * fb.lds;  // slot s = sl[3s .. 3s+2] = {id, arrival, departure}
   const float4* pb = fb.post + b * N;
   const float4 p = pb[i];
   const float4 r0 = fb.rec0[gid];
@@ -309,15 +323,15 @@ __global__ __launch_bounds__(FB) void k_fused_rows(const int32_t* __restrict__ o
   }
   if (popped_out) popped_out[gid] = pop ? 1 : 0;
 
-  // Direction update (every row)
+  // Direction update (every row, also when nothing was chosen): one 12-byte store
   const int q = (int)n0;
   const float t_cong = st.w / (st.x + 10.0f - n0);
   const float tt = (t_cong != t_cong) ? t_cong : fmaxf(st.y, t_cong);
   const float dep_new = t + tt;
   if (q >= 0 && q < Nmax) {
-    xi[q] = who;
-    xi[Nmax + q] = t;
-    xi[2 * Nmax + q] = dep_new;
+    sl[3 * q + 0] = who;
+    sl[3 * q + 1] = t;
+    sl[3 * q + 2] = dep_new;
   }
   float n = p.x;  // count after the Direction update
 
@@ -342,17 +356,15 @@ __global__ __launch_bounds__(FB) void k_fused_rows(const int32_t* __restrict__ o
       w1 = out_ptr[road + 1];
     }
     for (int s = 0; s < Nmax && (float)s < n; ++s) {
-      const int src = s + shift;  // slot of the row as it is in memory right now
+      int src = s + shift;          // slot of the row as it is in memory right now
+      if (src >= Nmax) src = Nmax - 1;  // the pop duplicates the last slot
       float idf, depf;
       if (src == 0) {
         idf = head_id;
         depf = head_dep;
-      } else if (src < Nmax) {
-        idf = xi[src];
-        depf = xi[2 * Nmax + src];
-      } else {  // the pop leaves the last slot duplicated: slot Nmax-1 of the shifted row == old slot Nmax-1
-        idf = xi[Nmax - 1];
-        depf = xi[3 * Nmax - 1];
+      } else {
+        idf = sl[3 * src];
+        depf = sl[3 * src + 2];
       }
       const long long id = (long long)idf;
       if (id < 0 || id >= A) break;
@@ -372,31 +384,58 @@ __global__ __launch_bounds__(FB) void k_fused_rows(const int32_t* __restrict__ o
 
   if (shift + c > 0) {
     // pop (shift by one, last slot keeps its stale value) followed by withdraw (shift by c, zero fill), in one sweep
-    for (int blk = 0; blk < 3; ++blk) {
-      float* f = xi + blk * Nmax;
-      const float last = f[Nmax - 1];
-      for (int s = 0; s < Nmax; ++s) {
-        float v;
-        if (shift == 0) {
-          v = (s + c < Nmax) ? f[s + c] : 0.0f;
-        } else {
-          const int k = s + c;  // index into the popped row
-          v = (k < Nmax - 1) ? f[k + 1] : (k == Nmax - 1 ? last : 0.0f);
-        }
-        f[s] = v;
+    const float l0 = sl[3 * (Nmax - 1)], l1 = sl[3 * (Nmax - 1) + 1], l2 = sl[3 * (Nmax - 1) + 2];
+    for (int s = 0; s < Nmax; ++s) {
+      float v0, v1, v2;
+      int from;
+      if (shift == 0) {
+        from = (s + c < Nmax) ? s + c : -1;
+      } else {
+        const int k = s + c;  // index into the popped row
+        from = (k < Nmax - 1) ? k + 1 : (k == Nmax - 1 ? -2 : -1);
       }
+      if (from >= 0) {
+        v0 = sl[3 * from];
+        v1 = sl[3 * from + 1];
+        v2 = sl[3 * from + 2];
+      } else if (from == -2) {
+        v0 = l0; v1 = l1; v2 = l2;
+      } else {
+        v0 = v1 = v2 = 0.0f;
+      }
+      sl[3 * s] = v0;
+      sl[3 * s + 1] = v1;
+      sl[3 * s + 2] = v2;
     }
     n = n - (float)c;
-    head_id = xi[0];
-    head_arr = xi[Nmax];
-    head_dep = xi[2 * Nmax];
+    head_id = sl[0];
+    head_arr = sl[1];
+    head_dep = sl[2];
     const int qn = (int)n;
-    tail_id = (qn >= 1 && qn <= Nmax) ? xi[qn - 1] : 0.0f;
+    tail_id = (qn >= 1 && qn <= Nmax) ? sl[3 * (qn - 1)] : 0.0f;
   }
-  if (n != n0) xi[L.col_n()] = n;
-  xi[L.col_sel()] = r0.w;  // the choice phase of this frame (k_fused_choice keeps it in the hot record)
   fb.rec0[gid] = make_float4(head_id, head_dep, n, r0.w);
   fb.rec1[gid] = make_float4(tail_id, head_arr, 0.0f, 0.0f);
+}
+
+// ---- export: rebuild the reference's x layout (three FIFO column blocks + NUMBER_OF_AGENT + SELECTED_ROAD) ----------
+__global__ __launch_bounds__(FB) void k_export_rows(float* __restrict__ x, Layout L, int64_t B, int64_t N, FusedBufs fb) {
+  const int64_t gid = (int64_t)blockIdx.x * FB + threadIdx.x;
+  const int Nmax = L.Nmax;
+  if (gid >= B * N * Nmax) return;
+  const int64_t row = gid / Nmax;
+  const int sidx = (int)(gid - row * Nmax);
+  const int64_t b = row / N, i = row - b * N;
+  float* xi = x + b * L.bstride + i * L.ldx;
+  const float* sl = fb.slots + row * fb.lds + 3 * sidx;
+  xi[sidx] = sl[0];
+  xi[Nmax + sidx] = sl[1];
+  xi[2 * Nmax + sidx] = sl[2];
+  if (sidx == 0) {
+    const float4 r0 = fb.rec0[row];
+    xi[L.col_n()] = r0.z;
+    xi[L.col_sel()] = r0.w;
+  }
 }
 
 // ---- insert + reward + counts on the hot records / agent SoA ----------------------------------------------------------
@@ -411,7 +450,7 @@ __device__ __forceinline__ bool fused_target(const FusedBufs& fb, int64_t b, int
   return room > 0;
 }
 
-__global__ __launch_bounds__(ENVB) void k_fused_insert(float* __restrict__ x, Layout L, int64_t N, FusedBufs fb,
+__global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t N, FusedBufs fb,
                                                        float* __restrict__ ag, int64_t A, int64_t a_bstride,
                                                        int use_cong, float t, int32_t* __restrict__ scratch,
                                                        float* __restrict__ reward, float* __restrict__ counts) {
@@ -420,12 +459,10 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(float* __restrict__ x, La
   __shared__ int32_t s_cnt;
   __shared__ int32_t s_un_agent[INS_CAP], s_un_road[INS_CAP];
   const int64_t b = blockIdx.x;
-  float* xb = x + b * L.bstride;
   float* agb = ag + b * a_bstride;
   int32_t* cand_agent = scratch + b * 2 * A;
   int32_t* cand_road = cand_agent + A;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int Nmax = L.Nmax;
 
   // phase 1: candidates (ready agent whose target road has room). Candidates are rare (a handful per frame), so they
   // are appended unordered to an LDS list with an atomic counter and then ranked by agent id (deterministic: the
@@ -506,10 +543,10 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(float* __restrict__ x, La
       const float t_cong = use_cong ? str.w / (str.x + 10.0f - (float)(long long)n0) : 0.0f;
       const float tt = (t_cong != t_cong) ? t_cong : fmaxf(str.y, t_cong);
       if (slot >= 0 && slot < Nmax) {
-        float* xr = xb + (int64_t)r * L.ldx;
-        xr[slot] = (float)a;
-        xr[Nmax + slot] = t;
-        xr[2 * Nmax + slot] = t + tt;
+        float* sr = fb.slots + (b * N + r) * fb.lds + 3 * slot;
+        sr[0] = (float)a;
+        sr[1] = t;
+        sr[2] = t + tt;
       }
       agb[(int64_t)a * AG_COLS + AG_ON_WAY] = 1.0f;
       fb.a_status[b * A + a] = 1;
@@ -530,9 +567,7 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(float* __restrict__ x, La
     const int32_t cmt = cand_agent[idx];
     if (cmt > 0) {
       const int32_t r = cand_road[idx];
-      const float nn = fb.rec0[b * N + r].z + (float)cmt;
-      fb.rec0[b * N + r].z = nn;
-      xb[(int64_t)r * L.ldx + L.col_n()] = nn;
+      fb.rec0[b * N + r].z = fb.rec0[b * N + r].z + (float)cmt;
     }
   }
   __threadfence_block();
@@ -559,19 +594,27 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(float* __restrict__ x, La
 hipEvent_t tarl_prof_event(hipStream_t s);  // sim.hip: live timing of the message-passing gather kernel
 
 static FusedBufs to_bufs(const tarl_fused* f) {
-  return FusedBufs{(float4*)f->rec0, (float4*)f->rec1, (float4*)f->post, (const float4*)f->st0,
+  return FusedBufs{(float4*)f->rec0, (float4*)f->rec1, (float4*)f->post, (const float4*)f->st0, f->slots, f->ld_slots,
                    f->a_origin,      f->a_dest,        f->a_dep,         f->a_status};
+}
+
+static int check_fused_core(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax) {
+  TARL_REQUIRE(plan && f, "null argument");
+  TARL_REQUIRE(f->rec0 && f->rec1 && f->post && f->st0 && f->slots, "fused node buffers missing");
+  TARL_REQUIRE(B >= 1 && B < ((int64_t)1 << 31) && Nmax >= 2, "bad sizes");
+  TARL_REQUIRE(f->ld_slots >= 3 * (int64_t)Nmax, "slot row stride smaller than 3*Nmax");
+  TARL_REQUIRE(((uintptr_t)f->rec0 | (uintptr_t)f->rec1 | (uintptr_t)f->post | (uintptr_t)f->st0) % 16 == 0,
+               "fused records must be 16-byte aligned");
+  return TARL_OK;
 }
 
 static int check_fused(const tarl_plan* plan, const tarl_fused* f, const float* x, int64_t B, int64_t bstride,
                        int64_t ldx, int32_t Nmax) {
-  TARL_REQUIRE(plan && f && x, "null argument");
-  TARL_REQUIRE(f->rec0 && f->rec1 && f->post && f->st0, "fused node buffers missing");
-  TARL_REQUIRE(B >= 1 && Nmax >= 2, "bad sizes");
+  int rc = check_fused_core(plan, f, B, Nmax);
+  if (rc) return rc;
+  TARL_REQUIRE(x != nullptr, "x is null");
   TARL_REQUIRE(ldx >= 3 * (int64_t)Nmax + 7, "row stride smaller than F");
   TARL_REQUIRE(B == 1 || bstride >= plan->N * ldx, "environment stride smaller than one environment");
-  TARL_REQUIRE(((uintptr_t)f->rec0 | (uintptr_t)f->rec1 | (uintptr_t)f->post | (uintptr_t)f->st0) % 16 == 0,
-               "fused records must be 16-byte aligned");
   return TARL_OK;
 }
 
@@ -624,21 +667,31 @@ extern "C" int tarl_fused_policy_step(const tarl_plan* plan, const tarl_fused* f
   return TARL_OK;
 }
 
-extern "C" int tarl_fused_env_step(const tarl_plan* plan, const tarl_fused* f, float* x, int64_t B, int64_t x_bstride,
-                                   int64_t ldx, int32_t Nmax, float* agent_features, int64_t A, int64_t a_bstride,
-                                   const float* edge_attr, const float* log_edge_attr, float log_eps, int use_cong,
-                                   float time, const float* gumbel, uint64_t seed, uint64_t counter,
-                                   float* delta_travel_time, uint8_t* popped, uint8_t* withdrawn, int32_t* ins_scratch,
-                                   float* reward, float* counts, tarl_stream stream) {
+extern "C" int tarl_fused_export(const tarl_plan* plan, const tarl_fused* f, float* x, int64_t B, int64_t x_bstride,
+                                 int64_t ldx, int32_t Nmax, tarl_stream stream) {
   int rc = check_fused(plan, f, x, B, x_bstride, ldx, Nmax);
+  if (rc) return rc;
+  if (plan->N == 0) return TARL_OK;
+  const Layout L{Nmax, ldx, x_bstride};
+  hipLaunchKernelGGL(k_export_rows, dim3((unsigned)ceil_div(B * plan->N * Nmax, FB)), dim3(FB), 0, (hipStream_t)stream,
+                     x, L, B, plan->N, to_bufs(f));
+  TARL_LAUNCH_CHECK();
+  return TARL_OK;
+}
+
+extern "C" int tarl_fused_env_step(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax,
+                                   float* agent_features, int64_t A, int64_t a_bstride, const float* edge_attr,
+                                   const float* log_edge_attr, float log_eps, int use_cong, float time,
+                                   const float* gumbel, uint64_t seed, uint64_t counter, float* delta_travel_time,
+                                   uint8_t* popped, uint8_t* withdrawn, int32_t* ins_scratch, float* reward,
+                                   float* counts, tarl_stream stream) {
+  int rc = check_fused_core(plan, f, B, Nmax);
   if (rc) return rc;
   TARL_REQUIRE(agent_features && A >= 1 && ins_scratch, "agents / scratch missing");
   TARL_REQUIRE(f->a_origin && f->a_dest && f->a_dep && f->a_status, "fused agent buffers missing");
   TARL_REQUIRE(B == 1 || a_bstride >= A * AG_COLS, "agent stride smaller than one population");
   TARL_REQUIRE(plan->E == 0 || (edge_attr && log_edge_attr), "edge constants missing");
-  TARL_REQUIRE(B < ((int64_t)1 << 31), "too many environments");
   if (plan->N == 0) return TARL_OK;
-  const Layout L{Nmax, ldx, x_bstride};
   const FusedBufs fb = to_bufs(f);
   hipStream_t s = (hipStream_t)stream;
   const unsigned grid = (unsigned)ceil_div(B * plan->N, FB);
@@ -647,10 +700,10 @@ extern "C" int tarl_fused_env_step(const tarl_plan* plan, const tarl_fused* f, f
                      plan->N, fb, edge_attr, log_edge_attr, log_eps, time, gumbel, seed, counter, delta_travel_time);
   TARL_LAUNCH_CHECK();
   if (timed) (void)tarl_prof_event(s);
-  hipLaunchKernelGGL(k_fused_rows, dim3(grid), dim3(FB), 0, s, plan->out_ptr, plan->out_dst, x, L, B, plan->N, fb,
+  hipLaunchKernelGGL(k_fused_rows, dim3(grid), dim3(FB), 0, s, plan->out_ptr, plan->out_dst, (int)Nmax, B, plan->N, fb,
                      agent_features, A, a_bstride, time, popped, withdrawn);
   TARL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(ENVB), 0, s, x, L, plan->N, fb, agent_features, A,
+  hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(ENVB), 0, s, (int)Nmax, plan->N, fb, agent_features, A,
                      a_bstride, use_cong, time, ins_scratch, reward, counts);
   TARL_LAUNCH_CHECK();
   return TARL_OK;

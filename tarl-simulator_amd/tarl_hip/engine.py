@@ -32,11 +32,13 @@ class SimEngine:
             return t.to(dev, torch.float32).unsqueeze(0).repeat(B, 1, 1).contiguous()
 
         B = x.size(0) if x.dim() == 3 else int(num_envs or 1)
-        self.x = batched(x, B)
-        self.B, self.N, self.F = self.x.shape
+        self._x = batched(x, B)
+        self._x_stale = False               # fused path: the packed state is ahead of the reference-layout tensor
+        self._packed_stale = False          # unfused step(): x is ahead of the packed state
+        self.B, self.N, self.F = self._x.shape
         self.agents = batched(agent_features, self.B)
         self.A = self.agents.size(1)
-        self.device = self.x.device
+        self.device = self._x.device
         self.edge_index = edge_index.to("cpu", torch.int64)
         self.E = self.edge_index.size(1)
         self.plan = plan if plan is not None else ops.Plan(self.edge_index, self.N)
@@ -54,15 +56,25 @@ class SimEngine:
         self.counts = torch.zeros((self.B, self.N), dtype=torch.float32, device=self.device)
         self.dtt = None
         # fused fast path (csrc/fused.hip): packed hot records + agent SoA mirroring x / agents
-        self.fs = ops.FusedState(self.B, self.N, self.A, self.device) if fused else None
+        self.fs = ops.FusedState(self.B, self.N, self.A, self.device, self.Nmax) if fused else None
         self.sample_counter = 0
         if self.fs is not None:
             self.resync()
+
+    @property
+    def x(self):
+        """The state in the reference's layout (B, N, F). On the fused path the packed slot store is authoritative
+        between frames; reading ``x`` exports it first (one launch), so what you see is always current."""
+        if self._x_stale:
+            ops.fused_export(self.plan, self.fs, self._x, self.Nmax)
+            self._x_stale = False
+        return self._x
 
     def resync(self):
         """Rebuild the fused side buffers from ``x`` / ``agents`` (after construction, reset, or external writes)."""
         if self.fs is not None:
             ops.fused_pack(self.plan, self.fs, self.x, self.Nmax, self.agents, self.cc)
+            self._packed_stale = False
 
     # -- observation -------------------------------------------------------------------------------------------------
     @property
@@ -87,6 +99,7 @@ class SimEngine:
         """One env step for all B environments. Noise: explicit ``gumbel`` (B,E) or device Philox keyed by
         (seed, noise_counter). Returns (reward (B,), done: bool). ``self.counts`` holds the new per-node counts."""
         t = float(self.time)
+        self._packed_stale = self.fs is not None
         ops.apply_action(self.plan, self.x, self.Nmax, action_onehot=action_onehot, choice=choice)
         self.noise_counter += 1
         self.dtt, _ = ops.core_step(self.plan, self.x, self.Nmax, self.ec, t, congestion_constant=self.cc, gumbel=gumbel,
@@ -106,13 +119,19 @@ class SimEngine:
     def policy_step_fused(self, *, choice=None, log_prob=None, entropy=None, uniform=None):
         """GraphDistribution sample -> log_prob -> choice phase for all B environments (one launch)."""
         self.sample_counter += 1
+        if self._packed_stale:
+            self.resync()
+        self._x_stale = True
         ops.fused_policy_step(self.plan, self.fs, self.tables, uniform=uniform, seed=self.seed ^ 0x5DEECE66D,
                               counter=self.sample_counter, choice=choice, log_prob=log_prob, entropy=entropy)
 
     def step_fused(self, *, reward=None, counts=None, gumbel=None, dtt=None, popped=None, withdrawn=None):
         """Core + withdraw + insert (three launches). Returns done (bool)."""
         self.noise_counter += 1
-        ops.fused_env_step(self.plan, self.fs, self.x, self.Nmax, self.agents, self.ec, float(self.time),
+        if self._packed_stale:
+            self.resync()
+        self._x_stale = True
+        ops.fused_env_step(self.plan, self.fs, self.agents, self.ec, float(self.time),
                            use_cong=self.cc is not None, gumbel=gumbel, seed=self.seed, counter=self.noise_counter,
                            dtt=dtt, popped=popped, withdrawn=withdrawn, scratch=self.ins_scratch,
                            reward=self.reward if reward is None else reward,

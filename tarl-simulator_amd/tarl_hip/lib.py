@@ -51,8 +51,9 @@ SIGNATURES = {
     "tarl_fused_pack": (C.c_int, [_p, _p] + _STATE + [_p, _p, _i64, _i64, _p]),
     "tarl_fused_policy_prepare": (C.c_int, [_p, _p, _p, _i64, _f32, _p, _p, _p, _p, _p]),
     "tarl_fused_policy_step": (C.c_int, [_p, _p, _i64, _p, _p, _p, _p, _u64, _u64, _p, _p, _p, _p]),
-    "tarl_fused_env_step": (C.c_int, [_p, _p] + _STATE + [_p, _i64, _i64, _p, _p, _f32, C.c_int, _f32, _p, _u64, _u64,
-                                                         _p, _p, _p, _p, _p, _p, _p]),
+    "tarl_fused_export": (C.c_int, [_p, _p] + _STATE + [_p]),
+    "tarl_fused_env_step": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _i64, _p, _p, _f32, C.c_int, _f32, _p, _u64, _u64,
+                                      _p, _p, _p, _p, _p, _p, _p]),
     "tarl_prof_enable": (C.c_int, [_i64]),
     "tarl_prof_collect": (C.c_int, [C.POINTER(_f64), C.POINTER(_i64)]),
 }
@@ -61,7 +62,8 @@ SIGNATURES = {
 
 class FusedStruct(C.Structure):
     """``tarl_fused`` of include/tarl_hip.h."""
-    _fields_ = [(n, C.c_void_p) for n in ("rec0", "rec1", "post", "st0", "a_origin", "a_dest", "a_dep", "a_status")]
+    _fields_ = ([(n, C.c_void_p) for n in ("rec0", "rec1", "post", "st0", "slots")] + [("ld_slots", C.c_int64)] +
+                [(n, C.c_void_p) for n in ("a_origin", "a_dest", "a_dep", "a_status")])
 
 
 _lib = None

@@ -427,8 +427,10 @@ class FusedState:
     """Side buffers of the fused path (``tarl_fused`` in include/tarl_hip.h): packed hot / post / static node records and
     the agent SoA. They mirror ``x`` / ``agent_features``; call :func:`fused_pack` after any external write to those."""
 
-    def __init__(self, B: int, N: int, A: int, device):
+    def __init__(self, B: int, N: int, A: int, device, Nmax: int = 15):
         f32 = dict(dtype=torch.float32, device=device)
+        self.ld_slots = ((3 * Nmax + 15) // 16) * 16
+        self.slots = torch.zeros((B, N, self.ld_slots), **f32)
         self.rec0 = torch.zeros((B, N, 4), **f32)
         self.rec1 = torch.zeros((B, N, 4), **f32)
         self.post = torch.zeros((B, N, 4), **f32)
@@ -437,9 +439,11 @@ class FusedState:
         self.a_dest = torch.zeros((B, A), dtype=torch.int32, device=device)
         self.a_dep = torch.zeros((B, A), **f32)
         self.a_status = torch.zeros((B, A), dtype=torch.uint8, device=device)
-        self.struct = _lib.FusedStruct(*(t.data_ptr() for t in (self.rec0, self.rec1, self.post, self.st0,
-                                                                self.a_origin, self.a_dest, self.a_dep, self.a_status)))
-        self.B, self.N, self.A = B, N, A
+        self.struct = _lib.FusedStruct(self.rec0.data_ptr(), self.rec1.data_ptr(), self.post.data_ptr(),
+                                       self.st0.data_ptr(), self.slots.data_ptr(), self.ld_slots,
+                                       self.a_origin.data_ptr(), self.a_dest.data_ptr(), self.a_dep.data_ptr(),
+                                       self.a_status.data_ptr())
+        self.B, self.N, self.A, self.Nmax = B, N, A, Nmax
 
     @property
     def ref(self):
@@ -491,19 +495,26 @@ def fused_policy_step(plan: Plan, fs: FusedState, tables: PolicyTables, *, unifo
                                         _lib.ptr(entropy), _lib.current_stream()))
 
 
-def fused_env_step(plan: Plan, fs: FusedState, x, Nmax, agent_features, ec: EdgeConst, t, *, use_cong=True, gumbel=None,
-                   seed=0, counter=0, dtt=None, popped=None, withdrawn=None, scratch=None, reward=None, counts=None):
+def fused_export(plan: Plan, fs: FusedState, x, Nmax):
+    """Write the packed state (FIFO columns, NUMBER_OF_AGENT, SELECTED_ROAD) back into ``x`` (reference layout)."""
     L = _lib.load()
     B, N, bs, ldx = _state(x, Nmax)
+    _lib.check(L.tarl_fused_export(plan.handle, fs.ref, x.data_ptr(), B, bs, ldx, Nmax, _lib.current_stream()))
+
+
+def fused_env_step(plan: Plan, fs: FusedState, agent_features, ec: EdgeConst, t, *, use_cong=True, gumbel=None,
+                   seed=0, counter=0, dtt=None, popped=None, withdrawn=None, scratch=None, reward=None, counts=None):
+    L = _lib.load()
+    B, Nmax = fs.B, fs.Nmax
     A, abs_ = _agents(agent_features, B)
     if scratch is None:
-        scratch = torch.empty((B, 2 * A), dtype=torch.int32, device=x.device)
+        scratch = torch.empty((B, 2 * A), dtype=torch.int32, device=agent_features.device)
     for n, tt, dt in (("gumbel", gumbel, torch.float32), ("dtt", dtt, torch.float32), ("reward", reward, torch.float32),
                       ("counts", counts, torch.float32), ("popped", popped, torch.uint8),
                       ("withdrawn", withdrawn, torch.uint8)):
         if tt is not None:
             _contig(tt, dt, n)
-    _lib.check(L.tarl_fused_env_step(plan.handle, fs.ref, x.data_ptr(), B, bs, ldx, Nmax, agent_features.data_ptr(), A,
+    _lib.check(L.tarl_fused_env_step(plan.handle, fs.ref, B, Nmax, agent_features.data_ptr(), A,
                                      abs_, ec.edge_attr.data_ptr(), ec.log_edge_attr.data_ptr(), ec.log_eps,
                                      1 if use_cong else 0, float(t), _lib.ptr(gumbel), int(seed), int(counter),
                                      _lib.ptr(dtt), _lib.ptr(popped), _lib.ptr(withdrawn), scratch.data_ptr(),

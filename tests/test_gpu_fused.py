@@ -22,9 +22,9 @@ def dev(t):
 
 def check_records(ops, plan, fs, x, Nmax, ag, cc):
     """The maintained hot records equal a fresh pack of x / agents (tail only where the FIFO is non-empty)."""
-    ref = ops.FusedState(fs.B, fs.N, fs.A, x.device)
+    ref = ops.FusedState(fs.B, fs.N, fs.A, x.device, Nmax)
     ops.fused_pack(plan, ref, x, Nmax, ag, cc)
-    assert torch.equal(fs.rec0, ref.rec0)
+    assert torch.equal(fs.rec0, ref.rec0) and torch.equal(fs.slots, ref.slots)
     nz = (ref.rec0[..., 2] > 0)
     assert torch.equal(fs.rec1[..., 0][nz], ref.rec1[..., 0][nz]) and torch.equal(fs.rec1[..., 1], ref.rec1[..., 1])
     assert torch.equal(fs.a_status, ref.a_status) and torch.equal(fs.st0, ref.st0)
@@ -42,7 +42,7 @@ def test_fused_equals_unfused_frame_by_frame(ops, W, H, het, B, A, frames, with_
     pops = torch.stack([synth.population(A, N, seed=40 + b, t0=100, t1=130) for b in range(B)])
     x1, a1 = dev(net.x.unsqueeze(0).repeat(B, 1, 1)), dev(pops.clone())
     x2, a2 = x1.clone(), a1.clone()
-    fs = ops.FusedState(B, N, A + 1, "cuda")
+    fs = ops.FusedState(B, N, A + 1, "cuda", Nmax)
     ops.fused_pack(plan, fs, x2, Nmax, a2, cc)
     emb = torch.randn(N, generator=torch.Generator().manual_seed(1)).cuda()
     tables = ops.fused_policy_prepare(plan, fs, emb, 0.9)
@@ -70,8 +70,9 @@ def test_fused_equals_unfused_frame_by_frame(ops, W, H, het, B, A, frames, with_
         ops.insert_step(x1, Nmax, a1, t, congestion_constant=cc, reward=r1, counts=c1)
         # fused chain
         ops.fused_policy_step(plan, fs, tables, uniform=u_s, choice=ch2, log_prob=lp2, entropy=en2)
-        ops.fused_env_step(plan, fs, x2, Nmax, a2, ec, t, use_cong=with_cc, gumbel=gum, dtt=dtt2, popped=pop2,
-                           withdrawn=wd2, reward=r2, counts=c2)
+        ops.fused_env_step(plan, fs, a2, ec, t, use_cong=with_cc, gumbel=gum, dtt=dtt2, popped=pop2, withdrawn=wd2,
+                           reward=r2, counts=c2)
+        ops.fused_export(plan, fs, x2, Nmax)          # back to the reference's column layout
         assert torch.equal(ch1, ch2) and torch.equal(lp1, lp2) and torch.equal(en1, en2), f"policy frame {s}"
         assert torch.equal(x1, x2), f"state frame {s}"
         assert torch.equal(a1, a2), f"agents frame {s}"
@@ -95,7 +96,7 @@ def test_fused_golden_rollout(ops):
     cc = dev(g["congestion_constant"])
     x, ag = dev(g["x_init"].clone()).unsqueeze(0), dev(g["agents0"].clone()).unsqueeze(0)
     ops.reset_state(x, Nmax, ag)
-    fs = ops.FusedState(1, N, A, "cuda")
+    fs = ops.FusedState(1, N, A, "cuda", Nmax)
     ops.fused_pack(plan, fs, x, Nmax, ag, cc)
     tables = ops.fused_policy_prepare(plan, fs, dev(g["w_emb"]))
     choice = torch.empty((1, N), dtype=torch.int32, device="cuda")
@@ -108,8 +109,9 @@ def test_fused_golden_rollout(ops):
         onehot[choice.cpu().view(-1).long()] = 1
         assert torch.equal(onehot, g["action"][s]), f"action differs at frame {s}"
         assert abs(lp.item() - g["log_prob"][s].item()) < 1e-4
-        ops.fused_env_step(plan, fs, x, Nmax, ag, ec, t, gumbel=dev(ops.gumbel_from_uniform_cpu(g["u_dir"][s])).view(1, -1).contiguous(),
+        ops.fused_env_step(plan, fs, ag, ec, t, gumbel=dev(ops.gumbel_from_uniform_cpu(g["u_dir"][s])).view(1, -1).contiguous(),
                            reward=reward)
+        ops.fused_export(plan, fs, x, Nmax)
         t += 1
         assert torch.equal(x[0].cpu(), g["x"][s]), f"state differs at frame {s}"
         assert torch.equal(ag[0].cpu(), g["agents"][s]) and torch.equal(reward.cpu(), g["reward"][s])
