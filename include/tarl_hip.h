@@ -190,7 +190,7 @@ int tarl_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
 
 /* ---- fused rollout frame (vectorised fast path; same results as the entry points above, 4 launches per frame) ----------
  * Caller-owned side buffers that mirror x / agent_features (all device memory, 16-byte aligned):
- *   rec0 [B][N][4] = {head_id, head_dep, n, sel}      rec1 [B][N][4] = {tail_id, head_arr, -, -}
+ *   rec0 [B][N][4] = {head_id, head_dep, n, sel}      rec1 [B][N][4] = {tail_id, head_arr, pending-garbage n0, flag}
  *   post [B][N][4] = {n', head', tail', chosen} (state after the Direction update, written by the gather kernel)
  *   st0  [N][4]    = {MAX_NUMBER_OF_AGENT, FREE_FLOW_TIME_TRAVEL, ROAD_INDEX, congestion_constant} (static, shared)
  *   slots [B][N][ld_slots]: slot-interleaved FIFO store, slot s at floats 3s..3s+2 = {agent id, arrival, departure};
@@ -232,8 +232,9 @@ int tarl_fused_policy_prepare(const tarl_plan* plan, const tarl_fused* f, const 
 int tarl_fused_policy_step(const tarl_plan* plan, const tarl_fused* f, int64_t B, const float* thresholds,
                            const float* log_probs, const float* entropy1, const float* uniform, uint64_t seed,
                            uint64_t counter, int32_t* choice, float* log_prob, float* entropy, tarl_stream stream);
+/* last_step_time: the clock value passed to the most recent tarl_fused_env_step (stamps the pending garbage slots). */
 int tarl_fused_export(const tarl_plan* plan, const tarl_fused* f, float* x, int64_t B, int64_t x_bstride, int64_t ldx,
-                      int32_t Nmax, tarl_stream stream);
+                      int32_t Nmax, float last_step_time, tarl_stream stream);
 /* == tarl_core_step + tarl_withdraw_step + tarl_insert_step in three launches (gather on the hot records; one row
  *   pass over the slot store; insert + reward + counts). use_cong = 0 reproduces a graph without congestion_constant
  *   in insert. All outputs after ins_scratch are nullable. */

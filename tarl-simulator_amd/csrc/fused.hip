@@ -14,6 +14,11 @@
 //     to 64 B) instead of the reference's three column blocks: the Direction update's unconditional per-row write is then
 //     ONE 12-byte store instead of three dwords in three different DRAM sectors (+ counter), and `n` / `sel` live only
 //     in the hot record. tarl_fused_export rebuilds the reference's x layout on demand.
+//   * LAZY GARBAGE SLOT: a row that receives nobody still gets (0, t, t + tt) written into its first dead slot by the
+//     reference. That value is never read by the simulation, is overwritten by the next frame's update (or
+//     by an insertion) before anything can move it, and only shows in x. The row pass therefore just records
+//     {flag, count-at-write} in rec1 and the export kernel materialises it (same fp32 expression, same slot). The one
+//     case where the pop's "last slot keeps its value" rule would duplicate it (count == Nmax-1) is written eagerly.
 // The packed state is authoritative between tarl_fused_pack and tarl_fused_export; the exported x and agent_features are
 // bit-identical to what the unfused kernels (and the reference) produce after every frame; tests/test_gpu_fused.py
 // checks that frame by frame.
@@ -32,7 +37,7 @@
 
 struct FusedBufs {
   float4* rec0;         // [B][N] {head_id, head_dep, n, sel}
-  float4* rec1;         // [B][N] {tail_id, head_arr, 0, 0}
+  float4* rec1;         // [B][N] {tail_id, head_arr, n0 of the pending garbage write, pending flag}
   float4* post;         // [B][N] {n', head', tail', chosen}
   const float4* st0;    // [N]    {maxn, ff, road_index, cong}
   float* slots;         // [B][N][lds] slot-interleaved FIFO store: slot s at floats 3s..3s+2 = {id, arrival, departure}
@@ -256,6 +261,7 @@ __global__ __launch_bounds__(FB) void k_fused_direction(const int32_t* __restric
   const float room_i = max_i - n_i;
   const bool has_room = n_i < max_i - TARL_CONGESTION_FILE;
   float P = 0.0f, best = -FLT_MAX, best_id = 0.0f;
+  PhiloxRun rng;
   const int32_t k1 = in_ptr[i + 1];
   for (int32_t k = in_ptr[i]; k < k1; ++k) {
     const int32_t j = in_src[k];
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(FB) void k_fused_direction(const int32_t* __restric
     if (gumbel) {
       g = gumbel[ge];
     } else {
-      const float u = philox_uniform(seed, counter, (uint64_t)ge);
+      const float u = rng.uniform(seed, counter, (uint64_t)(b * E + k));
       g = -logf(-logf(u));
     }
     const float score = (m ? log_edge_attr[e] : log_eps) + g;
@@ -323,12 +329,14 @@ __global__ __launch_bounds__(FB) void k_fused_rows(const int32_t* __restrict__ o
   }
   if (popped_out) popped_out[gid] = pop ? 1 : 0;
 
-  // Direction update (every row, also when nothing was chosen): one 12-byte store
+  // Direction update (every row, also when nothing was chosen): one 12-byte store — or, for a row that received nobody,
+  // a note in the hot record (lazy garbage slot, see the file header)
   const int q = (int)n0;
   const float t_cong = st.w / (st.x + 10.0f - n0);
   const float tt = (t_cong != t_cong) ? t_cong : fmaxf(st.y, t_cong);
   const float dep_new = t + tt;
-  if (q >= 0 && q < Nmax) {
+  const bool lazy = (who == 0.0f) && (q >= 0) && (q < Nmax - 1);
+  if (!lazy && q >= 0 && q < Nmax) {
     sl[3 * q + 0] = who;
     sl[3 * q + 1] = t;
     sl[3 * q + 2] = dep_new;
@@ -408,18 +416,25 @@ __global__ __launch_bounds__(FB) void k_fused_rows(const int32_t* __restrict__ o
       sl[3 * s + 2] = v2;
     }
     n = n - (float)c;
-    head_id = sl[0];
-    head_arr = sl[1];
-    head_dep = sl[2];
+    if (lazy && n == 0.0f) {  // the row emptied: its head slot is the (unmaterialised) garbage slot
+      head_id = 0.0f;
+      head_arr = t;
+      head_dep = dep_new;
+    } else {
+      head_id = sl[0];
+      head_arr = sl[1];
+      head_dep = sl[2];
+    }
     const int qn = (int)n;
     tail_id = (qn >= 1 && qn <= Nmax) ? sl[3 * (qn - 1)] : 0.0f;
   }
   fb.rec0[gid] = make_float4(head_id, head_dep, n, r0.w);
-  fb.rec1[gid] = make_float4(tail_id, head_arr, 0.0f, 0.0f);
+  fb.rec1[gid] = make_float4(tail_id, head_arr, n0, lazy ? 1.0f : 0.0f);
 }
 
 // ---- export: rebuild the reference's x layout (three FIFO column blocks + NUMBER_OF_AGENT + SELECTED_ROAD) ----------
-__global__ __launch_bounds__(FB) void k_export_rows(float* __restrict__ x, Layout L, int64_t B, int64_t N, FusedBufs fb) {
+__global__ __launch_bounds__(FB) void k_export_rows(float* __restrict__ x, Layout L, int64_t B, int64_t N, FusedBufs fb,
+                                                    float t_last) {
   const int64_t gid = (int64_t)blockIdx.x * FB + threadIdx.x;
   const int Nmax = L.Nmax;
   if (gid >= B * N * Nmax) return;
@@ -428,11 +443,21 @@ __global__ __launch_bounds__(FB) void k_export_rows(float* __restrict__ x, Layou
   const int64_t b = row / N, i = row - b * N;
   float* xi = x + b * L.bstride + i * L.ldx;
   const float* sl = fb.slots + row * fb.lds + 3 * sidx;
-  xi[sidx] = sl[0];
-  xi[Nmax + sidx] = sl[1];
-  xi[2 * Nmax + sidx] = sl[2];
+  const float4 r0 = fb.rec0[row];
+  const float4 r1 = fb.rec1[row];
+  if (r1.w != 0.0f && sidx == (int)r0.z) {  // pending garbage write of the last Direction update -> first dead slot
+    const float4 st = fb.st0[i];
+    const float t_cong = st.w / (st.x + 10.0f - r1.z);
+    const float tt = (t_cong != t_cong) ? t_cong : fmaxf(st.y, t_cong);
+    xi[sidx] = 0.0f;
+    xi[Nmax + sidx] = t_last;
+    xi[2 * Nmax + sidx] = t_last + tt;
+  } else {
+    xi[sidx] = sl[0];
+    xi[Nmax + sidx] = sl[1];
+    xi[2 * Nmax + sidx] = sl[2];
+  }
   if (sidx == 0) {
-    const float4 r0 = fb.rec0[row];
     xi[L.col_n()] = r0.z;
     xi[L.col_sel()] = r0.w;
   }
@@ -470,14 +495,26 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t N, Fuse
   // ballot compaction into the global scratch.
   if (tid == 0) s_cnt = 0;
   __syncthreads();
-  for (int64_t a = tid; a < A; a += ENVB) {
-    if (fb.a_status[b * A + a] == 0 && fb.a_dep[b * A + a] <= t) {
-      int32_t road = 0, cap = 0;
-      if (fused_target(fb, b, N, fb.a_origin[b * A + a], &road, &cap)) {
-        const int32_t pos = atomicAdd(&s_cnt, 1);
-        if (pos < INS_CAP) {
-          s_un_agent[pos] = (int32_t)a;
-          s_un_road[pos] = road;
+  for (int64_t a0 = tid; a0 < A; a0 += 4 * ENVB) {  // 4 independent (status, departure) loads in flight per thread
+    uint8_t stt[4];
+    float dp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t a = a0 + (int64_t)j * ENVB;
+      stt[j] = a < A ? fb.a_status[b * A + a] : (uint8_t)1;
+      dp[j] = a < A ? fb.a_dep[b * A + a] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (stt[j] == 0 && dp[j] <= t) {
+        const int64_t a = a0 + (int64_t)j * ENVB;
+        int32_t road = 0, cap = 0;
+        if (fused_target(fb, b, N, fb.a_origin[b * A + a], &road, &cap)) {
+          const int32_t pos = atomicAdd(&s_cnt, 1);
+          if (pos < INS_CAP) {
+            s_un_agent[pos] = (int32_t)a;
+            s_un_road[pos] = road;
+          }
         }
       }
     }
@@ -557,6 +594,7 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t N, Fuse
         fb.rec1[b * N + r].y = t;
       }
       if (rank == m - 1) fb.rec1[b * N + r].x = (float)a;
+      if (rank == 0) fb.rec1[b * N + r].w = 0.0f;  // the arrivals overwrite a pending garbage slot
       if (rank == 0) commit = (int32_t)m;
     }
     cand_agent[idx] = commit;
@@ -668,13 +706,13 @@ extern "C" int tarl_fused_policy_step(const tarl_plan* plan, const tarl_fused* f
 }
 
 extern "C" int tarl_fused_export(const tarl_plan* plan, const tarl_fused* f, float* x, int64_t B, int64_t x_bstride,
-                                 int64_t ldx, int32_t Nmax, tarl_stream stream) {
+                                 int64_t ldx, int32_t Nmax, float last_step_time, tarl_stream stream) {
   int rc = check_fused(plan, f, x, B, x_bstride, ldx, Nmax);
   if (rc) return rc;
   if (plan->N == 0) return TARL_OK;
   const Layout L{Nmax, ldx, x_bstride};
   hipLaunchKernelGGL(k_export_rows, dim3((unsigned)ceil_div(B * plan->N * Nmax, FB)), dim3(FB), 0, (hipStream_t)stream,
-                     x, L, B, plan->N, to_bufs(f));
+                     x, L, B, plan->N, to_bufs(f), last_step_time);
   TARL_LAUNCH_CHECK();
   return TARL_OK;
 }

@@ -49,6 +49,7 @@ __global__ __launch_bounds__(SIM_BLOCK) void k_direction_gather(PlanView pv, con
   float P = 0.0f;
   float best = -FLT_MAX;  // scatter_max starts from numeric_limits::lowest()
   float best_id = 0.0f;
+  PhiloxRun rng;          // device noise is keyed by the in-edge's CSC position: one Philox block per node at degree 4
   const int32_t k0 = pv.in_ptr[i], k1 = pv.in_ptr[i + 1];
   for (int32_t k = k0; k < k1; ++k) {
     const int32_t j = pv.in_src[k];
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(SIM_BLOCK) void k_direction_gather(PlanView pv, con
     if (gumbel) {
       g = gumbel[ge];
     } else {
-      const float u = philox_uniform(seed, counter, (uint64_t)ge);
+      const float u = rng.uniform(seed, counter, (uint64_t)(b * pv.E + k));
       g = -logf(-logf(u));
     }
     const float score = (m ? log_edge_attr[e] : log_eps) + g;

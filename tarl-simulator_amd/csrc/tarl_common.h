@@ -104,4 +104,23 @@ __device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t counter,
   return u01_open(o[index & 3]);
 }
 
+// uniforms for a run of nearby indices: the 128-bit Philox block is recomputed only when the index leaves it
+struct PhiloxRun {
+  uint32_t o0, o1, o2, o3;  // named registers: a runtime-indexed array would live in scratch memory
+  uint64_t blk;
+  __device__ __forceinline__ PhiloxRun() : o0(0), o1(0), o2(0), o3(0), blk(~0ull) {}
+  __device__ __forceinline__ float uniform(uint64_t seed, uint64_t counter, uint64_t index) {
+    const uint64_t b = index >> 2;
+    if (b != blk) {
+      blk = b;
+      uint32_t o[4];
+      philox4x32_10((uint32_t)b, (uint32_t)(b >> 32), (uint32_t)counter, (uint32_t)(counter >> 32), (uint32_t)seed,
+                    (uint32_t)(seed >> 32), o);
+      o0 = o[0]; o1 = o[1]; o2 = o[2]; o3 = o[3];
+    }
+    const uint32_t w = (uint32_t)(index & 3);
+    return u01_open(w == 0 ? o0 : (w == 1 ? o1 : (w == 2 ? o2 : o3)));
+  }
+};
+
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

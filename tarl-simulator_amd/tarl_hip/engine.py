@@ -35,6 +35,7 @@ class SimEngine:
         self._x = batched(x, B)
         self._x_stale = False               # fused path: the packed state is ahead of the reference-layout tensor
         self._packed_stale = False          # unfused step(): x is ahead of the packed state
+        self._last_step_time = 0.0
         self.B, self.N, self.F = self._x.shape
         self.agents = batched(agent_features, self.B)
         self.A = self.agents.size(1)
@@ -66,7 +67,7 @@ class SimEngine:
         """The state in the reference's layout (B, N, F). On the fused path the packed slot store is authoritative
         between frames; reading ``x`` exports it first (one launch), so what you see is always current."""
         if self._x_stale:
-            ops.fused_export(self.plan, self.fs, self._x, self.Nmax)
+            ops.fused_export(self.plan, self.fs, self._x, self.Nmax, self._last_step_time)
             self._x_stale = False
         return self._x
 
@@ -131,6 +132,7 @@ class SimEngine:
         if self._packed_stale:
             self.resync()
         self._x_stale = True
+        self._last_step_time = float(self.time)
         ops.fused_env_step(self.plan, self.fs, self.agents, self.ec, float(self.time),
                            use_cong=self.cc is not None, gumbel=gumbel, seed=self.seed, counter=self.noise_counter,
                            dtt=dtt, popped=popped, withdrawn=withdrawn, scratch=self.ins_scratch,

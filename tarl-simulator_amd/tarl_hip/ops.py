@@ -495,11 +495,13 @@ def fused_policy_step(plan: Plan, fs: FusedState, tables: PolicyTables, *, unifo
                                         _lib.ptr(entropy), _lib.current_stream()))
 
 
-def fused_export(plan: Plan, fs: FusedState, x, Nmax):
-    """Write the packed state (FIFO columns, NUMBER_OF_AGENT, SELECTED_ROAD) back into ``x`` (reference layout)."""
+def fused_export(plan: Plan, fs: FusedState, x, Nmax, last_step_time):
+    """Write the packed state (FIFO columns, NUMBER_OF_AGENT, SELECTED_ROAD) back into ``x`` (reference layout).
+    ``last_step_time``: the clock passed to the most recent :func:`fused_env_step`."""
     L = _lib.load()
     B, N, bs, ldx = _state(x, Nmax)
-    _lib.check(L.tarl_fused_export(plan.handle, fs.ref, x.data_ptr(), B, bs, ldx, Nmax, _lib.current_stream()))
+    _lib.check(L.tarl_fused_export(plan.handle, fs.ref, x.data_ptr(), B, bs, ldx, Nmax, float(last_step_time),
+                                   _lib.current_stream()))
 
 
 def fused_env_step(plan: Plan, fs: FusedState, agent_features, ec: EdgeConst, t, *, use_cong=True, gumbel=None,

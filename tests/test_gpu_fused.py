@@ -24,9 +24,10 @@ def check_records(ops, plan, fs, x, Nmax, ag, cc):
     """The maintained hot records equal a fresh pack of x / agents (tail only where the FIFO is non-empty)."""
     ref = ops.FusedState(fs.B, fs.N, fs.A, x.device, Nmax)
     ops.fused_pack(plan, ref, x, Nmax, ag, cc)
-    assert torch.equal(fs.rec0, ref.rec0) and torch.equal(fs.slots, ref.slots)
+    assert torch.equal(fs.rec0, ref.rec0)
     nz = (ref.rec0[..., 2] > 0)
     assert torch.equal(fs.rec1[..., 0][nz], ref.rec1[..., 0][nz]) and torch.equal(fs.rec1[..., 1], ref.rec1[..., 1])
+    assert float(fs.rec1[..., 3].sum()) > 0        # some rows carry a pending (lazy) garbage slot
     assert torch.equal(fs.a_status, ref.a_status) and torch.equal(fs.st0, ref.st0)
 
 
@@ -72,7 +73,7 @@ def test_fused_equals_unfused_frame_by_frame(ops, W, H, het, B, A, frames, with_
         ops.fused_policy_step(plan, fs, tables, uniform=u_s, choice=ch2, log_prob=lp2, entropy=en2)
         ops.fused_env_step(plan, fs, a2, ec, t, use_cong=with_cc, gumbel=gum, dtt=dtt2, popped=pop2, withdrawn=wd2,
                            reward=r2, counts=c2)
-        ops.fused_export(plan, fs, x2, Nmax)          # back to the reference's column layout
+        ops.fused_export(plan, fs, x2, Nmax, t)       # back to the reference's column layout
         assert torch.equal(ch1, ch2) and torch.equal(lp1, lp2) and torch.equal(en1, en2), f"policy frame {s}"
         assert torch.equal(x1, x2), f"state frame {s}"
         assert torch.equal(a1, a2), f"agents frame {s}"
@@ -111,7 +112,7 @@ def test_fused_golden_rollout(ops):
         assert abs(lp.item() - g["log_prob"][s].item()) < 1e-4
         ops.fused_env_step(plan, fs, ag, ec, t, gumbel=dev(ops.gumbel_from_uniform_cpu(g["u_dir"][s])).view(1, -1).contiguous(),
                            reward=reward)
-        ops.fused_export(plan, fs, x, Nmax)
+        ops.fused_export(plan, fs, x, Nmax, t)
         t += 1
         assert torch.equal(x[0].cpu(), g["x"][s]), f"state differs at frame {s}"
         assert torch.equal(ag[0].cpu(), g["agents"][s]) and torch.equal(reward.cpu(), g["reward"][s])
