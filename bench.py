@@ -131,6 +131,7 @@ def main():
     rank, world, local = dist_utils.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run for N>1)"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the product path has no CPU fallback)"
+    local = local % torch.cuda.device_count()      # (rehearsal: several ranks may share one GPU under gloo)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     L = lib.load()

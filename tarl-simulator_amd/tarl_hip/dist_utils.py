@@ -26,10 +26,10 @@ def init_from_env(backend=None):
     if ws > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+        if backend is None:   # TARL_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsals (RCCL refuses that)
+            backend = os.environ.get("TARL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=ws)
     return rank, ws, local
 
