@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--edges", type=int, default=10000)
     ap.add_argument("--agents", type=int, default=16384)
-    ap.add_argument("--envs", type=int, default=512, help="vectorised environments per GPU")
+    ap.add_argument("--envs", type=int, default=1024, help="vectorised environments per GPU")
     ap.add_argument("--rollout-steps", type=int, default=256)
     ap.add_argument("--epochs", type=int, default=1)
     ap.add_argument("--sub-batch", type=int, default=32)
@@ -169,7 +169,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"mpnn+ppo train, {E}-edge synthetic torus dual graph ({engine.N} roads), "
                                    f"{args.agents} agents per environment, rollout-steps {T}, epochs {args.epochs}, "
-                                   f"sub-batch {args.sub_batch} (BASELINE config 4)",
+                                   f"sub-batch {args.sub_batch}" +
+                                   (" (BASELINE config 4)" if (E, args.agents) == (10000, 16384) else ""),
                        "envs_per_gpu": B, "env_steps_per_step": B * T, "parallelism": f"dp{world} (rollouts sharded, "
                        "one gradient all-reduce per optimiser step)"},
             "msgpass_edges_per_sec": value * E,
