@@ -163,6 +163,16 @@ def main():
         avg_s = (k_ms.value / max(1, k_n.value)) * 1e-3
         alg_bytes = DIR_BYTES_PER_EDGE * B * E + DIR_BYTES_PER_NODE * B * engine.N
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+        # HBM traffic per launch from the PMC counters (2*FETCH_SIZE + WRITE_SIZE, collected in separate rocprofv3 --pmc
+        # passes of the same kernels at the same sizes and committed under profiles/); null when no matching record.
+        traffic, traffic_src = None, None
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", "r01_v2_pmc_traffic.json")))
+            if rec["config"] == {"edges": E, "agents": args.agents, "envs": B}:
+                traffic = rec["kernels"]["k_fused_direction"]["hbm_bytes_per_launch"]
+                traffic_src = "profiles/r01_v2_pmc_traffic.json (rocprofv3 --pmc, 2*FETCH_SIZE + WRITE_SIZE)"
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "ppo_env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -176,7 +186,8 @@ def main():
             "msgpass_edges_per_sec": value * E,
             "roofline": {"bound": "hbm", "kernel": "k_fused_direction (DirectionMPNN message+aggregate on the packed hot records)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": avg_s * 1e6, "launches_timed": k_n.value},
         }
         if world == 1 and args.cpu_seconds > 0:
