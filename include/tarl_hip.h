@@ -188,13 +188,23 @@ int tarl_ppo_loss(const float* log_prob_new, const float* log_prob_old, const fl
 int tarl_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,
                    double lr, double beta1, double beta2, double eps, float grad_scale, tarl_stream stream);
 
-/* ---- fused rollout frame (vectorised fast path; same results as the entry points above, 4 launches per frame) ----------
+/* tarl_critic_mlp_fwd_slabs: same network on the env-minor rollout buffer counts [M / rows_per_slab][N][rows_per_slab]
+ *   (= [frame][node][env]); rows_per_slab must be a multiple of 128 and M a whole number of slabs. value [M] is in
+ *   (frame, env) order. */
+int tarl_critic_mlp_fwd_slabs(const float* counts, int64_t rows_per_slab, int64_t M, int64_t N, const float* time_rows,
+                              int64_t rows_per_time, const float* w1, const float* b1, const float* w2, const float* b2,
+                              const float* w3, const float* b3, float* value, tarl_stream stream);
+
+/* ---- fused rollout frame (vectorised fast path; same results as the entry points above, 3 launches per frame) ----------
+ * ENV-MINOR layout: every per-(node, environment) buffer is stored [node][environment], so that a wavefront holds 64
+ * environments of one node: topology / table loads are wave-uniform and record gathers are coalesced.
  * Caller-owned side buffers that mirror x / agent_features (all device memory, 16-byte aligned):
- *   rec0 [B][N][4] = {head_id, head_dep, n, sel}      rec1 [B][N][4] = {tail_id, head_arr, pending-garbage n0, flag}
- *   post [B][N][4] = {n', head', tail', chosen} (state after the Direction update, written by the gather kernel)
+ *   rec0 [N][B][4] = {head_id, head_dep, n, sel}      rec1 [N][B][4] = {tail_id, head_arr, pending-garbage n0, flag}
+ *   post [N][B][4] = {n', head', tail', chosen} (state after the Direction update, written by the gather kernel)
  *   st0  [N][4]    = {MAX_NUMBER_OF_AGENT, FREE_FLOW_TIME_TRAVEL, ROAD_INDEX, congestion_constant} (static, shared)
- *   slots [B][N][ld_slots]: slot-interleaved FIFO store, slot s at floats 3s..3s+2 = {agent id, arrival, departure};
+ *   slots [N][B][ld_slots]: slot-interleaved FIFO store, slot s at floats 3s..3s+2 = {agent id, arrival, departure};
  *                  ld_slots >= 3*Nmax (pad to a multiple of 16 floats)
+ *   selnew [N][B], part [tarl_fused_num_chunks(plan)][B][4]: scratch
  *   a_origin / a_dest int32 [B][A], a_dep fp32 [B][A], a_status uint8 [B][A] (0 waiting, 1 on the way, 2 done).
  * tarl_fused_pack imports x / agent_features (call after construction, reset, or any external write to x); between
  * pack and export the packed state is authoritative for the FIFO columns, NUMBER_OF_AGENT and SELECTED_ROAD;
@@ -207,42 +217,44 @@ typedef struct tarl_fused {
   float* st0;
   float* slots;
   int64_t ld_slots;
+  float* selnew;
+  float* part;
   int32_t* a_origin;
   int32_t* a_dest;
   float* a_dep;
   uint8_t* a_status;
 } tarl_fused;
 
+int64_t tarl_fused_num_chunks(const tarl_plan* plan);
 int tarl_fused_pack(const tarl_plan* plan, const tarl_fused* f, const float* x, int64_t B, int64_t x_bstride,
                     int64_t ldx, int32_t Nmax, const float* congestion_constant, const float* agent_features,
                     int64_t num_agents, int64_t a_bstride, tarl_stream stream);
+/* last_step_time: the clock value passed to the most recent tarl_fused_frame (stamps the pending garbage slots). */
+int tarl_fused_export(const tarl_plan* plan, const tarl_fused* f, float* x, int64_t B, int64_t x_bstride, int64_t ldx,
+                      int32_t Nmax, float last_step_time, tarl_stream stream);
 /* The live policy (MPNNPolicyNet.forward: logits = emb[ROAD_INDEX(dst)]) does not read the dynamic state, so
  * GraphDistribution's probabilities are the same for every environment and frame between two optimiser steps.
  * tarl_fused_policy_prepare evaluates them once per parameter update — same arithmetic and reduction trees as
  * tarl_policy_edge_logits_fwd + tarl_graphdist_softmax + the cumsum of tarl_graphdist_sample +
  * tarl_graphdist_logprob_entropy_fwd — into per-edge tables in plan (CSR) order: thresholds [E] (fp32 inverse-CDF
- * thresholds), log_probs [E] (log(p + 1e-8)), entropy1 [1]; group_base: double scratch [num_groups + 1].
- * tarl_fused_policy_step == GraphDistribution.sample() + log_prob() (+ entropy) + the choice phase of
- * SimulatorEnv._step for B environments in one launch: choice int32 [B][N] (nullable), log_prob / entropy [B]
- * (nullable); uniform [B][num_groups] or NULL (Philox). SELECTED_ROAD goes to rec0 and reaches x in the row pass of
- * the same frame (tarl_fused_env_step). */
+ * thresholds), log_probs [E] (log(p + 1e-8)), entropy1 [1]; group_base: double scratch [num_groups + 1]. */
 int tarl_fused_policy_prepare(const tarl_plan* plan, const tarl_fused* f, const float* emb, int64_t num_embeddings,
                               float temperature, double* group_base, float* thresholds, float* log_probs,
                               float* entropy1, tarl_stream stream);
-int tarl_fused_policy_step(const tarl_plan* plan, const tarl_fused* f, int64_t B, const float* thresholds,
-                           const float* log_probs, const float* entropy1, const float* uniform, uint64_t seed,
-                           uint64_t counter, int32_t* choice, float* log_prob, float* entropy, tarl_stream stream);
-/* last_step_time: the clock value passed to the most recent tarl_fused_env_step (stamps the pending garbage slots). */
-int tarl_fused_export(const tarl_plan* plan, const tarl_fused* f, float* x, int64_t B, int64_t x_bstride, int64_t ldx,
-                      int32_t Nmax, float last_step_time, tarl_stream stream);
-/* == tarl_core_step + tarl_withdraw_step + tarl_insert_step in three launches (gather on the hot records; one row
- *   pass over the slot store; insert + reward + counts). use_cong = 0 reproduces a graph without congestion_constant
- *   in insert. All outputs after ins_scratch are nullable. */
-int tarl_fused_env_step(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, float* agent_features,
-                        int64_t num_agents, int64_t a_bstride, const float* edge_attr, const float* log_edge_attr,
-                        float log_eps, int use_cong, float time, const float* gumbel, uint64_t seed, uint64_t counter,
-                        float* delta_travel_time, uint8_t* popped, uint8_t* withdrawn, int32_t* ins_scratch,
-                        float* reward, float* counts, tarl_stream stream);
+/* tarl_fused_frame == one collector frame for B environments: GraphDistribution.sample() + log_prob() (+ entropy) and
+ *   the choice phase, then tarl_core_step + tarl_withdraw_step + tarl_insert_step, in three launches.
+ *   uniform [B][num_groups] or NULL (Philox keyed by policy_seed / policy_counter); gumbel [B][E] or NULL (Philox keyed
+ *   by seed / counter). Nullable outputs: delta_travel_time [B][E], popped / withdrawn uint8 [B][N] (env-major, like the
+ *   unfused entry points); choice int32 [N][B] and counts fp32 [N][B] (ENV-MINOR); log_prob, entropy, reward [B].
+ *   log_prob sums the same terms as tarl_graphdist_logprob_entropy_fwd in a different (fixed) order: equal to fp32
+ *   rounding, not bit-identical. use_cong = 0 reproduces a graph without congestion_constant in insert. */
+int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, const float* thresholds,
+                     const float* log_probs, const float* entropy1, const float* uniform, uint64_t policy_seed,
+                     uint64_t policy_counter, float* agent_features, int64_t num_agents, int64_t a_bstride,
+                     const float* edge_attr, const float* log_edge_attr, float log_eps, int use_cong, float time,
+                     const float* gumbel, uint64_t seed, uint64_t counter, float* delta_travel_time, uint8_t* popped,
+                     uint8_t* withdrawn, int32_t* ins_scratch, int32_t* choice, float* log_prob, float* entropy,
+                     float* reward, float* counts, tarl_stream stream);
 
 /* ---- measurement hook (bench.py roofline leg; nothing comparable in the reference) ------------------------------------
  * tarl_prof_enable(n > 0) brackets the next n launches of the Direction message+aggregate kernel with HIP events on

@@ -29,8 +29,12 @@ struct CriticParams {
 // C/D layout of the 32x32 f32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 __device__ __forceinline__ int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-__global__ __launch_bounds__(CR_THREADS) void k_critic_fwd(const float* __restrict__ counts, int64_t ldc, int64_t M,
-                                                           int64_t N, const float* __restrict__ time_rows,
+// rps == 0: counts is row-major [M][ldc]. rps > 0 ("slab" mode, rps % CR_BM == 0): counts is [M / rps][N][rps] — the
+// env-minor rollout buffer [frame][node][env] — i.e. k-major inside each slab of rps rows, which is exactly the order
+// the LDS staging wants (lanes along rows => coalesced).
+__global__ __launch_bounds__(CR_THREADS) void k_critic_fwd(const float* __restrict__ counts, int64_t ldc, int64_t rps,
+                                                           int64_t M, int64_t N,
+                                                           const float* __restrict__ time_rows,
                                                            int64_t rows_per_time, CriticParams P,
                                                            float* __restrict__ value, float* __restrict__ h1_out,
                                                            float* __restrict__ h2_out) {
@@ -44,13 +48,25 @@ __global__ __launch_bounds__(CR_THREADS) void k_critic_fwd(const float* __restri
 
   f32x16 acc0 = {0}, acc1 = {0};
   for (int64_t k0 = 0; k0 < N; k0 += CR_BK) {
-    // stage X tile: 128 rows x 32 k  (lanes along k => 128-B coalesced segments)
+    if (rps == 0) {
+      // stage X tile: 128 rows x 32 k  (row-major input: lanes along k => 128-B coalesced segments)
 #pragma unroll
-    for (int it = 0; it < (CR_BM * CR_BK) / CR_THREADS; ++it) {
-      const int idx = it * CR_THREADS + tid;
-      const int r = idx >> 5, k = idx & 31;
-      const int64_t gr = row0 + r, gk = k0 + k;
-      Xs[k * (CR_BM + 1) + r] = (gr < M && gk < N) ? counts[gr * ldc + gk] : 0.0f;
+      for (int it = 0; it < (CR_BM * CR_BK) / CR_THREADS; ++it) {
+        const int idx = it * CR_THREADS + tid;
+        const int r = idx >> 5, k = idx & 31;
+        const int64_t gr = row0 + r, gk = k0 + k;
+        Xs[k * (CR_BM + 1) + r] = (gr < M && gk < N) ? counts[gr * ldc + gk] : 0.0f;
+      }
+    } else {
+      // slab input: lanes along rows => 256-B coalesced segments, conflict-free LDS stores
+      const int64_t slab_base = (row0 / rps) * (N * rps) + (row0 % rps);
+#pragma unroll
+      for (int it = 0; it < (CR_BM * CR_BK) / CR_THREADS; ++it) {
+        const int idx = it * CR_THREADS + tid;
+        const int r = idx & (CR_BM - 1), k = idx >> 7;
+        const int64_t gr = row0 + r, gk = k0 + k;
+        Xs[k * (CR_BM + 1) + r] = (gr < M && gk < N) ? counts[slab_base + gk * rps + r] : 0.0f;
+      }
     }
 #pragma unroll
     for (int it = 0; it < (CR_H * CR_BK) / CR_THREADS; ++it) {
@@ -214,18 +230,37 @@ __global__ __launch_bounds__(CR_THREADS) void k_critic_bwd_w1(int64_t M, int64_t
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
+static int critic_fwd(const float* counts, int64_t ldc, int64_t rps, int64_t M, int64_t N, const float* time_rows,
+                      int64_t rows_per_time, const float* w1, const float* b1, const float* w2, const float* b2,
+                      const float* w3, const float* b3, float* value, float* h1_out, float* h2_out,
+                      tarl_stream stream) {
+  TARL_REQUIRE(counts && time_rows && w1 && b1 && w2 && b2 && w3 && b3 && value, "null argument");
+  TARL_REQUIRE(M >= 1 && N >= 1 && rows_per_time >= 1, "bad sizes");
+  TARL_REQUIRE(ceil_div(M, CR_BM) < ((int64_t)1 << 31), "too many rows");
+  const CriticParams P{w1, b1, w2, b2, w3, b3};
+  hipLaunchKernelGGL(k_critic_fwd, dim3((unsigned)ceil_div(M, CR_BM)), dim3(CR_THREADS), 0, (hipStream_t)stream, counts,
+                     ldc, rps, M, N, time_rows, rows_per_time, P, value, h1_out, h2_out);
+  TARL_LAUNCH_CHECK();
+  return TARL_OK;
+}
+
 extern "C" int tarl_critic_mlp_fwd(const float* counts, int64_t ldc, int64_t M, int64_t N, const float* time_rows,
                                    int64_t rows_per_time, const float* w1, const float* b1, const float* w2,
                                    const float* b2, const float* w3, const float* b3, float* value, float* h1_out,
                                    float* h2_out, tarl_stream stream) {
-  TARL_REQUIRE(counts && time_rows && w1 && b1 && w2 && b2 && w3 && b3 && value, "null argument");
-  TARL_REQUIRE(M >= 1 && N >= 1 && ldc >= N && rows_per_time >= 1, "bad sizes");
-  TARL_REQUIRE(ceil_div(M, CR_BM) < ((int64_t)1 << 31), "too many rows");
-  const CriticParams P{w1, b1, w2, b2, w3, b3};
-  hipLaunchKernelGGL(k_critic_fwd, dim3((unsigned)ceil_div(M, CR_BM)), dim3(CR_THREADS), 0, (hipStream_t)stream, counts,
-                     ldc, M, N, time_rows, rows_per_time, P, value, h1_out, h2_out);
-  TARL_LAUNCH_CHECK();
-  return TARL_OK;
+  TARL_REQUIRE(ldc >= N, "row stride smaller than N");
+  return critic_fwd(counts, ldc, 0, M, N, time_rows, rows_per_time, w1, b1, w2, b2, w3, b3, value, h1_out, h2_out,
+                    stream);
+}
+
+extern "C" int tarl_critic_mlp_fwd_slabs(const float* counts, int64_t rows_per_slab, int64_t M, int64_t N,
+                                         const float* time_rows, int64_t rows_per_time, const float* w1,
+                                         const float* b1, const float* w2, const float* b2, const float* w3,
+                                         const float* b3, float* value, tarl_stream stream) {
+  TARL_REQUIRE(rows_per_slab >= CR_BM && rows_per_slab % CR_BM == 0, "rows_per_slab must be a multiple of 128");
+  TARL_REQUIRE(M % rows_per_slab == 0, "M must be a whole number of slabs");
+  return critic_fwd(counts, 0, rows_per_slab, M, N, time_rows, rows_per_time, w1, b1, w2, b2, w3, b3, value, nullptr,
+                    nullptr, stream);
 }
 
 extern "C" int tarl_critic_mlp_bwd(const float* counts, int64_t ldc, int64_t M, int64_t N, const float* time_rows,

@@ -1,61 +1,68 @@
-// fused.hip — the vectorised rollout frame in 4 launches (v2 of the hot loop), bit-identical to the unfused kernels.
+// fused.hip — the vectorised rollout frame in 3 launches, bit-identical (state, agents, actions, rewards) to the unfused
+// kernels and therefore to the reference.
 //
 // Why: the reference's AoS row (F = 3*Nmax+7 floats, 208 B at Nmax = 15) scatters the ~10 scalars a message needs over
 // 2-3 cache lines, and eleven separate launches per frame each re-stream the whole state. Here
-//   * a packed per-(env,node) HOT RECORD  rec0 = {head_id, head_dep, n, sel}, rec1 = {tail_id, head_arr, -, -}
-//     and a per-node STATIC record st0 = {maxn, ff, road_index, cong} (shared by all environments) mirror the row, so
-//     the gather kernels read 16 B per neighbour and never touch x;
+//   * a packed per-(node, env) HOT RECORD  rec0 = {head_id, head_dep, n, sel}, rec1 = {tail_id, head_arr, pending-garbage
+//     n0, flag} and a per-node STATIC record st0 = {maxn, ff, road_index, cong} (shared by all environments) mirror the
+//     row, so the gather kernels read 16 B per neighbour and never touch the FIFO storage;
+//   * ENV-MINOR LAYOUT: every per-(node, env) array is stored [node][env]. A workgroup owns a tile of consecutive
+//     environments (one per lane) and walks a chunk of nodes: all topology / table / static loads are wave-uniform
+//     (scalar loads through the constant cache) and every record gather is a fully coalesced 16 B x 64 = 1 KiB load —
+//     there is no dependent index -> address -> data chain left in the vector memory path;
 //   * the Direction gather also emits post = {n', head', tail', chosen}: the state every row will have after the
-//     Direction update, from which the Response "accepted" test is evaluated without a second pass over x;
-//   * ONE row pass applies Direction update + Response pop + withdraw to x and refreshes the hot record;
-//   * the live policy (logits = emb[road_index(dst)]), segment softmax, inverse-CDF sample, log-prob and the choice
-//     phase are one launch; agent bookkeeping scans a 1-byte status + 4-byte departure SoA instead of 36-B AoS rows.
-//   * the FIFO contents live in a slot-interleaved store  slots[b][i][s] = {id, arrival, departure}  (row stride padded
-//     to 64 B) instead of the reference's three column blocks: the Direction update's unconditional per-row write is then
-//     ONE 12-byte store instead of three dwords in three different DRAM sectors (+ counter), and `n` / `sel` live only
-//     in the hot record. tarl_fused_export rebuilds the reference's x layout on demand.
+//     Direction update, from which the Response "accepted" test is evaluated without a second pass over the FIFOs;
+//   * the live policy's sample is state-independent (see k_policy_tables): the choice phase is folded into the
+//     Direction kernel, which re-derives each in-neighbour's selected road from that neighbour's Philox draw;
+//   * ONE row pass applies Direction update + Response pop + withdraw and refreshes the hot record;
+//   * the FIFO contents live in a slot-interleaved store  slots[node][env][s] = {id, arrival, departure}: the Direction
+//     update's per-row write is ONE 12-byte store instead of three dwords in three DRAM sectors (+ counter);
 //   * LAZY GARBAGE SLOT: a row that receives nobody still gets (0, t, t + tt) written into its first dead slot by the
 //     reference. That value is never read by the simulation, is overwritten by the next frame's update (or
-//     by an insertion) before anything can move it, and only shows in x. The row pass therefore just records
-//     {flag, count-at-write} in rec1 and the export kernel materialises it (same fp32 expression, same slot). The one
-//     case where the pop's "last slot keeps its value" rule would duplicate it (count == Nmax-1) is written eagerly.
+//     by an insertion) before anything can move it, and only shows in x. The row pass just records {flag, n0} in rec1 and
+//     the export kernel materialises it (same fp32 expression, same slot). The one case where the pop's "last slot keeps
+//     its value" rule would duplicate it (count == Nmax-1) is written eagerly;
+//   * agent bookkeeping scans a 1-byte status + 4-byte departure SoA instead of 36-B AoS rows.
 // The packed state is authoritative between tarl_fused_pack and tarl_fused_export; the exported x and agent_features are
-// bit-identical to what the unfused kernels (and the reference) produce after every frame; tests/test_gpu_fused.py
-// checks that frame by frame.
+// bit-identical to what the unfused kernels (and the reference) produce after every frame (tests/test_gpu_fused.py).
 //
-// Domain: pure road graph (plan nodes == rows of x, ROAD_INDEX(i) == i is NOT assumed: the static record carries it).
-// Counts that reach Nmax (outside the reference's defined domain) are not supported by this path.
+// Domain: pure road graph (plan nodes == rows of x). Counts that reach Nmax (outside the reference's defined domain,
+// DESIGN.md Q25) are not supported by this path.
 #include <float.h>
 #include <math.h>
 
 #include "tarl_common.h"
 
-#define FB 256
-#define ENVB 1024
+#define FB 256          // pack / export kernels
+#define ENVB 1024       // one-workgroup-per-environment kernels
+#define TILE 256        // environments per workgroup in the env-minor kernels (one per lane)
+#define NCHUNK 16       // nodes walked by one workgroup of the env-minor kernels
 #define LOG_EPS_P 1e-8f
-#define INS_CAP 2048   // LDS candidate list of the insert kernel (entries)
+#define INS_CAP 2048    // LDS candidate list of the insert kernel (entries)
 
 struct FusedBufs {
-  float4* rec0;         // [B][N] {head_id, head_dep, n, sel}
-  float4* rec1;         // [B][N] {tail_id, head_arr, n0 of the pending garbage write, pending flag}
-  float4* post;         // [B][N] {n', head', tail', chosen}
+  float4* rec0;         // [N][B] {head_id, head_dep, n, sel}
+  float4* rec1;         // [N][B] {tail_id, head_arr, n0 of the pending garbage write, pending flag}
+  float4* post;         // [N][B] {n', head', tail', chosen}
   const float4* st0;    // [N]    {maxn, ff, road_index, cong}
-  float* slots;         // [B][N][lds] slot-interleaved FIFO store: slot s at floats 3s..3s+2 = {id, arrival, departure}
+  float* slots;         // [N][B][lds] slot-interleaved FIFO store: slot s at floats 3s..3s+2 = {id, arrival, departure}
   int64_t lds;          // row stride of slots in floats (>= 3*Nmax, multiple of 16)
+  float* selnew;        // [N][B] road selected in this frame's choice phase (consumed by the row pass)
+  float* part;          // [chunks][B][4] per-chunk partials {log-prob sum, infeasible flag, count sum, -}
   int32_t* a_origin;    // [B][A]
   int32_t* a_dest;      // [B][A]
   float* a_dep;         // [B][A]
   uint8_t* a_status;    // [B][A] 0 waiting, 1 on the way, 2 done
 };
 
-// ---- pack: build the hot / static records and the agent SoA from x / agent_features ----------------------------------
+// ---- pack: build the hot / static records, the slot store and the agent SoA from x / agent_features ------------------
 __global__ __launch_bounds__(FB) void k_pack_nodes(const float* __restrict__ x, Layout L, int64_t B, int64_t N,
                                                    const float* __restrict__ cong, FusedBufs fb, float4* st0_out) {
-  const int64_t gid = (int64_t)blockIdx.x * FB + threadIdx.x;
+  const int64_t gid = (int64_t)blockIdx.x * FB + threadIdx.x;  // gid = i * B + b  (env-minor)
   if (gid >= B * N) return;
-  const int64_t b = gid / N;
-  const int32_t i = (int32_t)(gid - b * N);
-  const float* xi = x + b * L.bstride + (int64_t)i * L.ldx;
+  const int64_t i = gid / B;
+  const int64_t b = gid - i * B;
+  const float* xi = x + b * L.bstride + i * L.ldx;
   const int Nmax = L.Nmax;
   const float n = xi[L.col_n()];
   const int q = (int)n;
@@ -63,6 +70,7 @@ __global__ __launch_bounds__(FB) void k_pack_nodes(const float* __restrict__ x, 
   fb.rec0[gid] = make_float4(xi[0], xi[2 * Nmax], n, xi[L.col_sel()]);
   fb.rec1[gid] = make_float4(tail, xi[Nmax], 0.0f, 0.0f);
   fb.post[gid] = make_float4(n, xi[0], tail, 0.0f);
+  fb.selnew[gid] = xi[L.col_sel()];
   float* sl = fb.slots + gid * fb.lds;
   for (int sidx = 0; sidx < Nmax; ++sidx) {
     sl[3 * sidx + 0] = xi[sidx];
@@ -94,9 +102,42 @@ __global__ __launch_bounds__(FB) void k_pack_agents(const float* __restrict__ ag
   fb.a_status[gid] = row[AG_DONE] != 0.0f ? 2 : (row[AG_ON_WAY] != 0.0f ? 1 : 0);
 }
 
-// ---- fused policy: logits -> segment softmax -> sample -> log_prob (+entropy) -> choice phase ---------------------------
-// One workgroup per environment, same arithmetic and the same reduction trees as k_edge_logits_fwd + k_softmax +
-// k_sample + k_logprob_entropy_fwd + k_apply_action.
+// ---- export: rebuild the reference's x layout (three FIFO column blocks + NUMBER_OF_AGENT + SELECTED_ROAD) ----------
+__global__ __launch_bounds__(FB) void k_export_rows(float* __restrict__ x, Layout L, int64_t B, int64_t N, FusedBufs fb,
+                                                    float t_last) {
+  const int64_t gid = (int64_t)blockIdx.x * FB + threadIdx.x;
+  const int Nmax = L.Nmax;
+  if (gid >= B * N * Nmax) return;
+  const int64_t row = gid / Nmax;  // row = i * B + b
+  const int sidx = (int)(gid - row * Nmax);
+  const int64_t i = row / B, b = row - i * B;
+  float* xi = x + b * L.bstride + i * L.ldx;
+  const float* sl = fb.slots + row * fb.lds + 3 * sidx;
+  const float4 r0 = fb.rec0[row];
+  const float4 r1 = fb.rec1[row];
+  if (r1.w != 0.0f && sidx == (int)r0.z) {  // pending garbage write of the last Direction update -> first dead slot
+    const float4 st = fb.st0[i];
+    const float t_cong = st.w / (st.x + 10.0f - r1.z);
+    const float tt = (t_cong != t_cong) ? t_cong : fmaxf(st.y, t_cong);
+    xi[sidx] = 0.0f;
+    xi[Nmax + sidx] = t_last;
+    xi[2 * Nmax + sidx] = t_last + tt;
+  } else {
+    xi[sidx] = sl[0];
+    xi[Nmax + sidx] = sl[1];
+    xi[2 * Nmax + sidx] = sl[2];
+  }
+  if (sidx == 0) {
+    xi[L.col_n()] = r0.z;
+    xi[L.col_sel()] = r0.w;
+  }
+}
+
+// ---- policy tables ------------------------------------------------------------------------------------------------------
+// The live policy's logits depend only on (emb, static ROAD_INDEX of the target road): they are identical for every
+// environment and every frame between two optimiser steps. k_policy_tables evaluates, ONCE per parameter update and with
+// exactly the arithmetic / reduction trees of k_edge_logits_fwd + k_softmax + k_sample + k_logprob_entropy_fwd, the
+// per-edge tables (CSR order): thr[k] = fp32 inverse-CDF threshold, lg[k] = log(p + 1e-8), plus the entropy.
 __device__ __forceinline__ float fb_block_sum(float v, float* s_red) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
@@ -104,7 +145,7 @@ __device__ __forceinline__ float fb_block_sum(float v, float* s_red) {
   if (lane == 0) s_red[wid] = v;
   __syncthreads();
   float tot = 0.0f;
-  for (int w = 0; w < ENVB / 64; ++w) tot += s_red[w];
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += s_red[w];
   return tot;
 }
 
@@ -114,11 +155,6 @@ __device__ __forceinline__ float live_logit(const float* __restrict__ emb, int64
   return (idx >= 0 && idx < M) ? emb[idx] : 0.0f;
 }
 
-// The live policy's logits depend only on (emb, static ROAD_INDEX of the target road): they are identical for every
-// environment and every frame between two optimiser steps. k_policy_tables therefore evaluates, ONCE per parameter
-// update and with exactly the arithmetic / reduction trees of k_softmax + k_sample + k_logprob_entropy_fwd, the per-edge
-// tables (CSR order): thr[k] = fp32 inverse-CDF threshold, lg[k] = log(p + 1e-8), plus the entropy; k_fused_choice then
-// only draws one uniform per (environment, node), walks <= deg thresholds and reduces the log-prob (same tree).
 __global__ __launch_bounds__(ENVB) void k_policy_tables(const int32_t* __restrict__ out_ptr,
                                                         const int32_t* __restrict__ out_dst,
                                                         const int32_t* __restrict__ node_of_group, int64_t N, int64_t G,
@@ -194,294 +230,282 @@ __global__ __launch_bounds__(ENVB) void k_policy_tables(const int32_t* __restric
   if (tid == 0) entropy_out[0] = ent_t;
 }
 
-__global__ __launch_bounds__(ENVB) void k_fused_choice(const int32_t* __restrict__ out_ptr,
-                                                       const int32_t* __restrict__ out_dst,
-                                                       const int32_t* __restrict__ out_eid,
-                                                       const int32_t* __restrict__ group_of_node, int64_t N, int64_t G,
-                                                       const float* __restrict__ thr, const float* __restrict__ lgt,
-                                                       const float* __restrict__ entropy_in,
-                                                       const float* __restrict__ uniform, uint64_t seed,
-                                                       uint64_t counter, FusedBufs fb, int32_t* __restrict__ choice,
-                                                       float* __restrict__ log_prob, float* __restrict__ entropy) {
-  __shared__ float s_red[ENVB / 64];
-  const int64_t b = blockIdx.x;
-  const int tid = threadIdx.x;
-  float lp = 0.0f;
-  bool bad = false;
-  for (int64_t i = tid; i < N; i += ENVB) {
-    const int32_t k0 = out_ptr[i], k1 = out_ptr[i + 1];
-    if (k0 == k1) {
-      if (choice) choice[b * N + i] = -1;
-      continue;
+// CSR position of the edge node j picks in this frame: the first out-edge (plan order) whose threshold exceeds j's
+// uniform draw; -1 when none does (u >= last threshold through rounding: the action is then infeasible).
+__device__ __forceinline__ int32_t sample_node(const int32_t* __restrict__ out_ptr, const float* __restrict__ thr,
+                                               int32_t j, float u) {
+  const int32_t k1 = out_ptr[j + 1];
+  for (int32_t k = out_ptr[j]; k < k1; ++k)
+    if (u < thr[k]) return k;
+  return -1;
+}
+
+__device__ __forceinline__ float node_uniform(const float* __restrict__ uniform, uint64_t seed, uint64_t counter,
+                                              int64_t b, int64_t G, int32_t g) {
+  return uniform ? uniform[b * G + g] : philox_uniform(seed, counter, (uint64_t)(b * G + g));
+}
+
+// ---- choice phase + Direction gather on the hot records (env-minor: lane = environment) ------------------------------
+__global__ __launch_bounds__(TILE) void k_fused_direction(const int32_t* __restrict__ in_ptr,
+                                                          const int32_t* __restrict__ in_src,
+                                                          const int32_t* __restrict__ in_eid,
+                                                          const int32_t* __restrict__ out_ptr,
+                                                          const int32_t* __restrict__ out_dst,
+                                                          const int32_t* __restrict__ out_eid,
+                                                          const int32_t* __restrict__ group_of_node, int64_t E,
+                                                          int64_t G, int64_t B, int64_t N, FusedBufs fb,
+                                                          const float* __restrict__ thr, const float* __restrict__ lgt,
+                                                          const float* __restrict__ uniform, uint64_t pseed,
+                                                          uint64_t pcounter, const float* __restrict__ edge_attr,
+                                                          const float* __restrict__ log_edge_attr, float log_eps,
+                                                          float t, const float* __restrict__ gumbel, uint64_t seed,
+                                                          uint64_t counter, float* __restrict__ dtt,
+                                                          int32_t* __restrict__ choice) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = b < B;
+  const int64_t bb = live ? b : B - 1;  // idle lanes shadow the last environment (loads stay in bounds, stores masked)
+  const int32_t i0 = blockIdx.y * NCHUNK;
+  const int32_t i1 = (i0 + NCHUNK < N) ? i0 + NCHUNK : (int32_t)N;
+  float lp = 0.0f, bad = 0.0f;
+  for (int32_t i = i0; i < i1; ++i) {  // i, and everything indexed by it alone, is wave-uniform
+    const int64_t row = (int64_t)i * B + bb;
+    const float4 me = fb.rec0[row];
+    // -- choice phase for node i
+    float sel_i = me.w;
+    const int32_t gi = group_of_node[i];
+    if (gi >= 0) {
+      const int32_t pk = sample_node(out_ptr, thr, i, node_uniform(uniform, pseed, pcounter, bb, G, gi));
+      if (pk >= 0) {
+        sel_i = (float)out_dst[pk];
+        lp += lgt[pk];
+      } else {
+        bad = 1.0f;
+      }
+      if (choice && live) choice[row] = pk >= 0 ? out_eid[pk] : -1;
+    } else if (choice && live) {
+      choice[row] = -1;
     }
-    const int64_t g = group_of_node[i];
-    const float u = uniform ? uniform[b * G + g] : philox_uniform(seed, counter, (uint64_t)(b * G + g));
-    int32_t pick = -1;
-    for (int32_t k = k0; k < k1; ++k) {
-      if (u < thr[k]) {
-        pick = k;
-        break;
+    if (live) fb.selnew[row] = sel_i;
+    // -- Direction message + aggregate for downstream road i
+    const float4 sti = fb.st0[i];
+    const float max_i = sti.x, n_i = me.z, road_i = sti.z;
+    const float room_i = max_i - n_i;
+    const bool has_room = n_i < max_i - TARL_CONGESTION_FILE;
+    float P = 0.0f, best = -FLT_MAX, best_id = 0.0f;
+    PhiloxRun rng;
+    const int32_t k1 = in_ptr[i + 1];
+    for (int32_t k = in_ptr[i]; k < k1; ++k) {
+      const int32_t j = in_src[k];
+      const int32_t e = in_eid[k];
+      const float4 rj = fb.rec0[(int64_t)j * B + bb];
+      const float4 stj = fb.st0[j];
+      // road selected by upstream j in THIS frame's choice phase (re-derived from j's own draw)
+      float sel_j = rj.w;
+      const int32_t gj = group_of_node[j];
+      if (gj >= 0) {
+        const int32_t pj = sample_node(out_ptr, thr, j, node_uniform(uniform, pseed, pcounter, bb, G, gj));
+        if (pj >= 0) sel_j = (float)out_dst[pj];
+      }
+      const float id = rj.x, dep = rj.y, n_j = rj.z, max_j = stj.x;
+      const bool heads_here = sel_j == road_i;
+      const bool m1 = (dep <= t) && has_room && heads_here && (n_j > 0.0f);
+      const bool m2 = ((dep - t) < -10.0f) && ((max_j - TARL_CONGESTION_FILE) <= n_j) && ((max_j - n_j) <= room_i) &&
+                      heads_here;
+      const bool m = m1 || m2;
+      const float prob = edge_attr[e] * (m ? 1.0f : 0.0f);
+      P = P + prob;
+      float g;
+      if (gumbel) {
+        g = gumbel[bb * E + e];
+      } else {
+        const float u = rng.uniform(seed, counter, (uint64_t)(bb * E + k));
+        g = -logf(-logf(u));
+      }
+      const float score = (m ? log_edge_attr[e] : log_eps) + g;
+      if (score > best) {
+        best = score;
+        best_id = id;
+      }
+      if (dtt && live) {
+        const float d = (dep - fb.rec1[(int64_t)j * B + bb].y) - stj.y;
+        dtt[bb * E + e] = d > 0.0f ? d : (d != d ? d : 0.0f);
       }
     }
-    if (pick >= 0) {
-      lp += lgt[pick];
-      float4 r = fb.rec0[b * N + i];                  // SELECTED_ROAD lives in the hot record (whole-record store:
-      r.w = (float)out_dst[pick];                     // no partial-sector writes); x gets it at export
-      fb.rec0[b * N + i] = r;
-      if (choice) choice[b * N + i] = out_eid[pick];
-    } else {
-      bad = true;
-      if (choice) choice[b * N + i] = -1;
-    }
+    const float who = (P > 0.0f) ? best_id : 0.0f;
+    const float4 r1 = fb.rec1[row];
+    if (live)
+      fb.post[row] = make_float4(who != 0.0f ? n_i + 1.0f : n_i, n_i == 0.0f ? who : me.x, who != 0.0f ? who : r1.x, who);
   }
-  const float bad_t = fb_block_sum(bad ? 1.0f : 0.0f, s_red);
-  const float lp_t = fb_block_sum(lp, s_red);
-  if (tid == 0) {
-    if (log_prob) log_prob[b] = bad_t > 0.0f ? -INFINITY : lp_t;
-    if (entropy) entropy[b] = entropy_in[0];
+  if (live) {
+    float* pp = fb.part + ((int64_t)blockIdx.y * B + b) * 4;
+    pp[0] = lp;
+    pp[1] = bad;
   }
 }
 
-// ---- Direction gather on the hot records ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(FB) void k_fused_direction(const int32_t* __restrict__ in_ptr,
-                                                        const int32_t* __restrict__ in_src,
-                                                        const int32_t* __restrict__ in_eid, int64_t E, int64_t B,
-                                                        int64_t N, FusedBufs fb, const float* __restrict__ edge_attr,
-                                                        const float* __restrict__ log_edge_attr, float log_eps, float t,
-                                                        const float* __restrict__ gumbel, uint64_t seed,
-                                                        uint64_t counter, float* __restrict__ dtt) {
-  const int64_t gid = (int64_t)blockIdx.x * FB + threadIdx.x;
-  if (gid >= B * N) return;
-  const int64_t b = gid / N;
-  const int32_t i = (int32_t)(gid - b * N);
-  const float4* r0b = fb.rec0 + b * N;
-  const float4 me = r0b[i];
-  const float4 sti = fb.st0[i];
-  const float max_i = sti.x, n_i = me.z, road_i = sti.z;
-  const float room_i = max_i - n_i;
-  const bool has_room = n_i < max_i - TARL_CONGESTION_FILE;
-  float P = 0.0f, best = -FLT_MAX, best_id = 0.0f;
-  PhiloxRun rng;
-  const int32_t k1 = in_ptr[i + 1];
-  for (int32_t k = in_ptr[i]; k < k1; ++k) {
-    const int32_t j = in_src[k];
-    const int32_t e = in_eid[k];
-    const float4 rj = r0b[j];
-    const float4 stj = fb.st0[j];
-    const float id = rj.x, dep = rj.y, n_j = rj.z, sel_j = rj.w, max_j = stj.x;
-    const bool heads_here = sel_j == road_i;
-    const bool m1 = (dep <= t) && has_room && heads_here && (n_j > 0.0f);
-    const bool m2 = ((dep - t) < -10.0f) && ((max_j - TARL_CONGESTION_FILE) <= n_j) && ((max_j - n_j) <= room_i) &&
-                    heads_here;
-    const bool m = m1 || m2;
-    const float prob = edge_attr[e] * (m ? 1.0f : 0.0f);
-    P = P + prob;
-    const int64_t ge = b * E + e;
-    float g;
-    if (gumbel) {
-      g = gumbel[ge];
-    } else {
-      const float u = rng.uniform(seed, counter, (uint64_t)(b * E + k));
-      g = -logf(-logf(u));
-    }
-    const float score = (m ? log_edge_attr[e] : log_eps) + g;
-    if (score > best) {
-      best = score;
-      best_id = id;
-    }
-    if (dtt) {
-      const float d = (dep - fb.rec1[b * N + j].y) - stj.y;
-      dtt[ge] = d > 0.0f ? d : (d != d ? d : 0.0f);
-    }
-  }
-  const float who = (P > 0.0f) ? best_id : 0.0f;
-  const float4 r1 = fb.rec1[gid];
-  fb.post[gid] = make_float4(who != 0.0f ? n_i + 1.0f : n_i, n_i == 0.0f ? who : me.x, who != 0.0f ? who : r1.x, who);
-}
-
-// ---- the row pass: Direction update + Response pop + withdraw on x, then refresh the hot record -------------------------
-__global__ __launch_bounds__(FB) void k_fused_rows(const int32_t* __restrict__ out_ptr,
-                                                   const int32_t* __restrict__ out_dst, int Nmax, int64_t B, int64_t N,
-                                                   FusedBufs fb, float* __restrict__ ag, int64_t A, int64_t a_bstride,
-                                                   float t, uint8_t* __restrict__ popped_out,
-                                                   uint8_t* __restrict__ withdrawn_out) {
-  const int64_t gid = (int64_t)blockIdx.x * FB + threadIdx.x;
-  if (gid >= B * N) return;
-  const int64_t b = gid / N;
-  const int32_t i = (int32_t)(gid - b * N);
-  float* sl = fb.slots + gid * fb.lds;  // slot s = sl[3s .. 3s+2] = {id, arrival, departure}
-  const float4* pb = fb.post + b * N;
-  const float4 p = pb[i];
-  const float4 r0 = fb.rec0[gid];
-  const float4 r1 = fb.rec1[gid];
-  const float4 st = fb.st0[i];
-  const float n0 = r0.z, who = p.w;
-  const int32_t k0 = out_ptr[i], k1 = out_ptr[i + 1];
-
-  // Response message + max-aggregate from the post records (state after the Direction update of every row)
-  bool pop = false;
-  if ((long long)p.x > 0) {
-    const long long head = (long long)p.y;
-    for (int32_t k = k0; k < k1; ++k) {
-      const float4 pj = pb[out_dst[k]];
-      pop = pop || ((long long)pj.x > 0 && (long long)pj.z == head);
-    }
-  }
-  if (popped_out) popped_out[gid] = pop ? 1 : 0;
-
-  // Direction update (every row, also when nothing was chosen): one 12-byte store — or, for a row that received nobody,
-  // a note in the hot record (lazy garbage slot, see the file header)
-  const int q = (int)n0;
-  const float t_cong = st.w / (st.x + 10.0f - n0);
-  const float tt = (t_cong != t_cong) ? t_cong : fmaxf(st.y, t_cong);
-  const float dep_new = t + tt;
-  const bool lazy = (who == 0.0f) && (q >= 0) && (q < Nmax - 1);
-  if (!lazy && q >= 0 && q < Nmax) {
-    sl[3 * q + 0] = who;
-    sl[3 * q + 1] = t;
-    sl[3 * q + 2] = dep_new;
-  }
-  float n = p.x;  // count after the Direction update
-
-  // head / tail of the row after the Direction update (no memory reads needed)
-  float head_id = (n0 == 0.0f) ? who : r0.x;
-  float head_dep = (n0 == 0.0f) ? dep_new : r0.y;
-  float head_arr = (n0 == 0.0f) ? t : r1.y;
-  float tail_id = p.z;
-
-  int shift = 0;
-  if (pop) {
-    shift = 1;
-    n = n - 1.0f;
-  }
-  // withdraw: leading run of the (popped) row
-  int c = 0;
-  if (n > 0.0f) {
-    const long long road = (long long)st.z;
-    int32_t w0 = 0, w1 = 0;
-    if (road >= 0 && road < N) {
-      w0 = out_ptr[road];
-      w1 = out_ptr[road + 1];
-    }
-    for (int s = 0; s < Nmax && (float)s < n; ++s) {
-      int src = s + shift;          // slot of the row as it is in memory right now
-      if (src >= Nmax) src = Nmax - 1;  // the pop duplicates the last slot
-      float idf, depf;
-      if (src == 0) {
-        idf = head_id;
-        depf = head_dep;
-      } else {
-        idf = sl[3 * src];
-        depf = sl[3 * src + 2];
-      }
-      const long long id = (long long)idf;
-      if (id < 0 || id >= A) break;
-      const long long dest = (long long)fb.a_dest[b * A + id];
-      bool conn = false;
-      for (int32_t k = w0; k < w1; ++k) conn = conn || ((long long)out_dst[k] == dest);
-      if (!(conn && depf <= t)) break;
-      float* a = ag + b * a_bstride + id * AG_COLS;
-      a[AG_DONE] = 1.0f;
-      a[AG_ON_WAY] = 0.0f;
-      a[AG_ARR] = t;
-      fb.a_status[b * A + id] = 2;
-      ++c;
-    }
-  }
-  if (withdrawn_out) withdrawn_out[gid] = c > 0 ? 1 : 0;
-
-  if (shift + c > 0) {
-    // pop (shift by one, last slot keeps its stale value) followed by withdraw (shift by c, zero fill), in one sweep
-    const float l0 = sl[3 * (Nmax - 1)], l1 = sl[3 * (Nmax - 1) + 1], l2 = sl[3 * (Nmax - 1) + 2];
-    for (int s = 0; s < Nmax; ++s) {
-      float v0, v1, v2;
-      int from;
-      if (shift == 0) {
-        from = (s + c < Nmax) ? s + c : -1;
-      } else {
-        const int k = s + c;  // index into the popped row
-        from = (k < Nmax - 1) ? k + 1 : (k == Nmax - 1 ? -2 : -1);
-      }
-      if (from >= 0) {
-        v0 = sl[3 * from];
-        v1 = sl[3 * from + 1];
-        v2 = sl[3 * from + 2];
-      } else if (from == -2) {
-        v0 = l0; v1 = l1; v2 = l2;
-      } else {
-        v0 = v1 = v2 = 0.0f;
-      }
-      sl[3 * s] = v0;
-      sl[3 * s + 1] = v1;
-      sl[3 * s + 2] = v2;
-    }
-    n = n - (float)c;
-    if (lazy && n == 0.0f) {  // the row emptied: its head slot is the (unmaterialised) garbage slot
-      head_id = 0.0f;
-      head_arr = t;
-      head_dep = dep_new;
-    } else {
-      head_id = sl[0];
-      head_arr = sl[1];
-      head_dep = sl[2];
-    }
-    const int qn = (int)n;
-    tail_id = (qn >= 1 && qn <= Nmax) ? sl[3 * (qn - 1)] : 0.0f;
-  }
-  fb.rec0[gid] = make_float4(head_id, head_dep, n, r0.w);
-  fb.rec1[gid] = make_float4(tail_id, head_arr, n0, lazy ? 1.0f : 0.0f);
-}
-
-// ---- export: rebuild the reference's x layout (three FIFO column blocks + NUMBER_OF_AGENT + SELECTED_ROAD) ----------
-__global__ __launch_bounds__(FB) void k_export_rows(float* __restrict__ x, Layout L, int64_t B, int64_t N, FusedBufs fb,
-                                                    float t_last) {
-  const int64_t gid = (int64_t)blockIdx.x * FB + threadIdx.x;
-  const int Nmax = L.Nmax;
-  if (gid >= B * N * Nmax) return;
-  const int64_t row = gid / Nmax;
-  const int sidx = (int)(gid - row * Nmax);
-  const int64_t b = row / N, i = row - b * N;
-  float* xi = x + b * L.bstride + i * L.ldx;
-  const float* sl = fb.slots + row * fb.lds + 3 * sidx;
-  const float4 r0 = fb.rec0[row];
-  const float4 r1 = fb.rec1[row];
-  if (r1.w != 0.0f && sidx == (int)r0.z) {  // pending garbage write of the last Direction update -> first dead slot
+// ---- the row pass: Direction update + Response pop + withdraw on the slot store, then refresh the hot record -------------
+__global__ __launch_bounds__(TILE) void k_fused_rows(const int32_t* __restrict__ out_ptr,
+                                                     const int32_t* __restrict__ out_dst, int Nmax, int64_t B,
+                                                     int64_t N, FusedBufs fb, float* __restrict__ ag, int64_t A,
+                                                     int64_t a_bstride, float t, uint8_t* __restrict__ popped_out,
+                                                     uint8_t* __restrict__ withdrawn_out, float* __restrict__ counts) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int32_t i0 = blockIdx.y * NCHUNK;
+  const int32_t i1 = (i0 + NCHUNK < N) ? i0 + NCHUNK : (int32_t)N;
+  float nsum = 0.0f;
+  for (int32_t i = i0; i < i1; ++i) {
+    const int64_t row = (int64_t)i * B + b;
+    float* sl = fb.slots + row * fb.lds;  // slot s = sl[3s .. 3s+2] = {id, arrival, departure}
+    const float4 p = fb.post[row];
+    const float4 r0 = fb.rec0[row];
+    const float4 r1 = fb.rec1[row];
     const float4 st = fb.st0[i];
-    const float t_cong = st.w / (st.x + 10.0f - r1.z);
+    const float n0 = r0.z, who = p.w;
+    const int32_t k0 = out_ptr[i], k1 = out_ptr[i + 1];
+
+    // Response message + max-aggregate from the post records (state after the Direction update of every row)
+    bool pop = false;
+    {
+      const long long head = (long long)p.y;
+      const bool up = (long long)p.x > 0;
+      for (int32_t k = k0; k < k1; ++k) {  // uniform trip count: the post gathers stay coalesced and unconditional
+        const float4 pj = fb.post[(int64_t)out_dst[k] * B + b];
+        pop = pop || (up && (long long)pj.x > 0 && (long long)pj.z == head);
+      }
+    }
+    if (popped_out) popped_out[b * N + i] = pop ? 1 : 0;
+
+    // Direction update (every row, also when nothing was chosen): one 12-byte store — or, for a row that received
+    // nobody, a note in the hot record (lazy garbage slot, see the file header)
+    const int q = (int)n0;
+    const float t_cong = st.w / (st.x + 10.0f - n0);
     const float tt = (t_cong != t_cong) ? t_cong : fmaxf(st.y, t_cong);
-    xi[sidx] = 0.0f;
-    xi[Nmax + sidx] = t_last;
-    xi[2 * Nmax + sidx] = t_last + tt;
-  } else {
-    xi[sidx] = sl[0];
-    xi[Nmax + sidx] = sl[1];
-    xi[2 * Nmax + sidx] = sl[2];
+    const float dep_new = t + tt;
+    const bool lazy = (who == 0.0f) && (q >= 0) && (q < Nmax - 1);
+    if (!lazy && q >= 0 && q < Nmax) {
+      sl[3 * q + 0] = who;
+      sl[3 * q + 1] = t;
+      sl[3 * q + 2] = dep_new;
+    }
+    float n = p.x;  // count after the Direction update
+
+    // head / tail of the row after the Direction update (no memory reads needed)
+    float head_id = (n0 == 0.0f) ? who : r0.x;
+    float head_dep = (n0 == 0.0f) ? dep_new : r0.y;
+    float head_arr = (n0 == 0.0f) ? t : r1.y;
+    float tail_id = p.z;
+
+    int shift = 0;
+    if (pop) {
+      shift = 1;
+      n = n - 1.0f;
+    }
+    // withdraw: leading run of the (popped) row
+    int c = 0;
+    if (n > 0.0f) {
+      const long long road = (long long)st.z;
+      int32_t w0 = 0, w1 = 0;
+      if (road >= 0 && road < N) {
+        w0 = out_ptr[road];
+        w1 = out_ptr[road + 1];
+      }
+      for (int s = 0; s < Nmax && (float)s < n; ++s) {
+        int src = s + shift;              // slot of the row as it is in memory right now
+        if (src >= Nmax) src = Nmax - 1;  // the pop duplicates the last slot
+        float idf, depf;
+        if (src == 0) {
+          idf = head_id;
+          depf = head_dep;
+        } else {
+          idf = sl[3 * src];
+          depf = sl[3 * src + 2];
+        }
+        const long long id = (long long)idf;
+        if (id < 0 || id >= A) break;
+        if (!(depf <= t)) break;  // tested first: most heads are still travelling, and the lookup below is a gather
+        const long long dest = (long long)fb.a_dest[b * A + id];
+        bool conn = false;
+        for (int32_t k = w0; k < w1; ++k) conn = conn || ((long long)out_dst[k] == dest);
+        if (!conn) break;
+        float* a = ag + b * a_bstride + id * AG_COLS;
+        a[AG_DONE] = 1.0f;
+        a[AG_ON_WAY] = 0.0f;
+        a[AG_ARR] = t;
+        fb.a_status[b * A + id] = 2;
+        ++c;
+      }
+    }
+    if (withdrawn_out) withdrawn_out[b * N + i] = c > 0 ? 1 : 0;
+
+    if (shift + c > 0) {
+      // pop (shift by one, last slot keeps its stale value) followed by withdraw (shift by c, zero fill), in one sweep
+      const float l0 = sl[3 * (Nmax - 1)], l1 = sl[3 * (Nmax - 1) + 1], l2 = sl[3 * (Nmax - 1) + 2];
+      for (int s = 0; s < Nmax; ++s) {
+        float v0, v1, v2;
+        int from;
+        if (shift == 0) {
+          from = (s + c < Nmax) ? s + c : -1;
+        } else {
+          const int k = s + c;  // index into the popped row
+          from = (k < Nmax - 1) ? k + 1 : (k == Nmax - 1 ? -2 : -1);
+        }
+        if (from >= 0) {
+          v0 = sl[3 * from];
+          v1 = sl[3 * from + 1];
+          v2 = sl[3 * from + 2];
+        } else if (from == -2) {
+          v0 = l0; v1 = l1; v2 = l2;
+        } else {
+          v0 = v1 = v2 = 0.0f;
+        }
+        sl[3 * s] = v0;
+        sl[3 * s + 1] = v1;
+        sl[3 * s + 2] = v2;
+      }
+      n = n - (float)c;
+      if (lazy && n == 0.0f) {  // the row emptied: its head slot is the (unmaterialised) garbage slot
+        head_id = 0.0f;
+        head_arr = t;
+        head_dep = dep_new;
+      } else {
+        head_id = sl[0];
+        head_arr = sl[1];
+        head_dep = sl[2];
+      }
+      const int qn = (int)n;
+      tail_id = (qn >= 1 && qn <= Nmax) ? sl[3 * (qn - 1)] : 0.0f;
+    }
+    fb.rec0[row] = make_float4(head_id, head_dep, n, fb.selnew[row]);  // SELECTED_ROAD of this frame's choice phase
+    fb.rec1[row] = make_float4(tail_id, head_arr, n0, lazy ? 1.0f : 0.0f);
+    if (counts) counts[row] = n;  // per-node count before insertion; the insert kernel adds this frame's arrivals
+    nsum += n;
   }
-  if (sidx == 0) {
-    xi[L.col_n()] = r0.z;
-    xi[L.col_sel()] = r0.w;
-  }
+  fb.part[((int64_t)blockIdx.y * B + b) * 4 + 2] = nsum;
 }
 
-// ---- insert + reward + counts on the hot records / agent SoA ----------------------------------------------------------
-__device__ __forceinline__ bool fused_target(const FusedBufs& fb, int64_t b, int64_t N, int32_t origin, int32_t* road,
-                                             int32_t* cap) {
+// ---- insert + reward + log-prob reduction (one workgroup per environment) ----------------------------------------------
+__device__ __forceinline__ bool fused_target(const FusedBufs& fb, int64_t b, int64_t B, int64_t N, int32_t origin,
+                                             int32_t* road, int32_t* cap) {
   if (origin < 0 || origin >= N) return false;
-  const long long r = (long long)fb.rec0[b * N + origin].w;
+  const long long r = (long long)fb.rec0[(int64_t)origin * B + b].w;
   if (r < 0 || r >= N) return false;
-  const long long room = (long long)(fb.st0[r].x - TARL_CONGESTION_FILE - fb.rec0[b * N + r].z);
+  const long long room = (long long)(fb.st0[r].x - TARL_CONGESTION_FILE - fb.rec0[r * B + b].z);
   *road = (int32_t)r;
   *cap = (int32_t)(room > 0x7fffffff ? 0x7fffffff : room);
   return room > 0;
 }
 
-__global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t N, FusedBufs fb,
+__global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t B, int64_t N, int64_t chunks, FusedBufs fb,
                                                        float* __restrict__ ag, int64_t A, int64_t a_bstride,
                                                        int use_cong, float t, int32_t* __restrict__ scratch,
-                                                       float* __restrict__ reward, float* __restrict__ counts) {
+                                                       const float* __restrict__ entropy_in,
+                                                       float* __restrict__ reward, float* __restrict__ counts,
+                                                       float* __restrict__ log_prob, float* __restrict__ entropy) {
   __shared__ int32_t s_wave[ENVB / 64];
   __shared__ float s_red[ENVB / 64];
   __shared__ int32_t s_cnt;
+  __shared__ int32_t s_adm;
   __shared__ int32_t s_un_agent[INS_CAP], s_un_road[INS_CAP];
   const int64_t b = blockIdx.x;
   float* agb = ag + b * a_bstride;
@@ -493,7 +517,10 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t N, Fuse
   // are appended unordered to an LDS list with an atomic counter and then ranked by agent id (deterministic: the
   // reference admits agents in stable agent-id order). A backlog larger than the LDS list falls back to the ordered
   // ballot compaction into the global scratch.
-  if (tid == 0) s_cnt = 0;
+  if (tid == 0) {
+    s_cnt = 0;
+    s_adm = 0;
+  }
   __syncthreads();
   for (int64_t a0 = tid; a0 < A; a0 += 4 * ENVB) {  // 4 independent (status, departure) loads in flight per thread
     uint8_t stt[4];
@@ -509,7 +536,7 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t N, Fuse
       if (stt[j] == 0 && dp[j] <= t) {
         const int64_t a = a0 + (int64_t)j * ENVB;
         int32_t road = 0, cap = 0;
-        if (fused_target(fb, b, N, fb.a_origin[b * A + a], &road, &cap)) {
+        if (fused_target(fb, b, B, N, fb.a_origin[b * A + a], &road, &cap)) {
           const int32_t pos = atomicAdd(&s_cnt, 1);
           if (pos < INS_CAP) {
             s_un_agent[pos] = (int32_t)a;
@@ -538,7 +565,7 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t N, Fuse
       bool cnd = false;
       int32_t road = 0, cap = 0;
       if (a < A && fb.a_status[b * A + a] == 0 && fb.a_dep[b * A + a] <= t)
-        cnd = fused_target(fb, b, N, fb.a_origin[b * A + a], &road, &cap);
+        cnd = fused_target(fb, b, B, N, fb.a_origin[b * A + a], &road, &cap);
       const unsigned long long bal = __ballot(cnd);
       const int lane_off = __popcll(bal & ((1ull << lane) - 1ull));
       if (lane == 0) s_wave[wid] = __popcll(bal);
@@ -561,6 +588,7 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t N, Fuse
     __syncthreads();
   }
 
+  // phase 2: rank within road (stable), admit the first min(count, capacity), write slots / hot records
   for (int32_t idx = tid; idx < Lc; idx += ENVB) {
     const int32_t r = cand_road[idx];
     const int32_t a = cand_agent[idx];
@@ -570,8 +598,9 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t N, Fuse
       total += same ? 1 : 0;
       rank += (same && k < idx) ? 1 : 0;
     }
+    const int64_t rrow = (int64_t)r * B + b;
     const float4 str = fb.st0[r];
-    const float n0 = fb.rec0[b * N + r].z;
+    const float n0 = fb.rec0[rrow].z;
     const long long cap = (long long)(str.x - TARL_CONGESTION_FILE - n0);
     int32_t commit = 0;
     if (rank < cap) {
@@ -580,7 +609,7 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t N, Fuse
       const float t_cong = use_cong ? str.w / (str.x + 10.0f - (float)(long long)n0) : 0.0f;
       const float tt = (t_cong != t_cong) ? t_cong : fmaxf(str.y, t_cong);
       if (slot >= 0 && slot < Nmax) {
-        float* sr = fb.slots + (b * N + r) * fb.lds + 3 * slot;
+        float* sr = fb.slots + rrow * fb.lds + 3 * slot;
         sr[0] = (float)a;
         sr[1] = t;
         sr[2] = t + tt;
@@ -589,42 +618,45 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t N, Fuse
       fb.a_status[b * A + a] = 1;
       // hot record: only fields nobody reads in this phase (n is committed after the barrier)
       if (rank == 0 && n0 == 0.0f) {
-        fb.rec0[b * N + r].x = (float)a;
-        fb.rec0[b * N + r].y = t + tt;
-        fb.rec1[b * N + r].y = t;
+        fb.rec0[rrow].x = (float)a;
+        fb.rec0[rrow].y = t + tt;
+        fb.rec1[rrow].y = t;
       }
-      if (rank == m - 1) fb.rec1[b * N + r].x = (float)a;
-      if (rank == 0) fb.rec1[b * N + r].w = 0.0f;  // the arrivals overwrite a pending garbage slot
+      if (rank == m - 1) fb.rec1[rrow].x = (float)a;
+      if (rank == 0) fb.rec1[rrow].w = 0.0f;  // the arrivals overwrite a pending garbage slot
       if (rank == 0) commit = (int32_t)m;
     }
     cand_agent[idx] = commit;
   }
   __threadfence_block();
   __syncthreads();
+  // phase 3: commit the counters
   for (int32_t idx = tid; idx < Lc; idx += ENVB) {
     const int32_t cmt = cand_agent[idx];
     if (cmt > 0) {
-      const int32_t r = cand_road[idx];
-      fb.rec0[b * N + r].z = fb.rec0[b * N + r].z + (float)cmt;
+      const int64_t rrow = (int64_t)cand_road[idx] * B + b;
+      const float nn = fb.rec0[rrow].z + (float)cmt;
+      fb.rec0[rrow].z = nn;
+      if (counts) counts[rrow] = nn;
+      atomicAdd(&s_adm, cmt);
     }
   }
-  __threadfence_block();
   __syncthreads();
-  if (reward || counts) {
-    float acc = 0.0f;
-    for (int64_t i = tid; i < N; i += ENVB) {
-      const float v = fb.rec0[b * N + i].z;
-      if (counts) counts[b * N + i] = v;
-      acc += v;
-    }
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-    if (lane == 0) s_red[wid] = acc;
-    __syncthreads();
-    if (tid == 0 && reward) {
-      float tot = 0.0f;
-      for (int w = 0; w < ENVB / 64; ++w) tot += s_red[w];
-      reward[b] = -tot;
-    }
+  // phase 4: reduce the per-chunk partials of this environment (fixed order): reward, log-prob
+  float nsum = 0.0f, lp = 0.0f, bad = 0.0f;
+  for (int64_t cidx = tid; cidx < chunks; cidx += ENVB) {
+    const float* pp = fb.part + (cidx * B + b) * 4;
+    lp += pp[0];
+    bad += pp[1];
+    nsum += pp[2];
+  }
+  const float n_t = fb_block_sum(nsum, s_red);
+  const float lp_t = fb_block_sum(lp, s_red);
+  const float bad_t = fb_block_sum(bad, s_red);
+  if (tid == 0) {
+    if (reward) reward[b] = -(n_t + (float)s_adm);  // sums of small integers: exact in fp32 in any order
+    if (log_prob) log_prob[b] = bad_t > 0.0f ? -INFINITY : lp_t;
+    if (entropy) entropy[b] = entropy_in[0];
   }
 }
 
@@ -633,14 +665,17 @@ hipEvent_t tarl_prof_event(hipStream_t s);  // sim.hip: live timing of the messa
 
 static FusedBufs to_bufs(const tarl_fused* f) {
   return FusedBufs{(float4*)f->rec0, (float4*)f->rec1, (float4*)f->post, (const float4*)f->st0, f->slots, f->ld_slots,
-                   f->a_origin,      f->a_dest,        f->a_dep,         f->a_status};
+                   f->selnew,        f->part,          f->a_origin,      f->a_dest,             f->a_dep, f->a_status};
 }
+
+static int64_t num_chunks(const tarl_plan* plan) { return ceil_div(plan->N, NCHUNK); }
 
 static int check_fused_core(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax) {
   TARL_REQUIRE(plan && f, "null argument");
-  TARL_REQUIRE(f->rec0 && f->rec1 && f->post && f->st0 && f->slots, "fused node buffers missing");
+  TARL_REQUIRE(f->rec0 && f->rec1 && f->post && f->st0 && f->slots && f->selnew && f->part, "fused node buffers missing");
   TARL_REQUIRE(B >= 1 && B < ((int64_t)1 << 31) && Nmax >= 2, "bad sizes");
   TARL_REQUIRE(f->ld_slots >= 3 * (int64_t)Nmax, "slot row stride smaller than 3*Nmax");
+  TARL_REQUIRE(num_chunks(plan) < 65536, "too many node chunks for one launch");
   TARL_REQUIRE(((uintptr_t)f->rec0 | (uintptr_t)f->rec1 | (uintptr_t)f->post | (uintptr_t)f->st0) % 16 == 0,
                "fused records must be 16-byte aligned");
   return TARL_OK;
@@ -655,6 +690,10 @@ static int check_fused(const tarl_plan* plan, const tarl_fused* f, const float* 
   TARL_REQUIRE(B == 1 || bstride >= plan->N * ldx, "environment stride smaller than one environment");
   return TARL_OK;
 }
+
+static unsigned tile_threads(int64_t B) { return B >= TILE ? TILE : (unsigned)(ceil_div(B, 64) * 64); }
+
+extern "C" int64_t tarl_fused_num_chunks(const tarl_plan* plan) { return plan ? num_chunks(plan) : 0; }
 
 extern "C" int tarl_fused_pack(const tarl_plan* plan, const tarl_fused* f, const float* x, int64_t B, int64_t x_bstride,
                                int64_t ldx, int32_t Nmax, const float* cong, const float* agent_features, int64_t A,
@@ -678,6 +717,18 @@ extern "C" int tarl_fused_pack(const tarl_plan* plan, const tarl_fused* f, const
   return TARL_OK;
 }
 
+extern "C" int tarl_fused_export(const tarl_plan* plan, const tarl_fused* f, float* x, int64_t B, int64_t x_bstride,
+                                 int64_t ldx, int32_t Nmax, float last_step_time, tarl_stream stream) {
+  int rc = check_fused(plan, f, x, B, x_bstride, ldx, Nmax);
+  if (rc) return rc;
+  if (plan->N == 0) return TARL_OK;
+  const Layout L{Nmax, ldx, x_bstride};
+  hipLaunchKernelGGL(k_export_rows, dim3((unsigned)ceil_div(B * plan->N * Nmax, FB)), dim3(FB), 0, (hipStream_t)stream,
+                     x, L, B, plan->N, to_bufs(f), last_step_time);
+  TARL_LAUNCH_CHECK();
+  return TARL_OK;
+}
+
 extern "C" int tarl_fused_policy_prepare(const tarl_plan* plan, const tarl_fused* f, const float* emb,
                                          int64_t num_embeddings, float temperature, double* group_base,
                                          float* thresholds, float* log_probs, float* entropy1, tarl_stream stream) {
@@ -691,40 +742,17 @@ extern "C" int tarl_fused_policy_prepare(const tarl_plan* plan, const tarl_fused
   return TARL_OK;
 }
 
-extern "C" int tarl_fused_policy_step(const tarl_plan* plan, const tarl_fused* f, int64_t B, const float* thresholds,
-                                      const float* log_probs, const float* entropy1, const float* uniform,
-                                      uint64_t seed, uint64_t counter, int32_t* choice, float* log_prob, float* entropy,
-                                      tarl_stream stream) {
-  TARL_REQUIRE(plan && f && f->rec0 && thresholds && log_probs && entropy1, "null argument");
-  TARL_REQUIRE(B >= 1 && B < ((int64_t)1 << 31), "bad B");
-  if (plan->N == 0) return TARL_OK;
-  hipLaunchKernelGGL(k_fused_choice, dim3((unsigned)B), dim3(ENVB), 0, (hipStream_t)stream, plan->out_ptr, plan->out_dst,
-                     plan->out_eid, plan->group_of_node, plan->N, plan->G, thresholds, log_probs, entropy1, uniform, seed,
-                     counter, to_bufs(f), choice, log_prob, entropy);
-  TARL_LAUNCH_CHECK();
-  return TARL_OK;
-}
-
-extern "C" int tarl_fused_export(const tarl_plan* plan, const tarl_fused* f, float* x, int64_t B, int64_t x_bstride,
-                                 int64_t ldx, int32_t Nmax, float last_step_time, tarl_stream stream) {
-  int rc = check_fused(plan, f, x, B, x_bstride, ldx, Nmax);
-  if (rc) return rc;
-  if (plan->N == 0) return TARL_OK;
-  const Layout L{Nmax, ldx, x_bstride};
-  hipLaunchKernelGGL(k_export_rows, dim3((unsigned)ceil_div(B * plan->N * Nmax, FB)), dim3(FB), 0, (hipStream_t)stream,
-                     x, L, B, plan->N, to_bufs(f), last_step_time);
-  TARL_LAUNCH_CHECK();
-  return TARL_OK;
-}
-
-extern "C" int tarl_fused_env_step(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax,
-                                   float* agent_features, int64_t A, int64_t a_bstride, const float* edge_attr,
-                                   const float* log_edge_attr, float log_eps, int use_cong, float time,
-                                   const float* gumbel, uint64_t seed, uint64_t counter, float* delta_travel_time,
-                                   uint8_t* popped, uint8_t* withdrawn, int32_t* ins_scratch, float* reward,
-                                   float* counts, tarl_stream stream) {
+extern "C" int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax,
+                                const float* thresholds, const float* log_probs, const float* entropy1,
+                                const float* uniform, uint64_t policy_seed, uint64_t policy_counter,
+                                float* agent_features, int64_t A, int64_t a_bstride, const float* edge_attr,
+                                const float* log_edge_attr, float log_eps, int use_cong, float time, const float* gumbel,
+                                uint64_t seed, uint64_t counter, float* delta_travel_time, uint8_t* popped,
+                                uint8_t* withdrawn, int32_t* ins_scratch, int32_t* choice, float* log_prob,
+                                float* entropy, float* reward, float* counts, tarl_stream stream) {
   int rc = check_fused_core(plan, f, B, Nmax);
   if (rc) return rc;
+  TARL_REQUIRE(thresholds && log_probs && entropy1, "policy tables missing (call tarl_fused_policy_prepare)");
   TARL_REQUIRE(agent_features && A >= 1 && ins_scratch, "agents / scratch missing");
   TARL_REQUIRE(f->a_origin && f->a_dest && f->a_dep && f->a_status, "fused agent buffers missing");
   TARL_REQUIRE(B == 1 || a_bstride >= A * AG_COLS, "agent stride smaller than one population");
@@ -732,17 +760,21 @@ extern "C" int tarl_fused_env_step(const tarl_plan* plan, const tarl_fused* f, i
   if (plan->N == 0) return TARL_OK;
   const FusedBufs fb = to_bufs(f);
   hipStream_t s = (hipStream_t)stream;
-  const unsigned grid = (unsigned)ceil_div(B * plan->N, FB);
+  const unsigned threads = tile_threads(B);
+  const dim3 grid((unsigned)ceil_div(B, threads), (unsigned)num_chunks(plan));
   const bool timed = tarl_prof_event(s) != nullptr;
-  hipLaunchKernelGGL(k_fused_direction, dim3(grid), dim3(FB), 0, s, plan->in_ptr, plan->in_src, plan->in_eid, plan->E, B,
-                     plan->N, fb, edge_attr, log_edge_attr, log_eps, time, gumbel, seed, counter, delta_travel_time);
+  hipLaunchKernelGGL(k_fused_direction, grid, dim3(threads), 0, s, plan->in_ptr, plan->in_src, plan->in_eid,
+                     plan->out_ptr, plan->out_dst, plan->out_eid, plan->group_of_node, plan->E, plan->G, B, plan->N, fb,
+                     thresholds, log_probs, uniform, policy_seed, policy_counter, edge_attr, log_edge_attr, log_eps, time,
+                     gumbel, seed, counter, delta_travel_time, choice);
   TARL_LAUNCH_CHECK();
   if (timed) (void)tarl_prof_event(s);
-  hipLaunchKernelGGL(k_fused_rows, dim3(grid), dim3(FB), 0, s, plan->out_ptr, plan->out_dst, (int)Nmax, B, plan->N, fb,
-                     agent_features, A, a_bstride, time, popped, withdrawn);
+  hipLaunchKernelGGL(k_fused_rows, grid, dim3(threads), 0, s, plan->out_ptr, plan->out_dst, (int)Nmax, B, plan->N, fb,
+                     agent_features, A, a_bstride, time, popped, withdrawn, counts);
   TARL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(ENVB), 0, s, (int)Nmax, plan->N, fb, agent_features, A,
-                     a_bstride, use_cong, time, ins_scratch, reward, counts);
+  hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(ENVB), 0, s, (int)Nmax, B, plan->N, num_chunks(plan), fb,
+                     agent_features, A, a_bstride, use_cong, time, ins_scratch, entropy1, reward, counts, log_prob,
+                     entropy);
   TARL_LAUNCH_CHECK();
   return TARL_OK;
 }

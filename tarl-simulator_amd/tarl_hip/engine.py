@@ -57,7 +57,7 @@ class SimEngine:
         self.counts = torch.zeros((self.B, self.N), dtype=torch.float32, device=self.device)
         self.dtt = None
         # fused fast path (csrc/fused.hip): packed hot records + agent SoA mirroring x / agents
-        self.fs = ops.FusedState(self.B, self.N, self.A, self.device, self.Nmax) if fused else None
+        self.fs = ops.FusedState(self.plan, self.B, self.A, self.device, self.Nmax) if fused else None
         self.sample_counter = 0
         if self.fs is not None:
             self.resync()
@@ -117,26 +117,21 @@ class SimEngine:
         """Evaluate the live policy's distribution tables; call once per parameter update."""
         self.tables = ops.fused_policy_prepare(self.plan, self.fs, emb, temperature, getattr(self, "tables", None))
 
-    def policy_step_fused(self, *, choice=None, log_prob=None, entropy=None, uniform=None):
-        """GraphDistribution sample -> log_prob -> choice phase for all B environments (one launch)."""
+    def frame_fused(self, *, choice=None, log_prob=None, entropy=None, reward=None, counts=None, uniform=None,
+                    gumbel=None, dtt=None, popped=None, withdrawn=None):
+        """One collector frame (sample + log_prob + choice phase + env step) for all B environments in 3 launches.
+        ``choice`` (N, B) int32 and ``counts`` (N, B) are env-minor. Returns done (bool)."""
+        if self._packed_stale:
+            self.resync()
         self.sample_counter += 1
-        if self._packed_stale:
-            self.resync()
-        self._x_stale = True
-        ops.fused_policy_step(self.plan, self.fs, self.tables, uniform=uniform, seed=self.seed ^ 0x5DEECE66D,
-                              counter=self.sample_counter, choice=choice, log_prob=log_prob, entropy=entropy)
-
-    def step_fused(self, *, reward=None, counts=None, gumbel=None, dtt=None, popped=None, withdrawn=None):
-        """Core + withdraw + insert (three launches). Returns done (bool)."""
         self.noise_counter += 1
-        if self._packed_stale:
-            self.resync()
         self._x_stale = True
         self._last_step_time = float(self.time)
-        ops.fused_env_step(self.plan, self.fs, self.agents, self.ec, float(self.time),
-                           use_cong=self.cc is not None, gumbel=gumbel, seed=self.seed, counter=self.noise_counter,
-                           dtt=dtt, popped=popped, withdrawn=withdrawn, scratch=self.ins_scratch,
-                           reward=self.reward if reward is None else reward,
-                           counts=self.counts if counts is None else counts)
+        ops.fused_frame(self.plan, self.fs, self.tables, self.agents, self.ec, float(self.time),
+                        use_cong=self.cc is not None, uniform=uniform, policy_seed=self.seed ^ 0x5DEECE66D,
+                        policy_counter=self.sample_counter, gumbel=gumbel, seed=self.seed, counter=self.noise_counter,
+                        dtt=dtt, popped=popped, withdrawn=withdrawn, scratch=self.ins_scratch, choice=choice,
+                        log_prob=log_prob, entropy=entropy, reward=self.reward if reward is None else reward,
+                        counts=counts)
         self.time += self.timestep
         return self.time > EPISODE_END

@@ -48,12 +48,13 @@ SIGNATURES = {
     "tarl_advantage_normalize": (C.c_int, [_p, _i64, _p, _p]),
     "tarl_ppo_loss": (C.c_int, [_p] * 6 + [_i64, _f32, _f32, _f32, _f32, _p, _p, _p, _p, _p]),
     "tarl_adam_step": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _f64, _f64, _f64, _f64, _f32, _p]),
+    "tarl_critic_mlp_fwd_slabs": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64] + [_p] * 6 + [_p, _p]),
+    "tarl_fused_num_chunks": (_i64, [_p]),
     "tarl_fused_pack": (C.c_int, [_p, _p] + _STATE + [_p, _p, _i64, _i64, _p]),
-    "tarl_fused_policy_prepare": (C.c_int, [_p, _p, _p, _i64, _f32, _p, _p, _p, _p, _p]),
-    "tarl_fused_policy_step": (C.c_int, [_p, _p, _i64, _p, _p, _p, _p, _u64, _u64, _p, _p, _p, _p]),
     "tarl_fused_export": (C.c_int, [_p, _p] + _STATE + [_f32, _p]),
-    "tarl_fused_env_step": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _i64, _p, _p, _f32, C.c_int, _f32, _p, _u64, _u64,
-                                      _p, _p, _p, _p, _p, _p, _p]),
+    "tarl_fused_policy_prepare": (C.c_int, [_p, _p, _p, _i64, _f32, _p, _p, _p, _p, _p]),
+    "tarl_fused_frame": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _u64, _u64, _p, _i64, _i64, _p, _p, _f32, C.c_int,
+                                   _f32, _p, _u64, _u64] + [_p] * 10),
     "tarl_prof_enable": (C.c_int, [_i64]),
     "tarl_prof_collect": (C.c_int, [C.POINTER(_f64), C.POINTER(_i64)]),
 }
@@ -63,7 +64,7 @@ SIGNATURES = {
 class FusedStruct(C.Structure):
     """``tarl_fused`` of include/tarl_hip.h."""
     _fields_ = ([(n, C.c_void_p) for n in ("rec0", "rec1", "post", "st0", "slots")] + [("ld_slots", C.c_int64)] +
-                [(n, C.c_void_p) for n in ("a_origin", "a_dest", "a_dep", "a_status")])
+                [(n, C.c_void_p) for n in ("selnew", "part", "a_origin", "a_dest", "a_dep", "a_status")])
 
 
 _lib = None

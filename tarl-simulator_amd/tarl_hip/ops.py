@@ -424,25 +424,31 @@ def adam_step_(param, grad, exp_avg, exp_avg_sq, step, *, lr=1e-3, beta1=0.9, be
 
 # ---- fused rollout frame ----------------------------------------------------------------------------------------------
 class FusedState:
-    """Side buffers of the fused path (``tarl_fused`` in include/tarl_hip.h): packed hot / post / static node records and
-    the agent SoA. They mirror ``x`` / ``agent_features``; call :func:`fused_pack` after any external write to those."""
+    """Side buffers of the fused path (``tarl_fused`` in include/tarl_hip.h), ENV-MINOR ([node][env]): packed hot /
+    post / static node records, the slot-interleaved FIFO store and the agent SoA. They hold the state between
+    :func:`fused_pack` and :func:`fused_export`."""
 
-    def __init__(self, B: int, N: int, A: int, device, Nmax: int = 15):
+    def __init__(self, plan: Plan, B: int, A: int, device, Nmax: int = 15):
+        L = _lib.load()
+        N = plan.num_nodes
         f32 = dict(dtype=torch.float32, device=device)
         self.ld_slots = ((3 * Nmax + 15) // 16) * 16
-        self.slots = torch.zeros((B, N, self.ld_slots), **f32)
-        self.rec0 = torch.zeros((B, N, 4), **f32)
-        self.rec1 = torch.zeros((B, N, 4), **f32)
-        self.post = torch.zeros((B, N, 4), **f32)
+        self.chunks = int(L.tarl_fused_num_chunks(plan.handle))
+        self.slots = torch.zeros((N, B, self.ld_slots), **f32)
+        self.rec0 = torch.zeros((N, B, 4), **f32)
+        self.rec1 = torch.zeros((N, B, 4), **f32)
+        self.post = torch.zeros((N, B, 4), **f32)
         self.st0 = torch.zeros((N, 4), **f32)
+        self.selnew = torch.zeros((N, B), **f32)
+        self.part = torch.zeros((max(self.chunks, 1), B, 4), **f32)
         self.a_origin = torch.zeros((B, A), dtype=torch.int32, device=device)
         self.a_dest = torch.zeros((B, A), dtype=torch.int32, device=device)
         self.a_dep = torch.zeros((B, A), **f32)
         self.a_status = torch.zeros((B, A), dtype=torch.uint8, device=device)
         self.struct = _lib.FusedStruct(self.rec0.data_ptr(), self.rec1.data_ptr(), self.post.data_ptr(),
                                        self.st0.data_ptr(), self.slots.data_ptr(), self.ld_slots,
-                                       self.a_origin.data_ptr(), self.a_dest.data_ptr(), self.a_dep.data_ptr(),
-                                       self.a_status.data_ptr())
+                                       self.selnew.data_ptr(), self.part.data_ptr(), self.a_origin.data_ptr(),
+                                       self.a_dest.data_ptr(), self.a_dep.data_ptr(), self.a_status.data_ptr())
         self.B, self.N, self.A, self.Nmax = B, N, A, Nmax
 
     @property
@@ -456,6 +462,15 @@ def fused_pack(plan: Plan, fs: FusedState, x, Nmax, agent_features, congestion_c
     A, abs_ = _agents(agent_features, B)
     _lib.check(L.tarl_fused_pack(plan.handle, fs.ref, x.data_ptr(), B, bs, ldx, Nmax, _lib.ptr(congestion_constant),
                                  agent_features.data_ptr(), A, abs_, _lib.current_stream()))
+
+
+def fused_export(plan: Plan, fs: FusedState, x, Nmax, last_step_time):
+    """Write the packed state (FIFO columns, NUMBER_OF_AGENT, SELECTED_ROAD) back into ``x`` (reference layout).
+    ``last_step_time``: the clock passed to the most recent :func:`fused_frame`."""
+    L = _lib.load()
+    B, N, bs, ldx = _state(x, Nmax)
+    _lib.check(L.tarl_fused_export(plan.handle, fs.ref, x.data_ptr(), B, bs, ldx, Nmax, float(last_step_time),
+                                   _lib.current_stream()))
 
 
 class PolicyTables:
@@ -480,44 +495,46 @@ def fused_policy_prepare(plan: Plan, fs: FusedState, emb, temperature=1.0, table
     return tables
 
 
-def fused_policy_step(plan: Plan, fs: FusedState, tables: PolicyTables, *, uniform=None, seed=0, counter=0, choice=None,
-                      log_prob=None, entropy=None):
-    """GraphDistribution sample + log_prob (+ entropy) + choice phase for all B environments in one launch; outputs are
-    written into the tensors passed in (e.g. slices of the rollout buffers)."""
-    L = _lib.load()
-    for n, t, dt in (("choice", choice, torch.int32), ("log_prob", log_prob, torch.float32),
-                     ("entropy", entropy, torch.float32), ("uniform", uniform, torch.float32)):
-        if t is not None:
-            _contig(t, dt, n)
-    _lib.check(L.tarl_fused_policy_step(plan.handle, fs.ref, fs.B, tables.thresholds.data_ptr(),
-                                        tables.log_probs.data_ptr(), tables.entropy.data_ptr(), _lib.ptr(uniform),
-                                        int(seed), int(counter), _lib.ptr(choice), _lib.ptr(log_prob),
-                                        _lib.ptr(entropy), _lib.current_stream()))
-
-
-def fused_export(plan: Plan, fs: FusedState, x, Nmax, last_step_time):
-    """Write the packed state (FIFO columns, NUMBER_OF_AGENT, SELECTED_ROAD) back into ``x`` (reference layout).
-    ``last_step_time``: the clock passed to the most recent :func:`fused_env_step`."""
-    L = _lib.load()
-    B, N, bs, ldx = _state(x, Nmax)
-    _lib.check(L.tarl_fused_export(plan.handle, fs.ref, x.data_ptr(), B, bs, ldx, Nmax, float(last_step_time),
-                                   _lib.current_stream()))
-
-
-def fused_env_step(plan: Plan, fs: FusedState, agent_features, ec: EdgeConst, t, *, use_cong=True, gumbel=None,
-                   seed=0, counter=0, dtt=None, popped=None, withdrawn=None, scratch=None, reward=None, counts=None):
+def fused_frame(plan: Plan, fs: FusedState, tables: PolicyTables, agent_features, ec: EdgeConst, t, *, use_cong=True,
+                uniform=None, policy_seed=0, policy_counter=0, gumbel=None, seed=0, counter=0, dtt=None, popped=None,
+                withdrawn=None, scratch=None, choice=None, log_prob=None, entropy=None, reward=None, counts=None):
+    """One collector frame for all B environments (3 launches): sample + log_prob + choice phase, core step, withdraw,
+    insert, reward. ``choice`` (N, B) int32 and ``counts`` (N, B) fp32 are ENV-MINOR; ``dtt`` (B, E), ``popped`` /
+    ``withdrawn`` (B, N) uint8, ``log_prob`` / ``entropy`` / ``reward`` (B,). Outputs are written into the tensors
+    passed in (e.g. slices of the rollout buffers)."""
     L = _lib.load()
     B, Nmax = fs.B, fs.Nmax
     A, abs_ = _agents(agent_features, B)
     if scratch is None:
         scratch = torch.empty((B, 2 * A), dtype=torch.int32, device=agent_features.device)
-    for n, tt, dt in (("gumbel", gumbel, torch.float32), ("dtt", dtt, torch.float32), ("reward", reward, torch.float32),
-                      ("counts", counts, torch.float32), ("popped", popped, torch.uint8),
-                      ("withdrawn", withdrawn, torch.uint8)):
+    for n, tt, dt in (("gumbel", gumbel, torch.float32), ("uniform", uniform, torch.float32),
+                      ("dtt", dtt, torch.float32), ("reward", reward, torch.float32), ("counts", counts, torch.float32),
+                      ("popped", popped, torch.uint8), ("withdrawn", withdrawn, torch.uint8),
+                      ("choice", choice, torch.int32), ("log_prob", log_prob, torch.float32),
+                      ("entropy", entropy, torch.float32)):
         if tt is not None:
             _contig(tt, dt, n)
-    _lib.check(L.tarl_fused_env_step(plan.handle, fs.ref, B, Nmax, agent_features.data_ptr(), A,
-                                     abs_, ec.edge_attr.data_ptr(), ec.log_edge_attr.data_ptr(), ec.log_eps,
-                                     1 if use_cong else 0, float(t), _lib.ptr(gumbel), int(seed), int(counter),
-                                     _lib.ptr(dtt), _lib.ptr(popped), _lib.ptr(withdrawn), scratch.data_ptr(),
-                                     _lib.ptr(reward), _lib.ptr(counts), _lib.current_stream()))
+    _lib.check(L.tarl_fused_frame(plan.handle, fs.ref, B, Nmax, tables.thresholds.data_ptr(),
+                                  tables.log_probs.data_ptr(), tables.entropy.data_ptr(), _lib.ptr(uniform),
+                                  int(policy_seed), int(policy_counter), agent_features.data_ptr(), A, abs_,
+                                  ec.edge_attr.data_ptr(), ec.log_edge_attr.data_ptr(), ec.log_eps,
+                                  1 if use_cong else 0, float(t), _lib.ptr(gumbel), int(seed), int(counter),
+                                  _lib.ptr(dtt), _lib.ptr(popped), _lib.ptr(withdrawn), scratch.data_ptr(),
+                                  _lib.ptr(choice), _lib.ptr(log_prob), _lib.ptr(entropy), _lib.ptr(reward),
+                                  _lib.ptr(counts), _lib.current_stream()))
+
+
+def critic_forward_slabs(cw: CriticWeights, counts, time_rows):
+    """counts (S, N, R) fp32 contiguous = [frame][node][env] with R % 128 == 0 -> value (S*R,) in (frame, env) order;
+    ``time_rows`` (S,) is each frame's clock."""
+    L = _lib.load()
+    _contig(counts, torch.float32, "counts")
+    _contig(time_rows, torch.float32, "time_rows")
+    S, N, R = counts.shape
+    if N != cw.N or R % 128 or time_rows.numel() < S:
+        raise ValueError("counts must be (S, N, R) with R a multiple of 128 and one time per slab")
+    value = torch.empty(S * R, dtype=torch.float32, device=counts.device)
+    _lib.check(L.tarl_critic_mlp_fwd_slabs(counts.data_ptr(), R, S * R, N, time_rows.data_ptr(), R, cw.w1.data_ptr(),
+                                           cw.b1.data_ptr(), cw.w2.data_ptr(), cw.b2.data_ptr(), cw.w3.data_ptr(),
+                                           cw.b3.data_ptr(), value.data_ptr(), _lib.current_stream()))
+    return value

@@ -41,8 +41,11 @@ class VecPPOTrainer:
         # replicas start identical: rank 0's initial weights win
         dist_utils.broadcast_(self.flat.flat, src=0)
         B, N, dev = engine.B, engine.N, engine.device
-        self.counts = torch.zeros((self.T + 1, B, N), dtype=torch.float32, device=dev)
-        self.choice = torch.zeros((self.T, B, N), dtype=torch.int32, device=dev)
+        # rollout buffers; on the fused path they are ENV-MINOR ([frame][node][env]), written directly by the kernels
+        self.env_minor = engine.fs is not None
+        shp = (lambda t: (t, N, B)) if self.env_minor else (lambda t: (t, B, N))
+        self.counts = torch.zeros(shp(self.T + 1), dtype=torch.float32, device=dev)
+        self.choice = torch.zeros(shp(self.T), dtype=torch.int32, device=dev)
         self.logp = torch.zeros((self.T, B), dtype=torch.float32, device=dev)
         self.reward = torch.zeros((self.T, B), dtype=torch.float32, device=dev)
         self.times = torch.zeros(self.T + 1, dtype=torch.float32, device=dev)
@@ -75,8 +78,8 @@ class VecPPOTrainer:
             eng.prepare_policy(emb, self.temperature)      # once per parameter update, not per frame
             for t in range(self.T):
                 host_times.append(float(eng.time))
-                eng.policy_step_fused(choice=self.choice[t], log_prob=self.logp[t])
-                eng.step_fused(reward=self.reward[t], counts=self.counts[t + 1])
+                eng.frame_fused(choice=self.choice[t], log_prob=self.logp[t], reward=self.reward[t],
+                                counts=self.counts[t + 1])
             host_times.append(float(eng.time))
             self.times.copy_(torch.tensor(host_times, dtype=torch.float32))
             return self.T * eng.B
@@ -104,7 +107,11 @@ class VecPPOTrainer:
         eng = self.eng
         T, B, N = self.T, eng.B, eng.N
         cw = self._critic()
-        v, _, _ = ops.critic_forward(cw, self.counts.view((T + 1) * B, N), self.times, rows_per_time=B)
+        if self.env_minor and B % 128 == 0:
+            v = ops.critic_forward_slabs(cw, self.counts, self.times)           # reads [frame][node][env] as is
+        else:
+            rows = self.counts.permute(0, 2, 1).contiguous() if self.env_minor else self.counts
+            v, _, _ = ops.critic_forward(cw, rows.view((T + 1) * B, N), self.times, rows_per_time=B)
         self.values = v.view(T + 1, B)
         adv, target = ops.gae(self.reward, self.values[:T], self.values[1:], gamma=self.gamma, lmbda=self.lmbda)
         stats = ops.advantage_stats(adv)
@@ -117,8 +124,13 @@ class VecPPOTrainer:
         T, B, N, E = self.T, eng.B, eng.N, eng.E
         M = min(self.M, T * B)
         idx = torch.randperm(T * B, generator=self.gen, device=eng.device)[:M]
-        counts_mb = self.counts[:T].view(T * B, N).index_select(0, idx)
-        choice_mb = self.choice.view(T * B, N).index_select(0, idx)
+        if self.env_minor:
+            t_idx, b_idx = torch.div(idx, B, rounding_mode="floor"), idx % B
+            counts_mb = self.counts[t_idx, :, b_idx].contiguous()               # (M, N) rows of the sampled frames
+            choice_mb = self.choice[t_idx, :, b_idx].contiguous()
+        else:
+            counts_mb = self.counts[:T].view(T * B, N).index_select(0, idx)
+            choice_mb = self.choice.view(T * B, N).index_select(0, idx)
         lp_old = self.logp.view(-1).index_select(0, idx)
         adv_mb = adv.view(-1).index_select(0, idx)
         tgt_mb = target.view(-1).index_select(0, idx)

@@ -29,10 +29,10 @@ eng = SimEngine(net.x.cuda().unsqueeze(0).repeat(args.envs, 1, 1).contiguous(), 
 emb = torch.randn(N, device="cuda")
 eng.reset()
 eng.prepare_policy(emb)
-choice = torch.empty((args.envs, N), dtype=torch.int32, device="cuda")
+choice = torch.empty((N, args.envs), dtype=torch.int32, device="cuda")
+counts = torch.empty((N, args.envs), device="cuda")
 lp = torch.empty(args.envs, device="cuda")
 for _ in range(args.frames):
-    eng.policy_step_fused(choice=choice, log_prob=lp)
-    eng.step_fused()
+    eng.frame_fused(choice=choice, log_prob=lp, counts=counts)
 torch.cuda.synchronize()
 print("frames", args.frames, "on_way", float(eng.agents[:, :, 7].sum()))
