@@ -1,4 +1,4 @@
-// fused.hip — the vectorised rollout frame in 3 launches, bit-identical (state, agents, actions, rewards) to the unfused
+// fused.hip — the vectorised rollout frame in 4 launches, bit-identical (state, agents, actions, rewards) to the unfused
 // kernels and therefore to the reference.
 //
 // Why: the reference's AoS row (F = 3*Nmax+7 floats, 208 B at Nmax = 15) scatters the ~10 scalars a message needs over
@@ -12,8 +12,8 @@
 //     there is no dependent index -> address -> data chain left in the vector memory path;
 //   * the Direction gather also emits post = {n', head', tail', chosen}: the state every row will have after the
 //     Direction update, from which the Response "accepted" test is evaluated without a second pass over the FIFOs;
-//   * the live policy's sample is state-independent (see k_policy_tables): the choice phase is folded into the
-//     Direction kernel, which re-derives each in-neighbour's selected road from that neighbour's Philox draw;
+//   * the live policy's sample is state-independent (see k_policy_tables): the choice phase is a table walk per
+//     (node, env) with Philox blocks shared across consecutive nodes;
 //   * ONE row pass applies Direction update + Response pop + withdraw and refreshes the hot record;
 //   * the FIFO contents live in a slot-interleaved store  slots[node][env][s] = {id, arrival, departure}: the Direction
 //     update's per-row write is ONE 12-byte store instead of three dwords in three DRAM sectors (+ counter);
@@ -30,13 +30,13 @@
 // DESIGN.md Q25) are not supported by this path.
 #include <float.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "tarl_common.h"
 
 #define FB 256          // pack / export kernels
 #define ENVB 1024       // one-workgroup-per-environment kernels
 #define TILE 256        // environments per workgroup in the env-minor kernels (one per lane)
-#define NCHUNK 16       // nodes walked by one workgroup of the env-minor kernels
 #define LOG_EPS_P 1e-8f
 #define INS_CAP 2048    // LDS candidate list of the insert kernel (entries)
 
@@ -245,48 +245,62 @@ __device__ __forceinline__ float node_uniform(const float* __restrict__ uniform,
   return uniform ? uniform[b * G + g] : philox_uniform(seed, counter, (uint64_t)(b * G + g));
 }
 
-// ---- choice phase + Direction gather on the hot records (env-minor: lane = environment) ------------------------------
-__global__ __launch_bounds__(TILE) void k_fused_direction(const int32_t* __restrict__ in_ptr,
-                                                          const int32_t* __restrict__ in_src,
-                                                          const int32_t* __restrict__ in_eid,
-                                                          const int32_t* __restrict__ out_ptr,
-                                                          const int32_t* __restrict__ out_dst,
-                                                          const int32_t* __restrict__ out_eid,
-                                                          const int32_t* __restrict__ group_of_node, int64_t E,
-                                                          int64_t G, int64_t B, int64_t N, FusedBufs fb,
-                                                          const float* __restrict__ thr, const float* __restrict__ lgt,
-                                                          const float* __restrict__ uniform, uint64_t pseed,
-                                                          uint64_t pcounter, const float* __restrict__ edge_attr,
-                                                          const float* __restrict__ log_edge_attr, float log_eps,
-                                                          float t, const float* __restrict__ gumbel, uint64_t seed,
-                                                          uint64_t counter, float* __restrict__ dtt,
-                                                          int32_t* __restrict__ choice) {
+// ---- choice phase (env-minor: lane = environment, a workgroup walks a chunk of nodes) --------------------------------
+// Consecutive nodes of one environment share Philox blocks (index = b*G + g), so a chunk costs ~nchunk/4 + 1 Philox
+// evaluations per lane instead of one per node.
+__global__ __launch_bounds__(TILE) void k_fused_choice(const int32_t* __restrict__ out_ptr,
+                                                       const int32_t* __restrict__ out_dst,
+                                                       const int32_t* __restrict__ out_eid,
+                                                       const int32_t* __restrict__ group_of_node, int64_t G, int64_t B,
+                                                       int64_t N, FusedBufs fb, const float* __restrict__ thr,
+                                                       const float* __restrict__ lgt,
+                                                       const float* __restrict__ uniform, uint64_t pseed,
+                                                       uint64_t pcounter, int32_t* __restrict__ choice, int nchunk) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = b < B;
-  const int64_t bb = live ? b : B - 1;  // idle lanes shadow the last environment (loads stay in bounds, stores masked)
-  const int32_t i0 = blockIdx.y * NCHUNK;
-  const int32_t i1 = (i0 + NCHUNK < N) ? i0 + NCHUNK : (int32_t)N;
+  if (b >= B) return;
+  const int32_t i0 = blockIdx.y * nchunk;
+  const int32_t i1 = (i0 + nchunk < N) ? i0 + nchunk : (int32_t)N;
   float lp = 0.0f, bad = 0.0f;
-  for (int32_t i = i0; i < i1; ++i) {  // i, and everything indexed by it alone, is wave-uniform
-    const int64_t row = (int64_t)i * B + bb;
-    const float4 me = fb.rec0[row];
-    // -- choice phase for node i
-    float sel_i = me.w;
+  PhiloxRun rng;
+  for (int32_t i = i0; i < i1; ++i) {
+    const int64_t row = (int64_t)i * B + b;
+    float sel_i = fb.rec0[row].w;  // a node that picks nothing keeps its previous SELECTED_ROAD
+    int32_t ch = -1;
     const int32_t gi = group_of_node[i];
     if (gi >= 0) {
-      const int32_t pk = sample_node(out_ptr, thr, i, node_uniform(uniform, pseed, pcounter, bb, G, gi));
+      const float u = uniform ? uniform[b * G + gi] : rng.uniform(pseed, pcounter, (uint64_t)(b * G + gi));
+      const int32_t pk = sample_node(out_ptr, thr, i, u);
       if (pk >= 0) {
         sel_i = (float)out_dst[pk];
         lp += lgt[pk];
+        ch = out_eid[pk];
       } else {
         bad = 1.0f;
       }
-      if (choice && live) choice[row] = pk >= 0 ? out_eid[pk] : -1;
-    } else if (choice && live) {
-      choice[row] = -1;
     }
-    if (live) fb.selnew[row] = sel_i;
-    // -- Direction message + aggregate for downstream road i
+    fb.selnew[row] = sel_i;
+    if (choice) choice[row] = ch;
+  }
+  float* pp = fb.part + ((int64_t)blockIdx.y * B + b) * 4;
+  pp[0] = lp;
+  pp[1] = bad;
+}
+
+// ---- Direction gather on the hot records (env-minor: lane = environment) ---------------------------------------------------
+__global__ __launch_bounds__(TILE) void k_fused_direction(const int32_t* __restrict__ in_ptr,
+                                                          const int32_t* __restrict__ in_src,
+                                                          const int32_t* __restrict__ in_eid, int64_t E, int64_t B,
+                                                          int64_t N, FusedBufs fb, const float* __restrict__ edge_attr,
+                                                          const float* __restrict__ log_edge_attr, float log_eps,
+                                                          float t, const float* __restrict__ gumbel, uint64_t seed,
+                                                          uint64_t counter, float* __restrict__ dtt, int nchunk) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int32_t i0 = blockIdx.y * nchunk;
+  const int32_t i1 = (i0 + nchunk < N) ? i0 + nchunk : (int32_t)N;
+  for (int32_t i = i0; i < i1; ++i) {  // i, and everything indexed by it alone, is wave-uniform
+    const int64_t row = (int64_t)i * B + b;
+    const float4 me = fb.rec0[row];
     const float4 sti = fb.st0[i];
     const float max_i = sti.x, n_i = me.z, road_i = sti.z;
     const float room_i = max_i - n_i;
@@ -297,15 +311,10 @@ __global__ __launch_bounds__(TILE) void k_fused_direction(const int32_t* __restr
     for (int32_t k = in_ptr[i]; k < k1; ++k) {
       const int32_t j = in_src[k];
       const int32_t e = in_eid[k];
-      const float4 rj = fb.rec0[(int64_t)j * B + bb];
+      const int64_t jrow = (int64_t)j * B + b;
+      const float4 rj = fb.rec0[jrow];
+      const float sel_j = fb.selnew[jrow];  // road selected by upstream j in THIS frame's choice phase
       const float4 stj = fb.st0[j];
-      // road selected by upstream j in THIS frame's choice phase (re-derived from j's own draw)
-      float sel_j = rj.w;
-      const int32_t gj = group_of_node[j];
-      if (gj >= 0) {
-        const int32_t pj = sample_node(out_ptr, thr, j, node_uniform(uniform, pseed, pcounter, bb, G, gj));
-        if (pj >= 0) sel_j = (float)out_dst[pj];
-      }
       const float id = rj.x, dep = rj.y, n_j = rj.z, max_j = stj.x;
       const bool heads_here = sel_j == road_i;
       const bool m1 = (dep <= t) && has_room && heads_here && (n_j > 0.0f);
@@ -316,9 +325,9 @@ __global__ __launch_bounds__(TILE) void k_fused_direction(const int32_t* __restr
       P = P + prob;
       float g;
       if (gumbel) {
-        g = gumbel[bb * E + e];
+        g = gumbel[b * E + e];
       } else {
-        const float u = rng.uniform(seed, counter, (uint64_t)(bb * E + k));
+        const float u = rng.uniform(seed, counter, (uint64_t)(b * E + k));
         g = -logf(-logf(u));
       }
       const float score = (m ? log_edge_attr[e] : log_eps) + g;
@@ -326,20 +335,14 @@ __global__ __launch_bounds__(TILE) void k_fused_direction(const int32_t* __restr
         best = score;
         best_id = id;
       }
-      if (dtt && live) {
-        const float d = (dep - fb.rec1[(int64_t)j * B + bb].y) - stj.y;
-        dtt[bb * E + e] = d > 0.0f ? d : (d != d ? d : 0.0f);
+      if (dtt) {
+        const float d = (dep - fb.rec1[jrow].y) - stj.y;
+        dtt[b * E + e] = d > 0.0f ? d : (d != d ? d : 0.0f);
       }
     }
     const float who = (P > 0.0f) ? best_id : 0.0f;
     const float4 r1 = fb.rec1[row];
-    if (live)
-      fb.post[row] = make_float4(who != 0.0f ? n_i + 1.0f : n_i, n_i == 0.0f ? who : me.x, who != 0.0f ? who : r1.x, who);
-  }
-  if (live) {
-    float* pp = fb.part + ((int64_t)blockIdx.y * B + b) * 4;
-    pp[0] = lp;
-    pp[1] = bad;
+    fb.post[row] = make_float4(who != 0.0f ? n_i + 1.0f : n_i, n_i == 0.0f ? who : me.x, who != 0.0f ? who : r1.x, who);
   }
 }
 
@@ -348,11 +351,12 @@ __global__ __launch_bounds__(TILE) void k_fused_rows(const int32_t* __restrict__
                                                      const int32_t* __restrict__ out_dst, int Nmax, int64_t B,
                                                      int64_t N, FusedBufs fb, float* __restrict__ ag, int64_t A,
                                                      int64_t a_bstride, float t, uint8_t* __restrict__ popped_out,
-                                                     uint8_t* __restrict__ withdrawn_out, float* __restrict__ counts) {
+                                                     uint8_t* __restrict__ withdrawn_out, float* __restrict__ counts,
+                                                     int nchunk) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  const int32_t i0 = blockIdx.y * NCHUNK;
-  const int32_t i1 = (i0 + NCHUNK < N) ? i0 + NCHUNK : (int32_t)N;
+  const int32_t i0 = blockIdx.y * nchunk;
+  const int32_t i1 = (i0 + nchunk < N) ? i0 + nchunk : (int32_t)N;
   float nsum = 0.0f;
   for (int32_t i = i0; i < i1; ++i) {
     const int64_t row = (int64_t)i * B + b;
@@ -668,7 +672,17 @@ static FusedBufs to_bufs(const tarl_fused* f) {
                    f->selnew,        f->part,          f->a_origin,      f->a_dest,             f->a_dep, f->a_status};
 }
 
-static int64_t num_chunks(const tarl_plan* plan) { return ceil_div(plan->N, NCHUNK); }
+// nodes walked by one workgroup of the env-minor kernels (tunable: TARL_NCHUNK)
+static int nchunk() {
+  static int v = 0;
+  if (v == 0) {
+    const char* e = getenv("TARL_NCHUNK");
+    v = e ? atoi(e) : 4;
+    if (v < 1) v = 1;
+  }
+  return v;
+}
+static int64_t num_chunks(const tarl_plan* plan) { return ceil_div(plan->N, nchunk()); }
 
 static int check_fused_core(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax) {
   TARL_REQUIRE(plan && f, "null argument");
@@ -762,15 +776,18 @@ extern "C" int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int6
   hipStream_t s = (hipStream_t)stream;
   const unsigned threads = tile_threads(B);
   const dim3 grid((unsigned)ceil_div(B, threads), (unsigned)num_chunks(plan));
+  hipLaunchKernelGGL(k_fused_choice, grid, dim3(threads), 0, s, plan->out_ptr, plan->out_dst, plan->out_eid,
+                     plan->group_of_node, plan->G, B, plan->N, fb, thresholds, log_probs, uniform, policy_seed,
+                     policy_counter, choice, nchunk());
+  TARL_LAUNCH_CHECK();
   const bool timed = tarl_prof_event(s) != nullptr;
-  hipLaunchKernelGGL(k_fused_direction, grid, dim3(threads), 0, s, plan->in_ptr, plan->in_src, plan->in_eid,
-                     plan->out_ptr, plan->out_dst, plan->out_eid, plan->group_of_node, plan->E, plan->G, B, plan->N, fb,
-                     thresholds, log_probs, uniform, policy_seed, policy_counter, edge_attr, log_edge_attr, log_eps, time,
-                     gumbel, seed, counter, delta_travel_time, choice);
+  hipLaunchKernelGGL(k_fused_direction, grid, dim3(threads), 0, s, plan->in_ptr, plan->in_src, plan->in_eid, plan->E, B,
+                     plan->N, fb, edge_attr, log_edge_attr, log_eps, time, gumbel, seed, counter, delta_travel_time,
+                     nchunk());
   TARL_LAUNCH_CHECK();
   if (timed) (void)tarl_prof_event(s);
   hipLaunchKernelGGL(k_fused_rows, grid, dim3(threads), 0, s, plan->out_ptr, plan->out_dst, (int)Nmax, B, plan->N, fb,
-                     agent_features, A, a_bstride, time, popped, withdrawn, counts);
+                     agent_features, A, a_bstride, time, popped, withdrawn, counts, nchunk());
   TARL_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(ENVB), 0, s, (int)Nmax, B, plan->N, num_chunks(plan), fb,
                      agent_features, A, a_bstride, use_cong, time, ins_scratch, entropy1, reward, counts, log_prob,
