@@ -199,12 +199,12 @@ int tarl_critic_mlp_fwd_slabs(const float* counts, int64_t rows_per_slab, int64_
  * ENV-MINOR layout: every per-(node, environment) buffer is stored [node][environment], so that a wavefront holds 64
  * environments of one node: topology / table loads are wave-uniform and record gathers are coalesced.
  * Caller-owned side buffers that mirror x / agent_features (all device memory, 16-byte aligned):
- *   rec0 [N][B][4] = {head_id, head_dep, n, sel}      rec1 [N][B][4] = {tail_id, head_arr, pending-garbage n0, flag}
- *   post [N][B][4] = {n', head', tail', chosen} (state after the Direction update, written by the gather kernel)
+ *   rec0 [N][B][4] = {head_id, head_dep, n, tail_id}   rec1 [N][B][2] = {head_arr, pending-garbage n0 or -1}
+ *   post_a [N][B][2] = {n', tail'}, post_b [N][B][2] = {head', chosen} (state after the Direction update)
+ *   sel [N][B] = SELECTED_ROAD; acc_lp int64 [B], acc_n fp32 [B]: per-frame accumulators (zeroed by pack)
  *   st0  [N][4]    = {MAX_NUMBER_OF_AGENT, FREE_FLOW_TIME_TRAVEL, ROAD_INDEX, congestion_constant} (static, shared)
  *   slots [N][B][ld_slots]: slot-interleaved FIFO store, slot s at floats 3s..3s+2 = {agent id, arrival, departure};
  *                  ld_slots >= 3*Nmax (pad to a multiple of 16 floats)
- *   selnew [N][B], part [tarl_fused_num_chunks(plan)][B][4]: scratch
  *   a_origin / a_dest int32 [B][A], a_dep fp32 [B][A], a_status uint8 [B][A] (0 waiting, 1 on the way, 2 done).
  * tarl_fused_pack imports x / agent_features (call after construction, reset, or any external write to x); between
  * pack and export the packed state is authoritative for the FIFO columns, NUMBER_OF_AGENT and SELECTED_ROAD;
@@ -213,19 +213,20 @@ int tarl_critic_mlp_fwd_slabs(const float* counts, int64_t rows_per_slab, int64_
 typedef struct tarl_fused {
   float* rec0;
   float* rec1;
-  float* post;
+  float* post_a;
+  float* post_b;
   float* st0;
   float* slots;
   int64_t ld_slots;
-  float* selnew;
-  float* part;
+  float* sel;
+  int64_t* acc_lp;
+  float* acc_n;
   int32_t* a_origin;
   int32_t* a_dest;
   float* a_dep;
   uint8_t* a_status;
 } tarl_fused;
 
-int64_t tarl_fused_num_chunks(const tarl_plan* plan);
 int tarl_fused_pack(const tarl_plan* plan, const tarl_fused* f, const float* x, int64_t B, int64_t x_bstride,
                     int64_t ldx, int32_t Nmax, const float* congestion_constant, const float* agent_features,
                     int64_t num_agents, int64_t a_bstride, tarl_stream stream);
@@ -246,8 +247,8 @@ int tarl_fused_policy_prepare(const tarl_plan* plan, const tarl_fused* f, const 
  *   uniform [B][num_groups] or NULL (Philox keyed by policy_seed / policy_counter); gumbel [B][E] or NULL (Philox keyed
  *   by seed / counter). Nullable outputs: delta_travel_time [B][E], popped / withdrawn uint8 [B][N] (env-major, like the
  *   unfused entry points); choice int32 [N][B] and counts fp32 [N][B] (ENV-MINOR); log_prob, entropy, reward [B].
- *   log_prob sums the same terms as tarl_graphdist_logprob_entropy_fwd in a different (fixed) order: equal to fp32
- *   rounding, not bit-identical. use_cong = 0 reproduces a graph without congestion_constant in insert. */
+ *   log_prob sums the same terms as tarl_graphdist_logprob_entropy_fwd, accumulated in 2^-32 fixed point (order-
+ *   independent, hence deterministic): equal to fp32 rounding, not bit-identical. use_cong = 0 reproduces a graph without congestion_constant in insert. */
 int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, const float* thresholds,
                      const float* log_probs, const float* entropy1, const float* uniform, uint64_t policy_seed,
                      uint64_t policy_counter, float* agent_features, int64_t num_agents, int64_t a_bstride,

@@ -3,15 +3,16 @@
 //
 // Why: the reference's AoS row (F = 3*Nmax+7 floats, 208 B at Nmax = 15) scatters the ~10 scalars a message needs over
 // 2-3 cache lines, and eleven separate launches per frame each re-stream the whole state. Here
-//   * a packed per-(node, env) HOT RECORD  rec0 = {head_id, head_dep, n, sel}, rec1 = {tail_id, head_arr, pending-garbage
-//     n0, flag} and a per-node STATIC record st0 = {maxn, ff, road_index, cong} (shared by all environments) mirror the
-//     row, so the gather kernels read 16 B per neighbour and never touch the FIFO storage;
+//   * a packed per-(node, env) HOT RECORD  rec0 = {head_id, head_dep, n, tail_id} (+ sel [node][env], and the cold half
+//     rec1 = {head_arr, pending-garbage n0}) and a per-node STATIC record st0 = {maxn, ff, road_index, cong} (shared by
+//     all environments) mirror the row: the gather kernel reads 20 B per neighbour and never touches the FIFO storage;
 //   * ENV-MINOR LAYOUT: every per-(node, env) array is stored [node][env]. A workgroup owns a tile of consecutive
 //     environments (one per lane) and walks a chunk of nodes: all topology / table / static loads are wave-uniform
 //     (scalar loads through the constant cache) and every record gather is a fully coalesced 16 B x 64 = 1 KiB load —
 //     there is no dependent index -> address -> data chain left in the vector memory path;
-//   * the Direction gather also emits post = {n', head', tail', chosen}: the state every row will have after the
-//     Direction update, from which the Response "accepted" test is evaluated without a second pass over the FIFOs;
+//   * the Direction gather also emits postA = {n', tail'} / postB = {head', chosen}: the state every row will have after
+//     the Direction update, from which the Response "accepted" test is evaluated (8-B gathers of postA) without a second
+//     pass over the FIFOs;
 //   * the live policy's sample is state-independent (see k_policy_tables): the choice phase is a table walk per
 //     (node, env) with Philox blocks shared across consecutive nodes;
 //   * ONE row pass applies Direction update + Response pop + withdraw and refreshes the hot record;
@@ -41,19 +42,23 @@
 #define INS_CAP 2048    // LDS candidate list of the insert kernel (entries)
 
 struct FusedBufs {
-  float4* rec0;         // [N][B] {head_id, head_dep, n, sel}
-  float4* rec1;         // [N][B] {tail_id, head_arr, n0 of the pending garbage write, pending flag}
-  float4* post;         // [N][B] {n', head', tail', chosen}
+  float4* rec0;         // [N][B] {head_id, head_dep, n, tail_id}
+  float2* rec1;         // [N][B] {head_arr, pending-garbage n0 (or -1 when nothing is pending)}
+  float2* postA;        // [N][B] {n', tail'}   state after the Direction update, gathered by the upstream rows
+  float2* postB;        // [N][B] {head', chosen}  read by the row itself only
   const float4* st0;    // [N]    {maxn, ff, road_index, cong}
   float* slots;         // [N][B][lds] slot-interleaved FIFO store: slot s at floats 3s..3s+2 = {id, arrival, departure}
   int64_t lds;          // row stride of slots in floats (>= 3*Nmax, multiple of 16)
-  float* selnew;        // [N][B] road selected in this frame's choice phase (consumed by the row pass)
-  float* part;          // [chunks][B][4] per-chunk partials {log-prob sum, infeasible flag, count sum, -}
+  float* sel;           // [N][B] SELECTED_ROAD
+  long long* acc_lp;    // [B] log-prob of this frame's action, 2^-32 fixed point (order-independent => deterministic)
+  float* acc_n;         // [B] sum of the per-node counts after the row pass (small integers: exact in any order)
   int32_t* a_origin;    // [B][A]
   int32_t* a_dest;      // [B][A]
   float* a_dep;         // [B][A]
   uint8_t* a_status;    // [B][A] 0 waiting, 1 on the way, 2 done
 };
+
+#define LP_FIX 4294967296.0  // 2^32
 
 // ---- pack: build the hot / static records, the slot store and the agent SoA from x / agent_features ------------------
 __global__ __launch_bounds__(FB) void k_pack_nodes(const float* __restrict__ x, Layout L, int64_t B, int64_t N,
@@ -67,10 +72,15 @@ __global__ __launch_bounds__(FB) void k_pack_nodes(const float* __restrict__ x, 
   const float n = xi[L.col_n()];
   const int q = (int)n;
   const float tail = (q >= 1 && q <= Nmax) ? xi[q - 1] : 0.0f;
-  fb.rec0[gid] = make_float4(xi[0], xi[2 * Nmax], n, xi[L.col_sel()]);
-  fb.rec1[gid] = make_float4(tail, xi[Nmax], 0.0f, 0.0f);
-  fb.post[gid] = make_float4(n, xi[0], tail, 0.0f);
-  fb.selnew[gid] = xi[L.col_sel()];
+  fb.rec0[gid] = make_float4(xi[0], xi[2 * Nmax], n, tail);
+  fb.rec1[gid] = make_float2(xi[Nmax], -1.0f);
+  fb.postA[gid] = make_float2(n, tail);
+  fb.postB[gid] = make_float2(xi[0], 0.0f);
+  fb.sel[gid] = xi[L.col_sel()];
+  if (i == 0) {
+    fb.acc_lp[b] = 0;
+    fb.acc_n[b] = 0.0f;
+  }
   float* sl = fb.slots + gid * fb.lds;
   for (int sidx = 0; sidx < Nmax; ++sidx) {
     sl[3 * sidx + 0] = xi[sidx];
@@ -114,10 +124,10 @@ __global__ __launch_bounds__(FB) void k_export_rows(float* __restrict__ x, Layou
   float* xi = x + b * L.bstride + i * L.ldx;
   const float* sl = fb.slots + row * fb.lds + 3 * sidx;
   const float4 r0 = fb.rec0[row];
-  const float4 r1 = fb.rec1[row];
-  if (r1.w != 0.0f && sidx == (int)r0.z) {  // pending garbage write of the last Direction update -> first dead slot
+  const float2 r1 = fb.rec1[row];
+  if (r1.y >= 0.0f && sidx == (int)r0.z) {  // pending garbage write of the last Direction update -> first dead slot
     const float4 st = fb.st0[i];
-    const float t_cong = st.w / (st.x + 10.0f - r1.z);
+    const float t_cong = st.w / (st.x + 10.0f - r1.y);
     const float tt = (t_cong != t_cong) ? t_cong : fmaxf(st.y, t_cong);
     xi[sidx] = 0.0f;
     xi[Nmax + sidx] = t_last;
@@ -129,7 +139,7 @@ __global__ __launch_bounds__(FB) void k_export_rows(float* __restrict__ x, Layou
   }
   if (sidx == 0) {
     xi[L.col_n()] = r0.z;
-    xi[L.col_sel()] = r0.w;
+    xi[L.col_sel()] = fb.sel[row];
   }
 }
 
@@ -260,30 +270,28 @@ __global__ __launch_bounds__(TILE) void k_fused_choice(const int32_t* __restrict
   if (b >= B) return;
   const int32_t i0 = blockIdx.y * nchunk;
   const int32_t i1 = (i0 + nchunk < N) ? i0 + nchunk : (int32_t)N;
-  float lp = 0.0f, bad = 0.0f;
+  long long lp = 0;
+  bool bad = false;
   PhiloxRun rng;
   for (int32_t i = i0; i < i1; ++i) {
     const int64_t row = (int64_t)i * B + b;
-    float sel_i = fb.rec0[row].w;  // a node that picks nothing keeps its previous SELECTED_ROAD
     int32_t ch = -1;
     const int32_t gi = group_of_node[i];
     if (gi >= 0) {
       const float u = uniform ? uniform[b * G + gi] : rng.uniform(pseed, pcounter, (uint64_t)(b * G + gi));
       const int32_t pk = sample_node(out_ptr, thr, i, u);
       if (pk >= 0) {
-        sel_i = (float)out_dst[pk];
-        lp += lgt[pk];
+        fb.sel[row] = (float)out_dst[pk];  // a node that picks nothing keeps its previous SELECTED_ROAD
+        lp += (long long)((double)lgt[pk] * LP_FIX);
         ch = out_eid[pk];
       } else {
-        bad = 1.0f;
+        bad = true;
       }
     }
-    fb.selnew[row] = sel_i;
     if (choice) choice[row] = ch;
   }
-  float* pp = fb.part + ((int64_t)blockIdx.y * B + b) * 4;
-  pp[0] = lp;
-  pp[1] = bad;
+  // infeasible action (some node picked nothing): poison the accumulator far beyond any legitimate sum
+  atomicAdd((unsigned long long*)&fb.acc_lp[b], (unsigned long long)(bad ? -(1ll << 50) : lp));  // up to 2^13 chunks cannot wrap
 }
 
 // ---- Direction gather on the hot records (env-minor: lane = environment) ---------------------------------------------------
@@ -313,7 +321,7 @@ __global__ __launch_bounds__(TILE) void k_fused_direction(const int32_t* __restr
       const int32_t e = in_eid[k];
       const int64_t jrow = (int64_t)j * B + b;
       const float4 rj = fb.rec0[jrow];
-      const float sel_j = fb.selnew[jrow];  // road selected by upstream j in THIS frame's choice phase
+      const float sel_j = fb.sel[jrow];  // road selected by upstream j in THIS frame's choice phase
       const float4 stj = fb.st0[j];
       const float id = rj.x, dep = rj.y, n_j = rj.z, max_j = stj.x;
       const bool heads_here = sel_j == road_i;
@@ -336,13 +344,13 @@ __global__ __launch_bounds__(TILE) void k_fused_direction(const int32_t* __restr
         best_id = id;
       }
       if (dtt) {
-        const float d = (dep - fb.rec1[jrow].y) - stj.y;
+        const float d = (dep - fb.rec1[jrow].x) - stj.y;
         dtt[b * E + e] = d > 0.0f ? d : (d != d ? d : 0.0f);
       }
     }
     const float who = (P > 0.0f) ? best_id : 0.0f;
-    const float4 r1 = fb.rec1[row];
-    fb.post[row] = make_float4(who != 0.0f ? n_i + 1.0f : n_i, n_i == 0.0f ? who : me.x, who != 0.0f ? who : r1.x, who);
+    fb.postA[row] = make_float2(who != 0.0f ? n_i + 1.0f : n_i, who != 0.0f ? who : me.w);
+    fb.postB[row] = make_float2(n_i == 0.0f ? who : me.x, who);
   }
 }
 
@@ -361,21 +369,22 @@ __global__ __launch_bounds__(TILE) void k_fused_rows(const int32_t* __restrict__
   for (int32_t i = i0; i < i1; ++i) {
     const int64_t row = (int64_t)i * B + b;
     float* sl = fb.slots + row * fb.lds;  // slot s = sl[3s .. 3s+2] = {id, arrival, departure}
-    const float4 p = fb.post[row];
+    const float2 pa = fb.postA[row];   // {n', tail'}
+    const float2 pb = fb.postB[row];   // {head', chosen}
     const float4 r0 = fb.rec0[row];
-    const float4 r1 = fb.rec1[row];
+    const float2 r1 = fb.rec1[row];
     const float4 st = fb.st0[i];
-    const float n0 = r0.z, who = p.w;
+    const float n0 = r0.z, who = pb.y;
     const int32_t k0 = out_ptr[i], k1 = out_ptr[i + 1];
 
     // Response message + max-aggregate from the post records (state after the Direction update of every row)
     bool pop = false;
     {
-      const long long head = (long long)p.y;
-      const bool up = (long long)p.x > 0;
+      const long long head = (long long)pb.x;
+      const bool up = (long long)pa.x > 0;
       for (int32_t k = k0; k < k1; ++k) {  // uniform trip count: the post gathers stay coalesced and unconditional
-        const float4 pj = fb.post[(int64_t)out_dst[k] * B + b];
-        pop = pop || (up && (long long)pj.x > 0 && (long long)pj.z == head);
+        const float2 pj = fb.postA[(int64_t)out_dst[k] * B + b];
+        pop = pop || (up && (long long)pj.x > 0 && (long long)pj.y == head);
       }
     }
     if (popped_out) popped_out[b * N + i] = pop ? 1 : 0;
@@ -392,13 +401,13 @@ __global__ __launch_bounds__(TILE) void k_fused_rows(const int32_t* __restrict__
       sl[3 * q + 1] = t;
       sl[3 * q + 2] = dep_new;
     }
-    float n = p.x;  // count after the Direction update
+    float n = pa.x;  // count after the Direction update
 
     // head / tail of the row after the Direction update (no memory reads needed)
     float head_id = (n0 == 0.0f) ? who : r0.x;
     float head_dep = (n0 == 0.0f) ? dep_new : r0.y;
-    float head_arr = (n0 == 0.0f) ? t : r1.y;
-    float tail_id = p.z;
+    float head_arr = (n0 == 0.0f) ? t : r1.x;
+    float tail_id = pa.y;
 
     int shift = 0;
     if (pop) {
@@ -480,19 +489,19 @@ __global__ __launch_bounds__(TILE) void k_fused_rows(const int32_t* __restrict__
       const int qn = (int)n;
       tail_id = (qn >= 1 && qn <= Nmax) ? sl[3 * (qn - 1)] : 0.0f;
     }
-    fb.rec0[row] = make_float4(head_id, head_dep, n, fb.selnew[row]);  // SELECTED_ROAD of this frame's choice phase
-    fb.rec1[row] = make_float4(tail_id, head_arr, n0, lazy ? 1.0f : 0.0f);
+    fb.rec0[row] = make_float4(head_id, head_dep, n, tail_id);
+    fb.rec1[row] = make_float2(head_arr, lazy ? n0 : -1.0f);
     if (counts) counts[row] = n;  // per-node count before insertion; the insert kernel adds this frame's arrivals
     nsum += n;
   }
-  fb.part[((int64_t)blockIdx.y * B + b) * 4 + 2] = nsum;
+  atomicAdd(&fb.acc_n[b], nsum);
 }
 
 // ---- insert + reward + log-prob reduction (one workgroup per environment) ----------------------------------------------
 __device__ __forceinline__ bool fused_target(const FusedBufs& fb, int64_t b, int64_t B, int64_t N, int32_t origin,
                                              int32_t* road, int32_t* cap) {
   if (origin < 0 || origin >= N) return false;
-  const long long r = (long long)fb.rec0[(int64_t)origin * B + b].w;
+  const long long r = (long long)fb.sel[(int64_t)origin * B + b];
   if (r < 0 || r >= N) return false;
   const long long room = (long long)(fb.st0[r].x - TARL_CONGESTION_FILE - fb.rec0[r * B + b].z);
   *road = (int32_t)r;
@@ -500,14 +509,13 @@ __device__ __forceinline__ bool fused_target(const FusedBufs& fb, int64_t b, int
   return room > 0;
 }
 
-__global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t B, int64_t N, int64_t chunks, FusedBufs fb,
+__global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t B, int64_t N, FusedBufs fb,
                                                        float* __restrict__ ag, int64_t A, int64_t a_bstride,
                                                        int use_cong, float t, int32_t* __restrict__ scratch,
                                                        const float* __restrict__ entropy_in,
                                                        float* __restrict__ reward, float* __restrict__ counts,
                                                        float* __restrict__ log_prob, float* __restrict__ entropy) {
   __shared__ int32_t s_wave[ENVB / 64];
-  __shared__ float s_red[ENVB / 64];
   __shared__ int32_t s_cnt;
   __shared__ int32_t s_adm;
   __shared__ int32_t s_un_agent[INS_CAP], s_un_road[INS_CAP];
@@ -624,10 +632,10 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t B, int6
       if (rank == 0 && n0 == 0.0f) {
         fb.rec0[rrow].x = (float)a;
         fb.rec0[rrow].y = t + tt;
-        fb.rec1[rrow].y = t;
+        fb.rec1[rrow].x = t;
       }
-      if (rank == m - 1) fb.rec1[rrow].x = (float)a;
-      if (rank == 0) fb.rec1[rrow].w = 0.0f;  // the arrivals overwrite a pending garbage slot
+      if (rank == m - 1) fb.rec0[rrow].w = (float)a;  // new tail
+      if (rank == 0) fb.rec1[rrow].y = -1.0f;         // the arrivals overwrite a pending garbage slot
       if (rank == 0) commit = (int32_t)m;
     }
     cand_agent[idx] = commit;
@@ -646,21 +654,14 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t B, int6
     }
   }
   __syncthreads();
-  // phase 4: reduce the per-chunk partials of this environment (fixed order): reward, log-prob
-  float nsum = 0.0f, lp = 0.0f, bad = 0.0f;
-  for (int64_t cidx = tid; cidx < chunks; cidx += ENVB) {
-    const float* pp = fb.part + (cidx * B + b) * 4;
-    lp += pp[0];
-    bad += pp[1];
-    nsum += pp[2];
-  }
-  const float n_t = fb_block_sum(nsum, s_red);
-  const float lp_t = fb_block_sum(lp, s_red);
-  const float bad_t = fb_block_sum(bad, s_red);
+  // phase 4: the frame's accumulators (filled by the choice kernel and the row pass) -> reward, log-prob; re-arm them
   if (tid == 0) {
-    if (reward) reward[b] = -(n_t + (float)s_adm);  // sums of small integers: exact in fp32 in any order
-    if (log_prob) log_prob[b] = bad_t > 0.0f ? -INFINITY : lp_t;
+    const long long lpf = fb.acc_lp[b];
+    if (reward) reward[b] = -(fb.acc_n[b] + (float)s_adm);  // sums of small integers: exact in fp32 in any order
+    if (log_prob) log_prob[b] = (lpf < -(1ll << 49)) ? -INFINITY : (float)((double)lpf / LP_FIX);
     if (entropy) entropy[b] = entropy_in[0];
+    fb.acc_lp[b] = 0;
+    fb.acc_n[b] = 0.0f;
   }
 }
 
@@ -668,8 +669,10 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t B, int6
 hipEvent_t tarl_prof_event(hipStream_t s);  // sim.hip: live timing of the message-passing gather kernel
 
 static FusedBufs to_bufs(const tarl_fused* f) {
-  return FusedBufs{(float4*)f->rec0, (float4*)f->rec1, (float4*)f->post, (const float4*)f->st0, f->slots, f->ld_slots,
-                   f->selnew,        f->part,          f->a_origin,      f->a_dest,             f->a_dep, f->a_status};
+  return FusedBufs{(float4*)f->rec0,         (float2*)f->rec1, (float2*)f->post_a, (float2*)f->post_b,
+                   (const float4*)f->st0,    f->slots,         f->ld_slots,        f->sel,
+                   (long long*)f->acc_lp,    f->acc_n,         f->a_origin,        f->a_dest,
+                   f->a_dep,                 f->a_status};
 }
 
 // nodes walked by one workgroup of the env-minor kernels (tunable: TARL_NCHUNK)
@@ -686,11 +689,13 @@ static int64_t num_chunks(const tarl_plan* plan) { return ceil_div(plan->N, nchu
 
 static int check_fused_core(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax) {
   TARL_REQUIRE(plan && f, "null argument");
-  TARL_REQUIRE(f->rec0 && f->rec1 && f->post && f->st0 && f->slots && f->selnew && f->part, "fused node buffers missing");
+  TARL_REQUIRE(f->rec0 && f->rec1 && f->post_a && f->post_b && f->st0 && f->slots && f->sel && f->acc_lp && f->acc_n,
+               "fused node buffers missing");
   TARL_REQUIRE(B >= 1 && B < ((int64_t)1 << 31) && Nmax >= 2, "bad sizes");
   TARL_REQUIRE(f->ld_slots >= 3 * (int64_t)Nmax, "slot row stride smaller than 3*Nmax");
   TARL_REQUIRE(num_chunks(plan) < 65536, "too many node chunks for one launch");
-  TARL_REQUIRE(((uintptr_t)f->rec0 | (uintptr_t)f->rec1 | (uintptr_t)f->post | (uintptr_t)f->st0) % 16 == 0,
+  TARL_REQUIRE(((uintptr_t)f->rec0 | (uintptr_t)f->rec1 | (uintptr_t)f->post_a | (uintptr_t)f->post_b |
+                (uintptr_t)f->st0) % 16 == 0,
                "fused records must be 16-byte aligned");
   return TARL_OK;
 }
@@ -706,8 +711,6 @@ static int check_fused(const tarl_plan* plan, const tarl_fused* f, const float* 
 }
 
 static unsigned tile_threads(int64_t B) { return B >= TILE ? TILE : (unsigned)(ceil_div(B, 64) * 64); }
-
-extern "C" int64_t tarl_fused_num_chunks(const tarl_plan* plan) { return plan ? num_chunks(plan) : 0; }
 
 extern "C" int tarl_fused_pack(const tarl_plan* plan, const tarl_fused* f, const float* x, int64_t B, int64_t x_bstride,
                                int64_t ldx, int32_t Nmax, const float* cong, const float* agent_features, int64_t A,
@@ -789,7 +792,7 @@ extern "C" int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int6
   hipLaunchKernelGGL(k_fused_rows, grid, dim3(threads), 0, s, plan->out_ptr, plan->out_dst, (int)Nmax, B, plan->N, fb,
                      agent_features, A, a_bstride, time, popped, withdrawn, counts, nchunk());
   TARL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(ENVB), 0, s, (int)Nmax, B, plan->N, num_chunks(plan), fb,
+  hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(ENVB), 0, s, (int)Nmax, B, plan->N, fb,
                      agent_features, A, a_bstride, use_cong, time, ins_scratch, entropy1, reward, counts, log_prob,
                      entropy);
   TARL_LAUNCH_CHECK();

@@ -49,7 +49,6 @@ SIGNATURES = {
     "tarl_ppo_loss": (C.c_int, [_p] * 6 + [_i64, _f32, _f32, _f32, _f32, _p, _p, _p, _p, _p]),
     "tarl_adam_step": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _f64, _f64, _f64, _f64, _f32, _p]),
     "tarl_critic_mlp_fwd_slabs": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64] + [_p] * 6 + [_p, _p]),
-    "tarl_fused_num_chunks": (_i64, [_p]),
     "tarl_fused_pack": (C.c_int, [_p, _p] + _STATE + [_p, _p, _i64, _i64, _p]),
     "tarl_fused_export": (C.c_int, [_p, _p] + _STATE + [_f32, _p]),
     "tarl_fused_policy_prepare": (C.c_int, [_p, _p, _p, _i64, _f32, _p, _p, _p, _p, _p]),
@@ -63,8 +62,9 @@ SIGNATURES = {
 
 class FusedStruct(C.Structure):
     """``tarl_fused`` of include/tarl_hip.h."""
-    _fields_ = ([(n, C.c_void_p) for n in ("rec0", "rec1", "post", "st0", "slots")] + [("ld_slots", C.c_int64)] +
-                [(n, C.c_void_p) for n in ("selnew", "part", "a_origin", "a_dest", "a_dep", "a_status")])
+    _fields_ = ([(n, C.c_void_p) for n in ("rec0", "rec1", "post_a", "post_b", "st0", "slots")] +
+                [("ld_slots", C.c_int64)] +
+                [(n, C.c_void_p) for n in ("sel", "acc_lp", "acc_n", "a_origin", "a_dest", "a_dep", "a_status")])
 
 
 _lib = None

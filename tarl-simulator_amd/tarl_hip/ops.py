@@ -433,22 +433,24 @@ class FusedState:
         N = plan.num_nodes
         f32 = dict(dtype=torch.float32, device=device)
         self.ld_slots = ((3 * Nmax + 15) // 16) * 16
-        self.chunks = int(L.tarl_fused_num_chunks(plan.handle))
         self.slots = torch.zeros((N, B, self.ld_slots), **f32)
         self.rec0 = torch.zeros((N, B, 4), **f32)
-        self.rec1 = torch.zeros((N, B, 4), **f32)
-        self.post = torch.zeros((N, B, 4), **f32)
+        self.rec1 = torch.zeros((N, B, 2), **f32)
+        self.post_a = torch.zeros((N, B, 2), **f32)
+        self.post_b = torch.zeros((N, B, 2), **f32)
         self.st0 = torch.zeros((N, 4), **f32)
-        self.selnew = torch.zeros((N, B), **f32)
-        self.part = torch.zeros((max(self.chunks, 1), B, 4), **f32)
+        self.sel = torch.zeros((N, B), **f32)
+        self.acc_lp = torch.zeros(B, dtype=torch.int64, device=device)
+        self.acc_n = torch.zeros(B, **f32)
         self.a_origin = torch.zeros((B, A), dtype=torch.int32, device=device)
         self.a_dest = torch.zeros((B, A), dtype=torch.int32, device=device)
         self.a_dep = torch.zeros((B, A), **f32)
         self.a_status = torch.zeros((B, A), dtype=torch.uint8, device=device)
-        self.struct = _lib.FusedStruct(self.rec0.data_ptr(), self.rec1.data_ptr(), self.post.data_ptr(),
-                                       self.st0.data_ptr(), self.slots.data_ptr(), self.ld_slots,
-                                       self.selnew.data_ptr(), self.part.data_ptr(), self.a_origin.data_ptr(),
-                                       self.a_dest.data_ptr(), self.a_dep.data_ptr(), self.a_status.data_ptr())
+        self.struct = _lib.FusedStruct(self.rec0.data_ptr(), self.rec1.data_ptr(), self.post_a.data_ptr(),
+                                       self.post_b.data_ptr(), self.st0.data_ptr(), self.slots.data_ptr(),
+                                       self.ld_slots, self.sel.data_ptr(), self.acc_lp.data_ptr(),
+                                       self.acc_n.data_ptr(), self.a_origin.data_ptr(), self.a_dest.data_ptr(),
+                                       self.a_dep.data_ptr(), self.a_status.data_ptr())
         self.B, self.N, self.A, self.Nmax = B, N, A, Nmax
 
     @property

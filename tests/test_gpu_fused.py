@@ -25,11 +25,11 @@ def check_records(ops, plan, fs, x, Nmax, ag, cc):
     """The maintained hot records equal a fresh pack of the exported x / agents (tail only where the FIFO is non-empty)."""
     ref = ops.FusedState(plan, fs.B, fs.A, x.device, Nmax)
     ops.fused_pack(plan, ref, x, Nmax, ag, cc)
-    assert torch.equal(fs.rec0, ref.rec0)
+    assert torch.equal(fs.rec0[..., :3], ref.rec0[..., :3]) and torch.equal(fs.sel, ref.sel)
     nz = (ref.rec0[..., 2] > 0)
-    assert torch.equal(fs.rec1[..., 0][nz], ref.rec1[..., 0][nz]) and torch.equal(fs.rec1[..., 1], ref.rec1[..., 1])
+    assert torch.equal(fs.rec0[..., 3][nz], ref.rec0[..., 3][nz]) and torch.equal(fs.rec1[..., 0], ref.rec1[..., 0])
     assert torch.equal(fs.a_status, ref.a_status) and torch.equal(fs.st0, ref.st0)
-    assert float(fs.rec1[..., 3].sum()) > 0        # some rows carry a pending (lazy) garbage slot
+    assert int((fs.rec1[..., 1] >= 0).sum()) > 0   # some rows carry a pending (lazy) garbage slot
 
 
 @pytest.mark.parametrize("W,H,het,B,A,frames,with_cc,Nmax", [(3, 3, True, 3, 1500, 60, True, None),
