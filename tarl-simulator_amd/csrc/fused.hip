@@ -23,6 +23,10 @@
 //     by an insertion) before anything can move it, and only shows in x. The row pass just records {flag, n0} in rec1 and
 //     the export kernel materialises it (same fp32 expression, same slot). The one case where the pop's "last slot keeps
 //     its value" rule would duplicate it (count == Nmax-1) is written eagerly;
+//   * RING-BUFFER FIFOs: the reference pops by shifting all Nmax slots (and withdraws with a zero-filled shift). Here a
+//     per-row head offset makes the pop one triple copy (the slot that falls off the front receives the old last slot,
+//     which is exactly the reference's "last slot keeps its value") and a withdraw of c agents c zero-writes; the dead
+//     slots end up with exactly the reference's contents and tarl_fused_export un-rotates;
 //   * agent bookkeeping scans a 1-byte status + 4-byte departure SoA instead of 36-B AoS rows.
 // The packed state is authoritative between tarl_fused_pack and tarl_fused_export; the exported x and agent_features are
 // bit-identical to what the unfused kernels (and the reference) produce after every frame (tests/test_gpu_fused.py).
@@ -60,6 +64,17 @@ struct FusedBufs {
 
 #define LP_FIX 4294967296.0  // 2^32
 
+// rec1.y packs two small integers exactly in fp32: code = (g + 1) * 1024 + hoff, where g = count at the pending
+// (unmaterialised) garbage write or -1 when nothing is pending, and hoff = physical slot of logical slot 0 (ring buffer).
+__device__ __forceinline__ float r1_code(float g, int hoff) { return (g + 1.0f) * 1024.0f + (float)hoff; }
+__device__ __forceinline__ int r1_hoff(float code) { return ((int)code) & 1023; }
+__device__ __forceinline__ float r1_g(float code) { return (float)(((int)code) >> 10) - 1.0f; }
+// physical slot of logical slot s
+__device__ __forceinline__ int phys(int hoff, int s, int Nmax) {
+  int p = hoff + s;
+  return p >= Nmax ? p - Nmax : p;
+}
+
 // ---- pack: build the hot / static records, the slot store and the agent SoA from x / agent_features ------------------
 __global__ __launch_bounds__(FB) void k_pack_nodes(const float* __restrict__ x, Layout L, int64_t B, int64_t N,
                                                    const float* __restrict__ cong, FusedBufs fb, float4* st0_out) {
@@ -73,7 +88,7 @@ __global__ __launch_bounds__(FB) void k_pack_nodes(const float* __restrict__ x, 
   const int q = (int)n;
   const float tail = (q >= 1 && q <= Nmax) ? xi[q - 1] : 0.0f;
   fb.rec0[gid] = make_float4(xi[0], xi[2 * Nmax], n, tail);
-  fb.rec1[gid] = make_float2(xi[Nmax], -1.0f);
+  fb.rec1[gid] = make_float2(xi[Nmax], r1_code(-1.0f, 0));
   fb.postA[gid] = make_float2(n, tail);
   fb.postB[gid] = make_float2(xi[0], 0.0f);
   fb.sel[gid] = xi[L.col_sel()];
@@ -122,12 +137,13 @@ __global__ __launch_bounds__(FB) void k_export_rows(float* __restrict__ x, Layou
   const int sidx = (int)(gid - row * Nmax);
   const int64_t i = row / B, b = row - i * B;
   float* xi = x + b * L.bstride + i * L.ldx;
-  const float* sl = fb.slots + row * fb.lds + 3 * sidx;
   const float4 r0 = fb.rec0[row];
   const float2 r1 = fb.rec1[row];
-  if (r1.y >= 0.0f && sidx == (int)r0.z) {  // pending garbage write of the last Direction update -> first dead slot
+  const float g = r1_g(r1.y);
+  const float* sl = fb.slots + row * fb.lds + 3 * phys(r1_hoff(r1.y), sidx, Nmax);  // un-rotate the ring buffer
+  if (g >= 0.0f && sidx == (int)r0.z) {  // pending garbage write of the last Direction update -> first dead slot
     const float4 st = fb.st0[i];
-    const float t_cong = st.w / (st.x + 10.0f - r1.y);
+    const float t_cong = st.w / (st.x + 10.0f - g);
     const float tt = (t_cong != t_cong) ? t_cong : fmaxf(st.y, t_cong);
     xi[sidx] = 0.0f;
     xi[Nmax + sidx] = t_last;
@@ -390,16 +406,19 @@ __global__ __launch_bounds__(TILE) void k_fused_rows(const int32_t* __restrict__
     if (popped_out) popped_out[b * N + i] = pop ? 1 : 0;
 
     // Direction update (every row, also when nothing was chosen): one 12-byte store — or, for a row that received
-    // nobody, a note in the hot record (lazy garbage slot, see the file header)
+    // nobody, a note in the hot record (lazy garbage slot, see the file header). The FIFO is a ring buffer: logical
+    // slot s lives at physical slot (hoff + s) mod Nmax.
+    int hoff = r1_hoff(r1.y);
     const int q = (int)n0;
     const float t_cong = st.w / (st.x + 10.0f - n0);
     const float tt = (t_cong != t_cong) ? t_cong : fmaxf(st.y, t_cong);
     const float dep_new = t + tt;
     const bool lazy = (who == 0.0f) && (q >= 0) && (q < Nmax - 1);
     if (!lazy && q >= 0 && q < Nmax) {
-      sl[3 * q + 0] = who;
-      sl[3 * q + 1] = t;
-      sl[3 * q + 2] = dep_new;
+      float* w = sl + 3 * phys(hoff, q, Nmax);
+      w[0] = who;
+      w[1] = t;
+      w[2] = dep_new;
     }
     float n = pa.x;  // count after the Direction update
 
@@ -409,8 +428,17 @@ __global__ __launch_bounds__(TILE) void k_fused_rows(const int32_t* __restrict__
     float head_arr = (n0 == 0.0f) ? t : r1.x;
     float tail_id = pa.y;
 
+    // Response pop: logical shift by one where the LAST slot keeps its value. Ring form: the slot that falls off the
+    // front becomes the new logical last slot, so it receives a copy of the old last slot; then the head advances.
     int shift = 0;
     if (pop) {
+      const float* last = sl + 3 * phys(hoff, Nmax - 1, Nmax);
+      const float l0 = last[0], l1 = last[1], l2 = last[2];
+      float* front = sl + 3 * hoff;
+      front[0] = l0;
+      front[1] = l1;
+      front[2] = l2;
+      hoff = phys(hoff, 1, Nmax);
       shift = 1;
       n = n - 1.0f;
     }
@@ -423,16 +451,15 @@ __global__ __launch_bounds__(TILE) void k_fused_rows(const int32_t* __restrict__
         w0 = out_ptr[road];
         w1 = out_ptr[road + 1];
       }
-      for (int s = 0; s < Nmax && (float)s < n; ++s) {
-        int src = s + shift;              // slot of the row as it is in memory right now
-        if (src >= Nmax) src = Nmax - 1;  // the pop duplicates the last slot
+      for (int sx = 0; sx < Nmax && (float)sx < n; ++sx) {
         float idf, depf;
-        if (src == 0) {
+        if (sx == 0 && shift == 0) {   // the head is in registers unless the pop just exposed a new one
           idf = head_id;
           depf = head_dep;
         } else {
-          idf = sl[3 * src];
-          depf = sl[3 * src + 2];
+          const float* rd = sl + 3 * phys(hoff, sx, Nmax);
+          idf = rd[0];
+          depf = rd[2];
         }
         const long long id = (long long)idf;
         if (id < 0 || id >= A) break;
@@ -450,47 +477,33 @@ __global__ __launch_bounds__(TILE) void k_fused_rows(const int32_t* __restrict__
       }
     }
     if (withdrawn_out) withdrawn_out[b * N + i] = c > 0 ? 1 : 0;
-
-    if (shift + c > 0) {
-      // pop (shift by one, last slot keeps its stale value) followed by withdraw (shift by c, zero fill), in one sweep
-      const float l0 = sl[3 * (Nmax - 1)], l1 = sl[3 * (Nmax - 1) + 1], l2 = sl[3 * (Nmax - 1) + 2];
-      for (int s = 0; s < Nmax; ++s) {
-        float v0, v1, v2;
-        int from;
-        if (shift == 0) {
-          from = (s + c < Nmax) ? s + c : -1;
-        } else {
-          const int k = s + c;  // index into the popped row
-          from = (k < Nmax - 1) ? k + 1 : (k == Nmax - 1 ? -2 : -1);
-        }
-        if (from >= 0) {
-          v0 = sl[3 * from];
-          v1 = sl[3 * from + 1];
-          v2 = sl[3 * from + 2];
-        } else if (from == -2) {
-          v0 = l0; v1 = l1; v2 = l2;
-        } else {
-          v0 = v1 = v2 = 0.0f;
-        }
-        sl[3 * s] = v0;
-        sl[3 * s + 1] = v1;
-        sl[3 * s + 2] = v2;
-      }
+    // withdraw = logical shift by c with zero fill: the c slots that fall off the front become the zeroed tail
+    for (int k = 0; k < c; ++k) {
+      float* z = sl + 3 * phys(hoff, k, Nmax);
+      z[0] = 0.0f;
+      z[1] = 0.0f;
+      z[2] = 0.0f;
+    }
+    if (c > 0) {
+      hoff = phys(hoff, c, Nmax);   // c <= Nmax
       n = n - (float)c;
+    }
+    if (shift + c > 0) {
       if (lazy && n == 0.0f) {  // the row emptied: its head slot is the (unmaterialised) garbage slot
         head_id = 0.0f;
         head_arr = t;
         head_dep = dep_new;
       } else {
-        head_id = sl[0];
-        head_arr = sl[1];
-        head_dep = sl[2];
+        const float* hd = sl + 3 * hoff;
+        head_id = hd[0];
+        head_arr = hd[1];
+        head_dep = hd[2];
       }
       const int qn = (int)n;
-      tail_id = (qn >= 1 && qn <= Nmax) ? sl[3 * (qn - 1)] : 0.0f;
+      tail_id = (qn >= 1 && qn <= Nmax) ? sl[3 * phys(hoff, qn - 1, Nmax)] : 0.0f;
     }
     fb.rec0[row] = make_float4(head_id, head_dep, n, tail_id);
-    fb.rec1[row] = make_float2(head_arr, lazy ? n0 : -1.0f);
+    fb.rec1[row] = make_float2(head_arr, r1_code(lazy ? n0 : -1.0f, hoff));
     if (counts) counts[row] = n;  // per-node count before insertion; the insert kernel adds this frame's arrivals
     nsum += n;
   }
@@ -615,17 +628,20 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t B, int6
     const float n0 = fb.rec0[rrow].z;
     const long long cap = (long long)(str.x - TARL_CONGESTION_FILE - n0);
     int32_t commit = 0;
+    bool pend_clear = false;
     if (rank < cap) {
       const long long m = total < cap ? total : cap;  // arrivals admitted on this road
       const long long slot = (long long)n0 + rank;
       const float t_cong = use_cong ? str.w / (str.x + 10.0f - (float)(long long)n0) : 0.0f;
       const float tt = (t_cong != t_cong) ? t_cong : fmaxf(str.y, t_cong);
+      const float code = fb.rec1[rrow].y;   // nobody writes rec1.y before the barrier below
       if (slot >= 0 && slot < Nmax) {
-        float* sr = fb.slots + rrow * fb.lds + 3 * slot;
+        float* sr = fb.slots + rrow * fb.lds + 3 * phys(r1_hoff(code), (int)slot, Nmax);
         sr[0] = (float)a;
         sr[1] = t;
         sr[2] = t + tt;
       }
+      if (rank == 0) pend_clear = true;
       agb[(int64_t)a * AG_COLS + AG_ON_WAY] = 1.0f;
       fb.a_status[b * A + a] = 1;
       // hot record: only fields nobody reads in this phase (n is committed after the barrier)
@@ -635,18 +651,19 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t B, int6
         fb.rec1[rrow].x = t;
       }
       if (rank == m - 1) fb.rec0[rrow].w = (float)a;  // new tail
-      if (rank == 0) fb.rec1[rrow].y = -1.0f;         // the arrivals overwrite a pending garbage slot
       if (rank == 0) commit = (int32_t)m;
     }
     cand_agent[idx] = commit;
+    (void)pend_clear;
   }
   __threadfence_block();
   __syncthreads();
-  // phase 3: commit the counters
+  // phase 3: commit the counters; the arrivals overwrote a pending garbage slot: clear the flag, keep the head offset
   for (int32_t idx = tid; idx < Lc; idx += ENVB) {
     const int32_t cmt = cand_agent[idx];
     if (cmt > 0) {
       const int64_t rrow = (int64_t)cand_road[idx] * B + b;
+      fb.rec1[rrow].y = r1_code(-1.0f, r1_hoff(fb.rec1[rrow].y));
       const float nn = fb.rec0[rrow].z + (float)cmt;
       fb.rec0[rrow].z = nn;
       if (counts) counts[rrow] = nn;
@@ -686,6 +703,16 @@ static int nchunk() {
   return v;
 }
 static int64_t num_chunks(const tarl_plan* plan) { return ceil_div(plan->N, nchunk()); }
+// the choice kernel is light and ends in one accumulator atomic per lane: it walks longer chunks (TARL_NCHUNK_CHOICE)
+static int nchunk_choice() {
+  static int v = 0;
+  if (v == 0) {
+    const char* e = getenv("TARL_NCHUNK_CHOICE");
+    v = e ? atoi(e) : 8;
+    if (v < 1) v = 1;
+  }
+  return v;
+}
 
 static int check_fused_core(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax) {
   TARL_REQUIRE(plan && f, "null argument");
@@ -693,7 +720,8 @@ static int check_fused_core(const tarl_plan* plan, const tarl_fused* f, int64_t 
                "fused node buffers missing");
   TARL_REQUIRE(B >= 1 && B < ((int64_t)1 << 31) && Nmax >= 2, "bad sizes");
   TARL_REQUIRE(f->ld_slots >= 3 * (int64_t)Nmax, "slot row stride smaller than 3*Nmax");
-  TARL_REQUIRE(num_chunks(plan) < 65536, "too many node chunks for one launch");
+  TARL_REQUIRE(num_chunks(plan) < 65536 && ceil_div(plan->N, nchunk_choice()) < 65536,
+               "too many node chunks for one launch");
   TARL_REQUIRE(((uintptr_t)f->rec0 | (uintptr_t)f->rec1 | (uintptr_t)f->post_a | (uintptr_t)f->post_b |
                 (uintptr_t)f->st0) % 16 == 0,
                "fused records must be 16-byte aligned");
@@ -779,9 +807,10 @@ extern "C" int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int6
   hipStream_t s = (hipStream_t)stream;
   const unsigned threads = tile_threads(B);
   const dim3 grid((unsigned)ceil_div(B, threads), (unsigned)num_chunks(plan));
-  hipLaunchKernelGGL(k_fused_choice, grid, dim3(threads), 0, s, plan->out_ptr, plan->out_dst, plan->out_eid,
+  const dim3 grid_c((unsigned)ceil_div(B, threads), (unsigned)ceil_div(plan->N, nchunk_choice()));
+  hipLaunchKernelGGL(k_fused_choice, grid_c, dim3(threads), 0, s, plan->out_ptr, plan->out_dst, plan->out_eid,
                      plan->group_of_node, plan->G, B, plan->N, fb, thresholds, log_probs, uniform, policy_seed,
-                     policy_counter, choice, nchunk());
+                     policy_counter, choice, nchunk_choice());
   TARL_LAUNCH_CHECK();
   const bool timed = tarl_prof_event(s) != nullptr;
   hipLaunchKernelGGL(k_fused_direction, grid, dim3(threads), 0, s, plan->in_ptr, plan->in_src, plan->in_eid, plan->E, B,
