@@ -205,7 +205,9 @@ int tarl_critic_mlp_fwd_slabs(const float* counts, int64_t rows_per_slab, int64_
  *   st0  [N][4]    = {MAX_NUMBER_OF_AGENT, FREE_FLOW_TIME_TRAVEL, ROAD_INDEX, congestion_constant} (static, shared)
  *   slots [N][B][ld_slots]: slot-interleaved FIFO store, slot s at floats 3s..3s+2 = {agent id, arrival, departure};
  *                  ld_slots >= 3*Nmax (pad to a multiple of 16 floats)
- *   a_origin / a_dest int32 [B][A], a_dep fp32 [B][A], a_status uint8 [B][A] (0 waiting, 1 on the way, 2 done).
+ *   a_origin / a_dest int32 [B][A], a_dep fp32 [B][A], a_status uint8 [B][A] (0 waiting, 1 on the way, 2 done);
+ *   a_order int32 [B][A] (optional, may be NULL): each environment's agent ids sorted by DEPARTURE_TIME — with it the
+ *   insert kernel scans a window of that order from the cursor cur_lo int32 [B] instead of every agent every frame.
  * tarl_fused_pack imports x / agent_features (call after construction, reset, or any external write to x); between
  * pack and export the packed state is authoritative for the FIFO columns, NUMBER_OF_AGENT and SELECTED_ROAD;
  * tarl_fused_export writes them back into x in the reference's column layout, bit-identical to the unfused path.
@@ -225,6 +227,8 @@ typedef struct tarl_fused {
   int32_t* a_dest;
   float* a_dep;
   uint8_t* a_status;
+  const int32_t* a_order;
+  int32_t* cur_lo;
 } tarl_fused;
 
 int tarl_fused_pack(const tarl_plan* plan, const tarl_fused* f, const float* x, int64_t B, int64_t x_bstride,

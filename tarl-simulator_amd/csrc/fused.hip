@@ -60,6 +60,8 @@ struct FusedBufs {
   int32_t* a_dest;      // [B][A]
   float* a_dep;         // [B][A]
   uint8_t* a_status;    // [B][A] 0 waiting, 1 on the way, 2 done
+  const int32_t* a_order;  // [B][A] agent ids sorted by departure time (static), or NULL: scan all agents every frame
+  int32_t* cur_lo;      // [B] first position of a_order that may still hold a waiting agent
 };
 
 #define LP_FIX 4294967296.0  // 2^32
@@ -125,6 +127,7 @@ __global__ __launch_bounds__(FB) void k_pack_agents(const float* __restrict__ ag
   fb.a_dest[gid] = (int32_t)(long long)row[AG_DEST];
   fb.a_dep[gid] = row[AG_DEP];
   fb.a_status[gid] = row[AG_DONE] != 0.0f ? 2 : (row[AG_ON_WAY] != 0.0f ? 1 : 0);
+  if (a == 0 && fb.cur_lo) fb.cur_lo[b] = 0;
 }
 
 // ---- export: rebuild the reference's x layout (three FIFO column blocks + NUMBER_OF_AGENT + SELECTED_ROAD) ----------
@@ -531,6 +534,7 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t B, int6
   __shared__ int32_t s_wave[ENVB / 64];
   __shared__ int32_t s_cnt;
   __shared__ int32_t s_adm;
+  __shared__ int32_t s_lo;
   __shared__ int32_t s_un_agent[INS_CAP], s_un_road[INS_CAP];
   const int64_t b = blockIdx.x;
   float* agb = ag + b * a_bstride;
@@ -547,25 +551,58 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t B, int6
     s_adm = 0;
   }
   __syncthreads();
-  for (int64_t a0 = tid; a0 < A; a0 += 4 * ENVB) {  // 4 independent (status, departure) loads in flight per thread
-    uint8_t stt[4];
-    float dp[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t a = a0 + (int64_t)j * ENVB;
-      stt[j] = a < A ? fb.a_status[b * A + a] : (uint8_t)1;
-      dp[j] = a < A ? fb.a_dep[b * A + a] : 0.0f;
+  if (fb.a_order) {
+    // Windowed scan: agents sorted by departure time; everything before cur_lo is known not to be waiting any more and
+    // everything after the first not-yet-due entry is not due either, so a frame normally looks at one chunk.
+    const int32_t* ord = fb.a_order + b * A;
+    const int32_t lo = fb.cur_lo[b];
+    if (tid == 0) s_lo = 0x7fffffff;
+    __syncthreads();
+    for (int64_t k0 = lo; k0 < A; k0 += ENVB) {
+      const int64_t k = k0 + tid;
+      bool notdue = false;
+      if (k < A) {
+        const int32_t a = ord[k];
+        const bool due = fb.a_dep[b * A + a] <= t;
+        const bool waiting = fb.a_status[b * A + a] == 0;
+        notdue = !due;
+        if (!due || waiting) atomicMin(&s_lo, (int32_t)k);   // the cursor may not pass this entry
+        if (due && waiting) {
+          int32_t road = 0, cap = 0;
+          if (fused_target(fb, b, B, N, fb.a_origin[b * A + a], &road, &cap)) {
+            const int32_t pos = atomicAdd(&s_cnt, 1);
+            if (pos < INS_CAP) {
+              s_un_agent[pos] = a;
+              s_un_road[pos] = road;
+            }
+          }
+        }
+      }
+      if (__syncthreads_or(notdue ? 1 : 0)) break;   // sorted by departure: nothing beyond this chunk is due
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (stt[j] == 0 && dp[j] <= t) {
+    __syncthreads();
+    if (tid == 0) fb.cur_lo[b] = s_lo == 0x7fffffff ? (int32_t)A : s_lo;
+  } else {
+    for (int64_t a0 = tid; a0 < A; a0 += 4 * ENVB) {  // 4 independent (status, departure) loads in flight per thread
+      uint8_t stt[4];
+      float dp[4];
+  #pragma unroll
+      for (int j = 0; j < 4; ++j) {
         const int64_t a = a0 + (int64_t)j * ENVB;
-        int32_t road = 0, cap = 0;
-        if (fused_target(fb, b, B, N, fb.a_origin[b * A + a], &road, &cap)) {
-          const int32_t pos = atomicAdd(&s_cnt, 1);
-          if (pos < INS_CAP) {
-            s_un_agent[pos] = (int32_t)a;
-            s_un_road[pos] = road;
+        stt[j] = a < A ? fb.a_status[b * A + a] : (uint8_t)1;
+        dp[j] = a < A ? fb.a_dep[b * A + a] : 0.0f;
+      }
+  #pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (stt[j] == 0 && dp[j] <= t) {
+          const int64_t a = a0 + (int64_t)j * ENVB;
+          int32_t road = 0, cap = 0;
+          if (fused_target(fb, b, B, N, fb.a_origin[b * A + a], &road, &cap)) {
+            const int32_t pos = atomicAdd(&s_cnt, 1);
+            if (pos < INS_CAP) {
+              s_un_agent[pos] = (int32_t)a;
+              s_un_road[pos] = road;
+            }
           }
         }
       }
@@ -689,7 +726,7 @@ static FusedBufs to_bufs(const tarl_fused* f) {
   return FusedBufs{(float4*)f->rec0,         (float2*)f->rec1, (float2*)f->post_a, (float2*)f->post_b,
                    (const float4*)f->st0,    f->slots,         f->ld_slots,        f->sel,
                    (long long*)f->acc_lp,    f->acc_n,         f->a_origin,        f->a_dest,
-                   f->a_dep,                 f->a_status};
+                   f->a_dep,                 f->a_status,      f->a_order,         f->cur_lo};
 }
 
 // nodes walked by one workgroup of the env-minor kernels (tunable: TARL_NCHUNK)
@@ -697,7 +734,7 @@ static int nchunk() {
   static int v = 0;
   if (v == 0) {
     const char* e = getenv("TARL_NCHUNK");
-    v = e ? atoi(e) : 4;
+    v = e ? atoi(e) : 2;
     if (v < 1) v = 1;
   }
   return v;
@@ -800,6 +837,7 @@ extern "C" int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int6
   TARL_REQUIRE(thresholds && log_probs && entropy1, "policy tables missing (call tarl_fused_policy_prepare)");
   TARL_REQUIRE(agent_features && A >= 1 && ins_scratch, "agents / scratch missing");
   TARL_REQUIRE(f->a_origin && f->a_dest && f->a_dep && f->a_status, "fused agent buffers missing");
+  TARL_REQUIRE(f->a_order == nullptr || f->cur_lo != nullptr, "a_order needs cur_lo");
   TARL_REQUIRE(B == 1 || a_bstride >= A * AG_COLS, "agent stride smaller than one population");
   TARL_REQUIRE(plan->E == 0 || (edge_attr && log_edge_attr), "edge constants missing");
   if (plan->N == 0) return TARL_OK;

@@ -446,22 +446,37 @@ class FusedState:
         self.a_dest = torch.zeros((B, A), dtype=torch.int32, device=device)
         self.a_dep = torch.zeros((B, A), **f32)
         self.a_status = torch.zeros((B, A), dtype=torch.uint8, device=device)
+        self.a_order = torch.zeros((B, A), dtype=torch.int32, device=device)
+        self.cur_lo = torch.zeros(B, dtype=torch.int32, device=device)
+        self.order_valid = False
         self.struct = _lib.FusedStruct(self.rec0.data_ptr(), self.rec1.data_ptr(), self.post_a.data_ptr(),
                                        self.post_b.data_ptr(), self.st0.data_ptr(), self.slots.data_ptr(),
                                        self.ld_slots, self.sel.data_ptr(), self.acc_lp.data_ptr(),
                                        self.acc_n.data_ptr(), self.a_origin.data_ptr(), self.a_dest.data_ptr(),
-                                       self.a_dep.data_ptr(), self.a_status.data_ptr())
+                                       self.a_dep.data_ptr(), self.a_status.data_ptr(), None,
+                                       self.cur_lo.data_ptr())
         self.B, self.N, self.A, self.Nmax = B, N, A, Nmax
+
+    def sort_agents(self, agent_features):
+        """Departure-time order of every environment's population (static while DEPARTURE_TIME is not edited): lets the
+        insert kernel scan a small window per frame. Plain torch sort — set-up plumbing, not on the per-frame path."""
+        dep = agent_features.reshape(self.B, self.A, 9)[:, :, 2]
+        self.a_order.copy_(torch.argsort(dep, dim=1, stable=True).to(torch.int32))
+        self.struct.a_order = self.a_order.data_ptr()
+        self.order_valid = True
 
     @property
     def ref(self):
         return C.byref(self.struct)
 
 
-def fused_pack(plan: Plan, fs: FusedState, x, Nmax, agent_features, congestion_constant=None):
+def fused_pack(plan: Plan, fs: FusedState, x, Nmax, agent_features, congestion_constant=None, sort_agents=None):
+    """``sort_agents``: True = (re)build the departure-time order, None = build it once, False = never."""
     L = _lib.load()
     B, N, bs, ldx = _state(x, Nmax)
     A, abs_ = _agents(agent_features, B)
+    if sort_agents or (sort_agents is None and not fs.order_valid):
+        fs.sort_agents(agent_features)
     _lib.check(L.tarl_fused_pack(plan.handle, fs.ref, x.data_ptr(), B, bs, ldx, Nmax, _lib.ptr(congestion_constant),
                                  agent_features.data_ptr(), A, abs_, _lib.current_stream()))
 

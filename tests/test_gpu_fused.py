@@ -29,6 +29,10 @@ def check_records(ops, plan, fs, x, Nmax, ag, cc):
     nz = (ref.rec0[..., 2] > 0)
     assert torch.equal(fs.rec0[..., 3][nz], ref.rec0[..., 3][nz]) and torch.equal(fs.rec1[..., 0], ref.rec1[..., 0])
     assert torch.equal(fs.a_status, ref.a_status) and torch.equal(fs.st0, ref.st0)
+    # insert cursor: nobody before it is still waiting
+    pos = torch.arange(fs.A, device=x.device).unsqueeze(0)
+    st_sorted = torch.gather(fs.a_status, 1, fs.a_order.long())
+    assert not bool(((pos < fs.cur_lo.unsqueeze(1)) & (st_sorted == 0)).any())
     assert int((fs.rec1[..., 1] >= 0).sum()) > 0   # some rows carry a pending (lazy) garbage slot
 
 
