@@ -44,6 +44,7 @@
 #define TILE 256        // environments per workgroup in the env-minor kernels (one per lane)
 #define LOG_EPS_P 1e-8f
 #define INS_CAP 2048    // LDS candidate list of the insert kernel (entries)
+#define INSB 256        // insert kernel: one (small) workgroup per environment, so that all of them are resident at once
 
 struct FusedBufs {
   float4* rec0;         // [N][B] {head_id, head_dep, n, tail_id}
@@ -525,13 +526,13 @@ __device__ __forceinline__ bool fused_target(const FusedBufs& fb, int64_t b, int
   return room > 0;
 }
 
-__global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t B, int64_t N, FusedBufs fb,
+__global__ __launch_bounds__(INSB) void k_fused_insert(int Nmax, int64_t B, int64_t N, FusedBufs fb,
                                                        float* __restrict__ ag, int64_t A, int64_t a_bstride,
                                                        int use_cong, float t, int32_t* __restrict__ scratch,
                                                        const float* __restrict__ entropy_in,
                                                        float* __restrict__ reward, float* __restrict__ counts,
                                                        float* __restrict__ log_prob, float* __restrict__ entropy) {
-  __shared__ int32_t s_wave[ENVB / 64];
+  __shared__ int32_t s_wave[INSB / 64];
   __shared__ int32_t s_cnt;
   __shared__ int32_t s_adm;
   __shared__ int32_t s_lo;
@@ -558,7 +559,7 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t B, int6
     const int32_t lo = fb.cur_lo[b];
     if (tid == 0) s_lo = 0x7fffffff;
     __syncthreads();
-    for (int64_t k0 = lo; k0 < A; k0 += ENVB) {
+    for (int64_t k0 = lo; k0 < A; k0 += INSB) {
       const int64_t k = k0 + tid;
       bool notdue = false;
       if (k < A) {
@@ -583,19 +584,19 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t B, int6
     __syncthreads();
     if (tid == 0) fb.cur_lo[b] = s_lo == 0x7fffffff ? (int32_t)A : s_lo;
   } else {
-    for (int64_t a0 = tid; a0 < A; a0 += 4 * ENVB) {  // 4 independent (status, departure) loads in flight per thread
+    for (int64_t a0 = tid; a0 < A; a0 += 4 * INSB) {  // 4 independent (status, departure) loads in flight per thread
       uint8_t stt[4];
       float dp[4];
   #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int64_t a = a0 + (int64_t)j * ENVB;
+        const int64_t a = a0 + (int64_t)j * INSB;
         stt[j] = a < A ? fb.a_status[b * A + a] : (uint8_t)1;
         dp[j] = a < A ? fb.a_dep[b * A + a] : 0.0f;
       }
   #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (stt[j] == 0 && dp[j] <= t) {
-          const int64_t a = a0 + (int64_t)j * ENVB;
+          const int64_t a = a0 + (int64_t)j * INSB;
           int32_t road = 0, cap = 0;
           if (fused_target(fb, b, B, N, fb.a_origin[b * A + a], &road, &cap)) {
             const int32_t pos = atomicAdd(&s_cnt, 1);
@@ -611,7 +612,7 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t B, int6
   __syncthreads();
   int32_t Lc = s_cnt;
   if (Lc <= INS_CAP) {
-    for (int32_t idx = tid; idx < Lc; idx += ENVB) {
+    for (int32_t idx = tid; idx < Lc; idx += INSB) {
       const int32_t a = s_un_agent[idx];
       int32_t pos = 0;
       for (int32_t k = 0; k < Lc; ++k) pos += (s_un_agent[k] < a) ? 1 : 0;
@@ -622,7 +623,7 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t B, int6
     __syncthreads();
   } else {
     int32_t basec = 0;
-    for (int64_t a0 = 0; a0 < A; a0 += ENVB) {
+    for (int64_t a0 = 0; a0 < A; a0 += INSB) {
       const int64_t a = a0 + tid;
       bool cnd = false;
       int32_t road = 0, cap = 0;
@@ -633,7 +634,7 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t B, int6
       if (lane == 0) s_wave[wid] = __popcll(bal);
       __syncthreads();
       int32_t wbase = 0, tot = 0;
-      for (int w = 0; w < ENVB / 64; ++w) {
+      for (int w = 0; w < INSB / 64; ++w) {
         const int32_t v = s_wave[w];
         if (w < wid) wbase += v;
         tot += v;
@@ -651,7 +652,7 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t B, int6
   }
 
   // phase 2: rank within road (stable), admit the first min(count, capacity), write slots / hot records
-  for (int32_t idx = tid; idx < Lc; idx += ENVB) {
+  for (int32_t idx = tid; idx < Lc; idx += INSB) {
     const int32_t r = cand_road[idx];
     const int32_t a = cand_agent[idx];
     int32_t rank = 0, total = 0;
@@ -696,7 +697,7 @@ __global__ __launch_bounds__(ENVB) void k_fused_insert(int Nmax, int64_t B, int6
   __threadfence_block();
   __syncthreads();
   // phase 3: commit the counters; the arrivals overwrote a pending garbage slot: clear the flag, keep the head offset
-  for (int32_t idx = tid; idx < Lc; idx += ENVB) {
+  for (int32_t idx = tid; idx < Lc; idx += INSB) {
     const int32_t cmt = cand_agent[idx];
     if (cmt > 0) {
       const int64_t rrow = (int64_t)cand_road[idx] * B + b;
@@ -859,7 +860,7 @@ extern "C" int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int6
   hipLaunchKernelGGL(k_fused_rows, grid, dim3(threads), 0, s, plan->out_ptr, plan->out_dst, (int)Nmax, B, plan->N, fb,
                      agent_features, A, a_bstride, time, popped, withdrawn, counts, nchunk());
   TARL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(ENVB), 0, s, (int)Nmax, B, plan->N, fb,
+  hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(INSB), 0, s, (int)Nmax, B, plan->N, fb,
                      agent_features, A, a_bstride, use_cong, time, ins_scratch, entropy1, reward, counts, log_prob,
                      entropy);
   TARL_LAUNCH_CHECK();
