@@ -234,6 +234,10 @@ typedef struct tarl_fused {
 int tarl_fused_pack(const tarl_plan* plan, const tarl_fused* f, const float* x, int64_t B, int64_t x_bstride,
                     int64_t ldx, int32_t Nmax, const float* congestion_constant, const float* agent_features,
                     int64_t num_agents, int64_t a_bstride, tarl_stream stream);
+/* tarl_fused_reset == tarl_reset_state applied to the packed state (SimulatorEnv._reset): zero the FIFO store and the
+ *   counters, keep SELECTED_ROAD, clear ON_WAY / DONE in agent_features and the status SoA, re-arm the insert cursor. */
+int tarl_fused_reset(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, float* agent_features,
+                     int64_t num_agents, int64_t a_bstride, tarl_stream stream);
 /* last_step_time: the clock value passed to the most recent tarl_fused_frame (stamps the pending garbage slots). */
 int tarl_fused_export(const tarl_plan* plan, const tarl_fused* f, float* x, int64_t B, int64_t x_bstride, int64_t ldx,
                       int32_t Nmax, float last_step_time, tarl_stream stream);

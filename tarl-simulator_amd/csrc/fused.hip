@@ -131,6 +131,32 @@ __global__ __launch_bounds__(FB) void k_pack_agents(const float* __restrict__ ag
   if (a == 0 && fb.cur_lo) fb.cur_lo[b] = 0;
 }
 
+// ---- reset: SimulatorEnv._reset on the packed state (zero FIFOs and counters, clear ON_WAY / DONE, re-arm cursors) -------
+__global__ __launch_bounds__(FB) void k_fused_reset_nodes(int64_t B, int64_t N, FusedBufs fb) {
+  const int64_t gid = (int64_t)blockIdx.x * FB + threadIdx.x;
+  if (gid >= B * N) return;
+  fb.rec0[gid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  fb.rec1[gid] = make_float2(0.0f, r1_code(-1.0f, 0));
+  fb.postA[gid] = make_float2(0.0f, 0.0f);
+  fb.postB[gid] = make_float2(0.0f, 0.0f);
+  if (gid < B) {
+    fb.acc_lp[gid] = 0;
+    fb.acc_n[gid] = 0.0f;
+    if (fb.cur_lo) fb.cur_lo[gid] = 0;
+  }
+}
+
+__global__ __launch_bounds__(FB) void k_fused_reset_agents(float* __restrict__ ag, int64_t B, int64_t A,
+                                                           int64_t a_bstride, FusedBufs fb) {
+  const int64_t gid = (int64_t)blockIdx.x * FB + threadIdx.x;
+  if (gid >= B * A) return;
+  const int64_t b = gid / A, a = gid - b * A;
+  float* row = ag + b * a_bstride + a * AG_COLS;
+  row[AG_ON_WAY] = 0.0f;
+  row[AG_DONE] = 0.0f;
+  fb.a_status[gid] = 0;
+}
+
 // ---- export: rebuild the reference's x layout (three FIFO column blocks + NUMBER_OF_AGENT + SELECTED_ROAD) ----------
 __global__ __launch_bounds__(FB) void k_export_rows(float* __restrict__ x, Layout L, int64_t B, int64_t N, FusedBufs fb,
                                                     float t_last) {
@@ -356,7 +382,7 @@ __global__ __launch_bounds__(TILE) void k_fused_direction(const int32_t* __restr
         g = gumbel[b * E + e];
       } else {
         const float u = rng.uniform(seed, counter, (uint64_t)(b * E + k));
-        g = -logf(-logf(u));
+        g = gumbel_from_u01(u);
       }
       const float score = (m ? log_edge_attr[e] : log_eps) + g;
       if (score > best) {
@@ -741,6 +767,16 @@ static int nchunk() {
   return v;
 }
 static int64_t num_chunks(const tarl_plan* plan) { return ceil_div(plan->N, nchunk()); }
+// the Direction kernel has no per-lane epilogue: one node per workgroup pass maximises the waves in flight
+static int nchunk_dir() {
+  static int v = 0;
+  if (v == 0) {
+    const char* e = getenv("TARL_NCHUNK_DIR");
+    v = e ? atoi(e) : 1;
+    if (v < 1) v = 1;
+  }
+  return v;
+}
 // the choice kernel is light and ends in one accumulator atomic per lane: it walks longer chunks (TARL_NCHUNK_CHOICE)
 static int nchunk_choice() {
   static int v = 0;
@@ -758,7 +794,8 @@ static int check_fused_core(const tarl_plan* plan, const tarl_fused* f, int64_t 
                "fused node buffers missing");
   TARL_REQUIRE(B >= 1 && B < ((int64_t)1 << 31) && Nmax >= 2, "bad sizes");
   TARL_REQUIRE(f->ld_slots >= 3 * (int64_t)Nmax, "slot row stride smaller than 3*Nmax");
-  TARL_REQUIRE(num_chunks(plan) < 65536 && ceil_div(plan->N, nchunk_choice()) < 65536,
+  TARL_REQUIRE(num_chunks(plan) < 65536 && ceil_div(plan->N, nchunk_choice()) < 65536 &&
+                   ceil_div(plan->N, nchunk_dir()) < 65536,
                "too many node chunks for one launch");
   TARL_REQUIRE(((uintptr_t)f->rec0 | (uintptr_t)f->rec1 | (uintptr_t)f->post_a | (uintptr_t)f->post_b |
                 (uintptr_t)f->st0) % 16 == 0,
@@ -797,6 +834,24 @@ extern "C" int tarl_fused_pack(const tarl_plan* plan, const tarl_fused* f, const
                        a_bstride, fb);
     TARL_LAUNCH_CHECK();
   }
+  return TARL_OK;
+}
+
+extern "C" int tarl_fused_reset(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax,
+                                float* agent_features, int64_t A, int64_t a_bstride, tarl_stream stream) {
+  int rc = check_fused_core(plan, f, B, Nmax);
+  if (rc) return rc;
+  TARL_REQUIRE(agent_features && A >= 1 && f->a_status, "agents missing");
+  const FusedBufs fb = to_bufs(f);
+  hipStream_t s = (hipStream_t)stream;
+  TARL_CHECK_HIP(hipMemsetAsync(f->slots, 0, (size_t)(plan->N * B * f->ld_slots) * sizeof(float), s));
+  if (plan->N > 0) {
+    hipLaunchKernelGGL(k_fused_reset_nodes, dim3((unsigned)ceil_div(B * plan->N, FB)), dim3(FB), 0, s, B, plan->N, fb);
+    TARL_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_fused_reset_agents, dim3((unsigned)ceil_div(B * A, FB)), dim3(FB), 0, s, agent_features, B, A,
+                     a_bstride, fb);
+  TARL_LAUNCH_CHECK();
   return TARL_OK;
 }
 
@@ -852,9 +907,10 @@ extern "C" int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int6
                      policy_counter, choice, nchunk_choice());
   TARL_LAUNCH_CHECK();
   const bool timed = tarl_prof_event(s) != nullptr;
-  hipLaunchKernelGGL(k_fused_direction, grid, dim3(threads), 0, s, plan->in_ptr, plan->in_src, plan->in_eid, plan->E, B,
-                     plan->N, fb, edge_attr, log_edge_attr, log_eps, time, gumbel, seed, counter, delta_travel_time,
-                     nchunk());
+  const dim3 grid_d((unsigned)ceil_div(B, threads), (unsigned)ceil_div(plan->N, nchunk_dir()));
+  hipLaunchKernelGGL(k_fused_direction, grid_d, dim3(threads), 0, s, plan->in_ptr, plan->in_src, plan->in_eid, plan->E,
+                     B, plan->N, fb, edge_attr, log_edge_attr, log_eps, time, gumbel, seed, counter, delta_travel_time,
+                     nchunk_dir());
   TARL_LAUNCH_CHECK();
   if (timed) (void)tarl_prof_event(s);
   hipLaunchKernelGGL(k_fused_rows, grid, dim3(threads), 0, s, plan->out_ptr, plan->out_dst, (int)Nmax, B, plan->N, fb,

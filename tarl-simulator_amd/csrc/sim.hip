@@ -75,7 +75,7 @@ __global__ __launch_bounds__(SIM_BLOCK) void k_direction_gather(PlanView pv, con
       g = gumbel[ge];
     } else {
       const float u = rng.uniform(seed, counter, (uint64_t)(b * pv.E + k));
-      g = -logf(-logf(u));
+      g = gumbel_from_u01(u);
     }
     const float score = (m ? log_edge_attr[e] : log_eps) + g;
     if (score > best) {

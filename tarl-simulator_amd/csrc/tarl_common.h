@@ -123,4 +123,13 @@ struct PhiloxRun {
   }
 };
 
+// Gumbel(0,1) variate from a device-generated uniform in (0,1): -log(-log(u)) through the hardware log2 (v_log_f32).
+// Used ONLY for noise this library draws itself (Philox path). Parity runs pass the reference's own noise in, already
+// transformed by torch on the host, so nothing that is compared bit-for-bit goes through this approximation.
+__device__ __forceinline__ float gumbel_from_u01(float u) {
+  const float ln2 = 0.69314718055994531f;
+  const float e = -ln2 * __log2f(u);       // Exp(1) variate, > 0 because u < 1
+  return -ln2 * __log2f(e);
+}
+
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -90,11 +90,16 @@ class SimEngine:
     # -- control -----------------------------------------------------------------------------------------------------
     def reset(self):
         """SimulatorEnv._reset: zero FIFOs / counters, clear ON_WAY / DONE, clock = 6 h - 60 s."""
-        ops.reset_state(self.x, self.Nmax, self.agents)
+        if self.fs is not None and not self._packed_stale:
+            ops.fused_reset(self.plan, self.fs, self.agents)     # packed state stays authoritative; x exported on demand
+            self._x_stale = True
+            self._last_step_time = float(EPISODE_START)
+        else:
+            ops.reset_state(self.x, self.Nmax, self.agents)
+            self.resync()
         self.time = EPISODE_START
         self.counts.zero_()
         self.reward.zero_()
-        self.resync()
 
     def step(self, *, choice=None, action_onehot=None, gumbel=None, want_dtt=False):
         """One env step for all B environments. Noise: explicit ``gumbel`` (B,E) or device Philox keyed by

@@ -481,6 +481,14 @@ def fused_pack(plan: Plan, fs: FusedState, x, Nmax, agent_features, congestion_c
                                  agent_features.data_ptr(), A, abs_, _lib.current_stream()))
 
 
+def fused_reset(plan: Plan, fs: FusedState, agent_features):
+    """SimulatorEnv._reset on the packed state (no round trip through x)."""
+    L = _lib.load()
+    A, abs_ = _agents(agent_features, fs.B)
+    _lib.check(L.tarl_fused_reset(plan.handle, fs.ref, fs.B, fs.Nmax, agent_features.data_ptr(), A, abs_,
+                                  _lib.current_stream()))
+
+
 def fused_export(plan: Plan, fs: FusedState, x, Nmax, last_step_time):
     """Write the packed state (FIFO columns, NUMBER_OF_AGENT, SELECTED_ROAD) back into ``x`` (reference layout).
     ``last_step_time``: the clock passed to the most recent :func:`fused_frame`."""
