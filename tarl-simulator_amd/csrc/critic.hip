@@ -160,6 +160,146 @@ __global__ __launch_bounds__(CR_THREADS) void k_critic_fwd(const float* __restri
   }
 }
 
+// ---- slab-input forward, software pipelined ----------------------------------------------------------------------------
+// Same arithmetic as k_critic_fwd (same tiles, same k order, same MFMA chain => bit-identical values) for the env-minor
+// rollout buffer counts [M / rps][N][rps]. Differences are purely scheduling: the X / W1 tiles of K-chunk c+1 are
+// fetched into registers (float4 along the row dimension for X) BEFORE the MFMAs of chunk c and stored into the other
+// LDS buffer after them, so global-memory latency hides behind the matrix work and there is one barrier per chunk.
+#define CRS_LDX (CR_BM + 4)   // X tile row stride (floats): keeps the float4 LDS stores 16-byte aligned
+__global__ __launch_bounds__(CR_THREADS) void k_critic_fwd_slab(const float* __restrict__ counts, int64_t rps, int64_t M,
+                                                                int64_t N, const float* __restrict__ time_rows,
+                                                                int64_t rows_per_time, CriticParams P,
+                                                                float* __restrict__ value) {
+  // [2 buffers] x (Xs [32][132] + Ws [32][65]); the epilogue reuses the space as Hs [64][129] + W2s [64][65]
+  __shared__ __attribute__((aligned(16))) float lds[2 * (CR_BK * CRS_LDX + CR_BK * (CR_H + 1))];
+  const int XS = CR_BK * CRS_LDX, BUF = XS + CR_BK * (CR_H + 1);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t row0 = (int64_t)blockIdx.x * CR_BM;
+  const int64_t ldw = N + 1;
+  const float* xbase = counts + (row0 / rps) * (N * rps) + (row0 % rps);   // element (r, k) at xbase[k * rps + r]
+
+  float4 xr[4];
+  float wr[8];
+  auto fetch = [&](int64_t k0) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = it * CR_THREADS + tid;
+      const int r4 = (idx & 31) * 4, k = idx >> 5;
+      const int64_t gk = k0 + k;
+      xr[it] = (gk < N) ? *reinterpret_cast<const float4*>(xbase + gk * rps + r4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int idx = it * CR_THREADS + tid;
+      const int j = idx >> 5, k = idx & 31;
+      const int64_t gk = k0 + k;
+      wr[it] = (gk < N) ? P.w1[(int64_t)j * ldw + gk] : 0.0f;
+    }
+  };
+  auto stash = [&](int buf) {
+    float* Xs = lds + buf * BUF;
+    float* Ws = Xs + XS;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = it * CR_THREADS + tid;
+      const int r4 = (idx & 31) * 4, k = idx >> 5;
+      *reinterpret_cast<float4*>(Xs + k * CRS_LDX + r4) = xr[it];
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int idx = it * CR_THREADS + tid;
+      const int j = idx >> 5, k = idx & 31;
+      Ws[k * (CR_H + 1) + j] = wr[it];
+    }
+  };
+
+  f32x16 acc0 = {0}, acc1 = {0};
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  int buf = 0;
+  for (int64_t k0 = 0; k0 < N; k0 += CR_BK) {
+    const bool more = k0 + CR_BK < N;
+    if (more) fetch(k0 + CR_BK);             // global loads in flight during the MFMAs below
+    const float* Xs = lds + buf * BUF;
+    const float* Ws = Xs + XS;
+#pragma unroll
+    for (int kk = 0; kk < CR_BK; kk += 2) {
+      const int k = kk + (lane >> 5);
+      const float a = Xs[k * CRS_LDX + wave * 32 + (lane & 31)];
+      const float b0 = Ws[k * (CR_H + 1) + (lane & 31)];
+      const float b1 = Ws[k * (CR_H + 1) + 32 + (lane & 31)];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+    }
+    if (more) stash(buf ^ 1);                // the other buffer: nobody reads it in this iteration
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // epilogue: identical to k_critic_fwd
+  float* Hs = lds;                           // [j][row], stride 129
+  float* W2s = lds + CR_H * (CR_BM + 1);     // [k][j],  stride 65
+  {
+    const int j0 = lane & 31;
+    const float wt0 = P.w1[(int64_t)j0 * ldw + N], wt1 = P.w1[(int64_t)(j0 + 32) * ldw + N];
+    const float bb0 = P.b1[j0], bb1 = P.b1[j0 + 32];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int lr = wave * 32 + mfma_row(r, lane);
+      const int64_t gr = row0 + lr;
+      const float tm = (gr < M) ? time_rows[gr / rows_per_time] : 0.0f;
+      float v0 = acc0[r] + tm * wt0 + bb0;
+      float v1 = acc1[r] + tm * wt1 + bb1;
+      v0 = v0 > 0.0f ? v0 : 0.0f;
+      v1 = v1 > 0.0f ? v1 : 0.0f;
+      Hs[j0 * (CR_BM + 1) + lr] = v0;
+      Hs[(j0 + 32) * (CR_BM + 1) + lr] = v1;
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < (CR_H * CR_H) / CR_THREADS; ++it) {
+    const int idx = it * CR_THREADS + tid;
+    const int j = idx >> 6, k = idx & 63;
+    W2s[k * (CR_H + 1) + j] = P.w2[j * CR_H + k];
+  }
+  __syncthreads();
+  f32x16 c0 = {0}, c1 = {0};
+#pragma unroll
+  for (int kk = 0; kk < CR_H; kk += 2) {
+    const int k = kk + (lane >> 5);
+    const float a = Hs[k * (CR_BM + 1) + wave * 32 + (lane & 31)];
+    const float b0 = W2s[k * (CR_H + 1) + (lane & 31)];
+    const float b1 = W2s[k * (CR_H + 1) + 32 + (lane & 31)];
+    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, c1, 0, 0, 0);
+  }
+  __syncthreads();
+  {
+    const int j0 = lane & 31;
+    const float bb0 = P.b2[j0], bb1 = P.b2[j0 + 32];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int lr = wave * 32 + mfma_row(r, lane);
+      float v0 = c0[r] + bb0, v1 = c1[r] + bb1;
+      v0 = v0 > 0.0f ? v0 : 0.0f;
+      v1 = v1 > 0.0f ? v1 : 0.0f;
+      Hs[j0 * (CR_BM + 1) + lr] = v0;
+      Hs[(j0 + 32) * (CR_BM + 1) + lr] = v1;
+    }
+  }
+  __syncthreads();
+  if (tid < CR_BM) {
+    const int64_t gr = row0 + tid;
+    if (gr < M) {
+      float s = 0.0f;
+#pragma unroll 8
+      for (int j = 0; j < CR_H; ++j) s += Hs[j * (CR_BM + 1) + tid] * P.w3[j];
+      value[gr] = s + P.b3[0];
+    }
+  }
+}
+
 // ---- backward (minibatch-sized M) ------------------------------------------------------------------------------------
 // stage 1: one workgroup per row m: dh2, dh1 (masked by the ReLUs) -> scratch; stage 2: weight gradients as plain
 // reductions over m (deterministic order), dW1 over a (j, k) grid with k-coalesced reads of the counts.
@@ -259,8 +399,14 @@ extern "C" int tarl_critic_mlp_fwd_slabs(const float* counts, int64_t rows_per_s
                                          const float* b3, float* value, tarl_stream stream) {
   TARL_REQUIRE(rows_per_slab >= CR_BM && rows_per_slab % CR_BM == 0, "rows_per_slab must be a multiple of 128");
   TARL_REQUIRE(M % rows_per_slab == 0, "M must be a whole number of slabs");
-  return critic_fwd(counts, 0, rows_per_slab, M, N, time_rows, rows_per_time, w1, b1, w2, b2, w3, b3, value, nullptr,
-                    nullptr, stream);
+  TARL_REQUIRE(counts && time_rows && w1 && b1 && w2 && b2 && w3 && b3 && value, "null argument");
+  TARL_REQUIRE(M >= 1 && N >= 1 && rows_per_time >= 1, "bad sizes");
+  TARL_REQUIRE(((uintptr_t)counts) % 16 == 0, "counts must be 16-byte aligned");
+  const CriticParams P{w1, b1, w2, b2, w3, b3};
+  hipLaunchKernelGGL(k_critic_fwd_slab, dim3((unsigned)(M / CR_BM)), dim3(CR_THREADS), 0, (hipStream_t)stream, counts,
+                     rows_per_slab, M, N, time_rows, rows_per_time, P, value);
+  TARL_LAUNCH_CHECK();
+  return TARL_OK;
 }
 
 extern "C" int tarl_critic_mlp_bwd(const float* counts, int64_t ldc, int64_t M, int64_t N, const float* time_rows,

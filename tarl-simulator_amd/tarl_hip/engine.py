@@ -83,6 +83,12 @@ class SimEngine:
         """(B, N, 7) view: the observation columns x[:, 3*Nmax:] (TransportationSimulator.state)."""
         return self.x[:, :, 3 * self.Nmax:]
 
+    @property
+    def static_node_features(self):
+        """Same view WITHOUT refreshing the dynamic columns: for consumers that read only static columns (the live
+        policy reads ROAD_INDEX alone) — avoids an export of the packed state."""
+        return self._x[:, :, 3 * self.Nmax:]
+
     def refresh_counts(self):
         self.counts.copy_(self.x[:, :, 3 * self.Nmax + 1])
         return self.counts

@@ -136,7 +136,7 @@ class VecPPOTrainer:
         tgt_mb = target.view(-1).index_select(0, idx)
         time_mb = self.times[:T].index_select(0, torch.div(idx, B, rounding_mode="floor"))
         # actor forward (the live policy reads only the static ROAD_INDEX column: broadcast one observation over M rows)
-        nf = eng.node_features[:1].expand(M, N, 7)
+        nf = eng.static_node_features[:1].expand(M, N, 7)
         logits = ops.policy_edge_logits(eng.plan, nf, self._emb())
         proba = ops.graphdist_softmax(eng.plan, logits, self.temperature)
         lp_new, ent = ops.graphdist_logprob_entropy(eng.plan, proba, choice=choice_mb)
