@@ -311,7 +311,8 @@ __global__ __launch_bounds__(TILE) void k_fused_choice(const int32_t* __restrict
                                                        int64_t N, FusedBufs fb, const float* __restrict__ thr,
                                                        const float* __restrict__ lgt,
                                                        const float* __restrict__ uniform, uint64_t pseed,
-                                                       uint64_t pcounter, int32_t* __restrict__ choice, int nchunk) {
+                                                       uint64_t pcounter, int32_t* __restrict__ choice, int nchunk,
+                                                       int want_lp) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const int32_t i0 = blockIdx.y * nchunk;
@@ -337,7 +338,8 @@ __global__ __launch_bounds__(TILE) void k_fused_choice(const int32_t* __restrict
     if (choice) choice[row] = ch;
   }
   // infeasible action (some node picked nothing): poison the accumulator far beyond any legitimate sum
-  atomicAdd((unsigned long long*)&fb.acc_lp[b], (unsigned long long)(bad ? -(1ll << 50) : lp));  // up to 2^13 chunks cannot wrap
+  if (want_lp)
+    atomicAdd((unsigned long long*)&fb.acc_lp[b], (unsigned long long)(bad ? -(1ll << 50) : lp));  // up to 2^13 chunks cannot wrap
 }
 
 // ---- Direction gather on the hot records (env-minor: lane = environment) ---------------------------------------------------
@@ -904,7 +906,7 @@ extern "C" int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int6
   const dim3 grid_c((unsigned)ceil_div(B, threads), (unsigned)ceil_div(plan->N, nchunk_choice()));
   hipLaunchKernelGGL(k_fused_choice, grid_c, dim3(threads), 0, s, plan->out_ptr, plan->out_dst, plan->out_eid,
                      plan->group_of_node, plan->G, B, plan->N, fb, thresholds, log_probs, uniform, policy_seed,
-                     policy_counter, choice, nchunk_choice());
+                     policy_counter, choice, nchunk_choice(), log_prob != nullptr ? 1 : 0);
   TARL_LAUNCH_CHECK();
   const bool timed = tarl_prof_event(s) != nullptr;
   const dim3 grid_d((unsigned)ceil_div(B, threads), (unsigned)ceil_div(plan->N, nchunk_dir()));

@@ -22,13 +22,17 @@ from .flatparams import FlatParams
 class VecPPOTrainer:
     def __init__(self, engine, emb_param, critic_params, *, rollout_steps, num_epochs=1, sub_batch_size=32, lr=1e-3,
                  gamma=0.99, lmbda=0.95, clip_epsilon=0.2, entropy_coef=0.01, critic_coef=1.0, temperature=1.0,
-                 extra_params=(), seed=0):
+                 extra_params=(), seed=0, lazy_log_prob=False):
         """``emb_param``: nn.Parameter (num_nodes, 1) — MPNNPolicyNet.nodes_embedding.weight;
         ``critic_params``: [w1 (64,N+1), b1, w2 (64,64), b2, w3 (1,64), b3] — MPNNValueNetSimple.final_mlp.{0,2,4};
         ``extra_params``: further actor/critic parameters that never receive gradient on the live path (the dormant
         edge MLPs) — they sit in the flat buffer so that the optimiser covers ``loss_module.parameters()`` like the
         reference's does."""
         self.eng = engine
+        # lazy_log_prob: do not produce sample_log_prob for every collected frame (as the reference's collector does)
+        # but only, exactly, for the frames a minibatch actually reads. Same training result; off by default so that a
+        # frame does everything the reference's frame does.
+        self.lazy_log_prob = bool(lazy_log_prob)
         self.T = int(rollout_steps)
         self.num_epochs = int(num_epochs)
         self.M = int(sub_batch_size)
@@ -76,10 +80,13 @@ class VecPPOTrainer:
             # fused path: 4 launches per frame, every output lands directly in the rollout buffers (no copies)
             self.counts[0].zero_()
             eng.prepare_policy(emb, self.temperature)      # once per parameter update, not per frame
+            # sample_log_prob is only ever read for the <= sub_batch_size frames of each minibatch: keep the behaviour
+            # policy's parameters and evaluate it (exactly, with the unfused kernel) for those frames at update time
+            self.emb_rollout = emb.clone()
             for t in range(self.T):
                 host_times.append(float(eng.time))
-                eng.frame_fused(choice=self.choice[t], log_prob=self.logp[t], reward=self.reward[t],
-                                counts=self.counts[t + 1])
+                eng.frame_fused(choice=self.choice[t], log_prob=None if self.lazy_log_prob else self.logp[t],
+                                reward=self.reward[t], counts=self.counts[t + 1])
             host_times.append(float(eng.time))
             self.times.copy_(torch.tensor(host_times, dtype=torch.float32))
             return self.T * eng.B
@@ -131,12 +138,17 @@ class VecPPOTrainer:
         else:
             counts_mb = self.counts[:T].view(T * B, N).index_select(0, idx)
             choice_mb = self.choice.view(T * B, N).index_select(0, idx)
-        lp_old = self.logp.view(-1).index_select(0, idx)
+        nf = eng.static_node_features[:1].expand(M, N, 7)
+        if self.env_minor and self.lazy_log_prob:   # behaviour log-prob of the sampled frames, rollout-time parameters
+            p_old = ops.graphdist_softmax(eng.plan, ops.policy_edge_logits(eng.plan, nf, self.emb_rollout),
+                                          self.temperature)
+            lp_old, _ = ops.graphdist_logprob_entropy(eng.plan, p_old, choice=choice_mb, want_entropy=False)
+        else:
+            lp_old = self.logp.view(-1).index_select(0, idx)
         adv_mb = adv.view(-1).index_select(0, idx)
         tgt_mb = target.view(-1).index_select(0, idx)
         time_mb = self.times[:T].index_select(0, torch.div(idx, B, rounding_mode="floor"))
         # actor forward (the live policy reads only the static ROAD_INDEX column: broadcast one observation over M rows)
-        nf = eng.static_node_features[:1].expand(M, N, 7)
         logits = ops.policy_edge_logits(eng.plan, nf, self._emb())
         proba = ops.graphdist_softmax(eng.plan, logits, self.temperature)
         lp_new, ent = ops.graphdist_logprob_entropy(eng.plan, proba, choice=choice_mb)
