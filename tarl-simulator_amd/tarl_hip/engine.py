@@ -146,3 +146,37 @@ class SimEngine:
                         counts=counts)
         self.time += self.timestep
         return self.time > EPISODE_END
+
+    def rollout_fused(self, T, *, choice, log_prob, reward, counts):
+        """``T`` consecutive frames with the outputs of frame t written to ``choice[t]`` (T,N,B) int32, ``log_prob[t]``
+        (T,B) or None, ``reward[t]`` (T,B), ``counts[t + 1]`` (T+1,N,B). Same as T calls of :meth:`frame_fused` with the
+        per-frame Python overhead removed (arguments marshalled once). Returns the list of clock values."""
+        if self._packed_stale:
+            self.resync()
+        for n, t_, dt, shp in (("choice", choice, torch.int32, (T, self.N, self.B)),
+                               ("reward", reward, torch.float32, (T, self.B)),
+                               ("counts", counts, torch.float32, (T + 1, self.N, self.B))):
+            if t_.dtype != dt or tuple(t_.shape) != shp or not t_.is_contiguous() or not t_.is_cuda:
+                raise ValueError(f"{n} must be a contiguous cuda {dt} tensor of shape {shp}")
+        if log_prob is not None and (log_prob.dtype != torch.float32 or tuple(log_prob.shape) != (T, self.B)
+                                     or not log_prob.is_contiguous()):
+            raise ValueError("log_prob must be a contiguous float32 (T, B) tensor")
+        call = ops.FusedFrameLauncher(self.plan, self.fs, self.tables, self.agents, self.ec,
+                                      use_cong=self.cc is not None, policy_seed=self.seed ^ 0x5DEECE66D, seed=self.seed,
+                                      scratch=self.ins_scratch)
+        ch0, ch_s = choice.data_ptr(), choice.stride(0) * 4
+        rw0, rw_s = reward.data_ptr(), reward.stride(0) * 4
+        ct0, ct_s = counts.data_ptr(), counts.stride(0) * 4
+        lp0, lp_s = (log_prob.data_ptr(), log_prob.stride(0) * 4) if log_prob is not None else (None, 0)
+        times = []
+        self._x_stale = True
+        for t in range(T):
+            times.append(float(self.time))
+            self.sample_counter += 1
+            self.noise_counter += 1
+            call(float(self.time), self.sample_counter, self.noise_counter, ch0 + t * ch_s,
+                 None if lp0 is None else lp0 + t * lp_s, rw0 + t * rw_s, ct0 + (t + 1) * ct_s)
+            self._last_step_time = float(self.time)
+            self.time += self.timestep
+        times.append(float(self.time))
+        return times

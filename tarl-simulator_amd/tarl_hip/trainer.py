@@ -83,11 +83,9 @@ class VecPPOTrainer:
             # sample_log_prob is only ever read for the <= sub_batch_size frames of each minibatch: keep the behaviour
             # policy's parameters and evaluate it (exactly, with the unfused kernel) for those frames at update time
             self.emb_rollout = emb.clone()
-            for t in range(self.T):
-                host_times.append(float(eng.time))
-                eng.frame_fused(choice=self.choice[t], log_prob=None if self.lazy_log_prob else self.logp[t],
-                                reward=self.reward[t], counts=self.counts[t + 1])
-            host_times.append(float(eng.time))
+            host_times = eng.rollout_fused(self.T, choice=self.choice,
+                                           log_prob=None if self.lazy_log_prob else self.logp, reward=self.reward,
+                                           counts=self.counts)
             self.times.copy_(torch.tensor(host_times, dtype=torch.float32))
             return self.T * eng.B
         for t in range(self.T):

@@ -172,3 +172,31 @@ def test_critic_slab_mode_matches_row_major(ops):
     rows = counts.permute(0, 2, 1).contiguous().view(S * R, N)
     v_rows, _, _ = ops.critic_forward(cw, rows, times, rows_per_time=R)
     assert torch.equal(v_slab, v_rows)        # same tiles, same k order, same MFMA chain
+
+
+def test_rollout_launcher_equals_frame_loop(ops):
+    """SimEngine.rollout_fused (arguments marshalled once) == T calls of frame_fused."""
+    from tarl_hip import synth
+    from tarl_hip.engine import SimEngine
+    net = synth.torus_network(5, 5, heterogeneous=True, seed=3)
+    N = net.num_roads
+    B, A, T = 5, 700, 30
+    pops = torch.stack([synth.population(A, N, seed=b, t0=21540, t1=21560) for b in range(B)])
+    mk = lambda: SimEngine(dev(net.x.unsqueeze(0).repeat(B, 1, 1)), net.edge_index, net.edge_attr, net.Nmax,
+                           dev(pops.clone()), congestion_constant=net.congestion_constant, seed=9)
+    e1, e2 = mk(), mk()
+    emb = torch.randn(N, generator=torch.Generator().manual_seed(5)).cuda()
+    bufs = lambda: (torch.zeros((T, N, B), dtype=torch.int32, device="cuda"), torch.zeros((T, B), device="cuda"),
+                    torch.zeros((T, B), device="cuda"), torch.zeros((T + 1, N, B), device="cuda"))
+    ch1, lp1, rw1, ct1 = bufs()
+    ch2, lp2, rw2, ct2 = bufs()
+    for e in (e1, e2):
+        e.reset()
+        e.prepare_policy(emb)
+    for t in range(T):
+        e1.frame_fused(choice=ch1[t], log_prob=lp1[t], reward=rw1[t], counts=ct1[t + 1])
+    times = e2.rollout_fused(T, choice=ch2, log_prob=lp2, reward=rw2, counts=ct2)
+    assert len(times) == T + 1 and times[0] == 21540.0 and e1.time == e2.time
+    assert torch.equal(ch1, ch2) and torch.equal(lp1, lp2) and torch.equal(rw1, rw2) and torch.equal(ct1, ct2)
+    assert torch.equal(e1.x, e2.x) and torch.equal(e1.agents, e2.agents)
+    assert float(rw1.abs().sum()) > 0
