@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--edges", type=int, default=10000)
     ap.add_argument("--agents", type=int, default=16384)
-    ap.add_argument("--envs", type=int, default=1024, help="vectorised environments per GPU")
+    ap.add_argument("--envs", type=int, default=2048, help="vectorised environments per GPU")
     ap.add_argument("--rollout-steps", type=int, default=256)
     ap.add_argument("--epochs", type=int, default=1)
     ap.add_argument("--sub-batch", type=int, default=32)
@@ -167,10 +167,10 @@ def main():
         # passes of the same kernels at the same sizes and committed under profiles/); null when no matching record.
         traffic, traffic_src = None, None
         try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", "r01_v2_pmc_traffic.json")))
+            rec = json.load(open(os.path.join(ROOT, "profiles", "r01_v3_pmc_traffic.json")))
             if rec["config"] == {"edges": E, "agents": args.agents, "envs": B}:
                 traffic = rec["kernels"]["k_fused_direction"]["hbm_bytes_per_launch"]
-                traffic_src = "profiles/r01_v2_pmc_traffic.json (rocprofv3 --pmc, 2*FETCH_SIZE + WRITE_SIZE)"
+                traffic_src = "profiles/r01_v3_pmc_traffic.json (rocprofv3 --pmc, 2*FETCH_SIZE + WRITE_SIZE)"
         except (OSError, KeyError, ValueError):
             pass
         out = {

@@ -17,7 +17,7 @@ from tarl_hip.engine import SimEngine  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--edges", type=int, default=10000)
 ap.add_argument("--agents", type=int, default=16384)
-ap.add_argument("--envs", type=int, default=1024)
+ap.add_argument("--envs", type=int, default=2048)
 ap.add_argument("--frames", type=int, default=40)
 args = ap.parse_args()
 W, H = synth.torus_for_edges(args.edges)
