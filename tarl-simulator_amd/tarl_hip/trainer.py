@@ -124,11 +124,16 @@ class VecPPOTrainer:
         ops.advantage_normalize_(adv, stats)
         return adv, target
 
-    def minibatch_step(self, adv, target):
+    def minibatch_step(self, adv, target, idx=None):
+        """One minibatch + one Adam step. ``idx`` (test hook): flat frame indices t * B + b instead of a random draw."""
         eng = self.eng
         T, B, N, E = self.T, eng.B, eng.N, eng.E
         M = min(self.M, T * B)
-        idx = torch.randperm(T * B, generator=self.gen, device=eng.device)[:M]
+        if idx is None:
+            idx = torch.randperm(T * B, generator=self.gen, device=eng.device)[:M]
+        else:
+            idx = idx.to(eng.device)
+            M = idx.numel()
         if self.env_minor:
             t_idx, b_idx = torch.div(idx, B, rounding_mode="floor"), idx % B
             counts_mb = self.counts[t_idx, :, b_idx].contiguous()               # (M, N) rows of the sampled frames
@@ -166,6 +171,7 @@ class VecPPOTrainer:
         ops.critic_backward(cw, counts_mb, time_mb, 1, h1, h2, g_val,
                             (gw[0], gw[1], gw[2], gw[3], gw[4].view(-1), gw[5]))
         self.flat.allreduce_grads()               # ONE all-reduce of the fused gradient buffer (RCCL over xGMI)
+        self.last_grad = self.flat.grad.clone() if getattr(self, "keep_grad", False) else None
         self.flat.adam_step(lr=self.lr)
         return out
 
