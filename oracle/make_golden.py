@@ -337,6 +337,64 @@ def gen_nets():
          **{k.replace(".", "__"): v for k, v in sd.items()})
 
 
+from make_golden_fixtures import EQUIL_NETWORK_XML, EQUIL_POPULATION_XML, SIMPLE_NETWORK_XML  # noqa: E402
+
+
+def _graph_fields(g):
+    return dict(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr, edge_index_routes=g.edge_index_routes,
+                edge_attr_routes=g.edge_attr_routes, num_roads=g.num_roads, adj_matrix=g.adj_matrix, src_adj=g.src_adj,
+                critical_number=g.critical_number, congestion_constant=g.congestion_constant)
+
+
+def gen_builders():
+    """TransportationSimulator.config_network / Agents.config_agents_from_xml on the reference's own
+    test fixtures and on a synthetic MATSim torus; plus the classical run() loop on the 2-link network with SRC/DEST
+    pseudo-nodes (tests/transportation_simulator_test.py:17-25: the agent reaches DONE within 20 steps)."""
+    import contextlib
+    import io
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp, contextlib.redirect_stdout(io.StringIO()):
+        for tag, xml in (("simple", SIMPLE_NETWORK_XML), ("equil", EQUIL_NETWORK_XML)):
+            d = os.path.join(tmp, tag)
+            os.makedirs(d)
+            open(os.path.join(d, "network.xml"), "w").write(xml)
+        open(os.path.join(tmp, "equil", "population.xml"), "w").write(EQUIL_POPULATION_XML)
+        d = os.path.join(tmp, "torus")
+        os.makedirs(d)
+        synth.write_matsim_network_xml(os.path.join(d, "network.xml"), 3, 4, seed=5)
+        synth.write_matsim_population_xml(os.path.join(d, "population.xml"), 3, 4, 60, seed=6)
+        rec = {}
+        for tag in ("simple", "equil", "torus"):
+            sim = TransportationSimulator("cpu")
+            sim.config_network(os.path.join(tmp, tag, "network"))
+            rec.update({f"{tag}__{k}": v for k, v in _graph_fields(sim.graph).items()})
+            rec[f"{tag}__Nmax"] = sim.Nmax
+        for tag in ("equil", "torus"):
+            ag = Agents("cpu")
+            ag.config_agents_from_xml(os.path.join(tmp, tag), verbose=False)
+            rec[f"{tag}__agents"] = ag.agent_features
+        # classical loop on the simple network (tests/conftest.py:109-120)
+        sim = TransportationSimulator("cpu")
+        sim.config_network(os.path.join(tmp, "simple", "network"))
+        sim.agent.agent_features = torch.zeros((2, 9))
+        sim.agent.agent_features[0, sim.agent.DEPARTURE_TIME] = 25 * 3600
+        sim.agent.agent_features[1, 0] = 2
+        sim.agent.agent_features[1, 1] = 5
+        sim.config_parameters(start_time=1)
+        sim.agent.set_time(sim.time)
+        xs, ags = [], []
+        steps = 0
+        while sim.agent.agent_features[1, sim.agent.DONE] == 0 and steps < 20:
+            torch.manual_seed(700 + steps)
+            sim.run()
+            steps += 1
+            xs.append(sim.graph.x.clone())
+            ags.append(sim.agent.agent_features.clone())
+        rec.update(run_x=torch.stack(xs), run_agents=torch.stack(ags), run_steps=steps, run_time=sim.time)
+    save("builders", **rec)
+    print(f"  builders: classical run reached DONE after {steps} steps")
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), f"reference tree not found at {REF} (this script only runs in the build container)"
     gen_core_steps()
@@ -345,3 +403,4 @@ if __name__ == "__main__":
     gen_graphdist()
     gen_env_rollout()
     gen_nets()
+    gen_builders()

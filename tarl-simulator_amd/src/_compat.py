@@ -113,6 +113,24 @@ def cached_plan(edge_index: torch.Tensor, num_nodes: int):
     return hit[0]
 
 
+_ROUTING_CACHE: dict = {}
+
+
+def cached_routing_plan(edge_index: torch.Tensor, num_nodes: int, num_roads: int):
+    """Plan over the edges whose destination is a ROAD (road -> road and SRC -> road): the candidates of the classical
+    random agent (src/agents/base.py:447-495 samples inside ``adj[:, :num_roads]``; road -> DEST edges never compete)."""
+    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), str(edge_index.device), int(num_nodes),
+           int(num_roads))
+    hit = _ROUTING_CACHE.get(key)
+    if hit is None:
+        if len(_ROUTING_CACHE) > 64:
+            _ROUTING_CACHE.clear()
+        sub = edge_index[:, edge_index[1] < num_roads].contiguous()
+        hit = (cached_plan(sub, num_nodes), sub, edge_index)
+        _ROUTING_CACHE[key] = hit
+    return hit[0]
+
+
 _EC_CACHE: dict = {}
 
 

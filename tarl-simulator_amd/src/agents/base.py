@@ -2,8 +2,8 @@
 
 ``insert_agent_into_network`` / ``withdraw_agent_from_network`` keep the reference's signatures and in-place
 conventions and run as ``tarl_insert_step`` / ``tarl_withdraw_step``: no host sync, no Python loop over roads, no dense
-N x N adjacency (the plan's CSR rows answer "is there an edge road -> destination"). MATSim XML parsing and the
-Dijkstra baseline are outside this build's scope.
+N x N adjacency (the plan's CSR rows answer "is there an edge road -> destination"). ``config_agents_from_xml`` parses a
+MATSim population (src/matsim_io.py). The Dijkstra baseline is outside this build's scope.
 """
 from __future__ import annotations
 
@@ -11,7 +11,7 @@ import os
 
 import torch
 
-from .._compat import cached_plan, require_cuda
+from .._compat import cached_plan, cached_routing_plan, require_cuda
 from ..feature_helpers import AgentFeatureHelpers, FeatureHelpers
 
 
@@ -22,6 +22,22 @@ class Agents(AgentFeatureHelpers):
         self.time = 0
         self.device = device
         self.withdraw_history: list = []      # (time, uint8/Bool mask over the road rows), kept on the device
+
+    # -- population from MATSim XML ----------------------------------------------------------------------------------------
+    def config_agents_from_xml(self, scenario: str, *, verbose: bool = True) -> None:
+        """``data/<scenario>/population.xml[.gz]`` + ``data/<scenario>/network.xml[.gz]`` -> ``agent_features`` with one
+        row per trip (src/agents/base.py:36-242). An absolute ``scenario`` path is used as is (os.path.join)."""
+        from ..matsim_io import build_population
+        rows, stats = build_population(os.path.join("data", scenario, "population"),
+                                       os.path.join("data", scenario, "network"), log=print if verbose else None)
+        self.agent_features = rows.to(self.device)
+        print(f"Population: {stats['selected']}/{stats['total']} persons selected, {rows.size(0) - 1} trips")
+        if verbose:
+            excl = {k: stats[k] for k in ("car_avail_not_always", "no_plan", "too_few_activities", "no_valid_trip")}
+            print(f"  exclusion reasons: {excl}")
+            if stats["trips"]:
+                t = stats["trips"]
+                print(f"  trips per person: min {min(t)} max {max(t)} mean {sum(t) / len(t):.2f}")
 
     # -- per-step kernels -------------------------------------------------------------------------------------------------
     def insert_agent_into_network(self, graph, h: FeatureHelpers) -> torch.Tensor:
@@ -50,10 +66,11 @@ class Agents(AgentFeatureHelpers):
 
     @torch.no_grad()
     def choice(self, graph, h: FeatureHelpers):
-        """Random routing: every node with out-edges selects one of them uniformly (the classical ``random`` agent)."""
+        """Random routing: every node with a road among its successors selects one of them uniformly (the classical
+        ``random`` agent; road -> DEST edges are not candidates and nodes without a candidate keep their selection)."""
         from tarl_hip import ops
         x = graph.x
-        plan = cached_plan(graph.edge_index, x.size(0))
+        plan = cached_routing_plan(graph.edge_index, x.size(0), int(getattr(graph, "num_roads", x.size(0))))
         logits = torch.zeros(plan.num_edges, dtype=torch.float32, device=x.device)
         proba = ops.graphdist_softmax(plan, logits)
         self._choice_counter = getattr(self, "_choice_counter", 0) + 1
@@ -85,8 +102,12 @@ class Agents(AgentFeatureHelpers):
             self.agent_features = synth.population(spec["agents"], 4 * W * H, seed=spec["seed"]).to(self.device)
         else:
             path = os.path.join("save", scenario, "population.pt")
-            obj = torch.load(path, weights_only=True, map_location="cpu")
-            if not torch.is_tensor(obj):
-                raise TypeError(f"expected a Tensor in {path}, got {type(obj)}")
-            self.agent_features = obj.to(self.device, torch.float32).contiguous()
+            if not os.path.exists(path):   # src/agents/base.py load(): no cache -> parse the XML population, cache it
+                self.config_agents_from_xml(scenario)
+                self.save(path)
+            else:
+                obj = torch.load(path, weights_only=True, map_location="cpu")
+                if not torch.is_tensor(obj):
+                    raise TypeError(f"expected a Tensor in {path}, got {type(obj)}")
+                self.agent_features = obj.to(self.device, torch.float32).contiguous()
         self.agent_features[0, self.DEPARTURE_TIME] = 48 * 3600   # agent 0 never joins the network

@@ -1,8 +1,9 @@
 """TransportationSimulator — the graph container the env and the runner talk to (reference:
 src/transportation_simulator.py). In scope here: the graph layout contract (``graph.x``, ``edge_index``,
-``edge_index_routes``, ``edge_attr*``, ``num_roads``, ``congestion_constant``), ``load_network`` for synthetic
-scenarios and for the reference's ``save/<scenario>/network.pt`` cache, ``config_parameters / configure_core /
-set_time / reset / state / run``. MATSim XML ingestion, plots and CSV metrics are out of scope.
+``edge_index_routes``, ``edge_attr*``, ``num_roads``, ``congestion_constant``), ``config_network`` (MATSim XML ->
+graph, src/matsim_io.py), ``load_network`` for synthetic scenarios, the reference's ``save/<scenario>/network.pt`` cache
+and ``data/<scenario>/network.xml[.gz]``, ``config_parameters / configure_core / set_time / reset / state / run``.
+Plots and CSV metrics are out of scope.
 """
 from __future__ import annotations
 
@@ -33,9 +34,23 @@ class TransportationSimulator:
         self.done_before = 0
 
     # -- network ------------------------------------------------------------------------------------------------------
+    def config_network(self, file_path: str) -> None:
+        """Road graph (+ SRC/DEST pseudo-nodes) from ``<file_path>.xml[.gz]`` (src/transportation_simulator.py:61-228)."""
+        from .matsim_io import build_network
+        t0 = time.time()
+        self.graph, self.Nmax = build_network(file_path)
+        self.graph = self.graph.to(self.device)
+        self.h = FeatureHelpers(Nmax=self.Nmax)
+        print(f"Network configured from {file_path} in {time.time() - t0:.2f} seconds")
+
     def load_network(self, scenario: str) -> None:
         from tarl_hip import synth
         spec = synth.parse_scenario(scenario)
+        if spec is None and not os.path.exists(os.path.join("save", scenario, "network.pt")):
+            # src/transportation_simulator.py:255-259: no cache -> build from data/<scenario>/network.xml[.gz], cache it
+            self.config_network(os.path.join("data", scenario, "network"))
+            self.save_network(os.path.join("save", scenario, "network.pt"))
+            return
         if spec is not None:
             W, H = synth.torus_for_edges(spec["edges"])
             net = synth.torus_network(W, H)
@@ -56,7 +71,7 @@ class TransportationSimulator:
 
     def save_network(self, file_path: str) -> None:
         os.makedirs(os.path.dirname(file_path), exist_ok=True)
-        torch.save({"graph": self.graph, "Nmax": self.Nmax}, file_path)
+        torch.save({"graph": self.graph.clone().to("cpu"), "Nmax": self.Nmax}, file_path)
 
     def configure_core(self):
         self.model_core = SimulationCoreModel(self.Nmax, self.device, self.time, torch_compile=self.torch_compile)

@@ -149,3 +149,69 @@ def parse_scenario(name: str):
     if len(parts) < 3 or parts[0] != "synthetic":
         return None
     return {"edges": int(parts[1]), "agents": int(parts[2]), "seed": int(parts[3]) if len(parts) > 3 else 0}
+
+
+# ---- MATSim-format writers (inputs for the network / population builders; no reference scenario data ships) ------------
+def write_matsim_network_xml(path: str, W: int, H: int, *, seed: int = 0, heterogeneous: bool = True,
+                             effectivecellsize: float | None = 7.5) -> None:
+    """A ``W x H`` torus of intersections ("n<k>" ids, coordinates on a 100 m grid) with 4 outgoing links each, written
+    as a MATSim ``network.xml`` (nodes + links with from/to/length/capacity/freespeed/permlanes)."""
+    g = torch.Generator().manual_seed(seed)
+    V = W * H
+    lines = ['<?xml version="1.0" encoding="utf-8"?>', '<network name="synthetic torus">', "  <nodes>"]
+    for v in range(V):
+        lines.append(f'    <node id="n{v}" x="{(v % W) * 100.0}" y="{(v // W) * 100.0}"/>')
+    cs = "" if effectivecellsize is None else f' effectivecellsize="{effectivecellsize}"'
+    lines += ["  </nodes>", f'  <links capperiod="01:00:00"{cs}>']
+    lid = 0
+    for v in range(V):
+        vx, vy = v % W, v // W
+        for to in (((vx + 1) % W) + vy * W, ((vx - 1) % W) + vy * W, vx + ((vy + 1) % H) * W, vx + ((vy - 1) % H) * W):
+            if heterogeneous:
+                length = round(60.0 + 90.0 * float(torch.rand(1, generator=g)), 2)
+                cap = 300 + 100 * int(torch.randint(0, 6, (1,), generator=g))
+                speed = [8.33, 13.89, 16.67][int(torch.randint(0, 3, (1,), generator=g))]
+                lanes = 1 + int(torch.randint(0, 2, (1,), generator=g))
+            else:
+                length, cap, speed, lanes = 100, 10, 10, 1
+            lines.append(f'    <link id="{lid}" from="n{v}" to="n{to}" length="{length}" capacity="{cap}" '
+                         f'freespeed="{speed}" permlanes="{lanes}"/>')
+            lid += 1
+    lines += ["  </links>", "</network>"]
+    with open(path, "w", encoding="utf-8") as f:
+        f.write("\n".join(lines) + "\n")
+
+
+def write_matsim_population_xml(path: str, W: int, H: int, persons: int, *, seed: int = 0) -> None:
+    """Persons with 2-4 activities whose ``link`` attribute names an intersection id (the convention the reference's
+    parser uses), some with an unknown link + coordinates (nearest-intersection fallback), some without a car, some with
+    explicit attributes, ``HH:MM`` and ``HH:MM:SS`` end times."""
+    g = torch.Generator().manual_seed(seed)
+    V = W * H
+    r = lambda n: int(torch.randint(0, n, (1,), generator=g))
+    lines = ["<?xml version='1.0' encoding='utf-8'?>", "<population>"]
+    for p in range(persons):
+        attrs = ""
+        if r(5) == 0:
+            attrs += ' car_avail="never"'
+        if r(3) == 0:
+            attrs += f' sex="{"f" if r(2) else "m"}" age="{18 + r(60)}" employed="{"yes" if r(2) else "no"}"'
+        lines.append(f'  <person id="p{p}"{attrs}>')
+        if r(4) == 0:
+            lines.append(f'    <attributes><attribute name="age">{20 + r(50)}</attribute></attributes>')
+        lines.append("    <plan>")
+        t = 6 * 3600 + r(3600)
+        for a in range(2 + r(3) if r(12) else 1):
+            v = r(V)
+            if r(6) == 0:   # unknown link id, coordinates near intersection v
+                where = f'x="{(v % W) * 100.0 + 3.0}" y="{(v // W) * 100.0 - 2.0}" link="zz{r(99)}"'
+            else:
+                where = f'x="{(v % W) * 100.0}" y="{(v // W) * 100.0}" link="n{v}"'
+            hh, mm, ss = t // 3600, (t % 3600) // 60, t % 60
+            end = f"{hh:02d}:{mm:02d}:{ss:02d}" if r(2) else f"{hh:02d}:{mm:02d}"
+            lines.append(f'      <act type="{"h" if a % 2 == 0 else "w"}" {where} end_time="{end}"/>')
+            t += 600 + r(3000)
+        lines += ["    </plan>", "  </person>"]
+    lines.append("</population>")
+    with open(path, "w", encoding="utf-8") as f:
+        f.write("\n".join(lines) + "\n")

@@ -237,3 +237,34 @@ def test_ppo_train_and_runner_end_to_end(tmp_path, monkeypatch, capsys):
     main(["--algo", "random", "--mode", "eval", "--scenario", "synthetic-1024-256", "--steps", "15",
           "--start-end-time", "21540", "21600"])
     assert "Simulation Summary" in capsys.readouterr().out
+
+
+def test_classical_run_on_matsim_network_golden(tmp_path):
+    """The reference's tests/transportation_simulator_test.py:17-25 scenario (tests/conftest.py:94-120): 2-link MATSim
+    network with SRC/DEST pseudo-nodes, one agent SRC(A) -> DEST(B), classical ``run()`` loop until DONE. Every node has
+    one candidate successor, so the trajectory does not depend on the random draws: state and agent table must equal
+    the reference's after every step."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+    from make_golden_fixtures import SIMPLE_NETWORK_XML
+    from src.transportation_simulator import TransportationSimulator
+    g = load_golden("builders")
+    (tmp_path / "network.xml").write_text(SIMPLE_NETWORK_XML)
+    sim = TransportationSimulator("cuda")
+    sim.config_network(str(tmp_path / "network"))
+    a = torch.zeros((2, 9))
+    a[0, sim.agent.DEPARTURE_TIME] = 25 * 3600
+    a[1, 0], a[1, 1] = 2, 5
+    sim.agent.agent_features = a.cuda()
+    sim.config_parameters(start_time=1)
+    sim.agent.set_time(sim.time)
+    steps = 0
+    while sim.agent.agent_features[1, sim.agent.DONE] == 0 and steps < 20:
+        sim.run()
+        assert torch.equal(sim.graph.x.cpu(), g["run_x"][steps]), f"x after step {steps}"
+        assert torch.equal(sim.agent.agent_features.cpu(), g["run_agents"][steps]), f"agents after step {steps}"
+        steps += 1
+    assert steps == int(g["run_steps"]) and sim.time == g["run_time"]
+    assert sim.agent.agent_features[1, sim.agent.DONE] == 1
+    assert sim.agent.agent_features[1, sim.agent.ARRIVAL_TIME] > 0
