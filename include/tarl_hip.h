@@ -265,6 +265,29 @@ int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int64_t B, int3
                      uint8_t* withdrawn, int32_t* ins_scratch, int32_t* choice, float* log_prob, float* entropy,
                      float* reward, float* counts, tarl_stream stream);
 
+/* ---- shortest-path routing -----------------------------------------------------------------------
+ * tarl_edge_travel_time == the edge weights of DijkstraAgents.choice (src/agents/base.py:541-550):
+ *   travel_time[b][e] = max(FREE_FLOW[u], congestion_constant[v] / (MAX[u] + 10 - N[u])), u = src(e), v = dst(e),
+ *   original edge order, fp32.
+ * tarl_apsp == nx.all_pairs_dijkstra_path + the next-hop extraction of src/agents/base.py:556-570, and
+ *   nx.shortest_path_length of MPNNPolicyNet.refresh_dijkstra (src/agents/mpnn_agent.py:53-79), for B weight sets
+ *   (w_bstride = 0 shares one). Distances accumulate in double like networkx's Python floats; ties are broken exactly
+ *   as networkx 3.x's heap does ((distance, push order), successors in edge order), so next_hop is reproducible.
+ *   next_hop int64 [B][N][N]: first node after s on the path s -> t, s on the diagonal, -1 when unreachable.
+ *   dist fp32 [B][N][N]: +inf when unreachable, 0 on the diagonal. Either output may be NULL.
+ *   scratch: tarl_apsp_scratch_bytes(plan, B) bytes of device memory (0 => NULL is fine: state kept in LDS).
+ *   The graph must be simple (no duplicate (u, v) edges: a DiGraph would merge them).
+ * tarl_select_next_hop == src/agents/base.py:572-580: SELECTED_ROAD[i] = next_hop[i][DESTINATION[head agent of i]]
+ *   for every row i (rows with an empty FIFO read agent 0). nh_bstride = 0 shares one table between environments. */
+int tarl_edge_travel_time(const tarl_plan* plan, const float* x, int64_t B, int64_t x_bstride, int64_t ldx,
+                          int32_t Nmax, const float* congestion_constant, float* travel_time, tarl_stream stream);
+int64_t tarl_apsp_scratch_bytes(const tarl_plan* plan, int64_t B);
+int tarl_apsp(const tarl_plan* plan, const float* weights, int64_t B, int64_t w_bstride, void* scratch,
+              int64_t scratch_bytes, int64_t* next_hop, float* dist, tarl_stream stream);
+int tarl_select_next_hop(float* x, int64_t B, int64_t x_bstride, int64_t ldx, int32_t Nmax, int64_t num_nodes,
+                         const float* agent_features, int64_t num_agents, int64_t a_bstride, const int64_t* next_hop,
+                         int64_t nh_bstride, tarl_stream stream);
+
 /* ---- measurement hook (bench.py roofline leg; nothing comparable in the reference) ------------------------------------
  * tarl_prof_enable(n > 0) brackets the next n launches of the Direction message+aggregate kernel with HIP events on
  * their launch stream; tarl_prof_enable(0) turns it off. tarl_prof_collect synchronises those events and returns the

@@ -395,6 +395,68 @@ def gen_builders():
     print(f"  builders: classical run reached DONE after {steps} steps")
 
 
+def gen_routing():
+    """DijkstraAgents.choice (src/agents/base.py:527-584) driven by the classical run() loop on a MATSim grid with SRC/DEST
+    pseudo-nodes (BASELINE config 1's shape: 4 x 6 grid, 76 links, N = 124), on real networkx; one choice on a
+    heterogeneous torus with queues; and MPNNPolicyNet.refresh_dijkstra's distance matrix."""
+    import contextlib
+    import io
+    import tempfile
+    from src.agents.base import DijkstraAgents
+    rec = {}
+    with tempfile.TemporaryDirectory() as tmp, contextlib.redirect_stdout(io.StringIO()):
+        for tag, het in (("grid", False), ("gridhet", True)):
+            d = os.path.join(tmp, tag)
+            os.makedirs(d)
+            synth.write_matsim_grid_xml(os.path.join(d, "network.xml"), 4, 6, seed=3, heterogeneous=het)
+            synth.write_matsim_population_xml(os.path.join(d, "population.xml"), 4, 6, 260, seed=4,
+                                              first_departure=21600, spread=60)
+            sim = TransportationSimulator("cpu")
+            sim.config_network(os.path.join(d, "network"))
+            ag = DijkstraAgents("cpu")
+            ag.config_agents_from_xml(d, verbose=False)
+            ag.agent_features[0, ag.DEPARTURE_TIME] = 48 * 3600
+            sim.agent = ag
+            sim.config_parameters(timestep_size=1, start_time=21600)
+            ag.set_time(21600)
+            steps = 70 if not het else 45
+            xs, ags, hops = [], [], {}
+            for s_ in range(steps):
+                torch.manual_seed(900 + s_)
+                sim.run()
+                xs.append(sim.graph.x.clone())
+                ags.append(ag.agent_features.clone())
+                if s_ % 10 == 0:
+                    hops[s_] = ag.next_hop_tensor.clone()
+            rec.update({f"{tag}__x": torch.stack(xs), f"{tag}__agents": torch.stack(ags), f"{tag}__steps": steps,
+                        f"{tag}__agents0_n": ag.agent_features.size(0)})
+            for k in (0, 10, 40):
+                rec[f"{tag}__next_hop_{k}"] = hops[k].to(torch.int16)
+            print(f"  routing {tag}: done {int(ag.agent_features[:, ag.DONE].sum())}/{ag.agent_features.size(0) - 1}",
+                  file=sys.stderr)
+    # one choice on a heterogeneous torus with queues (pure road graph, every pair reachable, few ties)
+    net = synth.torus_network(3, 3, heterogeneous=True, seed=21)
+    pop = synth.population(400, net.num_roads, seed=22)
+    x = synth.random_state(net, seed=23, fill=0.5, num_agents=400)
+    g = Data(x=x.clone(), edge_index=net.edge_index, edge_attr=net.edge_attr, num_roads=net.num_roads,
+             congestion_constant=net.congestion_constant, num_nodes=net.num_roads)
+    ag = DijkstraAgents("cpu")
+    ag.agent_features = pop.clone()
+    h = FeatureHelpers(Nmax=net.Nmax)
+    with contextlib.redirect_stdout(io.StringIO()):
+        out = ag.choice(g, h)
+    rec.update(torus__x0=x, torus__agents=pop, torus__x1=out.x, torus__next_hop=ag.next_hop_tensor.to(torch.int16),
+               torus__seed=21, torus__Nmax=net.Nmax)
+    # refresh_dijkstra (free-flow prior of the policy)
+    from src.agents.mpnn_agent import MPNNPolicyNet
+    ff = net.x[:, h.FREE_FLOW_TIME_TRAVEL][net.edge_index[1]]
+    pol = MPNNPolicyNet(net.edge_index, net.num_roads, ff, device="cpu")
+    rec.update(torus__dist_matrix=pol.dist_matrix, torus__ff_edges=ff)
+    dest = torch.randint(0, net.num_roads, (net.edge_index.size(1),), generator=torch.Generator().manual_seed(5))
+    rec.update(torus__prior_dest=dest, torus__prior_logits=pol.compute_dijkstra_logits(dest, ff))
+    save("routing", **rec)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), f"reference tree not found at {REF} (this script only runs in the build container)"
     gen_core_steps()
@@ -404,3 +466,4 @@ if __name__ == "__main__":
     gen_env_rollout()
     gen_nets()
     gen_builders()
+    gen_routing()

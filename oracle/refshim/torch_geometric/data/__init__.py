@@ -8,6 +8,16 @@ class Data:
         for k, v in kwargs.items():
             setattr(self, k, v)
 
+    def __getattr__(self, name):
+        # torch_geometric infers num_nodes from x (or the largest edge index) when it was not given explicitly
+        if name == "num_nodes":
+            x = self.__dict__.get("x")
+            if x is not None:
+                return x.size(0)
+            ei = self.__dict__.get("edge_index")
+            return int(ei.max()) + 1 if ei is not None and ei.numel() else 0
+        raise AttributeError(name)
+
     def keys(self):
         return [k for k in self.__dict__ if not k.startswith("_")]
 

@@ -111,3 +111,29 @@ class Agents(AgentFeatureHelpers):
                     raise TypeError(f"expected a Tensor in {path}, got {type(obj)}")
                 self.agent_features = obj.to(self.device, torch.float32).contiguous()
         self.agent_features[0, self.DEPARTURE_TIME] = 48 * 3600   # agent 0 never joins the network
+
+
+class DijkstraAgents(Agents):
+    """Shortest-path routing (reference: src/agents/base.py:519-584): every ``refresh_rate`` calls the all-pairs next-hop
+    table is rebuilt from the current travel times, and every row selects the next hop towards its head agent's
+    destination. The table comes from ``tarl_apsp`` — one wave per source node, networkx's tie order — instead of
+    ``nx.all_pairs_dijkstra_path`` on the host."""
+
+    def __init__(self, device):
+        super().__init__(device)
+        self.count = 0
+        self.refresh_rate = 10
+        self.next_hop_tensor = None
+
+    @torch.no_grad()
+    def choice(self, graph, h: FeatureHelpers):
+        from tarl_hip import ops
+        x = graph.x
+        require_cuda(x, "graph.x")
+        if self.count % self.refresh_rate == 0:
+            plan = cached_plan(graph.edge_index, x.size(0))
+            w = ops.edge_travel_time(plan, x, h.Nmax, graph.congestion_constant)
+            self.next_hop_tensor = ops.all_pairs_shortest_paths(plan, w)[0][0]
+        ops.select_next_hop(x, h.Nmax, self.agent_features, self.next_hop_tensor)
+        self.count += 1
+        return graph

@@ -63,13 +63,22 @@ class MPNNPolicyNet(MessagePassingBase, Agents):
         return self._dist_matrix
 
     def refresh_dijkstra(self, edge_index: torch.Tensor, free_flow_travel: torch.Tensor):
-        import scipy.sparse as sp
-        from scipy.sparse.csgraph import dijkstra
+        """All-pairs free-flow distances (src/agents/mpnn_agent.py:53-79) by ``tarl_apsp`` on the device."""
+        from tarl_hip import ops
         assert free_flow_travel.size(0) == edge_index.size(1) and edge_index.size(0) == 2
-        ei = edge_index.cpu().numpy()
-        g = sp.csr_matrix((free_flow_travel.detach().cpu().numpy().astype("float64"), (ei[0], ei[1])),
-                          shape=(self.num_nodes, self.num_nodes))
-        self._dist_matrix = torch.tensor(dijkstra(g, directed=True), dtype=torch.float32, device=self.device)
+        plan = cached_plan(edge_index, self.num_nodes)
+        w = free_flow_travel.detach().to(self.device, torch.float32)
+        require_cuda(w, "free_flow_travel")
+        self._dist_matrix = ops.all_pairs_shortest_paths(plan, w, want_next_hop=False, want_dist=True)[1][0]
+
+    def compute_dijkstra_logits(self, agent_destination: torch.Tensor, time_travel: torch.Tensor) -> torch.Tensor:
+        """Shortest-path prior (src/agents/mpnn_agent.py:81-113; dormant in the live forward):
+        logits[e] = -dist[dst(e), destination[e]] - time_travel[e]; a destination vector of k * E entries is batched."""
+        E = self.edge_index.size(1)
+        rep = agent_destination.size(0) // E
+        head = self.edge_index[1].to(self.dist_matrix.device).repeat(rep)
+        logits = -self.dist_matrix[head, agent_destination.to(head.device)] - time_travel
+        return logits.view(rep, -1) if rep > 1 else logits.view(-1)
 
     def forward(self, node_features: torch.Tensor, edge_features: torch.Tensor, agent_index: torch.Tensor):
         """node_features (N,7) or (B,N,7) -> logits (E,) or (B,E)."""

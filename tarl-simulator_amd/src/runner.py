@@ -1,6 +1,6 @@
 """Runner / RunnerArgs — CLI-facing orchestration (reference: src/runner.py). ``mpnn`` and ``mpnn+ppo`` run on the HIP
-path; ``random`` runs the classical loop on the same kernels; ``dijkstra`` (networkx all-pairs routing, CPU plumbing)
-is outside this build's scope."""
+path; ``random`` and ``dijkstra`` run the classical loop on the same kernels (``dijkstra``: all-pairs next-hop table by
+``tarl_apsp`` instead of networkx)."""
 from __future__ import annotations
 
 from dataclasses import dataclass
@@ -37,15 +37,12 @@ class Runner:
     def setup(self):
         from .reinforcement_learning import SimulatorEnv
         from .transportation_simulator import TransportationSimulator
-        from .agents.base import Agents
+        from .agents.base import Agents, DijkstraAgents
         a = self.args
-        if a.algo == "dijkstra":
-            raise NotImplementedError("algo 'dijkstra' (networkx shortest-path routing) is CPU plumbing outside the "
-                                      "MI355X hot path; use the reference for it")
-        if a.algo == "random":
+        if a.algo in {"dijkstra", "random"}:
             self.simulator = TransportationSimulator(str(self.device), torch_compile=a.torch_compile)
             self.simulator.load_network(scenario=a.scenario)
-            self.agent = self.simulator.agent = Agents(str(self.device))
+            self.agent = self.simulator.agent = (DijkstraAgents if a.algo == "dijkstra" else Agents)(str(self.device))
             self.agent.load(scenario=a.scenario)
             self.simulator.config_parameters(timestep_size=a.timestep_size, start_time=a.start_end_time[0])
             self.agent.set_time(a.start_end_time[0])
@@ -94,7 +91,7 @@ class Runner:
     def eval(self):
         a = self.args
         n = a.steps if a.steps is not None else (a.start_end_time[1] - a.start_end_time[0]) // a.timestep_size
-        if a.algo == "random":
+        if a.algo in {"dijkstra", "random"}:
             for _ in range(n):
                 self.simulator.run()
             sim, agent = self.simulator, self.agent

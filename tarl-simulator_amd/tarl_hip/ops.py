@@ -196,6 +196,46 @@ def insert_step(x, Nmax, agent_features, t, *, congestion_constant=None, scratch
                                   _lib.ptr(counts), _lib.current_stream()))
 
 
+# ---- shortest-path routing -------------------------------------------------------------------------------------------------
+def edge_travel_time(plan: Plan, x, Nmax, congestion_constant):
+    """(B, E) current travel time of every edge, original edge order (src/agents/base.py:541-550)."""
+    L = _lib.load()
+    B, N, bs, ldx = _state(x, Nmax)
+    out = torch.empty((B, plan.num_edges), dtype=torch.float32, device=x.device)
+    cc = congestion_constant.to(torch.float32).contiguous()
+    _lib.check(L.tarl_edge_travel_time(plan.handle, x.data_ptr(), B, bs, ldx, Nmax, cc.data_ptr(), out.data_ptr(),
+                                       _lib.current_stream()))
+    return out
+
+
+def all_pairs_shortest_paths(plan: Plan, weights, *, want_next_hop=True, want_dist=False):
+    """``weights`` (E,) or (B, E) fp32 in original edge order -> (next_hop int64 (B, N, N) | None, dist fp32 (B, N, N) |
+    None), networkx-compatible tie order (tarl_apsp)."""
+    L = _lib.load()
+    w = weights.to(torch.float32).contiguous()
+    w = w.view(1, -1) if w.dim() == 1 else w
+    B, N = w.size(0), plan.num_nodes
+    assert w.size(1) == plan.num_edges, "one weight per edge"
+    nh = torch.empty((B, N, N), dtype=torch.int64, device=w.device) if want_next_hop else None
+    d = torch.empty((B, N, N), dtype=torch.float32, device=w.device) if want_dist else None
+    need = int(L.tarl_apsp_scratch_bytes(plan.handle, B))
+    scratch = torch.empty(need, dtype=torch.uint8, device=w.device) if need > 0 else None
+    _lib.check(L.tarl_apsp(plan.handle, w.data_ptr(), B, plan.num_edges, _lib.ptr(scratch), need, _lib.ptr(nh),
+                           _lib.ptr(d), _lib.current_stream()))
+    return nh, d
+
+
+def select_next_hop(x, Nmax, agent_features, next_hop):
+    """x[b, i, SELECTED_ROAD] = next_hop[b, i, DESTINATION[head agent of i]] (src/agents/base.py:572-580)."""
+    L = _lib.load()
+    B, N, bs, ldx = _state(x, Nmax)
+    A, abs_ = _agents(agent_features, B)
+    nh = next_hop.view(-1, N, N)
+    assert nh.dtype == torch.int64 and nh.is_contiguous() and nh.size(0) in (1, B)
+    _lib.check(L.tarl_select_next_hop(x.data_ptr(), B, bs, ldx, Nmax, N, agent_features.data_ptr(), A, abs_,
+                                      nh.data_ptr(), 0 if nh.size(0) == 1 else N * N, _lib.current_stream()))
+
+
 def reset_state(x, Nmax, agent_features=None):
     L = _lib.load()
     B, N, bs, ldx = _state(x, Nmax)

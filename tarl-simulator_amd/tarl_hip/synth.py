@@ -182,7 +182,37 @@ def write_matsim_network_xml(path: str, W: int, H: int, *, seed: int = 0, hetero
         f.write("\n".join(lines) + "\n")
 
 
-def write_matsim_population_xml(path: str, W: int, H: int, persons: int, *, seed: int = 0) -> None:
+def write_matsim_grid_xml(path: str, W: int, H: int, *, seed: int = 0, heterogeneous: bool = False) -> None:
+    """A ``W x H`` NON-torus grid with a link in both directions between 4-neighbours (4 x 6 -> 24 nodes / 76 links, the
+    size of Sioux Falls: BASELINE config 1), same node naming as the torus writer."""
+    g = torch.Generator().manual_seed(seed)
+    lines = ['<?xml version="1.0" encoding="utf-8"?>', '<network name="synthetic grid">', "  <nodes>"]
+    for v in range(W * H):
+        lines.append(f'    <node id="n{v}" x="{(v % W) * 100.0}" y="{(v // W) * 100.0}"/>')
+    lines += ["  </nodes>", '  <links capperiod="01:00:00" effectivecellsize="7.5">']
+    lid = 0
+    for v in range(W * H):
+        vx, vy = v % W, v // W
+        for dx, dy in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+            ux, uy = vx + dx, vy + dy
+            if not (0 <= ux < W and 0 <= uy < H):
+                continue
+            if heterogeneous:
+                length = round(60.0 + 90.0 * float(torch.rand(1, generator=g)), 2)
+                cap = 300 + 100 * int(torch.randint(0, 6, (1,), generator=g))
+                speed = [8.33, 13.89, 16.67][int(torch.randint(0, 3, (1,), generator=g))]
+            else:
+                length, cap, speed = 100, 10, 10
+            lines.append(f'    <link id="{lid}" from="n{v}" to="n{ux + uy * W}" length="{length}" capacity="{cap}" '
+                         f'freespeed="{speed}" permlanes="1"/>')
+            lid += 1
+    lines += ["  </links>", "</network>"]
+    with open(path, "w", encoding="utf-8") as f:
+        f.write("\n".join(lines) + "\n")
+
+
+def write_matsim_population_xml(path: str, W: int, H: int, persons: int, *, seed: int = 0,
+                                first_departure: int = 6 * 3600, spread: int = 3600) -> None:
     """Persons with 2-4 activities whose ``link`` attribute names an intersection id (the convention the reference's
     parser uses), some with an unknown link + coordinates (nearest-intersection fallback), some without a car, some with
     explicit attributes, ``HH:MM`` and ``HH:MM:SS`` end times."""
@@ -200,7 +230,7 @@ def write_matsim_population_xml(path: str, W: int, H: int, persons: int, *, seed
         if r(4) == 0:
             lines.append(f'    <attributes><attribute name="age">{20 + r(50)}</attribute></attributes>')
         lines.append("    <plan>")
-        t = 6 * 3600 + r(3600)
+        t = first_departure + r(spread)
         for a in range(2 + r(3) if r(12) else 1):
             v = r(V)
             if r(6) == 0:   # unknown link id, coordinates near intersection v

@@ -200,3 +200,60 @@ def test_gae_and_loss_formulas():
     assert abs(out["loss_objective"].item() + 1.0) < 1e-6      # ratio 1 => -mean(A)
     assert abs(out["loss_critic"].item() - 2.5) < 1e-6          # smooth_l1(3) = 2.5
     assert abs(out["loss_entropy"].item() + 0.01) < 1e-7
+
+
+# ---- shortest-path routing -----------------------------------------------------------------------------
+def _matsim_grid(tmp_path, het):
+    """The same MATSim documents the golden generator fed to the reference (tarl_hip.synth writers, seeded), parsed by
+    the build's own builders (themselves pinned by tests/test_builders.py)."""
+    from tarl_hip import synth
+    from src.matsim_io import build_network, build_population
+    synth.write_matsim_grid_xml(str(tmp_path / "network.xml"), 4, 6, seed=3, heterogeneous=het)
+    synth.write_matsim_population_xml(str(tmp_path / "population.xml"), 4, 6, 260, seed=4, first_departure=21600,
+                                      spread=60)
+    graph, Nmax = build_network(str(tmp_path / "network"))
+    agents, _ = build_population(str(tmp_path / "population"), str(tmp_path / "network"))
+    agents[0, 2] = 48 * 3600
+    return graph, Nmax, agents
+
+
+@pytest.mark.parametrize("tag,het", [("grid", False), ("gridhet", True)])
+def test_dijkstra_classical_run_vs_reference(tmp_path, tag, het):
+    """insert -> withdraw -> DijkstraAgents.choice (all-pairs refresh every 10 calls) -> core, replayed by the oracle
+    with the reference's per-step uniforms: state, agents and the next-hop tables equal the reference's (networkx)."""
+    from oracle import routing, sim
+    g = load_golden("routing")
+    graph, Nmax, agents = _matsim_grid(tmp_path, het)
+    assert agents.size(0) == int(g[f"{tag}__agents0_n"])
+    x, R = graph.x.clone(), int(graph.num_roads)
+    adj = graph.adj_matrix
+    next_hop = None
+    for s in range(int(g[f"{tag}__steps"])):
+        t = 21600 + s
+        sim.insert(x, agents, t, Nmax, graph.congestion_constant)
+        sim.withdraw(x, agents, adj, t, Nmax)
+        if s % 10 == 0:
+            next_hop = None
+        x, next_hop = routing.dijkstra_choice(x, agents, graph.edge_index, graph.congestion_constant, Nmax, next_hop)
+        if s in (0, 10, 40):
+            assert torch.equal(next_hop.to(torch.int16), g[f"{tag}__next_hop_{s}"]), f"next-hop table at step {s}"
+        u = torch.rand(graph.edge_index_routes.size(1), generator=torch.Generator().manual_seed(900 + s))
+        sim.core_step(x[:R], graph.edge_index_routes, graph.edge_attr_routes, t, Nmax, uniform=u,
+                      congestion_constant=graph.congestion_constant[:R])
+        assert torch.equal(x, g[f"{tag}__x"][s]), f"state after step {s}"
+        assert torch.equal(agents, g[f"{tag}__agents"][s]), f"agents after step {s}"
+    assert float(agents[:, 8].sum()) > 0
+
+
+def test_dijkstra_choice_and_prior_on_torus_vs_reference():
+    from oracle import routing
+    from tarl_hip import synth
+    g = load_golden("routing")
+    net = synth.torus_network(3, 3, heterogeneous=True, seed=int(g["torus__seed"]))
+    x1, nh = routing.dijkstra_choice(g["torus__x0"], g["torus__agents"], net.edge_index, net.congestion_constant,
+                                     net.Nmax)
+    assert torch.equal(nh.to(torch.int16), g["torus__next_hop"]) and torch.equal(x1, g["torus__x1"])
+    _, dist = routing.all_pairs(net.edge_index, g["torus__ff_edges"], net.num_roads)
+    assert torch.equal(dist, g["torus__dist_matrix"])
+    prior = -dist[net.edge_index[1], g["torus__prior_dest"]] - g["torus__ff_edges"]
+    assert torch.equal(prior, g["torus__prior_logits"])
