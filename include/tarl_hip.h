@@ -200,14 +200,16 @@ int tarl_critic_mlp_fwd_slabs(const float* counts, int64_t rows_per_slab, int64_
  * environments of one node: topology / table loads are wave-uniform and record gathers are coalesced.
  * Caller-owned side buffers that mirror x / agent_features (all device memory, 16-byte aligned):
  *   rec0 [N][B][4] = {head_id, head_dep, n, tail_id}   rec1 [N][B][2] = {head_arr, pending-garbage n0 or -1}
- *   post_a [N][B][2] = {n', tail'}, post_b [N][B][2] = {head', chosen} (state after the Direction update)
+ *   post_a [N][B][2] = {n', tail'} (state after the Direction update), post_b [N][B] = the agent the update enqueues (0: none)
  *   sel [N][B] = SELECTED_ROAD; acc_lp int64 [B], acc_n fp32 [B]: per-frame accumulators (zeroed by pack)
  *   st0  [N][4]    = {MAX_NUMBER_OF_AGENT, FREE_FLOW_TIME_TRAVEL, ROAD_INDEX, congestion_constant} (static, shared)
  *   slots [N][B][ld_slots]: slot-interleaved FIFO store, slot s at floats 3s..3s+2 = {agent id, arrival, departure};
  *                  ld_slots >= 3*Nmax (pad to a multiple of 16 floats)
  *   a_origin / a_dest int32 [B][A], a_dep fp32 [B][A], a_status uint8 [B][A] (0 waiting, 1 on the way, 2 done);
  *   a_order int32 [B][A] (optional, may be NULL): each environment's agent ids sorted by DEPARTURE_TIME — with it the
- *   insert kernel scans a window of that order from the cursor cur_lo int32 [B] instead of every agent every frame.
+ *   insert kernel scans a window of that order from the cursor cur_lo int32 [B] instead of every agent every frame;
+ *   a_dep_sorted fp32 [B][A] (required with a_order): DEPARTURE_TIME in that order, so the scan reads departures
+ *   sequentially and touches the per-agent arrays only for the few entries that are due.
  * tarl_fused_pack imports x / agent_features (call after construction, reset, or any external write to x); between
  * pack and export the packed state is authoritative for the FIFO columns, NUMBER_OF_AGENT and SELECTED_ROAD;
  * tarl_fused_export writes them back into x in the reference's column layout, bit-identical to the unfused path.
@@ -229,6 +231,7 @@ typedef struct tarl_fused {
   uint8_t* a_status;
   const int32_t* a_order;
   int32_t* cur_lo;
+  const float* a_dep_sorted;
 } tarl_fused;
 
 int tarl_fused_pack(const tarl_plan* plan, const tarl_fused* f, const float* x, int64_t B, int64_t x_bstride,

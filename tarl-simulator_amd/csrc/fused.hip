@@ -10,7 +10,7 @@
 //     environments (one per lane) and walks a chunk of nodes: all topology / table / static loads are wave-uniform
 //     (scalar loads through the constant cache) and every record gather is a fully coalesced 16 B x 64 = 1 KiB load —
 //     there is no dependent index -> address -> data chain left in the vector memory path;
-//   * the Direction gather also emits postA = {n', tail'} / postB = {head', chosen}: the state every row will have after
+//   * the Direction gather also emits postA = {n', tail'} / postB = chosen agent: the state every row will have after
 //     the Direction update, from which the Response "accepted" test is evaluated (8-B gathers of postA) without a second
 //     pass over the FIFOs;
 //   * the live policy's sample is state-independent (see k_policy_tables): the choice phase is a table walk per
@@ -50,7 +50,7 @@ struct FusedBufs {
   float4* rec0;         // [N][B] {head_id, head_dep, n, tail_id}
   float2* rec1;         // [N][B] {head_arr, pending-garbage n0 (or -1 when nothing is pending)}
   float2* postA;        // [N][B] {n', tail'}   state after the Direction update, gathered by the upstream rows
-  float2* postB;        // [N][B] {head', chosen}  read by the row itself only
+  float* postB;         // [N][B] chosen: the agent the Direction update enqueues (0: nobody); read by the row itself only
   const float4* st0;    // [N]    {maxn, ff, road_index, cong}
   float* slots;         // [N][B][lds] slot-interleaved FIFO store: slot s at floats 3s..3s+2 = {id, arrival, departure}
   int64_t lds;          // row stride of slots in floats (>= 3*Nmax, multiple of 16)
@@ -63,6 +63,7 @@ struct FusedBufs {
   uint8_t* a_status;    // [B][A] 0 waiting, 1 on the way, 2 done
   const int32_t* a_order;  // [B][A] agent ids sorted by departure time (static), or NULL: scan all agents every frame
   int32_t* cur_lo;      // [B] first position of a_order that may still hold a waiting agent
+  const float* a_dep_sorted;  // [B][A] departure times in a_order's order (sequential scan instead of a gather)
 };
 
 #define LP_FIX 4294967296.0  // 2^32
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(FB) void k_pack_nodes(const float* __restrict__ x, 
   fb.rec0[gid] = make_float4(xi[0], xi[2 * Nmax], n, tail);
   fb.rec1[gid] = make_float2(xi[Nmax], r1_code(-1.0f, 0));
   fb.postA[gid] = make_float2(n, tail);
-  fb.postB[gid] = make_float2(xi[0], 0.0f);
+  fb.postB[gid] = 0.0f;
   fb.sel[gid] = xi[L.col_sel()];
   if (i == 0) {
     fb.acc_lp[b] = 0;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(FB) void k_fused_reset_nodes(int64_t B, int64_t N, 
   fb.rec0[gid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   fb.rec1[gid] = make_float2(0.0f, r1_code(-1.0f, 0));
   fb.postA[gid] = make_float2(0.0f, 0.0f);
-  fb.postB[gid] = make_float2(0.0f, 0.0f);
+  fb.postB[gid] = 0.0f;
   if (gid < B) {
     fb.acc_lp[gid] = 0;
     fb.acc_n[gid] = 0.0f;
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(TILE) void k_fused_direction(const int32_t* __restr
     }
     const float who = (P > 0.0f) ? best_id : 0.0f;
     fb.postA[row] = make_float2(who != 0.0f ? n_i + 1.0f : n_i, who != 0.0f ? who : me.w);
-    fb.postB[row] = make_float2(n_i == 0.0f ? who : me.x, who);
+    fb.postB[row] = who;
   }
 }
 
@@ -418,17 +419,17 @@ __global__ __launch_bounds__(TILE) void k_fused_rows(const int32_t* __restrict__
     const int64_t row = (int64_t)i * B + b;
     float* sl = fb.slots + row * fb.lds;  // slot s = sl[3s .. 3s+2] = {id, arrival, departure}
     const float2 pa = fb.postA[row];   // {n', tail'}
-    const float2 pb = fb.postB[row];   // {head', chosen}
+    const float who = fb.postB[row];   // chosen
     const float4 r0 = fb.rec0[row];
     const float2 r1 = fb.rec1[row];
     const float4 st = fb.st0[i];
-    const float n0 = r0.z, who = pb.y;
+    const float n0 = r0.z;
     const int32_t k0 = out_ptr[i], k1 = out_ptr[i + 1];
 
     // Response message + max-aggregate from the post records (state after the Direction update of every row)
     bool pop = false;
     {
-      const long long head = (long long)pb.x;
+      const long long head = (long long)((n0 == 0.0f) ? who : r0.x);   // head after the Direction update
       const bool up = (long long)pa.x > 0;
       for (int32_t k = k0; k < k1; ++k) {  // uniform trip count: the post gathers stay coalesced and unconditional
         const float2 pj = fb.postA[(int64_t)out_dst[k] * B + b];
@@ -584,6 +585,7 @@ __global__ __launch_bounds__(INSB) void k_fused_insert(int Nmax, int64_t B, int6
     // Windowed scan: agents sorted by departure time; everything before cur_lo is known not to be waiting any more and
     // everything after the first not-yet-due entry is not due either, so a frame normally looks at one chunk.
     const int32_t* ord = fb.a_order + b * A;
+    const float* dsort = fb.a_dep_sorted + b * A;
     const int32_t lo = fb.cur_lo[b];
     if (tid == 0) s_lo = 0x7fffffff;
     __syncthreads();
@@ -591,18 +593,21 @@ __global__ __launch_bounds__(INSB) void k_fused_insert(int Nmax, int64_t B, int6
       const int64_t k = k0 + tid;
       bool notdue = false;
       if (k < A) {
-        const int32_t a = ord[k];
-        const bool due = fb.a_dep[b * A + a] <= t;
-        const bool waiting = fb.a_status[b * A + a] == 0;
+        const bool due = dsort[k] <= t;          // sequential read; per-agent arrays only for entries that are due
         notdue = !due;
-        if (!due || waiting) atomicMin(&s_lo, (int32_t)k);   // the cursor may not pass this entry
-        if (due && waiting) {
-          int32_t road = 0, cap = 0;
-          if (fused_target(fb, b, B, N, fb.a_origin[b * A + a], &road, &cap)) {
-            const int32_t pos = atomicAdd(&s_cnt, 1);
-            if (pos < INS_CAP) {
-              s_un_agent[pos] = a;
-              s_un_road[pos] = road;
+        if (!due) {
+          atomicMin(&s_lo, (int32_t)k);          // the cursor may not pass this entry
+        } else {
+          const int32_t a = ord[k];
+          if (fb.a_status[b * A + a] == 0) {
+            atomicMin(&s_lo, (int32_t)k);
+            int32_t road = 0, cap = 0;
+            if (fused_target(fb, b, B, N, fb.a_origin[b * A + a], &road, &cap)) {
+              const int32_t pos = atomicAdd(&s_cnt, 1);
+              if (pos < INS_CAP) {
+                s_un_agent[pos] = a;
+                s_un_road[pos] = road;
+              }
             }
           }
         }
@@ -752,10 +757,11 @@ __global__ __launch_bounds__(INSB) void k_fused_insert(int Nmax, int64_t B, int6
 hipEvent_t tarl_prof_event(hipStream_t s);  // sim.hip: live timing of the message-passing gather kernel
 
 static FusedBufs to_bufs(const tarl_fused* f) {
-  return FusedBufs{(float4*)f->rec0,         (float2*)f->rec1, (float2*)f->post_a, (float2*)f->post_b,
+  return FusedBufs{(float4*)f->rec0,         (float2*)f->rec1, (float2*)f->post_a, f->post_b,
                    (const float4*)f->st0,    f->slots,         f->ld_slots,        f->sel,
                    (long long*)f->acc_lp,    f->acc_n,         f->a_origin,        f->a_dest,
-                   f->a_dep,                 f->a_status,      f->a_order,         f->cur_lo};
+                   f->a_dep,                 f->a_status,      f->a_order,         f->cur_lo,
+                   f->a_dep_sorted};
 }
 
 // nodes walked by one workgroup of the env-minor kernels (tunable: TARL_NCHUNK)
@@ -895,7 +901,8 @@ extern "C" int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int6
   TARL_REQUIRE(thresholds && log_probs && entropy1, "policy tables missing (call tarl_fused_policy_prepare)");
   TARL_REQUIRE(agent_features && A >= 1 && ins_scratch, "agents / scratch missing");
   TARL_REQUIRE(f->a_origin && f->a_dest && f->a_dep && f->a_status, "fused agent buffers missing");
-  TARL_REQUIRE(f->a_order == nullptr || f->cur_lo != nullptr, "a_order needs cur_lo");
+  TARL_REQUIRE(f->a_order == nullptr || (f->cur_lo != nullptr && f->a_dep_sorted != nullptr),
+               "a_order needs cur_lo and a_dep_sorted");
   TARL_REQUIRE(B == 1 || a_bstride >= A * AG_COLS, "agent stride smaller than one population");
   TARL_REQUIRE(plan->E == 0 || (edge_attr && log_edge_attr), "edge constants missing");
   if (plan->N == 0) return TARL_OK;

@@ -477,7 +477,7 @@ class FusedState:
         self.rec0 = torch.zeros((N, B, 4), **f32)
         self.rec1 = torch.zeros((N, B, 2), **f32)
         self.post_a = torch.zeros((N, B, 2), **f32)
-        self.post_b = torch.zeros((N, B, 2), **f32)
+        self.post_b = torch.zeros((N, B), **f32)
         self.st0 = torch.zeros((N, 4), **f32)
         self.sel = torch.zeros((N, B), **f32)
         self.acc_lp = torch.zeros(B, dtype=torch.int64, device=device)
@@ -487,6 +487,7 @@ class FusedState:
         self.a_dep = torch.zeros((B, A), **f32)
         self.a_status = torch.zeros((B, A), dtype=torch.uint8, device=device)
         self.a_order = torch.zeros((B, A), dtype=torch.int32, device=device)
+        self.a_dep_sorted = torch.zeros((B, A), **f32)
         self.cur_lo = torch.zeros(B, dtype=torch.int32, device=device)
         self.order_valid = False
         self.struct = _lib.FusedStruct(self.rec0.data_ptr(), self.rec1.data_ptr(), self.post_a.data_ptr(),
@@ -494,15 +495,18 @@ class FusedState:
                                        self.ld_slots, self.sel.data_ptr(), self.acc_lp.data_ptr(),
                                        self.acc_n.data_ptr(), self.a_origin.data_ptr(), self.a_dest.data_ptr(),
                                        self.a_dep.data_ptr(), self.a_status.data_ptr(), None,
-                                       self.cur_lo.data_ptr())
+                                       self.cur_lo.data_ptr(), None)
         self.B, self.N, self.A, self.Nmax = B, N, A, Nmax
 
     def sort_agents(self, agent_features):
         """Departure-time order of every environment's population (static while DEPARTURE_TIME is not edited): lets the
         insert kernel scan a small window per frame. Plain torch sort — set-up plumbing, not on the per-frame path."""
         dep = agent_features.reshape(self.B, self.A, 9)[:, :, 2]
-        self.a_order.copy_(torch.argsort(dep, dim=1, stable=True).to(torch.int32))
+        order = torch.argsort(dep, dim=1, stable=True)
+        self.a_order.copy_(order.to(torch.int32))
+        self.a_dep_sorted.copy_(torch.gather(dep, 1, order))
         self.struct.a_order = self.a_order.data_ptr()
+        self.struct.a_dep_sorted = self.a_dep_sorted.data_ptr()
         self.order_valid = True
 
     @property
