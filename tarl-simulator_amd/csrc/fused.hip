@@ -327,11 +327,23 @@ __global__ __launch_bounds__(TILE) void k_fused_choice(const int32_t* __restrict
     const int32_t gi = group_of_node[i];
     if (gi >= 0) {
       const float u = uniform ? uniform[b * G + gi] : rng.uniform(pseed, pcounter, (uint64_t)(b * G + gi));
-      const int32_t pk = sample_node(out_ptr, thr, i, u);
-      if (pk >= 0) {
-        fb.sel[row] = (float)out_dst[pk];  // a node that picks nothing keeps its previous SELECTED_ROAD
-        lp += (long long)((double)lgt[pk] * LP_FIX);
-        ch = out_eid[pk];
+      // first out-edge (plan order) whose threshold exceeds u. Every table operand is wave-uniform (scalar loads), the
+      // per-lane part is compare + select: no dependent vector gathers
+      bool found = false;
+      float selv = 0.0f;
+      long long lpn = 0;
+      const int32_t k1 = out_ptr[i + 1];
+      for (int32_t k = out_ptr[i]; k < k1; ++k) {
+        const bool hit = !found && (u < thr[k]);
+        const long long lgk = (long long)((double)lgt[k] * LP_FIX);
+        selv = hit ? (float)out_dst[k] : selv;
+        ch = hit ? out_eid[k] : ch;
+        lpn = hit ? lgk : lpn;
+        found = found || hit;
+      }
+      if (found) {
+        fb.sel[row] = selv;  // a node that picks nothing keeps its previous SELECTED_ROAD
+        lp += lpn;
       } else {
         bad = true;
       }

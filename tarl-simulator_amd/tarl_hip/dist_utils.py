@@ -30,7 +30,10 @@ def init_from_env(backend=None):
             backend = os.environ.get("TARL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
             torch.cuda.set_device(local % torch.cuda.device_count())
-        dist.init_process_group(backend=backend, rank=rank, world_size=ws)
+        kw = {}
+        if backend == "nccl":    # bind the communicator to this rank's GPU up front (no "device under current context")
+            kw["device_id"] = torch.device("cuda", local % torch.cuda.device_count())
+        dist.init_process_group(backend=backend, rank=rank, world_size=ws, **kw)
     return rank, ws, local
 
 
