@@ -430,6 +430,12 @@ def gen_routing():
                     hops[s_] = ag.next_hop_tensor.clone()
             rec.update({f"{tag}__x": torch.stack(xs), f"{tag}__agents": torch.stack(ags), f"{tag}__steps": steps,
                         f"{tag}__agents0_n": ag.agent_features.size(0)})
+            # TransportationSimulator.compute_node_metrics (src/transportation_simulator.py:563-670) after that run
+            nm = sim.compute_node_metrics(output_dir=None)
+            rec.update({f"{tag}__nm_counts": torch.tensor([nm[n]["hourly_counts"] for n in range(len(nm))]),
+                        f"{tag}__nm_avg_vc": torch.tensor([nm[n]["avg_vc"] for n in range(len(nm))]),
+                        f"{tag}__nm_std_vc": torch.tensor([nm[n]["std_vc"] for n in range(len(nm))]),
+                        f"{tag}__leg_hist": torch.tensor([[float(v) for v in row] for row in sim.leg_histogram_values])})
             for k in (0, 10, 40):
                 rec[f"{tag}__next_hop_{k}"] = hops[k].to(torch.int16)
             print(f"  routing {tag}: done {int(ag.agent_features[:, ag.DONE].sum())}/{ag.agent_features.size(0) - 1}",

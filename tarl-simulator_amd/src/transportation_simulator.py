@@ -111,6 +111,48 @@ class TransportationSimulator:
         self.road_optimality_values.append(
             (self.time, self.model_core.direction_mpnn.road_optimality_data["delta_travel_time"]))
 
+    # -- metrics (tables only; the reference's matplotlib figures are not reproduced) -------------------------------------
+    def compute_node_metrics(self, output_dir: str | None = "data/outputs"):
+        """Hourly departures per road (Response pops + withdrawals), their V/C ratio against MAX_FLOW, mean and std over
+        the hours; ``node_metrics.csv`` with the reference's columns (src/transportation_simulator.py:563-670). The
+        per-step masks stay on the device; one (H, T) x (T, R) product and a single copy to the host."""
+        import csv
+        hist = list(getattr(self.model_core.response_mpnn, "update_history", [])) + \
+            list(getattr(self.agent, "withdraw_history", []))
+        if not hist:
+            print("No update history available for computing node metrics.")
+            return {}
+        dev = hist[0][1].device
+        times = torch.tensor([int(t) for t, _ in hist], dtype=torch.long, device=dev)
+        masks = torch.stack([m.view(-1) for _, m in hist]).to(torch.float32)             # (T, R)
+        hours = (times // 3600).clamp(min=0)
+        H = int(hours.max().item()) + 1
+        onehot = torch.nn.functional.one_hot(hours, num_classes=H).to(torch.float32)       # (T, H); counts < 2^24: exact
+        counts = (onehot.t() @ masks).t().contiguous()                                     # (R, H)
+        R = counts.size(0)
+        cap = self.graph.x[:R, self.h.MAX_FLOW].clone()
+        cap[cap == 0] = float("nan")
+        vc = counts / cap.unsqueeze(1)
+        avg, std = torch.nanmean(vc, dim=1), torch.std(vc, dim=1, unbiased=False)
+        counts_h, avg_h, std_h = counts.to(torch.long).cpu(), avg.cpu(), std.cpu()
+        if output_dir is not None:
+            os.makedirs(output_dir, exist_ok=True)
+            with open(os.path.join(output_dir, "node_metrics.csv"), "w", newline="") as f:
+                w = csv.writer(f)
+                w.writerow(["node_id", "avg_vc", "std_vc"] + [f"count_{k}h" for k in range(H)])
+                for n in range(R):
+                    w.writerow([n, float(avg_h[n]), float(std_h[n])] + counts_h[n].tolist())
+        return {n: {"avg_vc": float(avg_h[n]), "std_vc": float(std_h[n]), "hourly_counts": counts_h[n].tolist()}
+                for n in range(R)}
+
+    def leg_histogram(self):
+        """(T, 4) tensor [departures, arrivals, on the way, time] per step — the series behind the reference's
+        ``plot_leg_histogram`` (src/transportation_simulator.py:387-451), one host copy."""
+        if not self.leg_histogram_values:
+            return torch.zeros((0, 4))
+        return torch.stack([torch.stack([torch.as_tensor(v, dtype=torch.float32).reshape(()).cpu() for v in row])
+                            for row in self.leg_histogram_values])
+
     def reset(self):
         from tarl_hip import ops
         ops.reset_state(self.graph.x, self.Nmax)

@@ -80,6 +80,14 @@ def test_classical_dijkstra_run_golden(ops, tmp_path, tag, het):
         if s in (0, 10, 40):
             assert torch.equal(ag.next_hop_tensor.cpu().to(torch.int16), g[f"{tag}__next_hop_{s}"]), f"table {s}"
     assert float(ag.agent_features[:, ag.DONE].sum()) > 0
+    # metric tables of the same run (src/transportation_simulator.py:563-670, :387-451)
+    nm = sim.compute_node_metrics(output_dir=str(tmp_path / "out"))
+    R = int(sim.graph.num_roads)
+    assert len(nm) == R and os.path.exists(tmp_path / "out" / "node_metrics.csv")
+    assert torch.equal(torch.tensor([nm[n]["hourly_counts"] for n in range(R)]), g[f"{tag}__nm_counts"])
+    assert torch.allclose(torch.tensor([nm[n]["avg_vc"] for n in range(R)]), g[f"{tag}__nm_avg_vc"], rtol=1e-6, atol=0)
+    assert torch.allclose(torch.tensor([nm[n]["std_vc"] for n in range(R)]), g[f"{tag}__nm_std_vc"], rtol=1e-5, atol=1e-7)
+    assert torch.equal(sim.leg_histogram(), g[f"{tag}__leg_hist"])
 
 
 @pytest.mark.parametrize("kind,scratch", [("torus_hom", False), ("torus_het", False), ("grid_srcdest", False),
