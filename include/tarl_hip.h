@@ -268,6 +268,19 @@ int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int64_t B, int3
                      uint8_t* withdrawn, int32_t* ins_scratch, int32_t* choice, float* log_prob, float* entropy,
                      float* reward, float* counts, tarl_stream stream);
 
+/* tarl_fused_rollout == T consecutive tarl_fused_frame calls with device noise (uniform = gumbel = NULL), frame t at
+ *   clock times_host[t] (HOST array of T floats) with policy counter policy_counter0 + t and noise counter counter0 + t —
+ *   the collector loop of ppo_train (src/rl/ppo_trainer.py:129-133) in one call, same results as the frame-by-frame calls.
+ *   Outputs, each frame-major: choice int32 [T][N][B], counts fp32 [T][N][B] (ENV-MINOR inside a frame), log_prob /
+ *   entropy / reward fp32 [T][B]; choice, counts, log_prob, entropy, reward may be NULL.
+ *   Scratch (device): ins_scratch int32 [B][2A]. */
+int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, int64_t T,
+                       const float* times_host, const float* thresholds, const float* log_probs, const float* entropy1,
+                       uint64_t policy_seed, uint64_t policy_counter0, float* agent_features, int64_t num_agents,
+                       int64_t a_bstride, const float* edge_attr, const float* log_edge_attr, float log_eps, int use_cong,
+                       uint64_t seed, uint64_t counter0, int32_t* ins_scratch, int32_t* choice, float* log_prob,
+                       float* entropy, float* reward, float* counts, tarl_stream stream);
+
 /* ---- shortest-path routing -----------------------------------------------------------------------
  * tarl_edge_travel_time == the edge weights of DijkstraAgents.choice (src/agents/base.py:541-550):
  *   travel_time[b][e] = max(FREE_FLOW[u], congestion_constant[v] / (MAX[u] + 10 - N[u])), u = src(e), v = dst(e),

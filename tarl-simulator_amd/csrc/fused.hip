@@ -943,3 +943,58 @@ extern "C" int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int6
   TARL_LAUNCH_CHECK();
   return TARL_OK;
 }
+
+// T consecutive frames with device noise: the collector loop in one foreign call. Each frame is choice -> direction ->
+// rows -> insert on the caller's stream, in place. (Two alternatives were measured and rejected, DESIGN.md §4.2: folding
+// frame t+1's choice into the row pass, and running it on a side stream into double-buffered SELECTED_ROAD /
+// accumulators. Both lose the producer -> consumer adjacency that lets the Direction kernel read the 20 MB the choice
+// kernel just wrote from the Infinity Cache.)
+extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, int64_t T,
+                                  const float* times_host, const float* thresholds, const float* log_probs,
+                                  const float* entropy1, uint64_t policy_seed, uint64_t policy_counter0,
+                                  float* agent_features, int64_t A, int64_t a_bstride, const float* edge_attr,
+                                  const float* log_edge_attr, float log_eps, int use_cong, uint64_t seed,
+                                  uint64_t counter0, int32_t* ins_scratch, int32_t* choice, float* log_prob,
+                                  float* entropy, float* reward, float* counts, tarl_stream stream) {
+  int rc = check_fused_core(plan, f, B, Nmax);
+  if (rc) return rc;
+  TARL_REQUIRE(T >= 1 && times_host, "bad frame count / times");
+  TARL_REQUIRE(thresholds && log_probs && entropy1, "policy tables missing (call tarl_fused_policy_prepare)");
+  TARL_REQUIRE(agent_features && A >= 1 && ins_scratch, "agents / scratch missing");
+  TARL_REQUIRE(f->a_origin && f->a_dest && f->a_dep && f->a_status, "fused agent buffers missing");
+  TARL_REQUIRE(f->a_order == nullptr || (f->cur_lo != nullptr && f->a_dep_sorted != nullptr),
+               "a_order needs cur_lo and a_dep_sorted");
+  TARL_REQUIRE(B == 1 || a_bstride >= A * AG_COLS, "agent stride smaller than one population");
+  TARL_REQUIRE(plan->E == 0 || (edge_attr && log_edge_attr), "edge constants missing");
+  if (plan->N == 0) return TARL_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t N = plan->N, NB = N * B;
+  const unsigned threads = tile_threads(B);
+  const dim3 grid((unsigned)ceil_div(B, threads), (unsigned)num_chunks(plan));
+  const dim3 grid_c((unsigned)ceil_div(B, threads), (unsigned)ceil_div(N, nchunk_choice()));
+  const dim3 grid_d((unsigned)ceil_div(B, threads), (unsigned)ceil_div(N, nchunk_dir()));
+  const int want_lp = log_prob != nullptr ? 1 : 0;
+  const FusedBufs fb = to_bufs(f);
+  for (int64_t t = 0; t < T; ++t) {
+    const float time = times_host[t];
+    hipLaunchKernelGGL(k_fused_choice, grid_c, dim3(threads), 0, s, plan->out_ptr, plan->out_dst, plan->out_eid,
+                       plan->group_of_node, plan->G, B, N, fb, thresholds, log_probs, (const float*)nullptr, policy_seed,
+                       policy_counter0 + (uint64_t)t, choice ? choice + t * NB : nullptr, nchunk_choice(), want_lp);
+    TARL_LAUNCH_CHECK();
+    const bool timed = tarl_prof_event(s) != nullptr;
+    hipLaunchKernelGGL(k_fused_direction, grid_d, dim3(threads), 0, s, plan->in_ptr, plan->in_src, plan->in_eid,
+                       plan->E, B, N, fb, edge_attr, log_edge_attr, log_eps, time, (const float*)nullptr, seed,
+                       counter0 + (uint64_t)t, (float*)nullptr, nchunk_dir());
+    TARL_LAUNCH_CHECK();
+    if (timed) (void)tarl_prof_event(s);
+    float* counts_t = counts ? counts + t * NB : nullptr;
+    hipLaunchKernelGGL(k_fused_rows, grid, dim3(threads), 0, s, plan->out_ptr, plan->out_dst, (int)Nmax, B, N, fb,
+                       agent_features, A, a_bstride, time, (uint8_t*)nullptr, (uint8_t*)nullptr, counts_t, nchunk());
+    TARL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(INSB), 0, s, (int)Nmax, B, N, fb, agent_features, A,
+                       a_bstride, use_cong, time, ins_scratch, entropy1, reward ? reward + t * B : nullptr, counts_t,
+                       log_prob ? log_prob + t * B : nullptr, entropy ? entropy + t * B : nullptr);
+    TARL_LAUNCH_CHECK();
+  }
+  return TARL_OK;
+}

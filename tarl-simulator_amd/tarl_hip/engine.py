@@ -8,6 +8,8 @@ launch — every environment follows exactly the reference's
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -161,22 +163,19 @@ class SimEngine:
         if log_prob is not None and (log_prob.dtype != torch.float32 or tuple(log_prob.shape) != (T, self.B)
                                      or not log_prob.is_contiguous()):
             raise ValueError("log_prob must be a contiguous float32 (T, B) tensor")
-        call = ops.FusedFrameLauncher(self.plan, self.fs, self.tables, self.agents, self.ec,
-                                      use_cong=self.cc is not None, policy_seed=self.seed ^ 0x5DEECE66D, seed=self.seed,
-                                      scratch=self.ins_scratch)
-        ch0, ch_s = choice.data_ptr(), choice.stride(0) * 4
-        rw0, rw_s = reward.data_ptr(), reward.stride(0) * 4
-        ct0, ct_s = counts.data_ptr(), counts.stride(0) * 4
-        lp0, lp_s = (log_prob.data_ptr(), log_prob.stride(0) * 4) if log_prob is not None else (None, 0)
         times = []
+        t_clock = self.time
+        for _ in range(T):
+            times.append(float(t_clock))
+            t_clock += self.timestep
         self._x_stale = True
-        for t in range(T):
-            times.append(float(self.time))
-            self.sample_counter += 1
-            self.noise_counter += 1
-            call(float(self.time), self.sample_counter, self.noise_counter, ch0 + t * ch_s,
-                 None if lp0 is None else lp0 + t * lp_s, rw0 + t * rw_s, ct0 + (t + 1) * ct_s)
-            self._last_step_time = float(self.time)
-            self.time += self.timestep
+        ops.fused_rollout(self.plan, self.fs, self.tables, self.agents, self.ec, times, use_cong=self.cc is not None,
+                          policy_seed=self.seed ^ 0x5DEECE66D, policy_counter0=self.sample_counter + 1, seed=self.seed,
+                          counter0=self.noise_counter + 1, scratch=self.ins_scratch, choice=choice, log_prob=log_prob,
+                          reward=reward, counts=counts[1:])
+        self.sample_counter += T
+        self.noise_counter += T
+        self._last_step_time = times[-1]
+        self.time = t_clock
         times.append(float(self.time))
         return times

@@ -174,13 +174,15 @@ def test_critic_slab_mode_matches_row_major(ops):
     assert torch.equal(v_slab, v_rows)        # same tiles, same k order, same MFMA chain
 
 
-def test_rollout_launcher_equals_frame_loop(ops):
-    """SimEngine.rollout_fused (arguments marshalled once) == T calls of frame_fused."""
+@pytest.mark.parametrize("B,T", [(5, 30), (70, 7), (3, 1), (130, 2)])
+def test_rollout_launcher_equals_frame_loop(ops, B, T):
+    """SimEngine.rollout_fused (tarl_fused_rollout: the whole collector loop in one foreign call) == T calls of
+    frame_fused; then a second rollout continues from the state the first left."""
     from tarl_hip import synth
     from tarl_hip.engine import SimEngine
     net = synth.torus_network(5, 5, heterogeneous=True, seed=3)
     N = net.num_roads
-    B, A, T = 5, 700, 30
+    A = 700
     pops = torch.stack([synth.population(A, N, seed=b, t0=21540, t1=21560) for b in range(B)])
     mk = lambda: SimEngine(dev(net.x.unsqueeze(0).repeat(B, 1, 1)), net.edge_index, net.edge_attr, net.Nmax,
                            dev(pops.clone()), congestion_constant=net.congestion_constant, seed=9)
@@ -199,4 +201,10 @@ def test_rollout_launcher_equals_frame_loop(ops):
     assert len(times) == T + 1 and times[0] == 21540.0 and e1.time == e2.time
     assert torch.equal(ch1, ch2) and torch.equal(lp1, lp2) and torch.equal(rw1, rw2) and torch.equal(ct1, ct2)
     assert torch.equal(e1.x, e2.x) and torch.equal(e1.agents, e2.agents)
-    assert float(rw1.abs().sum()) > 0
+    # continue: the packed state (incl. the SELECTED_ROAD of the last frame) is where the frame loop left it
+    for t in range(T):
+        e1.frame_fused(choice=ch1[t], log_prob=lp1[t], reward=rw1[t], counts=ct1[t + 1])
+    e2.rollout_fused(T, choice=ch2, log_prob=lp2, reward=rw2, counts=ct2)
+    assert torch.equal(ch1, ch2) and torch.equal(lp1, lp2) and torch.equal(rw1, rw2) and torch.equal(ct1[1:], ct2[1:])
+    assert torch.equal(e1.x, e2.x) and torch.equal(e1.agents, e2.agents) and e1.time == e2.time
+    assert float(rw1.abs().sum()) > 0 or T < 5
