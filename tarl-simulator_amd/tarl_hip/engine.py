@@ -8,8 +8,6 @@ launch — every environment follows exactly the reference's
 """
 from __future__ import annotations
 
-import os
-
 import torch
 
 from . import ops

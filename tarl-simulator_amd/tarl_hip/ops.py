@@ -593,32 +593,6 @@ def fused_frame(plan: Plan, fs: FusedState, tables: PolicyTables, agent_features
                                   _lib.ptr(counts), _lib.current_stream()))
 
 
-class FusedFrameLauncher:
-    """Pre-validated, pre-marshalled ``tarl_fused_frame`` call for a rollout loop: everything that does not change from
-    frame to frame is converted to ctypes once; per frame only the clock, the two noise counters and the output
-    addresses are replaced (plain Python ints / floats), so the host cost of a frame is one foreign call."""
-
-    def __init__(self, plan: Plan, fs: FusedState, tables: PolicyTables, agent_features, ec: EdgeConst, *, use_cong,
-                 policy_seed, seed, scratch):
-        self._fn = _lib.load().tarl_fused_frame
-        A, abs_ = _agents(agent_features, fs.B)
-        _contig(scratch, torch.int32, "scratch")
-        self._keep = (plan, fs, tables, agent_features, ec, scratch)       # keep the buffers alive
-        self._args = [plan.handle, fs.ref, fs.B, fs.Nmax, tables.thresholds.data_ptr(), tables.log_probs.data_ptr(),
-                      tables.entropy.data_ptr(), None, int(policy_seed), 0, agent_features.data_ptr(), A, abs_,
-                      ec.edge_attr.data_ptr(), ec.log_edge_attr.data_ptr(), ec.log_eps, 1 if use_cong else 0, 0.0, None,
-                      int(seed), 0, None, None, None, scratch.data_ptr(), None, None, None, None, None,
-                      _lib.current_stream()]
-
-    def __call__(self, t, policy_counter, counter, choice_ptr, log_prob_ptr, reward_ptr, counts_ptr):
-        a = self._args
-        a[9], a[17], a[20] = policy_counter, t, counter
-        a[25], a[26], a[28], a[29] = choice_ptr, log_prob_ptr, reward_ptr, counts_ptr
-        rc = self._fn(*a)
-        if rc:
-            _lib.check(rc)
-
-
 def fused_rollout(plan: Plan, fs: FusedState, tables: PolicyTables, agent_features, ec: EdgeConst, times, *, use_cong,
                   policy_seed, policy_counter0, seed, counter0, scratch, choice=None, log_prob=None, entropy=None,
                   reward=None, counts=None):
