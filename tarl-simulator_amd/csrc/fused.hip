@@ -348,7 +348,7 @@ __global__ __launch_bounds__(TILE) void k_fused_choice(const int32_t* __restrict
         bad = true;
       }
     }
-    if (choice) choice[row] = ch;
+    if (choice) __builtin_nontemporal_store(ch, &choice[row]);  // write-once stream: keep it out of the caches
   }
   // infeasible action (some node picked nothing): poison the accumulator far beyond any legitimate sum
   if (want_lp)
@@ -549,7 +549,8 @@ __global__ __launch_bounds__(TILE) void k_fused_rows(const int32_t* __restrict__
     }
     fb.rec0[row] = make_float4(head_id, head_dep, n, tail_id);
     fb.rec1[row] = make_float2(head_arr, r1_code(lazy ? n0 : -1.0f, hoff));
-    if (counts) counts[row] = n;  // per-node count before insertion; the insert kernel adds this frame's arrivals
+    // per-node count before insertion (the insert kernel adds this frame's arrivals); write-once stream
+    if (counts) __builtin_nontemporal_store(n, &counts[row]);
     nsum += n;
   }
   atomicAdd(&fb.acc_n[b], nsum);
