@@ -167,10 +167,10 @@ def main():
         # passes of the same kernels at the same sizes and committed under profiles/); null when no matching record.
         traffic, traffic_src = None, None
         try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", "r01_v3_pmc_traffic.json")))
+            rec = json.load(open(os.path.join(ROOT, "profiles", "r01_v4_pmc_traffic.json")))
             if rec["config"] == {"edges": E, "agents": args.agents, "envs": B}:
                 traffic = rec["kernels"]["k_fused_direction"]["hbm_bytes_per_launch"]
-                traffic_src = "profiles/r01_v3_pmc_traffic.json (rocprofv3 --pmc, 2*FETCH_SIZE + WRITE_SIZE)"
+                traffic_src = "profiles/r01_v4_pmc_traffic.json (rocprofv3 --pmc, 2*FETCH_SIZE + WRITE_SIZE)"
         except (OSError, KeyError, ValueError):
             pass
         out = {

@@ -201,7 +201,8 @@ int tarl_critic_mlp_fwd_slabs(const float* counts, int64_t rows_per_slab, int64_
  * Caller-owned side buffers that mirror x / agent_features (all device memory, 16-byte aligned):
  *   rec0 [N][B][4] = {head_id, head_dep, n, tail_id}   rec1 [N][B][2] = {head_arr, pending-garbage n0 or -1}
  *   post_a [N][B][2] = {n', tail'} (state after the Direction update), post_b [N][B] = the agent the update enqueues (0: none)
- *   sel [N][B] = SELECTED_ROAD; acc_lp int64 [B], acc_n fp32 [B]: per-frame accumulators (zeroed by pack)
+ *   sel [N][B] = SELECTED_ROAD; acc_lp int64 [acc_slots][B], acc_n fp32 [acc_slots][B]: per-frame accumulator banks
+ *   (zeroed by pack; acc_slots >= 1 banks spread the atomics of the many workgroups that serve one environment)
  *   st0  [N][4]    = {MAX_NUMBER_OF_AGENT, FREE_FLOW_TIME_TRAVEL, ROAD_INDEX, congestion_constant} (static, shared)
  *   slots [N][B][ld_slots]: slot-interleaved FIFO store, slot s at floats 3s..3s+2 = {agent id, arrival, departure};
  *                  ld_slots >= 3*Nmax (pad to a multiple of 16 floats)
@@ -232,6 +233,7 @@ typedef struct tarl_fused {
   const int32_t* a_order;
   int32_t* cur_lo;
   const float* a_dep_sorted;
+  int64_t acc_slots;
 } tarl_fused;
 
 int tarl_fused_pack(const tarl_plan* plan, const tarl_fused* f, const float* x, int64_t B, int64_t x_bstride,

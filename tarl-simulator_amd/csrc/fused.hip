@@ -55,8 +55,9 @@ struct FusedBufs {
   float* slots;         // [N][B][lds] slot-interleaved FIFO store: slot s at floats 3s..3s+2 = {id, arrival, departure}
   int64_t lds;          // row stride of slots in floats (>= 3*Nmax, multiple of 16)
   float* sel;           // [N][B] SELECTED_ROAD
-  long long* acc_lp;    // [B] log-prob of this frame's action, 2^-32 fixed point (order-independent => deterministic)
-  float* acc_n;         // [B] sum of the per-node counts after the row pass (small integers: exact in any order)
+  long long* acc_lp;    // [S][B] log-prob of this frame's action, 2^-32 fixed point (order-independent => deterministic)
+  float* acc_n;         // [S][B] sum of the per-node counts after the row pass (small integers: exact in any order)
+                        // S = acc_slots banks spread the atomics of the N/chunk workgroups that serve one environment
   int32_t* a_origin;    // [B][A]
   int32_t* a_dest;      // [B][A]
   float* a_dep;         // [B][A]
@@ -64,6 +65,7 @@ struct FusedBufs {
   const int32_t* a_order;  // [B][A] agent ids sorted by departure time (static), or NULL: scan all agents every frame
   int32_t* cur_lo;      // [B] first position of a_order that may still hold a waiting agent
   const float* a_dep_sorted;  // [B][A] departure times in a_order's order (sequential scan instead of a gather)
+  int64_t acc_slots;    // accumulator banks: acc_lp / acc_n are [acc_slots][B]; a workgroup adds into bank (chunk % slots)
 };
 
 #define LP_FIX 4294967296.0  // 2^32
@@ -97,8 +99,10 @@ __global__ __launch_bounds__(FB) void k_pack_nodes(const float* __restrict__ x, 
   fb.postB[gid] = 0.0f;
   fb.sel[gid] = xi[L.col_sel()];
   if (i == 0) {
-    fb.acc_lp[b] = 0;
-    fb.acc_n[b] = 0.0f;
+    for (int64_t sl_ = 0; sl_ < fb.acc_slots; ++sl_) {
+      fb.acc_lp[sl_ * B + b] = 0;
+      fb.acc_n[sl_ * B + b] = 0.0f;
+    }
   }
   float* sl = fb.slots + gid * fb.lds;
   for (int sidx = 0; sidx < Nmax; ++sidx) {
@@ -141,8 +145,10 @@ __global__ __launch_bounds__(FB) void k_fused_reset_nodes(int64_t B, int64_t N, 
   fb.postA[gid] = make_float2(0.0f, 0.0f);
   fb.postB[gid] = 0.0f;
   if (gid < B) {
-    fb.acc_lp[gid] = 0;
-    fb.acc_n[gid] = 0.0f;
+    for (int64_t sl_ = 0; sl_ < fb.acc_slots; ++sl_) {
+      fb.acc_lp[sl_ * B + gid] = 0;
+      fb.acc_n[sl_ * B + gid] = 0.0f;
+    }
     if (fb.cur_lo) fb.cur_lo[gid] = 0;
   }
 }
@@ -352,7 +358,7 @@ __global__ __launch_bounds__(TILE) void k_fused_choice(const int32_t* __restrict
   }
   // infeasible action (some node picked nothing): poison the accumulator far beyond any legitimate sum
   if (want_lp)
-    atomicAdd((unsigned long long*)&fb.acc_lp[b], (unsigned long long)(bad ? -(1ll << 50) : lp));  // up to 2^13 chunks cannot wrap
+    atomicAdd((unsigned long long*)&fb.acc_lp[(int64_t)(blockIdx.y % (unsigned)fb.acc_slots) * B + b], (unsigned long long)(bad ? -(1ll << 50) : lp));  // up to 2^13 chunks cannot wrap
 }
 
 // ---- Direction gather on the hot records (env-minor: lane = environment) ---------------------------------------------------
@@ -553,7 +559,7 @@ __global__ __launch_bounds__(TILE) void k_fused_rows(const int32_t* __restrict__
     if (counts) __builtin_nontemporal_store(n, &counts[row]);
     nsum += n;
   }
-  atomicAdd(&fb.acc_n[b], nsum);
+  atomicAdd(&fb.acc_n[(int64_t)(blockIdx.y % (unsigned)fb.acc_slots) * B + b], nsum);
 }
 
 // ---- insert + reward + log-prob reduction (one workgroup per environment) ----------------------------------------------
@@ -755,14 +761,25 @@ __global__ __launch_bounds__(INSB) void k_fused_insert(int Nmax, int64_t B, int6
     }
   }
   __syncthreads();
-  // phase 4: the frame's accumulators (filled by the choice kernel and the row pass) -> reward, log-prob; re-arm them
-  if (tid == 0) {
-    const long long lpf = fb.acc_lp[b];
-    if (reward) reward[b] = -(fb.acc_n[b] + (float)s_adm);  // sums of small integers: exact in fp32 in any order
-    if (log_prob) log_prob[b] = (lpf < -(1ll << 49)) ? -INFINITY : (float)((double)lpf / LP_FIX);
-    if (entropy) entropy[b] = entropy_in[0];
-    fb.acc_lp[b] = 0;
-    fb.acc_n[b] = 0.0f;
+  // phase 4: the frame's accumulator banks (filled by the choice kernel and the row pass) -> reward, log-prob; re-arm
+  if (wid == 0) {
+    long long lpf = 0;
+    float nf = 0.0f;
+    for (int64_t sl_ = lane; sl_ < fb.acc_slots; sl_ += 64) {
+      lpf += fb.acc_lp[sl_ * B + b];
+      nf += fb.acc_n[sl_ * B + b];
+      fb.acc_lp[sl_ * B + b] = 0;
+      fb.acc_n[sl_ * B + b] = 0.0f;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      lpf += __shfl_down(lpf, off);
+      nf += __shfl_down(nf, off);      // sums of small integers: exact in fp32 in any order
+    }
+    if (lane == 0) {
+      if (reward) reward[b] = -(nf + (float)s_adm);
+      if (log_prob) log_prob[b] = (lpf < -(1ll << 49)) ? -INFINITY : (float)((double)lpf / LP_FIX);
+      if (entropy) entropy[b] = entropy_in[0];
+    }
   }
 }
 
@@ -774,7 +791,7 @@ static FusedBufs to_bufs(const tarl_fused* f) {
                    (const float4*)f->st0,    f->slots,         f->ld_slots,        f->sel,
                    (long long*)f->acc_lp,    f->acc_n,         f->a_origin,        f->a_dest,
                    f->a_dep,                 f->a_status,      f->a_order,         f->cur_lo,
-                   f->a_dep_sorted};
+                   f->a_dep_sorted,          f->acc_slots};
 }
 
 // nodes walked by one workgroup of the env-minor kernels (tunable: TARL_NCHUNK)
@@ -814,6 +831,7 @@ static int check_fused_core(const tarl_plan* plan, const tarl_fused* f, int64_t 
   TARL_REQUIRE(f->rec0 && f->rec1 && f->post_a && f->post_b && f->st0 && f->slots && f->sel && f->acc_lp && f->acc_n,
                "fused node buffers missing");
   TARL_REQUIRE(B >= 1 && B < ((int64_t)1 << 31) && Nmax >= 2, "bad sizes");
+  TARL_REQUIRE(f->acc_slots >= 1 && f->acc_slots <= 4096, "acc_slots out of range");
   TARL_REQUIRE(f->ld_slots >= 3 * (int64_t)Nmax, "slot row stride smaller than 3*Nmax");
   TARL_REQUIRE(num_chunks(plan) < 65536 && ceil_div(plan->N, nchunk_choice()) < 65536 &&
                    ceil_div(plan->N, nchunk_dir()) < 65536,

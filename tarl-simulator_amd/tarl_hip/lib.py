@@ -72,7 +72,8 @@ class FusedStruct(C.Structure):
     _fields_ = ([(n, C.c_void_p) for n in ("rec0", "rec1", "post_a", "post_b", "st0", "slots")] +
                 [("ld_slots", C.c_int64)] +
                 [(n, C.c_void_p) for n in ("sel", "acc_lp", "acc_n", "a_origin", "a_dest", "a_dep", "a_status", "a_order",
-                                           "cur_lo", "a_dep_sorted")])
+                                           "cur_lo", "a_dep_sorted")] +
+                [("acc_slots", C.c_int64)])
 
 
 _lib = None

@@ -480,8 +480,9 @@ class FusedState:
         self.post_b = torch.zeros((N, B), **f32)
         self.st0 = torch.zeros((N, 4), **f32)
         self.sel = torch.zeros((N, B), **f32)
-        self.acc_lp = torch.zeros(B, dtype=torch.int64, device=device)
-        self.acc_n = torch.zeros(B, **f32)
+        self.acc_slots = 32      # accumulator banks (spread the per-environment atomics of the N/chunk workgroups)
+        self.acc_lp = torch.zeros((self.acc_slots, B), dtype=torch.int64, device=device)
+        self.acc_n = torch.zeros((self.acc_slots, B), **f32)
         self.a_origin = torch.zeros((B, A), dtype=torch.int32, device=device)
         self.a_dest = torch.zeros((B, A), dtype=torch.int32, device=device)
         self.a_dep = torch.zeros((B, A), **f32)
@@ -495,7 +496,7 @@ class FusedState:
                                        self.ld_slots, self.sel.data_ptr(), self.acc_lp.data_ptr(),
                                        self.acc_n.data_ptr(), self.a_origin.data_ptr(), self.a_dest.data_ptr(),
                                        self.a_dep.data_ptr(), self.a_status.data_ptr(), None,
-                                       self.cur_lo.data_ptr(), None)
+                                       self.cur_lo.data_ptr(), None, self.acc_slots)
         self.B, self.N, self.A, self.Nmax = B, N, A, Nmax
 
     def sort_agents(self, agent_features):
