@@ -22,7 +22,7 @@ from .flatparams import FlatParams
 class VecPPOTrainer:
     def __init__(self, engine, emb_param, critic_params, *, rollout_steps, num_epochs=1, sub_batch_size=32, lr=1e-3,
                  gamma=0.99, lmbda=0.95, clip_epsilon=0.2, entropy_coef=0.01, critic_coef=1.0, temperature=1.0,
-                 extra_params=(), seed=0, lazy_log_prob=False):
+                 extra_params=(), seed=0, lazy_log_prob=False, rank_offset=True):
         """``emb_param``: nn.Parameter (num_nodes, 1) — MPNNPolicyNet.nodes_embedding.weight;
         ``critic_params``: [w1 (64,N+1), b1, w2 (64,64), b2, w3 (1,64), b3] — MPNNValueNetSimple.final_mlp.{0,2,4};
         ``extra_params``: further actor/critic parameters that never receive gradient on the live path (the dormant
@@ -54,9 +54,11 @@ class VecPPOTrainer:
         self.reward = torch.zeros((self.T, B), dtype=torch.float32, device=dev)
         self.times = torch.zeros(self.T + 1, dtype=torch.float32, device=dev)
         self.values = torch.zeros((self.T + 1, B), dtype=torch.float32, device=dev)
+        # every rank draws its own minibatches / action noise; rank_offset=False (test hook) makes replicas identical
+        off = self.rank if rank_offset else 0
         self.gen = torch.Generator(device=dev)
-        self.gen.manual_seed(int(seed) + 7919 * self.rank)
-        self.seed = int(seed) + self.rank
+        self.gen.manual_seed(int(seed) + 7919 * off)
+        self.seed = int(seed) + off
         self.sample_counter = 0
         self.last = {}
 
