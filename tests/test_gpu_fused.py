@@ -39,7 +39,8 @@ def check_records(ops, plan, fs, x, Nmax, ag, cc):
 @pytest.mark.parametrize("W,H,het,B,A,frames,with_cc,Nmax", [(3, 3, True, 3, 1500, 60, True, None),
                                                              (4, 4, False, 2, 600, 80, True, None),
                                                              (2, 3, True, 2, 300, 40, False, None),
-                                                             (3, 2, False, 70, 200, 30, True, 40)])
+                                                             (3, 2, False, 70, 200, 30, True, 40),
+                                                             (2, 2, True, 3, 400, 40, True, 100)])
 def test_fused_equals_unfused_frame_by_frame(ops, W, H, het, B, A, frames, with_cc, Nmax):
     from tarl_hip import synth
     net = synth.torus_network(W, H, heterogeneous=het, seed=W + 10 * H, Nmax=Nmax)

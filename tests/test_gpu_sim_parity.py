@@ -58,12 +58,15 @@ def test_braess_reference_fixture(ops):
     assert x[:, 3 * g["Nmax"] + 1].tolist() == [1.0, 1.0, 2.0]
 
 
-@pytest.mark.parametrize("W,H,het,B", [(4, 3, True, 5), (8, 8, False, 3), (5, 5, True, 2)])
-def test_core_batched_vs_oracle(ops, W, H, het, B):
-    """B environments with different states in ONE launch, strided views, several steps; oracle run per environment."""
+@pytest.mark.parametrize("W,H,het,B,length", [(4, 3, True, 5, 100.0), (8, 8, False, 3, 100.0), (5, 5, True, 2, 100.0),
+                                               (3, 3, False, 2, 740.0)])
+def test_core_batched_vs_oracle(ops, W, H, het, B, length):
+    """B environments with different states in ONE launch, strided views, several steps; oracle run per environment.
+    The 740 m links give MAX_NUMBER_OF_AGENT = 99, Nmax = 100, F = 307: SURVEY 8d's stress layout with long queues."""
     from oracle import sim
     from tarl_hip import synth
-    net = synth.torus_network(W, H, heterogeneous=het, seed=W * 31 + H)
+    net = synth.torus_network(W, H, heterogeneous=het, seed=W * 31 + H, length=length)
+    assert net.Nmax == (100 if length == 740.0 else net.Nmax)
     R, F, E, Nmax = net.num_roads, net.F, net.edge_index.size(1), net.Nmax
     plan = ops.Plan(net.edge_index, R)
     ec = ops.EdgeConst(net.edge_attr, "cuda")
