@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--sub-batch", type=int, default=32)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="do not bracket the Direction kernel with HIP events (lets small batches use the graph replay)")
     return ap.parse_args()
 
 
@@ -141,7 +143,8 @@ def main():
 
     for _ in range(args.warmup):
         trainer.train_iteration()
-    L.tarl_prof_enable(args.steps * T + 8)
+    if not args.no_kernel_timing:
+        L.tarl_prof_enable(args.steps * T + 8)
     dist_utils.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
