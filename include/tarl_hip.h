@@ -283,6 +283,21 @@ int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, int64_t B, in
                        uint64_t seed, uint64_t counter0, int32_t* ins_scratch, int32_t* choice, float* log_prob,
                        float* entropy, float* reward, float* counts, tarl_stream stream);
 
+/* tarl_rollout_env == tarl_fused_rollout with the other mapping: ONE workgroup per environment keeps that environment's
+ *   hot records in LDS (44 B per road + 16 KB; tarl_rollout_env_supported(plan) tells whether the graph fits the CU's
+ *   160 KB) and runs all T frames inside a single launch, with workgroup barriers where the env-minor path has kernel
+ *   boundaries. Same packed state in / out (tarl_fused), same noise streams, identical states / agents / actions /
+ *   rewards / counts / log-probs. Differences at the interface: times_dev is a DEVICE array of T floats, and the
+ *   per-frame outputs are ENV-MAJOR: choice int32 [T][B][N], counts fp32 [T][B][N] (log_prob / entropy / reward [T][B]).
+ *   Meant for the sizes where the four-launch frame is latency-bound, and the default rollout whenever it fits. */
+int tarl_rollout_env_supported(const tarl_plan* plan);
+int tarl_rollout_env(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, int64_t T,
+                     const float* times_dev, const float* thresholds, const float* log_probs, const float* entropy1,
+                     uint64_t policy_seed, uint64_t policy_counter0, float* agent_features, int64_t num_agents,
+                     int64_t a_bstride, const float* edge_attr, const float* log_edge_attr, float log_eps, int use_cong,
+                     uint64_t seed, uint64_t counter0, int32_t* ins_scratch, int32_t* choice, float* log_prob,
+                     float* entropy, float* reward, float* counts, tarl_stream stream);
+
 /* ---- shortest-path routing -----------------------------------------------------------------------
  * tarl_edge_travel_time == the edge weights of DijkstraAgents.choice (src/agents/base.py:541-550):
  *   travel_time[b][e] = max(FREE_FLOW[u], congestion_constant[v] / (MAX[u] + 10 - N[u])), u = src(e), v = dst(e),

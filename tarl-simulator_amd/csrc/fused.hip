@@ -33,53 +33,7 @@
 //
 // Domain: pure road graph (plan nodes == rows of x). Counts that reach Nmax (outside the reference's defined domain,
 // DESIGN.md Q25) are not supported by this path.
-#include <float.h>
-#include <math.h>
-#include <stdlib.h>
-
-#include "tarl_common.h"
-
-#define FB 256          // pack / export kernels
-#define ENVB 1024       // one-workgroup-per-environment kernels
-#define TILE 256        // environments per workgroup in the env-minor kernels (one per lane)
-#define LOG_EPS_P 1e-8f
-#define INS_CAP 2048    // LDS candidate list of the insert kernel (entries)
-#define INSB 256        // insert kernel: one (small) workgroup per environment, so that all of them are resident at once
-
-struct FusedBufs {
-  float4* rec0;         // [N][B] {head_id, head_dep, n, tail_id}
-  float2* rec1;         // [N][B] {head_arr, pending-garbage n0 (or -1 when nothing is pending)}
-  float2* postA;        // [N][B] {n', tail'}   state after the Direction update, gathered by the upstream rows
-  float* postB;         // [N][B] chosen: the agent the Direction update enqueues (0: nobody); read by the row itself only
-  const float4* st0;    // [N]    {maxn, ff, road_index, cong}
-  float* slots;         // [N][B][lds] slot-interleaved FIFO store: slot s at floats 3s..3s+2 = {id, arrival, departure}
-  int64_t lds;          // row stride of slots in floats (>= 3*Nmax, multiple of 16)
-  float* sel;           // [N][B] SELECTED_ROAD
-  long long* acc_lp;    // [S][B] log-prob of this frame's action, 2^-32 fixed point (order-independent => deterministic)
-  float* acc_n;         // [S][B] sum of the per-node counts after the row pass (small integers: exact in any order)
-                        // S = acc_slots banks spread the atomics of the N/chunk workgroups that serve one environment
-  int32_t* a_origin;    // [B][A]
-  int32_t* a_dest;      // [B][A]
-  float* a_dep;         // [B][A]
-  uint8_t* a_status;    // [B][A] 0 waiting, 1 on the way, 2 done
-  const int32_t* a_order;  // [B][A] agent ids sorted by departure time (static), or NULL: scan all agents every frame
-  int32_t* cur_lo;      // [B] first position of a_order that may still hold a waiting agent
-  const float* a_dep_sorted;  // [B][A] departure times in a_order's order (sequential scan instead of a gather)
-  int64_t acc_slots;    // accumulator banks: acc_lp / acc_n are [acc_slots][B]; a workgroup adds into bank (chunk % slots)
-};
-
-#define LP_FIX 4294967296.0  // 2^32
-
-// rec1.y packs two small integers exactly in fp32: code = (g + 1) * 1024 + hoff, where g = count at the pending
-// (unmaterialised) garbage write or -1 when nothing is pending, and hoff = physical slot of logical slot 0 (ring buffer).
-__device__ __forceinline__ float r1_code(float g, int hoff) { return (g + 1.0f) * 1024.0f + (float)hoff; }
-__device__ __forceinline__ int r1_hoff(float code) { return ((int)code) & 1023; }
-__device__ __forceinline__ float r1_g(float code) { return (float)(((int)code) >> 10) - 1.0f; }
-// physical slot of logical slot s
-__device__ __forceinline__ int phys(int hoff, int s, int Nmax) {
-  int p = hoff + s;
-  return p >= Nmax ? p - Nmax : p;
-}
+#include "fused_common.h"
 
 // ---- pack: build the hot / static records, the slot store and the agent SoA from x / agent_features ------------------
 __global__ __launch_bounds__(FB) void k_pack_nodes(const float* __restrict__ x, Layout L, int64_t B, int64_t N,
@@ -784,9 +738,7 @@ __global__ __launch_bounds__(INSB) void k_fused_insert(int Nmax, int64_t B, int6
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
-hipEvent_t tarl_prof_event(hipStream_t s);  // sim.hip: live timing of the message-passing gather kernel
-
-static FusedBufs to_bufs(const tarl_fused* f) {
+FusedBufs tarl_to_bufs(const tarl_fused* f) {
   return FusedBufs{(float4*)f->rec0,         (float2*)f->rec1, (float2*)f->post_a, f->post_b,
                    (const float4*)f->st0,    f->slots,         f->ld_slots,        f->sel,
                    (long long*)f->acc_lp,    f->acc_n,         f->a_origin,        f->a_dest,
@@ -826,7 +778,7 @@ static int nchunk_choice() {
   return v;
 }
 
-static int check_fused_core(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax) {
+int tarl_check_fused_core(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax) {
   TARL_REQUIRE(plan && f, "null argument");
   TARL_REQUIRE(f->rec0 && f->rec1 && f->post_a && f->post_b && f->st0 && f->slots && f->sel && f->acc_lp && f->acc_n,
                "fused node buffers missing");
@@ -844,7 +796,7 @@ static int check_fused_core(const tarl_plan* plan, const tarl_fused* f, int64_t 
 
 static int check_fused(const tarl_plan* plan, const tarl_fused* f, const float* x, int64_t B, int64_t bstride,
                        int64_t ldx, int32_t Nmax) {
-  int rc = check_fused_core(plan, f, B, Nmax);
+  int rc = tarl_check_fused_core(plan, f, B, Nmax);
   if (rc) return rc;
   TARL_REQUIRE(x != nullptr, "x is null");
   TARL_REQUIRE(ldx >= 3 * (int64_t)Nmax + 7, "row stride smaller than F");
@@ -860,7 +812,7 @@ extern "C" int tarl_fused_pack(const tarl_plan* plan, const tarl_fused* f, const
   int rc = check_fused(plan, f, x, B, x_bstride, ldx, Nmax);
   if (rc) return rc;
   const Layout L{Nmax, ldx, x_bstride};
-  const FusedBufs fb = to_bufs(f);
+  const FusedBufs fb = tarl_to_bufs(f);
   hipStream_t s = (hipStream_t)stream;
   if (plan->N > 0) {
     hipLaunchKernelGGL(k_pack_nodes, dim3((unsigned)ceil_div(B * plan->N, FB)), dim3(FB), 0, s, x, L, B, plan->N, cong,
@@ -878,10 +830,10 @@ extern "C" int tarl_fused_pack(const tarl_plan* plan, const tarl_fused* f, const
 
 extern "C" int tarl_fused_reset(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax,
                                 float* agent_features, int64_t A, int64_t a_bstride, tarl_stream stream) {
-  int rc = check_fused_core(plan, f, B, Nmax);
+  int rc = tarl_check_fused_core(plan, f, B, Nmax);
   if (rc) return rc;
   TARL_REQUIRE(agent_features && A >= 1 && f->a_status, "agents missing");
-  const FusedBufs fb = to_bufs(f);
+  const FusedBufs fb = tarl_to_bufs(f);
   hipStream_t s = (hipStream_t)stream;
   TARL_CHECK_HIP(hipMemsetAsync(f->slots, 0, (size_t)(plan->N * B * f->ld_slots) * sizeof(float), s));
   if (plan->N > 0) {
@@ -901,7 +853,7 @@ extern "C" int tarl_fused_export(const tarl_plan* plan, const tarl_fused* f, flo
   if (plan->N == 0) return TARL_OK;
   const Layout L{Nmax, ldx, x_bstride};
   hipLaunchKernelGGL(k_export_rows, dim3((unsigned)ceil_div(B * plan->N * Nmax, FB)), dim3(FB), 0, (hipStream_t)stream,
-                     x, L, B, plan->N, to_bufs(f), last_step_time);
+                     x, L, B, plan->N, tarl_to_bufs(f), last_step_time);
   TARL_LAUNCH_CHECK();
   return TARL_OK;
 }
@@ -927,7 +879,7 @@ extern "C" int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int6
                                 uint64_t seed, uint64_t counter, float* delta_travel_time, uint8_t* popped,
                                 uint8_t* withdrawn, int32_t* ins_scratch, int32_t* choice, float* log_prob,
                                 float* entropy, float* reward, float* counts, tarl_stream stream) {
-  int rc = check_fused_core(plan, f, B, Nmax);
+  int rc = tarl_check_fused_core(plan, f, B, Nmax);
   if (rc) return rc;
   TARL_REQUIRE(thresholds && log_probs && entropy1, "policy tables missing (call tarl_fused_policy_prepare)");
   TARL_REQUIRE(agent_features && A >= 1 && ins_scratch, "agents / scratch missing");
@@ -937,7 +889,7 @@ extern "C" int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int6
   TARL_REQUIRE(B == 1 || a_bstride >= A * AG_COLS, "agent stride smaller than one population");
   TARL_REQUIRE(plan->E == 0 || (edge_attr && log_edge_attr), "edge constants missing");
   if (plan->N == 0) return TARL_OK;
-  const FusedBufs fb = to_bufs(f);
+  const FusedBufs fb = tarl_to_bufs(f);
   hipStream_t s = (hipStream_t)stream;
   const unsigned threads = tile_threads(B);
   const dim3 grid((unsigned)ceil_div(B, threads), (unsigned)num_chunks(plan));
@@ -975,7 +927,7 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
                                   const float* log_edge_attr, float log_eps, int use_cong, uint64_t seed,
                                   uint64_t counter0, int32_t* ins_scratch, int32_t* choice, float* log_prob,
                                   float* entropy, float* reward, float* counts, tarl_stream stream) {
-  int rc = check_fused_core(plan, f, B, Nmax);
+  int rc = tarl_check_fused_core(plan, f, B, Nmax);
   if (rc) return rc;
   TARL_REQUIRE(T >= 1 && times_host, "bad frame count / times");
   TARL_REQUIRE(thresholds && log_probs && entropy1, "policy tables missing (call tarl_fused_policy_prepare)");
@@ -993,7 +945,7 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
   const dim3 grid_c((unsigned)ceil_div(B, threads), (unsigned)ceil_div(N, nchunk_choice()));
   const dim3 grid_d((unsigned)ceil_div(B, threads), (unsigned)ceil_div(N, nchunk_dir()));
   const int want_lp = log_prob != nullptr ? 1 : 0;
-  const FusedBufs fb = to_bufs(f);
+  const FusedBufs fb = tarl_to_bufs(f);
   for (int64_t t = 0; t < T; ++t) {
     const float time = times_host[t];
     hipLaunchKernelGGL(k_fused_choice, grid_c, dim3(threads), 0, s, plan->out_ptr, plan->out_dst, plan->out_eid,

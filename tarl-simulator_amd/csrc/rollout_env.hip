@@ -1,0 +1,537 @@
+// rollout_env.hip — the whole T-frame rollout of one environment in ONE workgroup, hot records resident in LDS.
+//
+// Why a second implementation: the env-minor path (fused.hip) streams every per-(node, environment) record through HBM
+// four times per frame and pays four dependent launches per frame; with few environments it is bound by those launches'
+// latency (~10 us each), with many by HBM. A CDNA4 CU has 160 KB of LDS — enough for ALL hot state of one environment
+// of a few thousand roads (40 B per road: rec0, rec1, the post record, the chosen agent, SELECTED_ROAD, plus the static
+// MAX column). So: one 1024-thread workgroup per environment loads its records once, runs the T frames with workgroup
+// barriers where the env-minor path has kernel boundaries, and writes the records back at the end. HBM then only sees
+// the FIFO slot store and the agent table where something actually happens (a few events per frame), and the rollout
+// outputs (ENV-MAJOR here: choice / counts [T][B][N], written coalesced by the workgroup). Static topology / tables are
+// shared by every environment and stay L2-resident.
+//
+// The arithmetic, the noise streams (Philox keys, counters, indices) and the order-sensitive rules are those of
+// fused.hip's kernels, so the two paths produce identical states, agents, actions, rewards and counts; the per-frame
+// log-prob is summed in the same 2^-32 fixed point (bit-identical, order-independent).
+//
+// Threads own CONTIGUOUS node ranges (consecutive nodes and consecutive CSC positions share Philox blocks).
+#include "fused_common.h"
+
+#define RE_MAX_WAVES 16
+
+struct EnvOut {
+  int32_t* choice;   // [T][B][N] or NULL
+  float* log_prob;   // [T][B] or NULL
+  float* entropy;    // [T][B] or NULL
+  float* reward;     // [T][B] or NULL
+  float* counts;     // [T][B][N] or NULL
+};
+
+struct EnvPlan {
+  const int32_t* in_ptr;
+  const int32_t* in_src;
+  const int32_t* in_eid;
+  const int32_t* out_ptr;
+  const int32_t* out_dst;
+  const int32_t* out_eid;
+  const int32_t* group_of_node;
+  int64_t N, E, G;
+};
+
+template <int WAVES>
+__device__ __forceinline__ float re_block_sum_f(float v, float* s_red) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  __syncthreads();
+  if (lane == 0) s_red[wid] = v;
+  __syncthreads();
+  float tot = 0.0f;
+  for (int w = 0; w < WAVES; ++w) tot += s_red[w];
+  return tot;
+}
+
+template <int WAVES>
+__device__ __forceinline__ long long re_block_sum_ll(long long v, long long* s_red) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  __syncthreads();
+  if (lane == 0) s_red[wid] = v;
+  __syncthreads();
+  long long tot = 0;
+  for (int w = 0; w < WAVES; ++w) tot += s_red[w];
+  return tot;
+}
+
+// RE_THREADS: 1024 for graphs of thousands of roads, 256 for small ones (several environments share a CU then)
+template <int RE_THREADS>
+__global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B, int Nmax, FusedBufs fb,
+                                                            const float* __restrict__ thr,
+                                                            const float* __restrict__ lgt,
+                                                            const float* __restrict__ entropy1,
+                                                            const float* __restrict__ edge_attr,
+                                                            const float* __restrict__ log_edge_attr, float log_eps,
+                                                            int use_cong, uint64_t pseed, uint64_t pcounter0,
+                                                            uint64_t seed, uint64_t counter0, int64_t T,
+                                                            const float* __restrict__ times, float* __restrict__ ag,
+                                                            int64_t A, int64_t a_bstride,
+                                                            int32_t* __restrict__ scratch, EnvOut out) {
+  extern __shared__ float4 re_lds[];
+  const int64_t N = P.N;
+  float4* r0 = re_lds;                            // [N] {head_id, head_dep, n, tail_id}
+  float2* r1 = (float2*)(r0 + N);                 // [N] {head_arr, code}
+  float2* pA = r1 + N;                            // [N] {n', tail'}
+  float* who_l = (float*)(pA + N);                // [N] chosen agent of the Direction update
+  float* sel_l = who_l + N;                       // [N] SELECTED_ROAD
+  float* maxn_l = sel_l + N;                      // [N] static MAX_NUMBER_OF_AGENT (upstream test of the Direction gather)
+  int32_t* s_un_agent = (int32_t*)(maxn_l + N);   // [INS_CAP]
+  int32_t* s_un_road = s_un_agent + INS_CAP;      // [INS_CAP]
+  constexpr int RE_WAVES = RE_THREADS / 64;
+  __shared__ float s_red_f[RE_MAX_WAVES];
+  __shared__ long long s_red_ll[RE_MAX_WAVES];
+  __shared__ int32_t s_wave[RE_MAX_WAVES];
+  __shared__ int32_t s_cnt, s_lo, s_bad, s_cur;
+
+  const int64_t b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int32_t npt = (int32_t)((N + RE_THREADS - 1) / RE_THREADS);
+  const int32_t i0 = tid * npt < N ? tid * npt : (int32_t)N;
+  const int32_t i1 = (i0 + npt < N) ? i0 + npt : (int32_t)N;
+  float* agb = ag + b * a_bstride;
+  int32_t* cand_agent = scratch + b * 2 * A;
+  int32_t* cand_road = cand_agent + A;
+
+  for (int32_t i = i0; i < i1; ++i) {
+    const int64_t row = (int64_t)i * B + b;
+    r0[i] = fb.rec0[row];
+    r1[i] = fb.rec1[row];
+    pA[i] = fb.postA[row];
+    who_l[i] = fb.postB[row];
+    sel_l[i] = fb.sel[row];
+    maxn_l[i] = fb.st0[i].x;
+  }
+  if (tid == 0) s_cur = fb.cur_lo ? fb.cur_lo[b] : 0;
+  __syncthreads();
+
+  for (int64_t f = 0; f < T; ++f) {
+    const float t = times[f];
+    const uint64_t pcounter = pcounter0 + (uint64_t)f, counter = counter0 + (uint64_t)f;
+
+    // ---- A. choice (k_fused_choice): GraphDistribution.sample + log_prob through the policy tables ---------------------
+    long long lp = 0;
+    bool bad = false;
+    {
+      PhiloxRun rng;
+      for (int32_t i = i0; i < i1; ++i) {
+        int32_t ch = -1;
+        const int32_t gi = P.group_of_node[i];
+        if (gi >= 0) {
+          const float u = rng.uniform(pseed, pcounter, (uint64_t)(b * P.G + gi));
+          bool found = false;
+          float selv = 0.0f;
+          long long lpn = 0;
+          const int32_t k1 = P.out_ptr[i + 1];
+          for (int32_t k = P.out_ptr[i]; k < k1; ++k) {
+            const bool hit = !found && (u < thr[k]);
+            if (hit) {
+              selv = (float)P.out_dst[k];
+              ch = P.out_eid[k];
+              lpn = (long long)((double)lgt[k] * LP_FIX);
+            }
+            found = found || hit;
+          }
+          if (found) {
+            sel_l[i] = selv;   // a node that picks nothing keeps its previous SELECTED_ROAD
+            lp += lpn;
+          } else {
+            bad = true;
+          }
+        }
+        if (out.choice) out.choice[(f * B + b) * N + i] = ch;
+      }
+    }
+    if (tid == 0) {
+      s_cnt = 0;
+      s_lo = 0x7fffffff;
+      s_bad = 0;
+    }
+    __syncthreads();
+    if (bad) s_bad = 1;
+
+    // ---- B. Direction gather (k_fused_direction) -------------------------------------------------------------------------
+    {
+      PhiloxRun rng;
+      for (int32_t i = i0; i < i1; ++i) {
+        const float4 me = r0[i];
+        const float max_i = maxn_l[i], n_i = me.z;
+        const float road_i = fb.st0[i].z;
+        const float room_i = max_i - n_i;
+        const bool has_room = n_i < max_i - TARL_CONGESTION_FILE;
+        float Psum = 0.0f, best = -FLT_MAX, best_id = 0.0f;
+        const int32_t k1 = P.in_ptr[i + 1];
+        for (int32_t k = P.in_ptr[i]; k < k1; ++k) {
+          const int32_t j = P.in_src[k];
+          const int32_t e = P.in_eid[k];
+          const float4 rj = r0[j];
+          const float sel_j = sel_l[j];
+          const float id = rj.x, dep = rj.y, n_j = rj.z, max_j = maxn_l[j];
+          const bool heads_here = sel_j == road_i;
+          const bool m1 = (dep <= t) && has_room && heads_here && (n_j > 0.0f);
+          const bool m2 = ((dep - t) < -10.0f) && ((max_j - TARL_CONGESTION_FILE) <= n_j) && ((max_j - n_j) <= room_i) &&
+                          heads_here;
+          const bool m = m1 || m2;
+          const float prob = edge_attr[e] * (m ? 1.0f : 0.0f);
+          Psum = Psum + prob;
+          const float u = rng.uniform(seed, counter, (uint64_t)(b * P.E + k));
+          const float g = gumbel_from_u01(u);
+          const float score = (m ? log_edge_attr[e] : log_eps) + g;
+          if (score > best) {
+            best = score;
+            best_id = id;
+          }
+        }
+        const float who = (Psum > 0.0f) ? best_id : 0.0f;
+        pA[i] = make_float2(who != 0.0f ? n_i + 1.0f : n_i, who != 0.0f ? who : me.w);
+        who_l[i] = who;
+      }
+    }
+    __syncthreads();
+
+    // ---- C. row pass (k_fused_rows): Direction update + Response pop + withdraw ------------------------------------------
+    for (int32_t i = i0; i < i1; ++i) {
+      const int64_t row = (int64_t)i * B + b;
+      float* sl = fb.slots + row * fb.lds;
+      const float2 pa = pA[i];
+      const float who = who_l[i];
+      const float4 q0 = r0[i];
+      const float2 q1 = r1[i];
+      const float4 st = fb.st0[i];
+      const float n0 = q0.z;
+      const int32_t k0 = P.out_ptr[i], k1 = P.out_ptr[i + 1];
+      bool pop = false;
+      {
+        const long long head = (long long)((n0 == 0.0f) ? who : q0.x);
+        const bool up = (long long)pa.x > 0;
+        for (int32_t k = k0; k < k1; ++k) {
+          const float2 pj = pA[P.out_dst[k]];
+          pop = pop || (up && (long long)pj.x > 0 && (long long)pj.y == head);
+        }
+      }
+      int hoff = r1_hoff(q1.y);
+      const int q = (int)n0;
+      const float t_cong = st.w / (st.x + 10.0f - n0);
+      const float tt = (t_cong != t_cong) ? t_cong : fmaxf(st.y, t_cong);
+      const float dep_new = t + tt;
+      const bool lazy = (who == 0.0f) && (q >= 0) && (q < Nmax - 1);
+      if (!lazy && q >= 0 && q < Nmax) {
+        float* w = sl + 3 * phys(hoff, q, Nmax);
+        w[0] = who;
+        w[1] = t;
+        w[2] = dep_new;
+      }
+      float n = pa.x;
+      float head_id = (n0 == 0.0f) ? who : q0.x;
+      float head_dep = (n0 == 0.0f) ? dep_new : q0.y;
+      float head_arr = (n0 == 0.0f) ? t : q1.x;
+      float tail_id = pa.y;
+      int shift = 0;
+      if (pop) {
+        const float* last = sl + 3 * phys(hoff, Nmax - 1, Nmax);
+        const float l0 = last[0], l1 = last[1], l2 = last[2];
+        float* front = sl + 3 * hoff;
+        front[0] = l0;
+        front[1] = l1;
+        front[2] = l2;
+        hoff = phys(hoff, 1, Nmax);
+        shift = 1;
+        n = n - 1.0f;
+      }
+      int c = 0;
+      if (n > 0.0f) {
+        const long long road = (long long)st.z;
+        int32_t w0 = 0, w1 = 0;
+        if (road >= 0 && road < N) {
+          w0 = P.out_ptr[road];
+          w1 = P.out_ptr[road + 1];
+        }
+        for (int sx = 0; sx < Nmax && (float)sx < n; ++sx) {
+          float idf, depf;
+          if (sx == 0 && shift == 0) {
+            idf = head_id;
+            depf = head_dep;
+          } else {
+            const float* rd = sl + 3 * phys(hoff, sx, Nmax);
+            idf = rd[0];
+            depf = rd[2];
+          }
+          const long long id = (long long)idf;
+          if (id < 0 || id >= A) break;
+          if (!(depf <= t)) break;
+          const long long dest = (long long)fb.a_dest[b * A + id];
+          bool conn = false;
+          for (int32_t k = w0; k < w1; ++k) conn = conn || ((long long)P.out_dst[k] == dest);
+          if (!conn) break;
+          float* a = agb + id * AG_COLS;
+          a[AG_DONE] = 1.0f;
+          a[AG_ON_WAY] = 0.0f;
+          a[AG_ARR] = t;
+          fb.a_status[b * A + id] = 2;
+          ++c;
+        }
+      }
+      for (int k = 0; k < c; ++k) {
+        float* z = sl + 3 * phys(hoff, k, Nmax);
+        z[0] = 0.0f;
+        z[1] = 0.0f;
+        z[2] = 0.0f;
+      }
+      if (c > 0) {
+        hoff = phys(hoff, c, Nmax);
+        n = n - (float)c;
+      }
+      if (shift + c > 0) {
+        if (lazy && n == 0.0f) {
+          head_id = 0.0f;
+          head_arr = t;
+          head_dep = dep_new;
+        } else {
+          const float* hd = sl + 3 * hoff;
+          head_id = hd[0];
+          head_arr = hd[1];
+          head_dep = hd[2];
+        }
+        const int qn = (int)n;
+        tail_id = (qn >= 1 && qn <= Nmax) ? sl[3 * phys(hoff, qn - 1, Nmax)] : 0.0f;
+      }
+      r0[i] = make_float4(head_id, head_dep, n, tail_id);
+      r1[i] = make_float2(head_arr, r1_code(lazy ? n0 : -1.0f, hoff));
+    }
+    __threadfence_block();   // the slot-store writes above are read by this workgroup's insert / later frames
+    __syncthreads();
+
+    // ---- D. insert (k_fused_insert) -----------------------------------------------------------------------------------------
+    {
+      auto target = [&](int32_t origin, int32_t* road) -> bool {
+        if (origin < 0 || origin >= N) return false;
+        const long long r = (long long)sel_l[origin];
+        if (r < 0 || r >= N) return false;
+        const long long room = (long long)(maxn_l[r] - TARL_CONGESTION_FILE - r0[r].z);
+        *road = (int32_t)r;
+        return room > 0;
+      };
+      if (fb.a_order) {
+        const int32_t* ord = fb.a_order + b * A;
+        const float* dsort = fb.a_dep_sorted + b * A;
+        const int32_t lo = s_cur;
+        for (int64_t k0 = lo; k0 < A; k0 += RE_THREADS) {
+          const int64_t k = k0 + tid;
+          bool notdue = false;
+          if (k < A) {
+            const bool due = dsort[k] <= t;
+            notdue = !due;
+            if (!due) {
+              atomicMin(&s_lo, (int32_t)k);
+            } else {
+              const int32_t a = ord[k];
+              if (fb.a_status[b * A + a] == 0) {
+                atomicMin(&s_lo, (int32_t)k);
+                int32_t road = 0;
+                if (target(fb.a_origin[b * A + a], &road)) {
+                  const int32_t pos = atomicAdd(&s_cnt, 1);
+                  if (pos < INS_CAP) {
+                    s_un_agent[pos] = a;
+                    s_un_road[pos] = road;
+                  }
+                }
+              }
+            }
+          }
+          if (__syncthreads_or(notdue ? 1 : 0)) break;
+        }
+        __syncthreads();
+        if (tid == 0) s_cur = s_lo == 0x7fffffff ? (int32_t)A : s_lo;   // read again only after the next barriers
+      } else {
+        for (int64_t a = tid; a < A; a += RE_THREADS) {
+          if (fb.a_status[b * A + a] == 0 && fb.a_dep[b * A + a] <= t) {
+            int32_t road = 0;
+            if (target(fb.a_origin[b * A + a], &road)) {
+              const int32_t pos = atomicAdd(&s_cnt, 1);
+              if (pos < INS_CAP) {
+                s_un_agent[pos] = (int32_t)a;
+                s_un_road[pos] = road;
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+      int32_t Lc = s_cnt;
+      if (Lc <= INS_CAP) {
+        for (int32_t idx = tid; idx < Lc; idx += RE_THREADS) {
+          const int32_t a = s_un_agent[idx];
+          int32_t pos = 0;
+          for (int32_t k = 0; k < Lc; ++k) pos += (s_un_agent[k] < a) ? 1 : 0;
+          cand_agent[pos] = a;
+          cand_road[pos] = s_un_road[idx];
+        }
+        __threadfence_block();
+        __syncthreads();
+      } else {   // backlog beyond the LDS list: ordered ballot compaction of all ready agents into the global scratch
+        int32_t basec = 0;
+        for (int64_t a0 = 0; a0 < A; a0 += RE_THREADS) {
+          const int64_t a = a0 + tid;
+          bool cnd = false;
+          int32_t road = 0;
+          if (a < A && fb.a_status[b * A + a] == 0 && fb.a_dep[b * A + a] <= t) cnd = target(fb.a_origin[b * A + a], &road);
+          const unsigned long long bal = __ballot(cnd);
+          const int lane_off = __popcll(bal & ((1ull << lane) - 1ull));
+          if (lane == 0) s_wave[wid] = __popcll(bal);
+          __syncthreads();
+          int32_t wbase = 0, tot = 0;
+          for (int w = 0; w < RE_WAVES; ++w) {
+            const int32_t v = s_wave[w];
+            if (w < wid) wbase += v;
+            tot += v;
+          }
+          if (cnd) {
+            cand_agent[basec + wbase + lane_off] = (int32_t)a;
+            cand_road[basec + wbase + lane_off] = road;
+          }
+          basec += tot;
+          __syncthreads();
+        }
+        Lc = basec;
+        __threadfence_block();
+        __syncthreads();
+      }
+      // rank within road (stable), admit the first min(count, capacity), write slots / hot records
+      for (int32_t idx = tid; idx < Lc; idx += RE_THREADS) {
+        const int32_t r = cand_road[idx];
+        const int32_t a = cand_agent[idx];
+        int32_t rank = 0, total = 0;
+        for (int32_t k = 0; k < Lc; ++k) {
+          const bool same = cand_road[k] == r;
+          total += same ? 1 : 0;
+          rank += (same && k < idx) ? 1 : 0;
+        }
+        const int64_t rrow = (int64_t)r * B + b;
+        const float4 str = fb.st0[r];
+        const float n0 = r0[r].z;
+        const long long cap = (long long)(str.x - TARL_CONGESTION_FILE - n0);
+        int32_t commit = 0;
+        if (rank < cap) {
+          const long long m = total < cap ? total : cap;
+          const long long slot = (long long)n0 + rank;
+          const float t_cong = use_cong ? str.w / (str.x + 10.0f - (float)(long long)n0) : 0.0f;
+          const float tt = (t_cong != t_cong) ? t_cong : fmaxf(str.y, t_cong);
+          const float code = r1[r].y;   // nobody writes r1.y before the barrier below
+          if (slot >= 0 && slot < Nmax) {
+            float* sr = fb.slots + rrow * fb.lds + 3 * phys(r1_hoff(code), (int)slot, Nmax);
+            sr[0] = (float)a;
+            sr[1] = t;
+            sr[2] = t + tt;
+          }
+          agb[(int64_t)a * AG_COLS + AG_ON_WAY] = 1.0f;
+          fb.a_status[b * A + a] = 1;
+          if (rank == 0 && n0 == 0.0f) {
+            r0[r].x = (float)a;
+            r0[r].y = t + tt;
+            r1[r].x = t;
+          }
+          if (rank == m - 1) r0[r].w = (float)a;  // new tail
+          if (rank == 0) commit = (int32_t)m;
+        }
+        cand_agent[idx] = commit;
+      }
+      __threadfence_block();
+      __syncthreads();
+      for (int32_t idx = tid; idx < Lc; idx += RE_THREADS) {
+        const int32_t cmt = cand_agent[idx];
+        if (cmt > 0) {
+          const int32_t r = cand_road[idx];
+          r1[r].y = r1_code(-1.0f, r1_hoff(r1[r].y));
+          r0[r].z = r0[r].z + (float)cmt;
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+
+    // ---- E. frame outputs: counts (critic observation), reward = -sum of counts, log-prob, entropy ------------------------
+    float nsum = 0.0f;
+    for (int32_t i = i0; i < i1; ++i) {
+      const float n = r0[i].z;
+      if (out.counts) __builtin_nontemporal_store(n, &out.counts[(f * B + b) * N + i]);
+      nsum += n;
+    }
+    const float ntot = re_block_sum_f<RE_WAVES>(nsum, s_red_f);          // sums of small integers: exact in fp32 in any order
+    const long long lptot = re_block_sum_ll<RE_WAVES>(lp, s_red_ll);
+    if (tid == 0) {
+      if (out.reward) out.reward[f * B + b] = -ntot;
+      if (out.log_prob) out.log_prob[f * B + b] = s_bad ? -INFINITY : (float)((double)lptot / LP_FIX);
+      if (out.entropy) out.entropy[f * B + b] = entropy1[0];
+    }
+    __syncthreads();
+  }
+
+  for (int32_t i = i0; i < i1; ++i) {
+    const int64_t row = (int64_t)i * B + b;
+    fb.rec0[row] = r0[i];
+    fb.rec1[row] = r1[i];
+    fb.postA[row] = pA[i];
+    fb.postB[row] = who_l[i];
+    fb.sel[row] = sel_l[i];
+  }
+  if (tid == 0 && fb.cur_lo) fb.cur_lo[b] = s_cur;
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------------
+static size_t re_lds_bytes(int64_t N) { return (size_t)N * 44 + (size_t)INS_CAP * 8; }
+
+extern "C" int tarl_rollout_env_supported(const tarl_plan* plan) {
+  return plan && re_lds_bytes(plan->N) + 1024 <= 160 * 1024 ? 1 : 0;
+}
+
+extern "C" int tarl_rollout_env(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, int64_t T,
+                                const float* times_dev, const float* thresholds, const float* log_probs,
+                                const float* entropy1, uint64_t policy_seed, uint64_t policy_counter0,
+                                float* agent_features, int64_t A, int64_t a_bstride, const float* edge_attr,
+                                const float* log_edge_attr, float log_eps, int use_cong, uint64_t seed,
+                                uint64_t counter0, int32_t* ins_scratch, int32_t* choice, float* log_prob,
+                                float* entropy, float* reward, float* counts, tarl_stream stream) {
+  int rc = tarl_check_fused_core(plan, f, B, Nmax);
+  if (rc) return rc;
+  TARL_REQUIRE(T >= 1 && times_dev, "bad frame count / times");
+  TARL_REQUIRE(thresholds && log_probs && entropy1, "policy tables missing (call tarl_fused_policy_prepare)");
+  TARL_REQUIRE(agent_features && A >= 1 && ins_scratch, "agents / scratch missing");
+  TARL_REQUIRE(f->a_origin && f->a_dest && f->a_dep && f->a_status, "fused agent buffers missing");
+  TARL_REQUIRE(f->a_order == nullptr || (f->cur_lo != nullptr && f->a_dep_sorted != nullptr),
+               "a_order needs cur_lo and a_dep_sorted");
+  TARL_REQUIRE(B == 1 || a_bstride >= A * AG_COLS, "agent stride smaller than one population");
+  TARL_REQUIRE(plan->E == 0 || (edge_attr && log_edge_attr), "edge constants missing");
+  TARL_REQUIRE(tarl_rollout_env_supported(plan), "graph too large for the LDS-resident rollout (tarl_rollout_env_supported)");
+  TARL_REQUIRE(B < 65536ll * 32768ll, "too many environments for one launch");
+  if (plan->N == 0) return TARL_OK;
+  const size_t lds = re_lds_bytes(plan->N);
+  const EnvPlan P{plan->in_ptr, plan->in_src, plan->in_eid, plan->out_ptr, plan->out_dst, plan->out_eid,
+                  plan->group_of_node, plan->N, plan->E, plan->G};
+  const EnvOut out{choice, log_prob, entropy, reward, counts};
+  if (plan->N <= 512) {
+    hipLaunchKernelGGL(k_rollout_env<256>, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, P, B, (int)Nmax,
+                       tarl_to_bufs(f), thresholds, log_probs, entropy1, edge_attr, log_edge_attr, log_eps, use_cong,
+                       policy_seed, policy_counter0, seed, counter0, T, times_dev, agent_features, A, a_bstride,
+                       ins_scratch, out);
+  } else {
+    static size_t lds_set = 0;
+    if (lds > 64 * 1024 && lds > lds_set) {
+      TARL_CHECK_HIP(hipFuncSetAttribute((const void*)k_rollout_env<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds));
+      lds_set = lds;
+    }
+    hipLaunchKernelGGL(k_rollout_env<1024>, dim3((unsigned)B), dim3(1024), lds, (hipStream_t)stream, P, B, (int)Nmax,
+                       tarl_to_bufs(f), thresholds, log_probs, entropy1, edge_attr, log_edge_attr, log_eps, use_cong,
+                       policy_seed, policy_counter0, seed, counter0, T, times_dev, agent_features, A, a_bstride,
+                       ins_scratch, out);
+  }
+  TARL_LAUNCH_CHECK();
+  return TARL_OK;
+}

@@ -147,6 +147,37 @@ class SimEngine:
         self.time += self.timestep
         return self.time > EPISODE_END
 
+    @property
+    def env_rollout_supported(self):
+        """True when one environment's hot records fit a CU's LDS (tarl_rollout_env)."""
+        return self.fs is not None and ops.rollout_env_supported(self.plan)
+
+    def rollout_env(self, T, *, choice, log_prob, reward, counts):
+        """Same frames as :meth:`rollout_fused` through ``tarl_rollout_env`` (one workgroup per environment, LDS-resident
+        records, a single launch); the buffers are ENV-MAJOR: ``choice`` (T,B,N) int32, ``counts`` (T+1,B,N) fp32 with
+        counts[t + 1] = the counts after frame t; ``log_prob`` (T,B) or None; ``reward`` (T,B)."""
+        if self._packed_stale:
+            self.resync()
+        if tuple(counts.shape) != (T + 1, self.B, self.N) or not counts.is_contiguous():
+            raise ValueError(f"counts must be a contiguous (T + 1, B, N) = {(T + 1, self.B, self.N)} tensor")
+        times = []
+        t_clock = self.time
+        for _ in range(T):
+            times.append(float(t_clock))
+            t_clock += self.timestep
+        self._x_stale = True
+        self._times_dev = ops.rollout_env(self.plan, self.fs, self.tables, self.agents, self.ec, times,
+                                          use_cong=self.cc is not None, policy_seed=self.seed ^ 0x5DEECE66D,
+                                          policy_counter0=self.sample_counter + 1, seed=self.seed,
+                                          counter0=self.noise_counter + 1, scratch=self.ins_scratch, choice=choice,
+                                          log_prob=log_prob, reward=reward, counts=counts[1:])
+        self.sample_counter += T
+        self.noise_counter += T
+        self._last_step_time = times[-1]
+        self.time = t_clock
+        times.append(float(self.time))
+        return times
+
     def rollout_fused(self, T, *, choice, log_prob, reward, counts):
         """``T`` consecutive frames with the outputs of frame t written to ``choice[t]`` (T,N,B) int32, ``log_prob[t]``
         (T,B) or None, ``reward[t]`` (T,B), ``counts[t + 1]`` (T+1,N,B). Same as T calls of :meth:`frame_fused` with the

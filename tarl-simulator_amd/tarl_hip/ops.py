@@ -618,6 +618,34 @@ def fused_rollout(plan: Plan, fs: FusedState, tables: PolicyTables, agent_featur
                                     _lib.ptr(entropy), _lib.ptr(reward), _lib.ptr(counts), _lib.current_stream()))
 
 
+def rollout_env_supported(plan: Plan) -> bool:
+    return bool(_lib.load().tarl_rollout_env_supported(plan.handle))
+
+
+def rollout_env(plan: Plan, fs: FusedState, tables: PolicyTables, agent_features, ec: EdgeConst, times, *, use_cong,
+                policy_seed, policy_counter0, seed, counter0, scratch, choice=None, log_prob=None, entropy=None,
+                reward=None, counts=None):
+    """Same contract as :func:`fused_rollout` through ``tarl_rollout_env`` (one workgroup per environment, LDS-resident
+    records, one launch for all frames); ``choice`` / ``counts`` are ENV-MAJOR (T, B, N)."""
+    L = _lib.load()
+    T, B, N = len(times), fs.B, fs.N
+    A, abs_ = _agents(agent_features, B)
+    _contig(scratch, torch.int32, "scratch")
+    for name, tns, dt, shp in (("choice", choice, torch.int32, (T, B, N)), ("counts", counts, torch.float32, (T, B, N)),
+                               ("log_prob", log_prob, torch.float32, (T, B)), ("entropy", entropy, torch.float32, (T, B)),
+                               ("reward", reward, torch.float32, (T, B))):
+        if tns is not None and (tns.dtype != dt or tuple(tns.shape) != shp or not tns.is_contiguous() or not tns.is_cuda):
+            raise ValueError(f"{name} must be a contiguous cuda {dt} tensor of shape {shp}")
+    tdev = torch.tensor([float(t) for t in times], dtype=torch.float32).to(fs.sel.device, non_blocking=True)
+    _lib.check(L.tarl_rollout_env(plan.handle, fs.ref, B, fs.Nmax, T, tdev.data_ptr(), tables.thresholds.data_ptr(),
+                                  tables.log_probs.data_ptr(), tables.entropy.data_ptr(), int(policy_seed),
+                                  int(policy_counter0), agent_features.data_ptr(), A, abs_, ec.edge_attr.data_ptr(),
+                                  ec.log_edge_attr.data_ptr(), ec.log_eps, 1 if use_cong else 0, int(seed),
+                                  int(counter0), scratch.data_ptr(), _lib.ptr(choice), _lib.ptr(log_prob),
+                                  _lib.ptr(entropy), _lib.ptr(reward), _lib.ptr(counts), _lib.current_stream()))
+    return tdev
+
+
 def critic_forward_slabs(cw: CriticWeights, counts, time_rows):
     """counts (S, N, R) fp32 contiguous = [frame][node][env] with R % 128 == 0 -> value (S*R,) in (frame, env) order;
     ``time_rows`` (S,) is each frame's clock."""

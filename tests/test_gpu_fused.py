@@ -209,3 +209,47 @@ def test_rollout_launcher_equals_frame_loop(ops, B, T):
     assert torch.equal(ch1, ch2) and torch.equal(lp1, lp2) and torch.equal(rw1, rw2) and torch.equal(ct1[1:], ct2[1:])
     assert torch.equal(e1.x, e2.x) and torch.equal(e1.agents, e2.agents) and e1.time == e2.time
     assert float(rw1.abs().sum()) > 0 or T < 5
+
+
+@pytest.mark.parametrize("W,H,B,T,A", [(5, 5, 5, 30, 700), (3, 3, 70, 7, 300), (8, 8, 3, 40, 1200), (12, 12, 2, 25, 3000)])
+def test_env_rollout_equals_frame_loop(ops, W, H, B, T, A):
+    """SimEngine.rollout_env (tarl_rollout_env: one workgroup per environment, records in LDS, all T frames in ONE
+    launch; 256-thread variant up to 512 roads, 1024-thread variant above) == T calls of frame_fused: actions, log-probs,
+    rewards, counts, exported state and agents bit-identical; a second rollout continues from the state it left, and a
+    frame-by-frame continuation after it agrees too (the packed records written back are complete)."""
+    from tarl_hip import synth
+    from tarl_hip.engine import SimEngine
+    net = synth.torus_network(W, H, heterogeneous=True, seed=3)
+    N = net.num_roads
+    pops = torch.stack([synth.population(A, N, seed=b, t0=21540, t1=21560) for b in range(B)])
+    mk = lambda: SimEngine(dev(net.x.unsqueeze(0).repeat(B, 1, 1)), net.edge_index, net.edge_attr, net.Nmax,
+                           dev(pops.clone()), congestion_constant=net.congestion_constant, seed=9)
+    e1, e2 = mk(), mk()
+    assert e2.env_rollout_supported
+    emb = torch.randn(N, generator=torch.Generator().manual_seed(5)).cuda()
+    ch1, lp1, rw1 = (torch.zeros((T, N, B), dtype=torch.int32, device="cuda"), torch.zeros((T, B), device="cuda"),
+                     torch.zeros((T, B), device="cuda"))
+    ct1 = torch.zeros((T + 1, N, B), device="cuda")
+    ch2, lp2, rw2 = (torch.zeros((T, B, N), dtype=torch.int32, device="cuda"), torch.zeros((T, B), device="cuda"),
+                     torch.zeros((T, B), device="cuda"))
+    ct2 = torch.zeros((T + 1, B, N), device="cuda")
+    for e in (e1, e2):
+        e.reset()
+        e.prepare_policy(emb)
+    for rep in range(2):
+        for t in range(T):
+            e1.frame_fused(choice=ch1[t], log_prob=lp1[t], reward=rw1[t], counts=ct1[t + 1])
+        times = e2.rollout_env(T, choice=ch2, log_prob=lp2, reward=rw2, counts=ct2)
+        assert len(times) == T + 1 and e1.time == e2.time
+        assert torch.equal(ch1.permute(0, 2, 1), ch2), f"actions (rollout {rep})"
+        assert torch.equal(lp1, lp2) and torch.equal(rw1, rw2), f"log-prob / reward (rollout {rep})"
+        assert torch.equal(ct1[1:].permute(0, 2, 1), ct2[1:]), f"counts (rollout {rep})"
+        assert torch.equal(e1.x, e2.x) and torch.equal(e1.agents, e2.agents), f"state / agents (rollout {rep})"
+    assert float(rw1.abs().sum()) > 0
+    ca, cb = torch.zeros_like(ch1[0]), torch.zeros_like(ch1[0])
+    ra, rb = torch.zeros(B, device="cuda"), torch.zeros(B, device="cuda")
+    for t in range(5):      # hand the state back to the four-launch path
+        e1.frame_fused(choice=ca, reward=ra)
+        e2.frame_fused(choice=cb, reward=rb)
+        assert torch.equal(ca, cb) and torch.equal(ra, rb)
+    assert torch.equal(e1.x, e2.x) and torch.equal(e1.agents, e2.agents)
