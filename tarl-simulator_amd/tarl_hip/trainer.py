@@ -22,7 +22,7 @@ from .flatparams import FlatParams
 class VecPPOTrainer:
     def __init__(self, engine, emb_param, critic_params, *, rollout_steps, num_epochs=1, sub_batch_size=32, lr=1e-3,
                  gamma=0.99, lmbda=0.95, clip_epsilon=0.2, entropy_coef=0.01, critic_coef=1.0, temperature=1.0,
-                 extra_params=(), seed=0, lazy_log_prob=False, rank_offset=True):
+                 extra_params=(), seed=0, lazy_log_prob=False, rank_offset=True, rollout=None):
         """``emb_param``: nn.Parameter (num_nodes, 1) — MPNNPolicyNet.nodes_embedding.weight;
         ``critic_params``: [w1 (64,N+1), b1, w2 (64,64), b2, w3 (1,64), b3] — MPNNValueNetSimple.final_mlp.{0,2,4};
         ``extra_params``: further actor/critic parameters that never receive gradient on the live path (the dormant
@@ -45,8 +45,24 @@ class VecPPOTrainer:
         # replicas start identical: rank 0's initial weights win
         dist_utils.broadcast_(self.flat.flat, src=0)
         B, N, dev = engine.B, engine.N, engine.device
-        # rollout buffers; on the fused path they are ENV-MINOR ([frame][node][env]), written directly by the kernels
-        self.env_minor = engine.fs is not None
+        # which rollout kernel family: "env" = one workgroup per environment, records in LDS, one launch for all frames
+        # (tarl_rollout_env; env-major buffers), "frames" = four env-minor launches per frame (tarl_fused_rollout).
+        # Default (TARL_ROLLOUT or "auto"): "env" when the graph fits a CU's LDS AND B * N <= 800k (node, environment)
+        # pairs — measured crossover on MI355X: N = 256: env 2.1x at B = 1, 2.7x at B = 256, 1.5x at B = 2048, tie at
+        # 8192; N = 1024, B = 1024: frames 1.24x; N = 2500: env +19 % at B = 256, frames +13 % at B = 512. One environment
+        # keeps one CU busy for the whole frame; the four-launch path spreads the same work over the chip but needs
+        # enough environments to fill its lanes and hide four dependent launches.
+        import os
+        mode = rollout or os.environ.get("TARL_ROLLOUT", "auto")
+        if engine.fs is None:
+            mode = "unfused"
+        elif mode == "auto":
+            mode = "env" if (engine.env_rollout_supported and engine.B * engine.N <= 800_000) else "frames"
+        elif mode == "env" and not engine.env_rollout_supported:
+            raise ValueError("rollout='env' needs a graph whose hot records fit the LDS (tarl_rollout_env_supported)")
+        self.rollout = mode
+        # rollout buffers, written directly by the kernels: ENV-MINOR ([frame][node][env]) for "frames"
+        self.env_minor = mode == "frames"
         shp = (lambda t: (t, N, B)) if self.env_minor else (lambda t: (t, B, N))
         self.counts = torch.zeros(shp(self.T + 1), dtype=torch.float32, device=dev)
         self.choice = torch.zeros(shp(self.T), dtype=torch.int32, device=dev)
@@ -85,9 +101,9 @@ class VecPPOTrainer:
             # sample_log_prob is only ever read for the <= sub_batch_size frames of each minibatch: keep the behaviour
             # policy's parameters and evaluate it (exactly, with the unfused kernel) for those frames at update time
             self.emb_rollout = emb.clone()
-            host_times = eng.rollout_fused(self.T, choice=self.choice,
-                                           log_prob=None if self.lazy_log_prob else self.logp, reward=self.reward,
-                                           counts=self.counts)
+            run = eng.rollout_env if self.rollout == "env" else eng.rollout_fused
+            host_times = run(self.T, choice=self.choice, log_prob=None if self.lazy_log_prob else self.logp,
+                             reward=self.reward, counts=self.counts)
             self.times.copy_(torch.tensor(host_times, dtype=torch.float32))
             return self.T * eng.B
         for t in range(self.T):
@@ -144,7 +160,7 @@ class VecPPOTrainer:
             counts_mb = self.counts[:T].view(T * B, N).index_select(0, idx)
             choice_mb = self.choice.view(T * B, N).index_select(0, idx)
         nf = eng.static_node_features[:1].expand(M, N, 7)
-        if self.env_minor and self.lazy_log_prob:   # behaviour log-prob of the sampled frames, rollout-time parameters
+        if eng.fs is not None and self.lazy_log_prob:   # behaviour log-prob of the sampled frames, rollout-time parameters
             p_old = ops.graphdist_softmax(eng.plan, ops.policy_edge_logits(eng.plan, nf, self.emb_rollout),
                                           self.temperature)
             lp_old, _ = ops.graphdist_logprob_entropy(eng.plan, p_old, choice=choice_mb, want_entropy=False)

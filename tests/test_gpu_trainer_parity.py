@@ -15,8 +15,9 @@ def close(a, b, what):
     assert err <= TOL * scale, f"{what}: max abs err {err:.3e} vs scale {scale:.3e}"
 
 
-@pytest.mark.parametrize("fused,lazy", [(True, False), (True, True), (False, False)])
-def test_ppo_update_matches_oracle_autograd(fused, lazy):
+@pytest.mark.parametrize("fused,lazy,rollout", [(True, False, "frames"), (True, True, "frames"), (True, False, "env"),
+                                                (True, True, "env"), (False, False, None)])
+def test_ppo_update_matches_oracle_autograd(fused, lazy, rollout):
     assert torch.cuda.is_available()
     from oracle import dist, nets, ppo
     from src.agents.mpnn_agent import MPNNPolicyNet, MPNNValueNetSimple
@@ -37,7 +38,8 @@ def test_ppo_update_matches_oracle_autograd(fused, lazy):
     crit = [l[0].weight, l[0].bias, l[2].weight, l[2].bias, l[4].weight, l[4].bias]
     tr = VecPPOTrainer(eng, pol.nodes_embedding.weight, crit, rollout_steps=T, num_epochs=1, sub_batch_size=M,
                        extra_params=[p for n, p in pol.named_parameters() if not n.startswith("nodes_embedding")],
-                       lazy_log_prob=lazy)
+                       lazy_log_prob=lazy, rollout=rollout)
+    assert tr.rollout == (rollout or "unfused")
     tr.keep_grad = True
     tr.collect()
     # ---- snapshot everything the update reads (CPU copies, reference (frame, env, node) order) ----
