@@ -75,10 +75,13 @@ enum { AG_ORIGIN = 0, AG_DEST = 1, AG_DEP = 2, AG_ARR = 3, AG_ON_WAY = 7, AG_DON
 #define TARL_CONGESTION_FILE 3.0f  // src/feature_helpers.py:54
 
 // ---- Philox4x32-10 (counter-based; one 128-bit block per call) ------------------------------------------------------
+#ifndef PHILOX_ROUNDS
+#define PHILOX_ROUNDS 10
+#endif
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t out[4]) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < PHILOX_ROUNDS; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
