@@ -1,0 +1,98 @@
+"""GPU: size-independent properties of the rollout at BASELINE config 4's FULL size (10 000 route edges, 2 500 roads,
+16 384 agents, 256 frames) — where the oracle is too slow to replay everything. Checked on both rollout kernels:
+  * batch independence: an environment's trajectory does not depend on which other environments share the launch
+    (Philox streams are indexed by the environment's seed, not by lanes) — env b of a batch == the same env run alone;
+  * determinism: the same seed gives the same bits, run after run;
+  * state invariants of the domain after every probe: FIFO counts within [0, MAX], every queued agent id unique and
+    marked ON_WAY, nobody DONE is still queued, ON_WAY >= queued (the reference's U-turn double pop can only lose queued
+    agents, DESIGN Q24), arrivals stamped within the episode, per-frame reward == -sum of the counts;
+  * the two kernels agree with each other at this size."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(B, seeds, seed=11):
+    from tarl_hip import synth
+    from tarl_hip.engine import SimEngine
+    net = synth.torus_network(25, 25)
+    N = net.num_roads
+    pops = torch.stack([synth.population(16384, N, seed=s) for s in seeds])
+    eng = SimEngine(net.x.cuda().unsqueeze(0).repeat(B, 1, 1).contiguous(), net.edge_index, net.edge_attr, net.Nmax,
+                    pops.cuda(), congestion_constant=net.congestion_constant, seed=seed)
+    eng.reset()
+    eng.prepare_policy(torch.randn(N, generator=torch.Generator().manual_seed(1)).cuda())
+    return net, eng
+
+
+def _rollout(eng, T, mode):
+    N, B = eng.N, eng.B
+    if mode == "env":
+        ch = torch.zeros((T, B, N), dtype=torch.int32, device="cuda")
+        ct = torch.zeros((T + 1, B, N), device="cuda")
+        run = eng.rollout_env
+    else:
+        ch = torch.zeros((T, N, B), dtype=torch.int32, device="cuda")
+        ct = torch.zeros((T + 1, N, B), device="cuda")
+        run = eng.rollout_fused
+    lp, rw = torch.zeros((T, B), device="cuda"), torch.zeros((T, B), device="cuda")
+    run(T, choice=ch, log_prob=lp, reward=rw, counts=ct)
+    if mode != "env":
+        ch, ct = ch.permute(0, 2, 1).contiguous(), ct.permute(0, 2, 1).contiguous()
+    return ch, lp, rw, ct
+
+
+def _check_invariants(net, eng, rw, ct):
+    Nmax = net.Nmax
+    x, ag = eng.x, eng.agents
+    n = x[:, :, 3 * Nmax + 1]
+    maxn = x[:, :, 3 * Nmax]
+    assert bool((n >= 0).all()) and bool((n <= maxn).all())
+    assert torch.equal(rw[-1], -n.sum(dim=1)) and torch.equal(ct[-1], n)
+    assert torch.equal(rw, -ct[1:].sum(dim=2))                        # every frame, not only the last
+    for b in range(eng.B):
+        ids = x[b, :, :Nmax]
+        slot = torch.arange(Nmax, device="cuda").unsqueeze(0)
+        live = ids[slot < n[b].unsqueeze(1)].long()                   # agent ids in the occupied FIFO prefixes
+        assert bool((live > 0).all()) and live.numel() == live.unique().numel(), "a queued agent appears twice"
+        assert bool((ag[b, live, 7] == 1).all()) and bool((ag[b, live, 8] == 0).all())
+        on_way = int(ag[b, :, 7].sum())
+        assert on_way >= live.numel()
+        done = ag[b, :, 8] == 1
+        assert bool((ag[b, done, 7] == 0).all())
+        if bool(done.any()):
+            assert bool((ag[b, done, 3] >= ag[b, done, 2]).all()) and float(ag[b, done, 3].max()) < eng.time
+    assert int(ag[:, :, 7].sum()) > 0
+
+
+@pytest.mark.parametrize("mode", ["frames", "env"])
+def test_full_size_batch_independence_determinism_invariants(mode):
+    assert torch.cuda.is_available()
+    T = 256
+    seeds = [3, 4, 5, 6, 7, 8]
+    net, eng = _engine(len(seeds), seeds)
+    ch, lp, rw, ct = _rollout(eng, T, mode)
+    _check_invariants(net, eng, rw, ct)
+    # determinism: a fresh engine with the same seeds reproduces every bit
+    _, eng2 = _engine(len(seeds), seeds)
+    ch2, lp2, rw2, ct2 = _rollout(eng2, T, mode)
+    assert torch.equal(ch, ch2) and torch.equal(lp, lp2) and torch.equal(rw, rw2) and torch.equal(ct, ct2)
+    assert torch.equal(eng.x, eng2.x) and torch.equal(eng.agents, eng2.agents)
+    # batch independence: environment 0 alone (same engine seed: the Philox streams are indexed by env id 0)
+    _, solo = _engine(1, seeds[:1])
+    ch1, lp1, rw1, ct1 = _rollout(solo, T, mode)
+    assert torch.equal(ch1[:, 0], ch[:, 0]) and torch.equal(lp1[:, 0], lp[:, 0]) and torch.equal(rw1[:, 0], rw[:, 0])
+    assert torch.equal(ct1[:, 0], ct[:, 0]) and torch.equal(solo.x[0], eng.x[0]) and torch.equal(solo.agents[0], eng.agents[0])
+
+
+def test_full_size_both_rollout_kernels_agree():
+    T = 256
+    seeds = [20, 21, 22]
+    net, e1 = _engine(3, seeds)
+    _, e2 = _engine(3, seeds)
+    a, b = _rollout(e1, T, "frames"), _rollout(e2, T, "env")
+    for u, v, what in zip(a, b, ("actions", "log-prob", "reward", "counts")):
+        assert torch.equal(u, v), what
+    assert torch.equal(e1.x, e2.x) and torch.equal(e1.agents, e2.agents)
+    _check_invariants(net, e2, b[2], b[3])
