@@ -251,9 +251,10 @@ int tarl_fused_export(const tarl_plan* plan, const tarl_fused* f, float* x, int6
  * tarl_fused_policy_prepare evaluates them once per parameter update — same arithmetic and reduction trees as
  * tarl_policy_edge_logits_fwd + tarl_graphdist_softmax + the cumsum of tarl_graphdist_sample +
  * tarl_graphdist_logprob_entropy_fwd — into per-edge tables in plan (CSR) order: thresholds [E] (fp32 inverse-CDF
- * thresholds), log_probs [E] (log(p + 1e-8)), entropy1 [1]; group_base: double scratch [num_groups + 1]. */
+ * thresholds), log_probs int64 [E] (log(p + 1e-8) in 2^-32 fixed point: the unit the frame kernels accumulate in),
+ * entropy1 [1]; group_base: double scratch [num_groups + 1]. */
 int tarl_fused_policy_prepare(const tarl_plan* plan, const tarl_fused* f, const float* emb, int64_t num_embeddings,
-                              float temperature, double* group_base, float* thresholds, float* log_probs,
+                              float temperature, double* group_base, float* thresholds, int64_t* log_probs,
                               float* entropy1, tarl_stream stream);
 /* tarl_fused_frame == one collector frame for B environments: GraphDistribution.sample() + log_prob() (+ entropy) and
  *   the choice phase, then tarl_core_step + tarl_withdraw_step + tarl_insert_step, in three launches.
@@ -263,7 +264,7 @@ int tarl_fused_policy_prepare(const tarl_plan* plan, const tarl_fused* f, const 
  *   log_prob sums the same terms as tarl_graphdist_logprob_entropy_fwd, accumulated in 2^-32 fixed point (order-
  *   independent, hence deterministic): equal to fp32 rounding, not bit-identical. use_cong = 0 reproduces a graph without congestion_constant in insert. */
 int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, const float* thresholds,
-                     const float* log_probs, const float* entropy1, const float* uniform, uint64_t policy_seed,
+                     const int64_t* log_probs, const float* entropy1, const float* uniform, uint64_t policy_seed,
                      uint64_t policy_counter, float* agent_features, int64_t num_agents, int64_t a_bstride,
                      const float* edge_attr, const float* log_edge_attr, float log_eps, int use_cong, float time,
                      const float* gumbel, uint64_t seed, uint64_t counter, float* delta_travel_time, uint8_t* popped,
@@ -277,7 +278,7 @@ int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int64_t B, int3
  *   entropy / reward fp32 [T][B]; choice, counts, log_prob, entropy, reward may be NULL.
  *   Scratch (device): ins_scratch int32 [B][2A]. */
 int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, int64_t T,
-                       const float* times_host, const float* thresholds, const float* log_probs, const float* entropy1,
+                       const float* times_host, const float* thresholds, const int64_t* log_probs, const float* entropy1,
                        uint64_t policy_seed, uint64_t policy_counter0, float* agent_features, int64_t num_agents,
                        int64_t a_bstride, const float* edge_attr, const float* log_edge_attr, float log_eps, int use_cong,
                        uint64_t seed, uint64_t counter0, int32_t* ins_scratch, int32_t* choice, float* log_prob,
@@ -292,7 +293,7 @@ int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, int64_t B, in
  *   Meant for the sizes where the four-launch frame is latency-bound, and the default rollout whenever it fits. */
 int tarl_rollout_env_supported(const tarl_plan* plan);
 int tarl_rollout_env(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, int64_t T,
-                     const float* times_dev, const float* thresholds, const float* log_probs, const float* entropy1,
+                     const float* times_dev, const float* thresholds, const int64_t* log_probs, const float* entropy1,
                      uint64_t policy_seed, uint64_t policy_counter0, float* agent_features, int64_t num_agents,
                      int64_t a_bstride, const float* edge_attr, const float* log_edge_attr, float log_eps, int use_cong,
                      uint64_t seed, uint64_t counter0, int32_t* ins_scratch, int32_t* choice, float* log_prob,

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(ENVB) void k_policy_tables(const int32_t* __restric
                                                         const int32_t* __restrict__ node_of_group, int64_t N, int64_t G,
                                                         const float* __restrict__ emb, int64_t M, float temperature,
                                                         const float4* __restrict__ st0, double* __restrict__ base,
-                                                        float* __restrict__ thr, float* __restrict__ lgt,
+                                                        float* __restrict__ thr, long long* __restrict__ lgt,
                                                         float* __restrict__ entropy_out) {
   __shared__ double s_wave[ENVB / 64];
   __shared__ float s_red[ENVB / 64];
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(ENVB) void k_policy_tables(const int32_t* __restric
       ent -= p * lg;
       run += (double)p;
       thr[k] = (float)run - bg32;
-      lgt[k] = lg;
+      lgt[k] = (long long)((double)lg * LP_FIX);   // the frame kernels only ever add it up in 2^-32 fixed point
     }
   }
   const float ent_t = fb_block_sum(ent, s_red);
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(TILE) void k_fused_choice(const int32_t* __restrict
                                                        const int32_t* __restrict__ out_eid,
                                                        const int32_t* __restrict__ group_of_node, int64_t G, int64_t B,
                                                        int64_t N, FusedBufs fb, const float* __restrict__ thr,
-                                                       const float* __restrict__ lgt,
+                                                       const long long* __restrict__ lgt,
                                                        const float* __restrict__ uniform, uint64_t pseed,
                                                        uint64_t pcounter, int32_t* __restrict__ choice, int nchunk,
                                                        int want_lp) {
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(TILE) void k_fused_choice(const int32_t* __restrict
       const int32_t k1 = out_ptr[i + 1];
       for (int32_t k = out_ptr[i]; k < k1; ++k) {
         const bool hit = !found && (u < thr[k]);
-        const long long lgk = (long long)((double)lgt[k] * LP_FIX);
+        const long long lgk = lgt[k];
         selv = hit ? (float)out_dst[k] : selv;
         ch = hit ? out_eid[k] : ch;
         lpn = hit ? lgk : lpn;
@@ -860,19 +860,19 @@ extern "C" int tarl_fused_export(const tarl_plan* plan, const tarl_fused* f, flo
 
 extern "C" int tarl_fused_policy_prepare(const tarl_plan* plan, const tarl_fused* f, const float* emb,
                                          int64_t num_embeddings, float temperature, double* group_base,
-                                         float* thresholds, float* log_probs, float* entropy1, tarl_stream stream) {
+                                         float* thresholds, int64_t* log_probs, float* entropy1, tarl_stream stream) {
   TARL_REQUIRE(plan && f && f->st0 && emb && group_base && thresholds && log_probs && entropy1, "null argument");
   TARL_REQUIRE(num_embeddings >= 1, "bad sizes");
   if (plan->N == 0) return TARL_OK;
   hipLaunchKernelGGL(k_policy_tables, dim3(1), dim3(ENVB), 0, (hipStream_t)stream, plan->out_ptr, plan->out_dst,
                      plan->node_of_group, plan->N, plan->G, emb, num_embeddings, temperature, (const float4*)f->st0,
-                     group_base, thresholds, log_probs, entropy1);
+                     group_base, thresholds, (long long*)log_probs, entropy1);
   TARL_LAUNCH_CHECK();
   return TARL_OK;
 }
 
 extern "C" int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax,
-                                const float* thresholds, const float* log_probs, const float* entropy1,
+                                const float* thresholds, const int64_t* log_probs, const float* entropy1,
                                 const float* uniform, uint64_t policy_seed, uint64_t policy_counter,
                                 float* agent_features, int64_t A, int64_t a_bstride, const float* edge_attr,
                                 const float* log_edge_attr, float log_eps, int use_cong, float time, const float* gumbel,
@@ -895,7 +895,7 @@ extern "C" int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int6
   const dim3 grid((unsigned)ceil_div(B, threads), (unsigned)num_chunks(plan));
   const dim3 grid_c((unsigned)ceil_div(B, threads), (unsigned)ceil_div(plan->N, nchunk_choice()));
   hipLaunchKernelGGL(k_fused_choice, grid_c, dim3(threads), 0, s, plan->out_ptr, plan->out_dst, plan->out_eid,
-                     plan->group_of_node, plan->G, B, plan->N, fb, thresholds, log_probs, uniform, policy_seed,
+                     plan->group_of_node, plan->G, B, plan->N, fb, thresholds, (const long long*)log_probs, uniform, policy_seed,
                      policy_counter, choice, nchunk_choice(), log_prob != nullptr ? 1 : 0);
   TARL_LAUNCH_CHECK();
   const bool timed = tarl_prof_event(s) != nullptr;
@@ -921,7 +921,7 @@ extern "C" int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int6
 // accumulators. Both lose the producer -> consumer adjacency that lets the Direction kernel read the 20 MB the choice
 // kernel just wrote from the Infinity Cache.)
 extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, int64_t T,
-                                  const float* times_host, const float* thresholds, const float* log_probs,
+                                  const float* times_host, const float* thresholds, const int64_t* log_probs,
                                   const float* entropy1, uint64_t policy_seed, uint64_t policy_counter0,
                                   float* agent_features, int64_t A, int64_t a_bstride, const float* edge_attr,
                                   const float* log_edge_attr, float log_eps, int use_cong, uint64_t seed,
@@ -949,7 +949,7 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
   for (int64_t t = 0; t < T; ++t) {
     const float time = times_host[t];
     hipLaunchKernelGGL(k_fused_choice, grid_c, dim3(threads), 0, s, plan->out_ptr, plan->out_dst, plan->out_eid,
-                       plan->group_of_node, plan->G, B, N, fb, thresholds, log_probs, (const float*)nullptr, policy_seed,
+                       plan->group_of_node, plan->G, B, N, fb, thresholds, (const long long*)log_probs, (const float*)nullptr, policy_seed,
                        policy_counter0 + (uint64_t)t, choice ? choice + t * NB : nullptr, nchunk_choice(), want_lp);
     TARL_LAUNCH_CHECK();
     const bool timed = tarl_prof_event(s) != nullptr;

@@ -66,7 +66,7 @@ __device__ __forceinline__ long long re_block_sum_ll(long long v, long long* s_r
 template <int RE_THREADS>
 __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B, int Nmax, FusedBufs fb,
                                                             const float* __restrict__ thr,
-                                                            const float* __restrict__ lgt,
+                                                            const long long* __restrict__ lgt,
                                                             const float* __restrict__ entropy1,
                                                             const float* __restrict__ edge_attr,
                                                             const float* __restrict__ log_edge_attr, float log_eps,
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
             if (hit) {
               selv = (float)P.out_dst[k];
               ch = P.out_eid[k];
-              lpn = (long long)((double)lgt[k] * LP_FIX);
+              lpn = lgt[k];
             }
             found = found || hit;
           }
@@ -492,7 +492,7 @@ extern "C" int tarl_rollout_env_supported(const tarl_plan* plan) {
 }
 
 extern "C" int tarl_rollout_env(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, int64_t T,
-                                const float* times_dev, const float* thresholds, const float* log_probs,
+                                const float* times_dev, const float* thresholds, const int64_t* log_probs,
                                 const float* entropy1, uint64_t policy_seed, uint64_t policy_counter0,
                                 float* agent_features, int64_t A, int64_t a_bstride, const float* edge_attr,
                                 const float* log_edge_attr, float log_eps, int use_cong, uint64_t seed,
@@ -517,7 +517,7 @@ extern "C" int tarl_rollout_env(const tarl_plan* plan, const tarl_fused* f, int6
   const EnvOut out{choice, log_prob, entropy, reward, counts};
   if (plan->N <= 512) {
     hipLaunchKernelGGL(k_rollout_env<256>, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, P, B, (int)Nmax,
-                       tarl_to_bufs(f), thresholds, log_probs, entropy1, edge_attr, log_edge_attr, log_eps, use_cong,
+                       tarl_to_bufs(f), thresholds, (const long long*)log_probs, entropy1, edge_attr, log_edge_attr, log_eps, use_cong,
                        policy_seed, policy_counter0, seed, counter0, T, times_dev, agent_features, A, a_bstride,
                        ins_scratch, out);
   } else {
@@ -528,7 +528,7 @@ extern "C" int tarl_rollout_env(const tarl_plan* plan, const tarl_fused* f, int6
       lds_set = lds;
     }
     hipLaunchKernelGGL(k_rollout_env<1024>, dim3((unsigned)B), dim3(1024), lds, (hipStream_t)stream, P, B, (int)Nmax,
-                       tarl_to_bufs(f), thresholds, log_probs, entropy1, edge_attr, log_edge_attr, log_eps, use_cong,
+                       tarl_to_bufs(f), thresholds, (const long long*)log_probs, entropy1, edge_attr, log_edge_attr, log_eps, use_cong,
                        policy_seed, policy_counter0, seed, counter0, T, times_dev, agent_features, A, a_bstride,
                        ins_scratch, out);
   }

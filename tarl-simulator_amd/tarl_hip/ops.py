@@ -548,7 +548,7 @@ class PolicyTables:
 
     def __init__(self, plan: Plan, device):
         self.thresholds = torch.empty(plan.num_edges, dtype=torch.float32, device=device)
-        self.log_probs = torch.empty(plan.num_edges, dtype=torch.float32, device=device)
+        self.log_probs = torch.empty(plan.num_edges, dtype=torch.int64, device=device)   # 2^-32 fixed point
         self.entropy = torch.empty(1, dtype=torch.float32, device=device)
         self.base = torch.empty(plan.num_groups + 1, dtype=torch.float64, device=device)
 
