@@ -1,5 +1,7 @@
-"""Unified entry point (reference: main.py) — same flags, plus ``--steps`` (used by the reference's README but missing
-from its CLI) and ``--num-envs`` (vectorised environments per GPU)."""
+"""Command line of the MI355X build. The flag set is the reference CLI's contract (main.py of the reference: --algo,
+--scenario, --mode, --timestep_size, --start-end-time, --epochs, --rollout-steps, --seed, --device, --output-dir,
+--profile, --torch-compile) plus ``--steps`` (used by the reference's README but missing from its parser) and
+``--num-envs`` (vectorised environments per GPU)."""
 import argparse
 import os
 import sys
@@ -8,28 +10,40 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from src.runner import Runner, RunnerArgs  # noqa: E402
 
+ALGOS = ("dijkstra", "random", "mpnn", "mpnn+ppo")
+
+# (flag, argparse keyword arguments)
+OPTIONS = (
+    ("--algo", dict(choices=ALGOS, default="dijkstra", help="routing agent")),
+    ("--scenario", dict(type=str, default="Easy",
+                        help="data/<scenario>/ (MATSim XML), save/<scenario>/ cache, or synthetic-<edges>-<agents>[-seed]")),
+    ("--mode", dict(choices=("eval", "train"), default="eval")),
+    ("--timestep_size", dict(type=int, default=1, help="seconds per simulation step")),
+    ("--start-end-time", dict(type=int, nargs=2, default=[0, 86400], metavar=("START", "END"))),
+    ("--epochs", dict(type=int, default=1, help="PPO minibatch steps on the collected batch")),
+    ("--rollout-steps", dict(type=int, default=32, help="frames collected per environment")),
+    ("--seed", dict(type=int, default=0)),
+    ("--device", dict(type=str, default="cpu", help="kept for compatibility: the path always runs on the GPU")),
+    ("--output-dir", dict(type=str, default="runs")),
+    ("--profile", dict(action="store_true")),
+    ("--torch-compile", dict(action="store_true", help="accepted and ignored: the kernels are hand-written HIP")),
+    ("--steps", dict(type=int, default=None, help="number of eval steps (overrides start/end time)")),
+    ("--num-envs", dict(type=int, default=1, help="vectorised environments per GPU for mpnn+ppo training")),
+)
+
+
+def build_parser() -> argparse.ArgumentParser:
+    parser = argparse.ArgumentParser(description="TARL routing experiments on MI355X (classical agents, MPNN policy, PPO)")
+    for flag, kw in OPTIONS:
+        parser.add_argument(flag, **kw)
+    return parser
+
 
 def main(argv=None):
-    p = argparse.ArgumentParser(description="Unified runner for classical and RL experiments (MI355X hot path)")
-    p.add_argument("--algo", choices=["dijkstra", "random", "mpnn", "mpnn+ppo"], default="dijkstra")
-    p.add_argument("--scenario", type=str, default="Easy",
-                   help="save/<scenario>/ cache of the reference, or synthetic-<edges>-<agents>[-seed]")
-    p.add_argument("--mode", choices=["eval", "train"], default="eval")
-    p.add_argument("--timestep_size", type=int, default=1)
-    p.add_argument("--start-end-time", type=int, nargs=2, default=[0, 86400])
-    p.add_argument("--epochs", type=int, default=1)
-    p.add_argument("--rollout-steps", type=int, default=32)
-    p.add_argument("--seed", type=int, default=0)
-    p.add_argument("--device", type=str, default="cpu")
-    p.add_argument("--output-dir", type=str, default="runs")
-    p.add_argument("--profile", action="store_true")
-    p.add_argument("--torch-compile", action="store_true")
-    p.add_argument("--steps", type=int, default=None, help="number of eval steps (overrides start/end time)")
-    p.add_argument("--num-envs", type=int, default=1, help="vectorised environments per GPU for mpnn+ppo training")
-    args = p.parse_args(argv)
-    runner = Runner(RunnerArgs(**vars(args)))
+    ns = build_parser().parse_args(argv)
+    runner = Runner(RunnerArgs(**vars(ns)))
     runner.setup()
-    if args.mode == "train":
+    if ns.mode == "train":
         runner.train()
     runner.eval()
 
