@@ -195,6 +195,22 @@ int tarl_critic_mlp_fwd_slabs(const float* counts, int64_t rows_per_slab, int64_
                               int64_t rows_per_time, const float* w1, const float* b1, const float* w2, const float* b2,
                               const float* w3, const float* b3, float* value, tarl_stream stream);
 
+/* ---- MPNNValueNet (src/agents/mpnn_agent.py:265-402; the message-passing critic the reference defines but never
+ * instantiates) in evaluation mode (Dropout = identity), M samples:
+ *   value[m] = W_f . [tanh(w_n * mean_{e=(u->v)} tanh(W_m . [node_features[m][v] (7), agent_rows[m][v] (9), edge_features[m][e]] + b_m) + b_n) for u, time_net(time[m])] + b_f
+ * node_features [M][N][7]; agent_rows [M][N][9] = agent_features[agent_index] gathered by the caller (NULL: zeros);
+ * edge_features [M][E] with stride ef_mstride (0 = shared); time [M].
+ * params / grads: HOST arrays of 12 device pointers in the order message_mlp.1.{weight [17], bias}, node_mlp.0.{weight,
+ * bias}, final_mlp.0.{weight [N+1], bias}, time_net.0.{weight [32], bias [32]}, time_net.3.{weight [32][32], bias [32]},
+ * time_net.6.{weight [32], bias}. fwd optionally saves node_act / agg [M][N] (needed by bwd). bwd ACCUMULATES into grads. */
+int tarl_value_mpnn_fwd(const tarl_plan* plan, const float* node_features, int64_t M, const float* agent_rows,
+                        const float* edge_features, int64_t ef_mstride, const float* time, const float* const* params,
+                        float* value, float* node_act, float* agg, tarl_stream stream);
+int tarl_value_mpnn_bwd(const tarl_plan* plan, const float* node_features, int64_t M, const float* agent_rows,
+                        const float* edge_features, int64_t ef_mstride, const float* time, const float* const* params,
+                        const float* grad_value, const float* node_act, const float* agg, float* const* grads,
+                        tarl_stream stream);
+
 /* ---- fused rollout frame (vectorised fast path; same results as the entry points above, 3 launches per frame) ----------
  * ENV-MINOR layout: every per-(node, environment) buffer is stored [node][environment], so that a wavefront holds 64
  * environments of one node: topology / table loads are wave-uniform and record gathers are coalesced.

@@ -337,6 +337,33 @@ def gen_nets():
          **{k.replace(".", "__"): v for k, v in sd.items()})
 
 
+def gen_value_mpnn():
+    """MPNNValueNet (src/agents/mpnn_agent.py:265-402), the message-passing critic the reference defines but never
+    instantiates, in eval mode (Dropout = identity): unbatched and batched forward with its own random weights."""
+    from src.agents.mpnn_agent import MPNNValueNet
+    net = synth.torus_network(3, 2, heterogeneous=True, seed=4)
+    R = net.num_roads
+    torch.manual_seed(21)
+    val = MPNNValueNet(net.edge_index, R, device="cpu")
+    val.agent_features = synth.population(60, R, seed=2)
+    val.eval()
+    x = synth.random_state(net, seed=14, t=30.0, num_agents=60)
+    node_features = x[:, 3 * net.Nmax:]
+    agent_index = x[:, 0].long().clamp(max=60)
+    time = torch.tensor([21600.0])
+    with torch.no_grad():
+        value = val(node_features, net.edge_attr, agent_index, time)
+        nb = torch.stack([node_features, node_features.flip(0) * 1.0, node_features * 0.5])
+        ab = torch.stack([agent_index, agent_index.flip(0), agent_index])
+        tb = torch.tensor([[21600.0], [21700.0], [30000.0]])
+        eb = torch.stack([net.edge_attr, net.edge_attr * 2.0, net.edge_attr])
+        value_b = val(nb, eb, ab, tb)
+    save("value_mpnn", edge_index=net.edge_index, edge_attr=net.edge_attr, node_features=node_features,
+         agent_index=agent_index, agent_features=val.agent_features, time=time, value=value, node_features_b=nb,
+         agent_index_b=ab, time_b=tb, edge_attr_b=eb, value_b=value_b,
+         **{k.replace(".", "__"): v for k, v in val.state_dict().items()})
+
+
 from make_golden_fixtures import EQUIL_NETWORK_XML, EQUIL_POPULATION_XML, SIMPLE_NETWORK_XML  # noqa: E402
 
 
@@ -471,5 +498,6 @@ if __name__ == "__main__":
     gen_graphdist()
     gen_env_rollout()
     gen_nets()
+    gen_value_mpnn()
     gen_builders()
     gen_routing()

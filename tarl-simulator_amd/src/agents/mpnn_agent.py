@@ -112,6 +112,70 @@ class _CriticMLP(torch.autograd.Function):
         return None, None, grads[0], grads[1], grads[2], grads[3], grads[4].view(ctx.w3_shape), grads[5]
 
 
+class _ValueMPNN(torch.autograd.Function):
+    """MPNNValueNet forward / backward on the HIP kernels (tarl_value_mpnn_{fwd,bwd}); gradients for the 12 parameters."""
+
+    @staticmethod
+    def forward(ctx, plan, nf, ar, ef, tm, *params):
+        from tarl_hip import ops
+        value, act, agg = ops.value_mpnn_forward(plan, nf, ar, ef, tm, params, keep=True)
+        ctx.plan, ctx.saved, ctx.params = plan, (nf, ar, ef, tm, act, agg), params
+        return value
+
+    @staticmethod
+    def backward(ctx, grad_value):
+        from tarl_hip import ops
+        nf, ar, ef, tm, act, agg = ctx.saved
+        grads = ops.value_mpnn_backward(ctx.plan, nf, ar, ef, tm, ctx.params, grad_value.contiguous(), act, agg)
+        return (None, None, None, None, None) + tuple(g.view_as(p) for g, p in zip(grads, ctx.params))
+
+
+class MPNNValueNet(MessagePassingBase, Agents):
+    """The message-passing critic of the reference (src/agents/mpnn_agent.py:265-402; never instantiated by its runner):
+    per-edge message tanh(Linear(17,1)), mean over a road's out-edges, tanh(Linear(1,1)), a 1-32-32-1 time MLP and a
+    final Linear(N+1, 1). Same module tree / state-dict keys. The Dropout(0.05) layers are kept in the tree but the
+    kernels implement evaluation-mode semantics (identity); ``forward`` refuses training-mode dropout explicitly."""
+
+    def __init__(self, edge_index, num_nodes, device):
+        Agents.__init__(self, device=device)
+        MessagePassingBase.__init__(self, aggr="mean", flow="target_to_source")
+        self.edge_index = edge_index
+        self.num_nodes = num_nodes
+        self.num_edges = edge_index.size(1)
+        self.dim_nodes_features = 16
+        self.dim_edges_features = 1
+        self.message_mlp = nn.Sequential(nn.Dropout(0.05), nn.Linear(17, 1), nn.Tanh())
+        self.node_mlp = nn.Sequential(nn.Linear(1, 1), nn.Tanh())
+        self.final_mlp = nn.Sequential(nn.Linear(num_nodes + 1, 1))
+        self.time_net = nn.Sequential(nn.Linear(1, 32), nn.Dropout(0.05), nn.ReLU(), nn.Linear(32, 32), nn.Dropout(0.05),
+                                      nn.ReLU(), nn.Linear(32, 1))
+        self.to(device)
+
+    def _params(self):
+        m, n, f, t = self.message_mlp[1], self.node_mlp[0], self.final_mlp[0], self.time_net
+        return (m.weight, m.bias, n.weight, n.bias, f.weight, f.bias, t[0].weight, t[0].bias, t[3].weight, t[3].bias,
+                t[6].weight, t[6].bias)
+
+    def forward(self, node_features, edge_features, agent_index, time):
+        """node_features (N,7) or (B,N,7); edge_features (E,1) or (B,E,1); agent_index (N,) or (B,N); time (1,) or
+        (B,1) -> (1,) or (B,1)."""
+        require_cuda(node_features, "node_features")
+        if self.training:
+            raise RuntimeError("MPNNValueNet runs with evaluation-mode dropout only: call .eval() (the kernels implement "
+                               "Dropout as the identity)")
+        batched = node_features.dim() == 3
+        nf = node_features.reshape(-1, self.num_nodes, node_features.size(-1)).to(torch.float32).contiguous()
+        M = nf.size(0)
+        ar = None
+        if self.agent_features is not None:
+            ar = self.agent_features[agent_index.reshape(M, self.num_nodes).long()].to(torch.float32).contiguous()
+        ef = edge_features.reshape(-1, self.num_edges).to(torch.float32).contiguous()
+        tm = time.reshape(-1).to(torch.float32).contiguous()
+        plan = cached_plan(self.edge_index, self.num_nodes)
+        v = _ValueMPNN.apply(plan, nf, ar, ef, tm, *self._params())
+        return v.view(M, 1) if batched else v.view(1)
+
+
 class MPNNValueNetSimple(MessagePassingBase, Agents):
     """Critic actually used by the runner: ``final_mlp`` = Linear(N+1,64)-ReLU-Linear(64,64)-ReLU-Linear(64,1)."""
 

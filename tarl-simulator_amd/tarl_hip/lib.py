@@ -43,6 +43,8 @@ SIGNATURES = {
     "tarl_policy_edge_logits_bwd": (C.c_int, [_p, _p, _i64, _i64, _i64, _p, _p, _i64, _p]),
     "tarl_critic_mlp_fwd": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64] + [_p] * 6 + [_p, _p, _p, _p]),
     "tarl_critic_mlp_bwd": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64] + [_p] * 3 + [_p, _p, _p, _p] + [_p] * 6 + [_p]),
+    "tarl_value_mpnn_fwd": (C.c_int, [_p, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
+    "tarl_value_mpnn_bwd": (C.c_int, [_p, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p]),
     "tarl_gae": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _f32, _f32, _p, _p, _p]),
     "tarl_advantage_stats": (C.c_int, [_p, _i64, _p, _p, _p]),
     "tarl_advantage_normalize": (C.c_int, [_p, _i64, _p, _p]),

@@ -618,6 +618,51 @@ def fused_rollout(plan: Plan, fs: FusedState, tables: PolicyTables, agent_featur
                                     _lib.ptr(entropy), _lib.ptr(reward), _lib.ptr(counts), _lib.current_stream()))
 
 
+# ---- MPNNValueNet (dormant message-passing critic) ---------------------------------------------------------------------------
+def _ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+def value_mpnn_forward(plan: Plan, node_features, agent_rows, edge_features, time, params, *, keep=False):
+    """``node_features`` (M, N, 7), ``agent_rows`` (M, N, 9) or None, ``edge_features`` (M, E) or (E,), ``time`` (M,),
+    ``params`` = the 12 parameter tensors in tarl_value_mpnn_fwd's order -> value (M,) [+ node_act, agg (M, N)]."""
+    L = _lib.load()
+    M, N = node_features.size(0), node_features.size(1)
+    if N != plan.num_nodes or node_features.size(2) != 7:
+        raise ValueError("node_features must be (M, num_nodes, 7)")
+    nf = _contig(node_features, torch.float32, "node_features")
+    ar = None if agent_rows is None else _contig(agent_rows, torch.float32, "agent_rows")
+    ef = _contig(edge_features, torch.float32, "edge_features")
+    ef_stride = 0 if ef.dim() == 1 or ef.size(0) == 1 else plan.num_edges
+    tm = _contig(time, torch.float32, "time")
+    ps = [_contig(p.detach(), torch.float32, "param") for p in params]
+    value = torch.empty(M, dtype=torch.float32, device=nf.device)
+    act = torch.empty((M, N), dtype=torch.float32, device=nf.device) if keep else None
+    agg = torch.empty((M, N), dtype=torch.float32, device=nf.device) if keep else None
+    _lib.check(L.tarl_value_mpnn_fwd(plan.handle, nf.data_ptr(), M, _lib.ptr(ar), ef.data_ptr(), ef_stride, tm.data_ptr(),
+                                     _ptr_array(ps), value.data_ptr(), _lib.ptr(act), _lib.ptr(agg),
+                                     _lib.current_stream()))
+    return value, act, agg
+
+
+def value_mpnn_backward(plan: Plan, node_features, agent_rows, edge_features, time, params, grad_value, act, agg):
+    """Parameter gradients (list of 12 tensors shaped like ``params``) of sum(grad_value * value)."""
+    L = _lib.load()
+    M = node_features.size(0)
+    nf = _contig(node_features, torch.float32, "node_features")
+    ar = None if agent_rows is None else _contig(agent_rows, torch.float32, "agent_rows")
+    ef = _contig(edge_features, torch.float32, "edge_features")
+    ef_stride = 0 if ef.dim() == 1 or ef.size(0) == 1 else plan.num_edges
+    ps = [_contig(p.detach(), torch.float32, "param") for p in params]
+    grads = [torch.zeros_like(p) for p in ps]
+    gv = _contig(grad_value, torch.float32, "grad_value")
+    _lib.check(L.tarl_value_mpnn_bwd(plan.handle, nf.data_ptr(), M, _lib.ptr(ar), ef.data_ptr(), ef_stride,
+                                     _contig(time, torch.float32, "time").data_ptr(), _ptr_array(ps), gv.data_ptr(),
+                                     act.data_ptr(), agg.data_ptr(), _ptr_array(grads), _lib.current_stream()))
+    return grads
+
+
 def rollout_env_supported(plan: Plan) -> bool:
     return bool(_lib.load().tarl_rollout_env_supported(plan.handle))
 
