@@ -12,20 +12,8 @@ RTOL = 1e-5
 
 
 def _torch_reference(sd, edge_index, agent_features, nf, ef, ai, tm):
-    """Plain torch restatement: (M,N,7), (M,E), (M,N), (M,) -> (M,)."""
-    M, N = nf.shape[:2]
-    x = torch.cat([nf, agent_features[ai.long()]], dim=-1)                                # (M, N, 16)
-    src, dst = edge_index
-    msg_in = torch.cat([x[:, dst], ef.unsqueeze(-1)], dim=-1)                              # (M, E, 17)
-    m = torch.tanh(msg_in @ sd["message_mlp.1.weight"].t() + sd["message_mlp.1.bias"]).squeeze(-1)
-    summ = torch.zeros((M, N)).index_add_(1, src, m)
-    deg = torch.zeros(N).index_add_(0, src, torch.ones(src.numel()))
-    a = torch.where(deg > 0, summ / deg.clamp(min=1), torch.zeros_like(summ))
-    nd = torch.tanh(a * sd["node_mlp.0.weight"].view(()) + sd["node_mlp.0.bias"].view(()))
-    h = torch.relu(tm.view(M, 1) @ sd["time_net.0.weight"].t() + sd["time_net.0.bias"])
-    h = torch.relu(h @ sd["time_net.3.weight"].t() + sd["time_net.3.bias"])
-    te = h @ sd["time_net.6.weight"].t() + sd["time_net.6.bias"]
-    return (torch.cat([nd, te], dim=1) @ sd["final_mlp.0.weight"].t() + sd["final_mlp.0.bias"]).view(M)
+    from oracle import nets
+    return nets.value_mpnn(sd, edge_index, agent_features, nf, ef, ai, tm)
 
 
 def _module(g):

@@ -257,3 +257,17 @@ def test_dijkstra_choice_and_prior_on_torus_vs_reference():
     assert torch.equal(dist, g["torus__dist_matrix"])
     prior = -dist[net.edge_index[1], g["torus__prior_dest"]] - g["torus__ff_edges"]
     assert torch.equal(prior, g["torus__prior_logits"])
+
+
+def test_value_mpnn_oracle_vs_reference():
+    """MPNNValueNet (the reference's dormant message-passing critic, eval mode): oracle restatement vs the reference's
+    own class with the same weights — unbatched and batched."""
+    from oracle import nets
+    g = load_golden("value_mpnn")
+    sd = {k.replace("__", "."): v for k, v in g.items() if "__" in k}
+    v = nets.value_mpnn(sd, g["edge_index"], g["agent_features"], g["node_features"].unsqueeze(0),
+                        g["edge_attr"].view(1, -1), g["agent_index"].unsqueeze(0), g["time"].view(-1))
+    assert torch.allclose(v, g["value"], rtol=1e-6, atol=1e-7)
+    vb = nets.value_mpnn(sd, g["edge_index"], g["agent_features"], g["node_features_b"], g["edge_attr_b"].squeeze(-1),
+                         g["agent_index_b"], g["time_b"].view(-1))
+    assert torch.allclose(vb, g["value_b"].view(-1), rtol=1e-6, atol=1e-7)
