@@ -227,6 +227,10 @@ def test_ppo_train_and_runner_end_to_end(tmp_path, monkeypatch, capsys):
     import json
     logs = [json.loads(l) for l in open(tmp_path / "run" / "train_log.jsonl")]
     assert logs and all(math.isfinite(v) for v in logs[-1].values())
+    for tag in ("PPO/avg_episode_return", "loss/objective", "loss/value", "loss/entropy", "loss/total", "approx_kl",
+                "clip_fraction", "grad_global_norm", "transport/avg_vc_ratio", "transport/std_vc_ratio"):
+        assert tag in logs[-1], tag                       # the scalar tags of the reference's _log_training (:60-88)
+    assert logs[-1]["grad_global_norm"] > 0
     torch.manual_seed(1)
     from src.agents.mpnn_agent import MPNNPolicyNet
     fresh = MPNNPolicyNet(r.policy_net.edge_index, r.policy_net.num_nodes, None, device="cuda")
