@@ -15,7 +15,9 @@ region. The timed region is bracketed by barrier + synchronize on both sides; th
 
 Also reported on the same JSON line:
   roofline      — the Direction message+aggregate kernel (the scatter kernel named by the north star): algorithmic bytes
-                  per launch / average launch duration measured live with HIP events on the launch stream, vs 8 TB/s.
+                  per launch / average launch duration measured live with HIP events on the launch stream (the T frames
+                  of the first timed iteration), vs 8 TB/s; roofline_row_pass: the same for the row pass (Direction
+                  update + Response + withdraw), the kernel with the largest share of a frame.
   cpu_baseline  — the oracle (CPU restatement of the reference path, torch CPU) timed on this host's cores on a bounded
                   sample of the same workload (rank 0, N=1 only). A reported baseline, not a target.
 """
@@ -41,6 +43,11 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 T
 # HBM (parity mode) + 4 when delta_travel_time is materialised. The bench draws noise in-kernel and skips dtt -> 52.
 DIR_BYTES_PER_EDGE = 52.0
 DIR_BYTES_PER_NODE = 4.0  # chosen[] out
+# Row pass = DirectionMPNN.update (32 B/node: max, n, ff, cong in; id, arr, dep, n out) + ResponseMPNN message+aggregate
+# (24 B/edge: indices 8 + upstream n, head 8 + downstream n, tail 8); the per-pop FIFO movement (344 B/pop in the
+# reference's layout) is not counted (SURVEY 8d's per-unit figures).
+ROWS_BYTES_PER_EDGE = 24.0
+ROWS_BYTES_PER_NODE = 32.0
 
 
 def parse():
@@ -144,7 +151,7 @@ def main():
     for _ in range(args.warmup):
         trainer.train_iteration()
     if not args.no_kernel_timing:
-        L.tarl_prof_enable(args.steps * T + 8)
+        L.tarl_prof_enable(T)      # HIP events around the two message-passing kernels of the first timed iteration's frames
     dist_utils.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -156,8 +163,8 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = dist_utils.allreduce_max_float(elapsed, device)
 
-    k_ms, k_n = ctypes.c_double(0.0), ctypes.c_int64(0)
-    lib.check(L.tarl_prof_collect(ctypes.byref(k_ms), ctypes.byref(k_n)))
+    k_ms, r_ms, k_n = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_int64(0)
+    lib.check(L.tarl_prof_collect2(ctypes.byref(k_ms), ctypes.byref(r_ms), ctypes.byref(k_n)))
     L.tarl_prof_enable(0)
 
     if rank == 0:
@@ -168,14 +175,18 @@ def main():
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
         # HBM traffic per launch from the PMC counters (2*FETCH_SIZE + WRITE_SIZE, collected in separate rocprofv3 --pmc
         # passes of the same kernels at the same sizes and committed under profiles/); null when no matching record.
-        traffic, traffic_src = None, None
+        traffic, traffic_rows, traffic_src = None, None, None
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", "r01_v4_pmc_traffic.json")))
             if rec["config"] == {"edges": E, "agents": args.agents, "envs": B}:
                 traffic = rec["kernels"]["k_fused_direction"]["hbm_bytes_per_launch"]
+                traffic_rows = rec["kernels"]["k_fused_rows"]["hbm_bytes_per_launch"]
                 traffic_src = "profiles/r01_v4_pmc_traffic.json (rocprofv3 --pmc, 2*FETCH_SIZE + WRITE_SIZE)"
         except (OSError, KeyError, ValueError):
             pass
+        rows_s = (r_ms.value / max(1, k_n.value)) * 1e-3
+        rows_bytes = ROWS_BYTES_PER_EDGE * B * E + ROWS_BYTES_PER_NODE * B * engine.N
+        rows_achieved = rows_bytes / rows_s / 1e9 if rows_s > 0 else 0.0
         out = {
             "metric": "ppo_env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -187,11 +198,19 @@ def main():
                        "envs_per_gpu": B, "env_steps_per_step": B * T, "parallelism": f"dp{world} (rollouts sharded, "
                        "one gradient all-reduce per optimiser step)"},
             "msgpass_edges_per_sec": value * E,
+            # Direction + Response pair alone (SURVEY 8d's second metric): B*E edges per frame / the two kernels' live time
+            "msgpass_pair_edges_per_sec": (B * E) / (avg_s + rows_s) if (avg_s + rows_s) > 0 else None,
             "roofline": {"bound": "hbm", "kernel": "k_fused_direction (DirectionMPNN message+aggregate on the packed hot records)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": avg_s * 1e6, "launches_timed": k_n.value},
+            # the kernel with the largest share of the frame (35 %): Direction update + Response + withdraw
+            "roofline_row_pass": {"bound": "hbm", "kernel": "k_fused_rows (DirectionMPNN.update + ResponseMPNN + withdraw)",
+                                  "achieved": rows_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": rows_achieved / HBM_PEAK_GBS, "traffic": traffic_rows,
+                                  "traffic_source": traffic_src, "algorithmic_bytes_per_launch": rows_bytes,
+                                  "avg_launch_us": rows_s * 1e6, "launches_timed": k_n.value},
         }
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args, net)

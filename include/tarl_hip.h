@@ -344,6 +344,8 @@ int tarl_select_next_hop(float* x, int64_t B, int64_t x_bstride, int64_t ldx, in
  * summed kernel time (ms) and the number of timed launches. */
 int tarl_prof_enable(int64_t max_launches);
 int tarl_prof_collect(double* total_ms_host, int64_t* launches_host);
+/* the same, plus the summed time of the row pass (Direction update + Response + withdraw) of the timed fused frames */
+int tarl_prof_collect2(double* direction_ms_host, double* rows_ms_host, int64_t* launches_host);
 
 #ifdef __cplusplus
 }

@@ -898,16 +898,17 @@ extern "C" int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int6
                      plan->group_of_node, plan->G, B, plan->N, fb, thresholds, (const long long*)log_probs, uniform, policy_seed,
                      policy_counter, choice, nchunk_choice(), log_prob != nullptr ? 1 : 0);
   TARL_LAUNCH_CHECK();
-  const bool timed = tarl_prof_event(s) != nullptr;
+  const bool timed = tarl_prof_mark(s, 0) != nullptr;
   const dim3 grid_d((unsigned)ceil_div(B, threads), (unsigned)ceil_div(plan->N, nchunk_dir()));
   hipLaunchKernelGGL(k_fused_direction, grid_d, dim3(threads), 0, s, plan->in_ptr, plan->in_src, plan->in_eid, plan->E,
                      B, plan->N, fb, edge_attr, log_edge_attr, log_eps, time, gumbel, seed, counter, delta_travel_time,
                      nchunk_dir());
   TARL_LAUNCH_CHECK();
-  if (timed) (void)tarl_prof_event(s);
+  if (timed) (void)tarl_prof_mark(s, 1);
   hipLaunchKernelGGL(k_fused_rows, grid, dim3(threads), 0, s, plan->out_ptr, plan->out_dst, (int)Nmax, B, plan->N, fb,
                      agent_features, A, a_bstride, time, popped, withdrawn, counts, nchunk());
   TARL_LAUNCH_CHECK();
+  if (timed) (void)tarl_prof_mark(s, 2);
   hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(INSB), 0, s, (int)Nmax, B, plan->N, fb,
                      agent_features, A, a_bstride, use_cong, time, ins_scratch, entropy1, reward, counts, log_prob,
                      entropy);
@@ -952,16 +953,17 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
                        plan->group_of_node, plan->G, B, N, fb, thresholds, (const long long*)log_probs, (const float*)nullptr, policy_seed,
                        policy_counter0 + (uint64_t)t, choice ? choice + t * NB : nullptr, nchunk_choice(), want_lp);
     TARL_LAUNCH_CHECK();
-    const bool timed = tarl_prof_event(s) != nullptr;
+    const bool timed = tarl_prof_mark(s, 0) != nullptr;
     hipLaunchKernelGGL(k_fused_direction, grid_d, dim3(threads), 0, s, plan->in_ptr, plan->in_src, plan->in_eid,
                        plan->E, B, N, fb, edge_attr, log_edge_attr, log_eps, time, (const float*)nullptr, seed,
                        counter0 + (uint64_t)t, (float*)nullptr, nchunk_dir());
     TARL_LAUNCH_CHECK();
-    if (timed) (void)tarl_prof_event(s);
+    if (timed) (void)tarl_prof_mark(s, 1);
     float* counts_t = counts ? counts + t * NB : nullptr;
     hipLaunchKernelGGL(k_fused_rows, grid, dim3(threads), 0, s, plan->out_ptr, plan->out_dst, (int)Nmax, B, N, fb,
                        agent_features, A, a_bstride, time, (uint8_t*)nullptr, (uint8_t*)nullptr, counts_t, nchunk());
     TARL_LAUNCH_CHECK();
+    if (timed) (void)tarl_prof_mark(s, 2);
     hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(INSB), 0, s, (int)Nmax, B, N, fb, agent_features, A,
                        a_bstride, use_cong, time, ins_scratch, entropy1, reward ? reward + t * B : nullptr, counts_t,
                        log_prob ? log_prob + t * B : nullptr, entropy ? entropy + t * B : nullptr);

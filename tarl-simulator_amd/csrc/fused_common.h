@@ -54,4 +54,4 @@ __device__ __forceinline__ int phys(int hoff, int s, int Nmax) {
 // fused.hip
 FusedBufs tarl_to_bufs(const tarl_fused* f);
 int tarl_check_fused_core(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax);
-hipEvent_t tarl_prof_event(hipStream_t s);  // sim.hip: live timing of the message-passing gather kernel
+hipEvent_t tarl_prof_mark(hipStream_t s, int tag);  // sim.hip: live timing of the message-passing kernels (tag 0/1/2)

@@ -180,42 +180,60 @@ __global__ __launch_bounds__(SIM_BLOCK) void k_response_update(float* __restrict
 // the launch path); tarl_prof_collect() synchronises them after the timed region and returns the summed duration.
 #include <vector>
 static bool g_prof_on = false;
-static std::vector<hipEvent_t> g_prof_events;  // pairs: start, stop
+static std::vector<hipEvent_t> g_prof_events;   // marks in launch order
+static std::vector<int> g_prof_tags;            // 0 = before Direction gather, 1 = after it, 2 = after the row pass
 static size_t g_prof_used = 0;
 
 extern "C" int tarl_prof_enable(int64_t max_launches) {
   for (hipEvent_t e : g_prof_events) (void)hipEventDestroy(e);
   g_prof_events.clear();
+  g_prof_tags.clear();
   g_prof_used = 0;
   g_prof_on = max_launches > 0;
-  for (int64_t i = 0; i < 2 * max_launches; ++i) {
+  for (int64_t i = 0; i < 3 * max_launches; ++i) {
     hipEvent_t e;
     TARL_CHECK_HIP(hipEventCreate(&e));
     g_prof_events.push_back(e);
+    g_prof_tags.push_back(-1);
   }
+  return TARL_OK;
+}
+
+// Summed durations of the two message-passing kernels and the number of timed frames; re-arms the pool.
+extern "C" int tarl_prof_collect2(double* direction_ms, double* rows_ms, int64_t* launches) {
+  TARL_REQUIRE(direction_ms && rows_ms && launches, "null argument");
+  double dir = 0.0, rows = 0.0;
+  int64_t n = 0;
+  for (size_t i = 0; i + 1 < g_prof_used; ++i) {
+    const int ta = g_prof_tags[i], tb = g_prof_tags[i + 1];
+    if (!((ta == 0 && tb == 1) || (ta == 1 && tb == 2))) continue;
+    TARL_CHECK_HIP(hipEventSynchronize(g_prof_events[i + 1]));
+    float ms = 0.0f;
+    TARL_CHECK_HIP(hipEventElapsedTime(&ms, g_prof_events[i], g_prof_events[i + 1]));
+    if (ta == 0) {
+      dir += ms;
+      ++n;
+    } else {
+      rows += ms;
+    }
+  }
+  *direction_ms = dir;
+  *rows_ms = rows;
+  *launches = n;
+  g_prof_used = 0;
   return TARL_OK;
 }
 
 extern "C" int tarl_prof_collect(double* total_ms, int64_t* launches) {
   TARL_REQUIRE(total_ms && launches, "null argument");
-  double tot = 0.0;
-  for (size_t i = 0; i + 1 < g_prof_used; i += 2) {
-    TARL_CHECK_HIP(hipEventSynchronize(g_prof_events[i + 1]));
-    float ms = 0.0f;
-    TARL_CHECK_HIP(hipEventElapsedTime(&ms, g_prof_events[i], g_prof_events[i + 1]));
-    tot += ms;
-  }
-  *total_ms = tot;
-  *launches = (int64_t)(g_prof_used / 2);
-  g_prof_used = 0;
-  return TARL_OK;
+  double rows = 0.0;
+  return tarl_prof_collect2(total_ms, &rows, launches);
 }
 
-hipEvent_t tarl_prof_event(hipStream_t s);  // shared with fused.hip
-static inline hipEvent_t prof_event(hipStream_t s) { return tarl_prof_event(s); }
-hipEvent_t tarl_prof_event(hipStream_t s) {
+hipEvent_t tarl_prof_mark(hipStream_t s, int tag) {
   if (!g_prof_on || g_prof_used >= g_prof_events.size()) return nullptr;
-  hipEvent_t e = g_prof_events[g_prof_used++];
+  hipEvent_t e = g_prof_events[g_prof_used];
+  g_prof_tags[g_prof_used++] = tag;
   (void)hipEventRecord(e, s);
   return e;
 }
@@ -246,11 +264,11 @@ extern "C" int tarl_direction_step(const tarl_plan* plan, float* x, int64_t B, i
   const Layout L{Nmax, ldx, x_bstride};
   const unsigned grid = (unsigned)ceil_div(B * R, SIM_BLOCK);
   hipStream_t s = (hipStream_t)stream;
-  const bool timed = prof_event(s) != nullptr;
+  const bool timed = tarl_prof_mark(s, 0) != nullptr;
   hipLaunchKernelGGL(k_direction_gather, dim3(grid), dim3(SIM_BLOCK), 0, s, view(plan), x, L, B, R, edge_attr,
                      log_edge_attr, log_eps, time, gumbel, seed, counter, dtt, chosen);
   TARL_LAUNCH_CHECK();
-  if (timed) (void)prof_event(s);
+  if (timed) (void)tarl_prof_mark(s, 1);
   hipLaunchKernelGGL(k_direction_update, dim3(grid), dim3(SIM_BLOCK), 0, s, x, L, B, R, cong, time, chosen);
   TARL_LAUNCH_CHECK();
   return TARL_OK;
