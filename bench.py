@@ -143,6 +143,8 @@ def main():
     local = local % torch.cuda.device_count()      # (rehearsal: several ranks may share one GPU under gloo)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    if world > 1:     # N ranks share the host: keep each rank's CPU-side set-up (population generation) in its share
+        torch.set_num_threads(max(1, (os.cpu_count() or 1) // world))
     L = lib.load()
 
     net, engine, trainer = build_trainer(args, rank, device)
