@@ -316,6 +316,13 @@ __global__ __launch_bounds__(TILE) void k_fused_choice(const int32_t* __restrict
 }
 
 // ---- Direction gather on the hot records (env-minor: lane = environment) ---------------------------------------------------
+// Two passes inside the workgroup. Pass 1 (every (node, environment) pair of the chunk): admissibility masks and the
+// summed turn probability P — no random numbers — and the default post record (nobody chosen). A pair needs the Gumbel
+// race only when P > 0, i.e. when some in-edge is admissible; that is a few percent of the pairs, but scattered over all
+// lanes, so every wave would still pay for the Philox block and the two logs per edge. The pairs with P > 0 are
+// therefore appended to an LDS list and pass 2 walks that list densely (one lane per pair), re-evaluating the pair with
+// its noise — same Philox indices, same expressions: the result is bit-identical to evaluating everything.
+#define DIR_LIST (TILE * 8)
 __global__ __launch_bounds__(TILE) void k_fused_direction(const int32_t* __restrict__ in_ptr,
                                                           const int32_t* __restrict__ in_src,
                                                           const int32_t* __restrict__ in_eid, int64_t E, int64_t B,
@@ -323,12 +330,55 @@ __global__ __launch_bounds__(TILE) void k_fused_direction(const int32_t* __restr
                                                           const float* __restrict__ log_edge_attr, float log_eps,
                                                           float t, const float* __restrict__ gumbel, uint64_t seed,
                                                           uint64_t counter, float* __restrict__ dtt, int nchunk) {
+  __shared__ int32_t s_n;
+  __shared__ uint16_t s_item[DIR_LIST];   // (node offset in the chunk) * TILE + lane
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  const bool valid = b < B;
   const int32_t i0 = blockIdx.y * nchunk;
   const int32_t i1 = (i0 + nchunk < N) ? i0 + nchunk : (int32_t)N;
-  for (int32_t i = i0; i < i1; ++i) {  // i, and everything indexed by it alone, is wave-uniform
-    const int64_t row = (int64_t)i * B + b;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  if (valid) {
+    for (int32_t i = i0; i < i1; ++i) {  // i, and everything indexed by it alone, is wave-uniform
+      const int64_t row = (int64_t)i * B + b;
+      const float4 me = fb.rec0[row];
+      const float4 sti = fb.st0[i];
+      const float max_i = sti.x, n_i = me.z, road_i = sti.z;
+      const float room_i = max_i - n_i;
+      const bool has_room = n_i < max_i - TARL_CONGESTION_FILE;
+      float P = 0.0f;
+      const int32_t k1 = in_ptr[i + 1];
+      for (int32_t k = in_ptr[i]; k < k1; ++k) {
+        const int32_t j = in_src[k];
+        const int32_t e = in_eid[k];
+        const int64_t jrow = (int64_t)j * B + b;
+        const float4 rj = fb.rec0[jrow];
+        const float sel_j = fb.sel[jrow];  // road selected by upstream j in THIS frame's choice phase
+        const float4 stj = fb.st0[j];
+        const float dep = rj.y, n_j = rj.z, max_j = stj.x;
+        const bool heads_here = sel_j == road_i;
+        const bool m1 = (dep <= t) && has_room && heads_here && (n_j > 0.0f);
+        const bool m2 = ((dep - t) < -10.0f) && ((max_j - TARL_CONGESTION_FILE) <= n_j) && ((max_j - n_j) <= room_i) &&
+                        heads_here;
+        const float prob = edge_attr[e] * ((m1 || m2) ? 1.0f : 0.0f);
+        P = P + prob;
+        if (dtt) {
+          const float d = (dep - fb.rec1[jrow].x) - stj.y;
+          dtt[b * E + e] = d > 0.0f ? d : (d != d ? d : 0.0f);
+        }
+      }
+      fb.postA[row] = make_float2(n_i, me.w);   // nobody chosen; overwritten by pass 2 where P > 0
+      fb.postB[row] = 0.0f;
+      if (P > 0.0f) s_item[atomicAdd(&s_n, 1)] = (uint16_t)((i - i0) * TILE + threadIdx.x);
+    }
+  }
+  __syncthreads();
+  const int32_t cnt = s_n;
+  for (int32_t idx = threadIdx.x; idx < cnt; idx += blockDim.x) {
+    const int32_t item = s_item[idx];
+    const int32_t i = i0 + item / TILE;
+    const int64_t bb = (int64_t)blockIdx.x * blockDim.x + (item % TILE);
+    const int64_t row = (int64_t)i * B + bb;
     const float4 me = fb.rec0[row];
     const float4 sti = fb.st0[i];
     const float max_i = sti.x, n_i = me.z, road_i = sti.z;
@@ -340,11 +390,10 @@ __global__ __launch_bounds__(TILE) void k_fused_direction(const int32_t* __restr
     for (int32_t k = in_ptr[i]; k < k1; ++k) {
       const int32_t j = in_src[k];
       const int32_t e = in_eid[k];
-      const int64_t jrow = (int64_t)j * B + b;
+      const int64_t jrow = (int64_t)j * B + bb;
       const float4 rj = fb.rec0[jrow];
-      const float sel_j = fb.sel[jrow];  // road selected by upstream j in THIS frame's choice phase
-      const float4 stj = fb.st0[j];
-      const float id = rj.x, dep = rj.y, n_j = rj.z, max_j = stj.x;
+      const float sel_j = fb.sel[jrow];
+      const float id = rj.x, dep = rj.y, n_j = rj.z, max_j = fb.st0[j].x;
       const bool heads_here = sel_j == road_i;
       const bool m1 = (dep <= t) && has_room && heads_here && (n_j > 0.0f);
       const bool m2 = ((dep - t) < -10.0f) && ((max_j - TARL_CONGESTION_FILE) <= n_j) && ((max_j - n_j) <= room_i) &&
@@ -354,19 +403,15 @@ __global__ __launch_bounds__(TILE) void k_fused_direction(const int32_t* __restr
       P = P + prob;
       float g;
       if (gumbel) {
-        g = gumbel[b * E + e];
+        g = gumbel[bb * E + e];
       } else {
-        const float u = rng.uniform(seed, counter, (uint64_t)(b * E + k));
+        const float u = rng.uniform(seed, counter, (uint64_t)(bb * E + k));
         g = gumbel_from_u01(u);
       }
       const float score = (m ? log_edge_attr[e] : log_eps) + g;
       if (score > best) {
         best = score;
         best_id = id;
-      }
-      if (dtt) {
-        const float d = (dep - fb.rec1[jrow].x) - stj.y;
-        dtt[b * E + e] = d > 0.0f ? d : (d != d ? d : 0.0f);
       }
     }
     const float who = (P > 0.0f) ? best_id : 0.0f;
@@ -757,13 +802,16 @@ static int nchunk() {
   return v;
 }
 static int64_t num_chunks(const tarl_plan* plan) { return ceil_div(plan->N, nchunk()); }
-// the Direction kernel has no per-lane epilogue: one node per workgroup pass maximises the waves in flight
+// nodes per workgroup pass of the Direction kernel (measured: 1 -> 53.5 us, 2 -> 48.2, 3 -> 49.9, 4 -> 64, 8 -> 85 per
+// launch at B = 2048): two give the dense second pass ~25 pairs per workgroup without starving the chip of workgroups;
+// at most 8 (capacity of the LDS list and of the 16-bit item code)
 static int nchunk_dir() {
   static int v = 0;
   if (v == 0) {
     const char* e = getenv("TARL_NCHUNK_DIR");
-    v = e ? atoi(e) : 1;
+    v = e ? atoi(e) : 2;
     if (v < 1) v = 1;
+    if (v > 8) v = 8;
   }
   return v;
 }
