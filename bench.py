@@ -179,11 +179,11 @@ def main():
         # passes of the same kernels at the same sizes and committed under profiles/); null when no matching record.
         traffic, traffic_rows, traffic_src = None, None, None
         try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", "r01_v4_pmc_traffic.json")))
+            rec = json.load(open(os.path.join(ROOT, "profiles", "r01_v5_pmc_traffic.json")))
             if rec["config"] == {"edges": E, "agents": args.agents, "envs": B}:
                 traffic = rec["kernels"]["k_fused_direction"]["hbm_bytes_per_launch"]
                 traffic_rows = rec["kernels"]["k_fused_rows"]["hbm_bytes_per_launch"]
-                traffic_src = "profiles/r01_v4_pmc_traffic.json (rocprofv3 --pmc, 2*FETCH_SIZE + WRITE_SIZE)"
+                traffic_src = "profiles/r01_v5_pmc_traffic.json (rocprofv3 --pmc, 2*FETCH_SIZE + WRITE_SIZE)"
         except (OSError, KeyError, ValueError):
             pass
         rows_s = (r_ms.value / max(1, k_n.value)) * 1e-3
