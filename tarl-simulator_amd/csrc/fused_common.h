@@ -13,7 +13,7 @@
 #define TILE 256        // environments per workgroup in the env-minor kernels (one per lane)
 #define LOG_EPS_P 1e-8f
 #define INS_CAP 2048    // LDS candidate list of the insert kernel (entries)
-#define INSB 256        // insert kernel: one (small) workgroup per environment, so that all of them are resident at once
+#define INSB 64         // insert kernel: one wave per environment (all resident at once, 3/4 of the wave slots left free)
 
 struct FusedBufs {
   float4* rec0;         // [N][B] {head_id, head_dep, n, tail_id}
