@@ -256,7 +256,8 @@ int tarl_fused_pack(const tarl_plan* plan, const tarl_fused* f, const float* x, 
                     int64_t ldx, int32_t Nmax, const float* congestion_constant, const float* agent_features,
                     int64_t num_agents, int64_t a_bstride, tarl_stream stream);
 /* tarl_fused_reset == tarl_reset_state applied to the packed state (SimulatorEnv._reset): zero the FIFO store and the
- *   counters, keep SELECTED_ROAD, clear ON_WAY / DONE in agent_features and the status SoA, re-arm the insert cursor. */
+ *   counters, keep SELECTED_ROAD, clear ON_WAY / DONE in agent_features (for the agents the status SoA marks as on the
+ *   way / done, i.e. everything that changed since tarl_fused_pack) and the status SoA, re-arm the insert cursor. */
 int tarl_fused_reset(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, float* agent_features,
                      int64_t num_agents, int64_t a_bstride, tarl_stream stream);
 /* last_step_time: the clock value passed to the most recent tarl_fused_frame (stamps the pending garbage slots). */

@@ -111,6 +111,9 @@ __global__ __launch_bounds__(FB) void k_fused_reset_agents(float* __restrict__ a
                                                            int64_t a_bstride, FusedBufs fb) {
   const int64_t gid = (int64_t)blockIdx.x * FB + threadIdx.x;
   if (gid >= B * A) return;
+  // only agents that left the "waiting" state have flags to clear (the status SoA mirrors ON_WAY / DONE since the last
+  // pack): a sequential 1-byte scan instead of two scattered stores into every 36-byte row
+  if (fb.a_status[gid] == 0) return;
   const int64_t b = gid / A, a = gid - b * A;
   float* row = ag + b * a_bstride + a * AG_COLS;
   row[AG_ON_WAY] = 0.0f;
