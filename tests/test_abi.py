@@ -53,3 +53,24 @@ def test_cpu_tensor_is_refused():
     from tarl_hip import lib, ops
     with pytest.raises(lib.TarlError):
         ops._check_dev(torch.zeros(4), torch.float32, "x")
+
+
+def test_entry_points_reject_bad_arguments_on_the_host():
+    """Every entry point validates its arguments before the first HIP call and reports through the error code +
+    tarl_last_error (no exceptions cross the ABI): exercised here without a GPU."""
+    import ctypes as C
+    from tarl_hip import lib
+    L = lib.load()
+    null = None
+    assert L.tarl_rollout_env_supported(null) == 0
+    assert L.tarl_apsp_scratch_bytes(null, 1) == -1
+    assert L.tarl_apsp(null, null, 1, 0, null, 0, null, null, null) == -1
+    assert b"null" in L.tarl_last_error()
+    assert L.tarl_fused_rollout(null, null, 1, 15, 1, null, null, null, null, 0, 0, null, 1, 9, null, null, 0.0, 0, 0, 0,
+                                null, null, null, null, null, null, null) == -1
+    assert L.tarl_rollout_env(null, null, 1, 15, 1, null, null, null, null, 0, 0, null, 1, 9, null, null, 0.0, 0, 0, 0,
+                              null, null, null, null, null, null, null) == -1
+    assert L.tarl_value_mpnn_fwd(null, null, 1, null, null, 0, null, null, null, null, null, null) == -1
+    assert L.tarl_select_next_hop(null, 1, 0, 52, 15, 4, null, 1, 9, null, 0, null) == -1
+    d, r, n = C.c_double(), C.c_double(), C.c_int64()
+    assert L.tarl_prof_collect2(C.byref(d), C.byref(r), C.byref(n)) == 0 and n.value == 0
