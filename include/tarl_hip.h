@@ -307,14 +307,16 @@ int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, int64_t B, in
  *   boundaries. Same packed state in / out (tarl_fused), same noise streams, identical states / agents / actions /
  *   rewards / counts / log-probs. Differences at the interface: times_dev is a DEVICE array of T floats, and the
  *   per-frame outputs are ENV-MAJOR: choice int32 [T][B][N], counts fp32 [T][B][N] (log_prob / entropy / reward [T][B]).
- *   Meant for the sizes where the four-launch frame is latency-bound, and the default rollout whenever it fits. */
+ *   static_scratch: tarl_rollout_env_scratch_bytes(plan) bytes of 16-byte aligned device memory (the per-edge statics
+ *   are packed into 16-byte records there by every call). */
 int tarl_rollout_env_supported(const tarl_plan* plan);
+int64_t tarl_rollout_env_scratch_bytes(const tarl_plan* plan);
 int tarl_rollout_env(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, int64_t T,
                      const float* times_dev, const float* thresholds, const int64_t* log_probs, const float* entropy1,
                      uint64_t policy_seed, uint64_t policy_counter0, float* agent_features, int64_t num_agents,
                      int64_t a_bstride, const float* edge_attr, const float* log_edge_attr, float log_eps, int use_cong,
-                     uint64_t seed, uint64_t counter0, int32_t* ins_scratch, int32_t* choice, float* log_prob,
-                     float* entropy, float* reward, float* counts, tarl_stream stream);
+                     uint64_t seed, uint64_t counter0, int32_t* ins_scratch, void* static_scratch, int32_t* choice,
+                     float* log_prob, float* entropy, float* reward, float* counts, tarl_stream stream);
 
 /* ---- shortest-path routing -----------------------------------------------------------------------
  * tarl_edge_travel_time == the edge weights of DijkstraAgents.choice (src/agents/base.py:541-550):

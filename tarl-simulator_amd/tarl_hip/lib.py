@@ -60,8 +60,9 @@ SIGNATURES = {
     "tarl_fused_rollout": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _u64, _u64, _p, _i64, _i64, _p, _p, _f32,
                                      C.c_int, _u64, _u64] + [_p] * 7),
     "tarl_rollout_env_supported": (C.c_int, [_p]),
+    "tarl_rollout_env_scratch_bytes": (_i64, [_p]),
     "tarl_rollout_env": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _u64, _u64, _p, _i64, _i64, _p, _p, _f32,
-                                   C.c_int, _u64, _u64] + [_p] * 7),
+                                   C.c_int, _u64, _u64] + [_p] * 8),
     "tarl_edge_travel_time": (C.c_int, [_p] + _STATE + [_p, _p, _p]),
     "tarl_apsp_scratch_bytes": (_i64, [_p, _i64]),
     "tarl_apsp": (C.c_int, [_p, _p, _i64, _i64, _p, _i64, _p, _p, _p]),

@@ -682,12 +682,16 @@ def rollout_env(plan: Plan, fs: FusedState, tables: PolicyTables, agent_features
         if tns is not None and (tns.dtype != dt or tuple(tns.shape) != shp or not tns.is_contiguous() or not tns.is_cuda):
             raise ValueError(f"{name} must be a contiguous cuda {dt} tensor of shape {shp}")
     tdev = torch.tensor([float(t) for t in times], dtype=torch.float32).to(fs.sel.device, non_blocking=True)
+    if getattr(fs, "env_scratch", None) is None:
+        fs.env_scratch = torch.empty(int(L.tarl_rollout_env_scratch_bytes(plan.handle)), dtype=torch.uint8,
+                                     device=fs.sel.device)
     _lib.check(L.tarl_rollout_env(plan.handle, fs.ref, B, fs.Nmax, T, tdev.data_ptr(), tables.thresholds.data_ptr(),
                                   tables.log_probs.data_ptr(), tables.entropy.data_ptr(), int(policy_seed),
                                   int(policy_counter0), agent_features.data_ptr(), A, abs_, ec.edge_attr.data_ptr(),
                                   ec.log_edge_attr.data_ptr(), ec.log_eps, 1 if use_cong else 0, int(seed),
-                                  int(counter0), scratch.data_ptr(), _lib.ptr(choice), _lib.ptr(log_prob),
-                                  _lib.ptr(entropy), _lib.ptr(reward), _lib.ptr(counts), _lib.current_stream()))
+                                  int(counter0), scratch.data_ptr(), fs.env_scratch.data_ptr(), _lib.ptr(choice),
+                                  _lib.ptr(log_prob), _lib.ptr(entropy), _lib.ptr(reward), _lib.ptr(counts),
+                                  _lib.current_stream()))
     return tdev
 
 

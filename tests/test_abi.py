@@ -69,7 +69,7 @@ def test_entry_points_reject_bad_arguments_on_the_host():
     assert L.tarl_fused_rollout(null, null, 1, 15, 1, null, null, null, null, 0, 0, null, 1, 9, null, null, 0.0, 0, 0, 0,
                                 null, null, null, null, null, null, null) == -1
     assert L.tarl_rollout_env(null, null, 1, 15, 1, null, null, null, null, 0, 0, null, 1, 9, null, null, 0.0, 0, 0, 0,
-                              null, null, null, null, null, null, null) == -1
+                              null, null, null, null, null, null, null, null) == -1
     assert L.tarl_value_mpnn_fwd(null, null, 1, null, null, 0, null, null, null, null, null, null) == -1
     assert L.tarl_select_next_hop(null, 1, 0, 52, 15, 4, null, 1, 9, null, 0, null) == -1
     d, r, n = C.c_double(), C.c_double(), C.c_int64()
