@@ -302,8 +302,8 @@ int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, int64_t B, in
                        float* entropy, float* reward, float* counts, tarl_stream stream);
 
 /* tarl_rollout_env == tarl_fused_rollout with the other mapping: ONE workgroup per environment keeps that environment's
- *   hot records in LDS (44 B per road + 16 KB; tarl_rollout_env_supported(plan) tells whether the graph fits the CU's
- *   160 KB) and runs all T frames inside a single launch, with workgroup barriers where the env-minor path has kernel
+ *   hot records and static columns in LDS (56 B per road + 16 KB; tarl_rollout_env_supported(plan) tells whether the
+ *   graph fits the CU's 160 KB, i.e. up to ~2 600 roads) and runs all T frames inside a single launch, with workgroup barriers where the env-minor path has kernel
  *   boundaries. Same packed state in / out (tarl_fused), same noise streams, identical states / agents / actions /
  *   rewards / counts / log-probs. Differences at the interface: times_dev is a DEVICE array of T floats, and the
  *   per-frame outputs are ENV-MAJOR: choice int32 [T][B][N], counts fp32 [T][B][N] (log_prob / entropy / reward [T][B]).

@@ -3,8 +3,8 @@
 // Why a second implementation: the env-minor path (fused.hip) streams every per-(node, environment) record through HBM
 // four times per frame and pays four dependent launches per frame; with few environments it is bound by those launches'
 // latency (~10 us each), with many by HBM. A CDNA4 CU has 160 KB of LDS — enough for ALL hot state of one environment
-// of a few thousand roads (40 B per road: rec0, rec1, the post record, the chosen agent, SELECTED_ROAD, plus the static
-// MAX column). So: one 1024-thread workgroup per environment loads its records once, runs the T frames with workgroup
+// of a few thousand roads (56 B per road: rec0, rec1, the post record, the chosen agent, SELECTED_ROAD, plus the static
+// MAX / free-flow / congestion / road-index columns). So: one 1024-thread workgroup per environment loads its records once, runs the T frames with workgroup
 // barriers where the env-minor path has kernel boundaries, and writes the records back at the end. HBM then only sees
 // the FIFO slot store and the agent table where something actually happens (a few events per frame), and the rollout
 // outputs (ENV-MAJOR here: choice / counts [T][B][N], written coalesced by the workgroup). Static topology / tables are
