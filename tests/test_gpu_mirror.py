@@ -297,3 +297,50 @@ def test_all_algorithms_on_a_matsim_scenario(tmp_path, monkeypatch, capsys):
     assert all(v > 0 for v in arrived.values()), arrived
     assert arrived["dijkstra"] >= arrived["random"]          # shortest paths beat a random walk
     assert os.path.exists(tmp_path / "runs" / "policy.pt") and os.path.exists("save/grid/network.pt")
+
+
+def test_env_metrics_like_reference_rl_metrics_test(tmp_path, monkeypatch):
+    """The reference's tests/rl_metrics_test.py:8-57 through the mirror on the GPU: a SimulatorEnv on the 2-link MATSim
+    network (load_network patched to config_network, agent insert / withdraw / reset patched out), stepped with float
+    one-hot actions derived from a parameter that a hand-rolled SGD loop updates; the env's clock advances and the
+    metric series (leg histogram, road optimality) and phase timers are collected."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+    from make_golden_fixtures import SIMPLE_NETWORK_XML
+    from src._compat import TensorDict
+    from src.agents.base import Agents
+    from src.reinforcement_learning import SimulatorEnv
+    from src.transportation_simulator import TransportationSimulator
+    (tmp_path / "network.xml").write_text(SIMPLE_NETWORK_XML)
+    monkeypatch.setattr(TransportationSimulator, "load_network",
+                        lambda self, scenario: self.config_network(str(tmp_path / "network")))
+    monkeypatch.setattr(Agents, "reset", lambda self: None)
+    monkeypatch.setattr(Agents, "withdraw_agent_from_network", lambda self, g, h: g.x)
+    monkeypatch.setattr(Agents, "insert_agent_into_network", lambda self, g, h: g.x)
+    env = SimulatorEnv(device="cuda", timestep_size=1, start_time=0, scenario="Easy")
+    eval_env = SimulatorEnv(device="cuda", timestep_size=1, start_time=0, scenario="Easy")
+    for e in (env, eval_env):
+        e.simulator.agent.agent_features = torch.zeros((1, 9), device="cuda")
+        e.simulator.agent.set_time(e.simulator.time)
+    num_edges = env.simulator.graph.edge_index.size(1)
+    assert num_edges == 6
+    param = torch.nn.Parameter(torch.zeros(num_edges, device="cuda"))
+    optim = torch.optim.SGD([param], lr=0.1)
+    env._reset()
+    for _ in range(2):
+        action = (param > 0).to(torch.bool).float()
+        env._step(TensorDict({"action": action}, batch_size=[]))
+        param.sum().backward()
+        optim.step()
+        optim.zero_grad()
+    assert env.simulator.time > 0
+    assert bool(torch.any(param != 0))
+    eval_env._reset()
+    for _ in range(2):
+        action = (param > 0).to(torch.bool).float()
+        out = eval_env._step(TensorDict({"action": action}, batch_size=[]))
+    assert eval_env.simulator.leg_histogram_values and eval_env.simulator.road_optimality_values
+    sim = eval_env.simulator
+    assert sim.inserting_time + sim.core_time + sim.withdraw_time > 0
+    assert out["node_features"].shape == (6, 7) and out["reward"].shape == (1,)
