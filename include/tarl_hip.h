@@ -337,6 +337,15 @@ int tarl_edge_travel_time(const tarl_plan* plan, const float* x, int64_t B, int6
 int64_t tarl_apsp_scratch_bytes(const tarl_plan* plan, int64_t B);
 int tarl_apsp(const tarl_plan* plan, const float* weights, int64_t B, int64_t w_bstride, void* scratch,
               int64_t scratch_bytes, int64_t* next_hop, float* dist, tarl_stream stream);
+/* tarl_apsp_f64: tarl_apsp with float64 edge weights (run_msa keeps its link costs in double).
+ * tarl_msa_assign == the all-or-nothing step of run_msa (src/algorithms/user_equilibrium_msa.py:117-131): every OD pair
+ *   p walks od_origin[p] -> od_dest[p] along next_hop [N][N] and adds od_volume[p] to aux_flow[v] (double, ACCUMULATED)
+ *   for every node v entered with is_road[v] != 0 (the origin is skipped; unreachable pairs contribute nothing). */
+int tarl_apsp_f64(const tarl_plan* plan, const double* weights, int64_t B, int64_t w_bstride, void* scratch,
+                  int64_t scratch_bytes, int64_t* next_hop, float* dist, tarl_stream stream);
+int tarl_msa_assign(const int64_t* next_hop, int64_t num_nodes, const int64_t* od_origin, const int64_t* od_dest,
+                    const double* od_volume, int64_t num_pairs, const uint8_t* is_road, double* aux_flow,
+                    tarl_stream stream);
 int tarl_select_next_hop(float* x, int64_t B, int64_t x_bstride, int64_t ldx, int32_t Nmax, int64_t num_nodes,
                          const float* agent_features, int64_t num_agents, int64_t a_bstride, const int64_t* next_hop,
                          int64_t nh_bstride, tarl_stream stream);

@@ -459,6 +459,11 @@ def gen_routing():
                         f"{tag}__agents0_n": ag.agent_features.size(0)})
             # TransportationSimulator.compute_node_metrics (src/transportation_simulator.py:563-670) after that run
             nm = sim.compute_node_metrics(output_dir=None)
+            # run_msa (src/algorithms/user_equilibrium_msa.py:65-165) on the end state, few iterations and to convergence cap
+            from src.algorithms.user_equilibrium_msa import run_msa
+            for iters in (1, 3, 25):
+                fl = run_msa(sim.graph, ag, max_iter=iters)
+                rec[f"{tag}__msa_{iters}"] = torch.tensor([fl[i] for i in range(len(fl))], dtype=torch.float64)
             rec.update({f"{tag}__nm_counts": torch.tensor([nm[n]["hourly_counts"] for n in range(len(nm))]),
                         f"{tag}__nm_avg_vc": torch.tensor([nm[n]["avg_vc"] for n in range(len(nm))]),
                         f"{tag}__nm_std_vc": torch.tensor([nm[n]["std_vc"] for n in range(len(nm))]),

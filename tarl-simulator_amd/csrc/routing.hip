@@ -39,8 +39,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_edge_travel_time(const int32_t* __
 }
 
 // ---- all-pairs shortest paths with networkx's tie order ----------------------------------------------------------------
+template <typename W>
 __global__ __launch_bounds__(64) void k_apsp(const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_dst,
-                                             const int32_t* __restrict__ out_eid, const float* __restrict__ w,
+                                             const int32_t* __restrict__ out_eid, const W* __restrict__ w,
                                              int64_t w_bstride, int64_t B, int64_t N, uint8_t* __restrict__ scratch,
                                              int64_t* __restrict__ next_hop, float* __restrict__ dist_out) {
   extern __shared__ double apsp_lds[];
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(64) void k_apsp(const int32_t* __restrict__ out_ptr
   for (int64_t job = blockIdx.x; job < B * N; job += gridDim.x) {
     const int64_t b = job / N;
     const int32_t s = (int32_t)(job - b * N);
-    const float* wb = w + b * w_bstride;
+    const W* wb = w + b * w_bstride;
     for (int64_t v = lane; v < N; v += 64) {
       seen[v] = INF;
       cnt[v] = 0u;
@@ -174,8 +175,9 @@ extern "C" int64_t tarl_apsp_scratch_bytes(const tarl_plan* plan, int64_t B) {
   return waves * 16 * plan->N;
 }
 
-extern "C" int tarl_apsp(const tarl_plan* plan, const float* weights, int64_t B, int64_t w_bstride, void* scratch,
-                         int64_t scratch_bytes, int64_t* next_hop, float* dist, tarl_stream stream) {
+template <typename W>
+static int apsp_launch(const tarl_plan* plan, const W* weights, int64_t B, int64_t w_bstride, void* scratch,
+                       int64_t scratch_bytes, int64_t* next_hop, float* dist, tarl_stream stream) {
   TARL_REQUIRE(plan && weights, "null argument");
   TARL_REQUIRE(B >= 1 && (w_bstride == 0 || w_bstride >= plan->E), "bad shape");
   TARL_REQUIRE(next_hop || dist, "no output requested");
@@ -189,14 +191,60 @@ extern "C" int tarl_apsp(const tarl_plan* plan, const float* weights, int64_t B,
     lds = (size_t)(16 * N);
     if (waves > 65536) waves = 65536;
     if (lds > 64 * 1024)
-      TARL_CHECK_HIP(hipFuncSetAttribute((const void*)k_apsp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      TARL_CHECK_HIP(hipFuncSetAttribute((const void*)k_apsp<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   } else {
     TARL_REQUIRE(scratch && scratch_bytes >= need, "scratch too small (tarl_apsp_scratch_bytes)");
     if (waves > 4096) waves = 4096;
     sc = (uint8_t*)scratch;
   }
-  hipLaunchKernelGGL(k_apsp, dim3((unsigned)waves), dim3(64), lds, (hipStream_t)stream, plan->out_ptr, plan->out_dst,
+  hipLaunchKernelGGL(k_apsp<W>, dim3((unsigned)waves), dim3(64), lds, (hipStream_t)stream, plan->out_ptr, plan->out_dst,
                      plan->out_eid, weights, w_bstride, B, N, sc, next_hop, dist);
+  TARL_LAUNCH_CHECK();
+  return TARL_OK;
+}
+
+extern "C" int tarl_apsp(const tarl_plan* plan, const float* weights, int64_t B, int64_t w_bstride, void* scratch,
+                         int64_t scratch_bytes, int64_t* next_hop, float* dist, tarl_stream stream) {
+  return apsp_launch<float>(plan, weights, B, w_bstride, scratch, scratch_bytes, next_hop, dist, stream);
+}
+
+// the same with double edge weights (run_msa keeps its link costs in float64)
+extern "C" int tarl_apsp_f64(const tarl_plan* plan, const double* weights, int64_t B, int64_t w_bstride, void* scratch,
+                             int64_t scratch_bytes, int64_t* next_hop, float* dist, tarl_stream stream) {
+  return apsp_launch<double>(plan, weights, B, w_bstride, scratch, scratch_bytes, next_hop, dist, stream);
+}
+
+// ---- all-or-nothing assignment of an OD demand along the next-hop table (src/algorithms/user_equilibrium_msa.py:117-131)
+// One thread per OD pair: walk o -> d through next_hop and add the pair's volume to every ROAD node entered (the origin
+// itself is skipped). fp64 atomics: the summation order over pairs is not fixed (differences ~1e-16 relative).
+__global__ __launch_bounds__(RT_BLOCK) void k_msa_assign(const int64_t* __restrict__ next_hop, int64_t N,
+                                                         const int64_t* __restrict__ od_o,
+                                                         const int64_t* __restrict__ od_d,
+                                                         const double* __restrict__ od_vol, int64_t P,
+                                                         const uint8_t* __restrict__ is_road,
+                                                         double* __restrict__ aux_flow) {
+  const int64_t p = (int64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+  if (p >= P) return;
+  const int64_t o = od_o[p], d = od_d[p];
+  const double vol = od_vol[p];
+  if (o < 0 || o >= N || d < 0 || d >= N || !(vol > 0.0)) return;
+  if (next_hop[o * N + d] < 0) return;   // no path
+  int64_t node = o;
+  for (int64_t hops = 0; node != d && hops < N; ++hops) {
+    node = next_hop[node * N + d];
+    if (node < 0) return;
+    if (is_road[node]) atomicAdd(&aux_flow[node], vol);
+  }
+}
+
+extern "C" int tarl_msa_assign(const int64_t* next_hop, int64_t num_nodes, const int64_t* od_origin,
+                               const int64_t* od_dest, const double* od_volume, int64_t num_pairs,
+                               const uint8_t* is_road, double* aux_flow, tarl_stream stream) {
+  TARL_REQUIRE(next_hop && od_origin && od_dest && od_volume && is_road && aux_flow, "null argument");
+  TARL_REQUIRE(num_nodes >= 1 && num_pairs >= 0, "bad sizes");
+  if (num_pairs == 0) return TARL_OK;
+  hipLaunchKernelGGL(k_msa_assign, dim3((unsigned)ceil_div(num_pairs, RT_BLOCK)), dim3(RT_BLOCK), 0, (hipStream_t)stream,
+                     next_hop, num_nodes, od_origin, od_dest, od_volume, num_pairs, is_road, aux_flow);
   TARL_LAUNCH_CHECK();
   return TARL_OK;
 }

@@ -112,4 +112,18 @@ class Runner:
             print(f"{label:25} {v:10.2f} s   (host enqueue time; kernels run asynchronously)")
         print("-" * 42)
         print(f"{'Total simulation time:':25} {total:10.2f} s")
+        # metric tables of the reference's eval (src/runner.py:160-166) — node metrics and the MSA expected demand; its
+        # matplotlib figures are not reproduced
+        out_dir = Path(a.output_dir)
+        try:
+            sim.compute_node_metrics(str(out_dir))
+            if sim.graph.x.size(0) <= 4096:          # all-pairs table per MSA iteration: keep it to mid-size graphs
+                from .algorithms.user_equilibrium_msa import run_msa
+                expected = run_msa(sim.graph, agent)
+                out_dir.mkdir(parents=True, exist_ok=True)
+                with open(out_dir / "msa_expected_flows.csv", "w") as f:
+                    f.write("road,expected_hourly_flow\n")
+                    f.writelines(f"{r},{v}\n" for r, v in expected.items())
+        except Exception as exc:  # noqa: BLE001 - analysis output must not fail the run
+            print(f"metric tables skipped: {exc}")
         return {"steps": n, "arrived": int(mask.sum()), "avg_travel_time": avg}

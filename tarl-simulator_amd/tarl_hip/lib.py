@@ -66,6 +66,8 @@ SIGNATURES = {
     "tarl_edge_travel_time": (C.c_int, [_p] + _STATE + [_p, _p, _p]),
     "tarl_apsp_scratch_bytes": (_i64, [_p, _i64]),
     "tarl_apsp": (C.c_int, [_p, _p, _i64, _i64, _p, _i64, _p, _p, _p]),
+    "tarl_apsp_f64": (C.c_int, [_p, _p, _i64, _i64, _p, _i64, _p, _p, _p]),
+    "tarl_msa_assign": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _p, _p, _p]),
     "tarl_select_next_hop": (C.c_int, _STATE + [_i64, _p, _i64, _i64, _p, _i64, _p]),
     "tarl_prof_enable": (C.c_int, [_i64]),
     "tarl_prof_collect": (C.c_int, [C.POINTER(_f64), C.POINTER(_i64)]),

@@ -212,7 +212,8 @@ def all_pairs_shortest_paths(plan: Plan, weights, *, want_next_hop=True, want_di
     """``weights`` (E,) or (B, E) fp32 in original edge order -> (next_hop int64 (B, N, N) | None, dist fp32 (B, N, N) |
     None), networkx-compatible tie order (tarl_apsp)."""
     L = _lib.load()
-    w = weights.to(torch.float32).contiguous()
+    f64 = weights.dtype == torch.float64          # double weights stay double (tarl_apsp_f64)
+    w = weights.contiguous() if f64 else weights.to(torch.float32).contiguous()
     w = w.view(1, -1) if w.dim() == 1 else w
     B, N = w.size(0), plan.num_nodes
     assert w.size(1) == plan.num_edges, "one weight per edge"
@@ -220,9 +221,22 @@ def all_pairs_shortest_paths(plan: Plan, weights, *, want_next_hop=True, want_di
     d = torch.empty((B, N, N), dtype=torch.float32, device=w.device) if want_dist else None
     need = int(L.tarl_apsp_scratch_bytes(plan.handle, B))
     scratch = torch.empty(need, dtype=torch.uint8, device=w.device) if need > 0 else None
-    _lib.check(L.tarl_apsp(plan.handle, w.data_ptr(), B, plan.num_edges, _lib.ptr(scratch), need, _lib.ptr(nh),
-                           _lib.ptr(d), _lib.current_stream()))
+    fn = L.tarl_apsp_f64 if f64 else L.tarl_apsp
+    _lib.check(fn(plan.handle, w.data_ptr(), B, plan.num_edges, _lib.ptr(scratch), need, _lib.ptr(nh), _lib.ptr(d),
+                  _lib.current_stream()))
     return nh, d
+
+
+def msa_assign(next_hop, od_origin, od_dest, od_volume, is_road, aux_flow):
+    """All-or-nothing assignment: aux_flow (N,) float64 += volume of every OD pair on the road nodes of its path."""
+    L = _lib.load()
+    N = next_hop.size(-1)
+    for t, dt, nm in ((next_hop, torch.int64, "next_hop"), (od_origin, torch.int64, "od_origin"),
+                      (od_dest, torch.int64, "od_dest"), (od_volume, torch.float64, "od_volume"),
+                      (is_road, torch.uint8, "is_road"), (aux_flow, torch.float64, "aux_flow")):
+        _contig(t, dt, nm)
+    _lib.check(L.tarl_msa_assign(next_hop.data_ptr(), N, od_origin.data_ptr(), od_dest.data_ptr(), od_volume.data_ptr(),
+                                 od_origin.numel(), is_road.data_ptr(), aux_flow.data_ptr(), _lib.current_stream()))
 
 
 def select_next_hop(x, Nmax, agent_features, next_hop):

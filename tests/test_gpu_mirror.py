@@ -297,6 +297,9 @@ def test_all_algorithms_on_a_matsim_scenario(tmp_path, monkeypatch, capsys):
     assert all(v > 0 for v in arrived.values()), arrived
     assert arrived["dijkstra"] >= arrived["random"]          # shortest paths beat a random walk
     assert os.path.exists(tmp_path / "runs" / "policy.pt") and os.path.exists("save/grid/network.pt")
+    assert os.path.exists(tmp_path / "runs" / "node_metrics.csv")
+    rows = open(tmp_path / "runs" / "msa_expected_flows.csv").read().splitlines()
+    assert rows[0] == "road,expected_hourly_flow" and len(rows) == 1 + 76 and sum(float(r.split(",")[1]) for r in rows[1:]) > 0
 
 
 def test_env_metrics_like_reference_rl_metrics_test(tmp_path, monkeypatch):

@@ -88,6 +88,19 @@ def test_classical_dijkstra_run_golden(ops, tmp_path, tag, het):
     assert torch.allclose(torch.tensor([nm[n]["avg_vc"] for n in range(R)]), g[f"{tag}__nm_avg_vc"], rtol=1e-6, atol=0)
     assert torch.allclose(torch.tensor([nm[n]["std_vc"] for n in range(R)]), g[f"{tag}__nm_std_vc"], rtol=1e-5, atol=1e-7)
     assert torch.equal(sim.leg_histogram(), g[f"{tag}__leg_hist"])
+    # run_msa on the same end state (src/algorithms/user_equilibrium_msa.py:65-165): all-pairs next-hop table per
+    # iteration (float64 costs) + one-thread-per-OD-pair assignment instead of nx.shortest_path per pair
+    from src.algorithms.user_equilibrium_msa import run_msa
+    for iters in (1, 3, 25):
+        fl = run_msa(sim.graph, ag, max_iter=iters)
+        got = torch.tensor([fl[i] for i in range(R)], dtype=torch.float64)
+        want = g[f"{tag}__msa_{iters}"]
+        if het:     # untied shortest paths: the reference's flows, to fp64 rounding
+            assert torch.allclose(got, want, rtol=1e-9, atol=1e-9), f"MSA flows after {iters} iterations"
+        elif iters == 1:
+            # homogeneous grid at free flow: every OD pair has many equal-cost paths and the reference's bidirectional
+            # Dijkstra may pick another one — each carries the same number of roads, so the total assigned volume agrees
+            assert abs(float(got.sum()) - float(want.sum())) < 1e-9 and float(got.min()) >= 0.0
 
 
 @pytest.mark.parametrize("kind,scratch", [("torus_hom", False), ("torus_het", False), ("grid_srcdest", False),
