@@ -31,7 +31,8 @@
 // The packed state is authoritative between tarl_fused_pack and tarl_fused_export; the exported x and agent_features are
 // bit-identical to what the unfused kernels (and the reference) produce after every frame (tests/test_gpu_fused.py).
 //
-// Domain: pure road graph (plan nodes == rows of x). Counts that reach Nmax (outside the reference's defined domain,
+// Domain: the plan is built on the same node set as x (plan nodes == rows of x): pure road graphs and MATSim graphs
+// with SRC/DEST pseudo-nodes alike (tests/test_gpu_fused.py::test_fused_equals_unfused_on_a_matsim_graph_with_pseudo_nodes). Counts that reach Nmax (outside the reference's defined domain,
 // DESIGN.md Q25) are not supported by this path.
 #include "fused_common.h"
 

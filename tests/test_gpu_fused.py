@@ -253,3 +253,49 @@ def test_env_rollout_equals_frame_loop(ops, W, H, B, T, A):
         e2.frame_fused(choice=cb, reward=rb)
         assert torch.equal(ca, cb) and torch.equal(ra, rb)
     assert torch.equal(e1.x, e2.x) and torch.equal(e1.agents, e2.agents)
+
+
+def test_fused_equals_unfused_on_a_matsim_graph_with_pseudo_nodes(ops, tmp_path):
+    """Outside the synthetic pure-road family: the graph config_network builds for a MATSim grid (76 roads + 24 SRC + 24
+    DEST pseudo-nodes, SRC -> road and road -> DEST edges with zero turn probability) and a population whose origins /
+    destinations are pseudo-nodes. Fused frames, the one-call rollout and the LDS-resident rollout against the per-op
+    kernels with the same device noise: identical actions, rewards, state and agents."""
+    from src.matsim_io import build_network, build_population
+    from tarl_hip import synth
+    from tarl_hip.engine import SimEngine
+    synth.write_matsim_grid_xml(str(tmp_path / "network.xml"), 4, 6, seed=3, heterogeneous=True)
+    synth.write_matsim_population_xml(str(tmp_path / "population.xml"), 4, 6, 260, seed=4, first_departure=21540, spread=40)
+    graph, Nmax = build_network(str(tmp_path / "network"))
+    agents, _ = build_population(str(tmp_path / "population"), str(tmp_path / "network"))
+    agents[0, 2] = 48 * 3600
+    N, B, T = graph.x.size(0), 3, 60
+    assert N == 124 and int(graph.num_roads) == 76
+    mk = lambda fused: SimEngine(dev(graph.x.unsqueeze(0).repeat(B, 1, 1)), graph.edge_index, graph.edge_attr, Nmax,
+                                 dev(agents.unsqueeze(0).repeat(B, 1, 1)),
+                                 congestion_constant=graph.congestion_constant, seed=5, fused=fused)
+    e1, e2, e3 = mk(False), mk(True), mk(True)
+    emb = torch.randn(N, generator=torch.Generator().manual_seed(3)).cuda()
+    for e in (e1, e2, e3):
+        e.reset()
+    e2.prepare_policy(emb)
+    e3.prepare_policy(emb)
+    ch2 = torch.empty((N, B), dtype=torch.int32, device="cuda")
+    r2 = torch.empty(B, device="cuda")
+    ch3 = torch.zeros((T, B, N), dtype=torch.int32, device="cuda")
+    rw3, ct3 = torch.zeros((T, B), device="cuda"), torch.zeros((T + 1, B, N), device="cuda")
+    assert e3.env_rollout_supported
+    e3.rollout_env(T, choice=ch3, log_prob=None, reward=rw3, counts=ct3)
+    for s in range(T):
+        logits = ops.policy_edge_logits(e1.plan, e1.node_features, emb)
+        p = ops.graphdist_softmax(e1.plan, logits)
+        _, ch1 = ops.graphdist_sample(e1.plan, p, seed=e2.seed ^ 0x5DEECE66D, counter=s + 1, want_onehot=False,
+                                      want_choice=True)
+        e1.step(choice=ch1)
+        e2.frame_fused(choice=ch2, reward=r2)
+        assert torch.equal(ch1, ch2.t()) and torch.equal(ch1, ch3[s]), f"actions frame {s}"
+        assert torch.equal(e1.reward, r2) and torch.equal(e1.reward, rw3[s]), f"reward frame {s}"
+        assert torch.equal(e1.agents, e2.agents), f"agents frame {s}"
+        if s % 10 == 0 or s == T - 1:
+            assert torch.equal(e1.x, e2.x), f"state frame {s}"
+    assert torch.equal(e1.x, e3.x) and torch.equal(e1.agents, e3.agents)
+    assert float(e1.agents[:, :, 8].sum()) > 0 and float(e1.agents[:, :, 7].sum()) > 0      # arrivals and travellers
