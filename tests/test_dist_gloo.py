@@ -9,6 +9,13 @@ import torch.multiprocessing as mp
 from conftest import PKG, ROOT
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _worker(rank, world, port, q):
     import sys
     for p in (ROOT, PKG):
@@ -39,7 +46,7 @@ def _worker(rank, world, port, q):
 def test_two_rank_exchange_matches_single_process():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()

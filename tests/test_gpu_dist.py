@@ -41,6 +41,13 @@ def _one_iteration(tr):
     return tr.last_grad.cpu(), tr.flat.flat.detach().cpu().clone(), adv.cpu()
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _worker(rank, world, port, identical, q):
     import sys
     for p in (ROOT, PKG):
@@ -61,7 +68,7 @@ def _worker(rank, world, port, identical, q):
 def _run_two(identical):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 1500) + (7 if identical else 0)
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, identical, q)) for r in range(2)]
     for p in procs:
         p.start()
