@@ -293,13 +293,17 @@ int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int64_t B, int3
  *   the collector loop of ppo_train (src/rl/ppo_trainer.py:129-133) in one call, same results as the frame-by-frame calls.
  *   Outputs, each frame-major: choice int32 [T][N][B], counts fp32 [T][N][B] (ENV-MINOR inside a frame), log_prob /
  *   entropy / reward fp32 [T][B]; choice, counts, log_prob, entropy, reward may be NULL.
- *   Scratch (device): ins_scratch int32 [B][2A]. */
+ *   Scratch (device): ins_scratch int32 [B][2A]; optional sel_scratch fp32 [N][B] + acc_scratch int64 [acc_slots][B]
+ *   (both or neither): with them frame t+1's choice work shares ONE launch with frame t's insert (a latency chain that
+ *   leaves the chip idle), SELECTED_ROAD and the log-prob accumulator being double-buffered (TARL_ROLLOUT_MERGE=0
+ *   disables it). */
 int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, int64_t T,
                        const float* times_host, const float* thresholds, const int64_t* log_probs, const float* entropy1,
                        uint64_t policy_seed, uint64_t policy_counter0, float* agent_features, int64_t num_agents,
                        int64_t a_bstride, const float* edge_attr, const float* log_edge_attr, float log_eps, int use_cong,
-                       uint64_t seed, uint64_t counter0, int32_t* ins_scratch, int32_t* choice, float* log_prob,
-                       float* entropy, float* reward, float* counts, tarl_stream stream);
+                       uint64_t seed, uint64_t counter0, int32_t* ins_scratch, float* sel_scratch, int64_t* acc_scratch,
+                       int32_t* choice, float* log_prob, float* entropy, float* reward, float* counts,
+                       tarl_stream stream);
 
 /* tarl_rollout_env == tarl_fused_rollout with the other mapping: ONE workgroup per environment keeps that environment's
  *   hot records and static columns in LDS (56 B per road + 16 KB; tarl_rollout_env_supported(plan) tells whether the

@@ -269,7 +269,7 @@ __device__ __forceinline__ float node_uniform(const float* __restrict__ uniform,
 // ---- choice phase (env-minor: lane = environment, a workgroup walks a chunk of nodes) --------------------------------
 // Consecutive nodes of one environment share Philox blocks (index = b*G + g), so a chunk costs ~nchunk/4 + 1 Philox
 // evaluations per lane instead of one per node.
-__global__ __launch_bounds__(TILE) void k_fused_choice(const int32_t* __restrict__ out_ptr,
+__device__ __forceinline__ void fused_choice_body(unsigned bx, unsigned by, const int32_t* __restrict__ out_ptr,
                                                        const int32_t* __restrict__ out_dst,
                                                        const int32_t* __restrict__ out_eid,
                                                        const int32_t* __restrict__ group_of_node, int64_t G, int64_t B,
@@ -277,10 +277,10 @@ __global__ __launch_bounds__(TILE) void k_fused_choice(const int32_t* __restrict
                                                        const long long* __restrict__ lgt,
                                                        const float* __restrict__ uniform, uint64_t pseed,
                                                        uint64_t pcounter, int32_t* __restrict__ choice, int nchunk,
-                                                       int want_lp) {
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                                       int want_lp, const float* __restrict__ sel_prev) {
+  const int64_t b = (int64_t)bx * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  const int32_t i0 = blockIdx.y * nchunk;
+  const int32_t i0 = by * nchunk;
   const int32_t i1 = (i0 + nchunk < N) ? i0 + nchunk : (int32_t)N;
   long long lp = 0;
   bool bad = false;
@@ -305,18 +305,36 @@ __global__ __launch_bounds__(TILE) void k_fused_choice(const int32_t* __restrict
         lpn = hit ? lgk : lpn;
         found = found || hit;
       }
+      // a node that picks nothing keeps its previous SELECTED_ROAD (sel_prev = the other buffer when the rollout
+      // double-buffers sel: the value is carried over)
       if (found) {
-        fb.sel[row] = selv;  // a node that picks nothing keeps its previous SELECTED_ROAD
+        fb.sel[row] = selv;
         lp += lpn;
       } else {
         bad = true;
+        if (sel_prev) fb.sel[row] = sel_prev[row];
       }
+    } else if (sel_prev) {
+      fb.sel[row] = sel_prev[row];
     }
     if (choice) __builtin_nontemporal_store(ch, &choice[row]);  // write-once stream: keep it out of the caches
   }
   // infeasible action (some node picked nothing): poison the accumulator far beyond any legitimate sum
   if (want_lp)
-    atomicAdd((unsigned long long*)&fb.acc_lp[(int64_t)(blockIdx.y % (unsigned)fb.acc_slots) * B + b], (unsigned long long)(bad ? -(1ll << 50) : lp));  // up to 2^13 chunks cannot wrap
+    atomicAdd((unsigned long long*)&fb.acc_lp[(int64_t)(by % (unsigned)fb.acc_slots) * B + b], (unsigned long long)(bad ? -(1ll << 50) : lp));  // up to 2^13 chunks cannot wrap
+}
+
+__global__ __launch_bounds__(TILE) void k_fused_choice(const int32_t* __restrict__ out_ptr,
+                                                       const int32_t* __restrict__ out_dst,
+                                                       const int32_t* __restrict__ out_eid,
+                                                       const int32_t* __restrict__ group_of_node, int64_t G, int64_t B,
+                                                       int64_t N, FusedBufs fb, const float* __restrict__ thr,
+                                                       const long long* __restrict__ lgt,
+                                                       const float* __restrict__ uniform, uint64_t pseed,
+                                                       uint64_t pcounter, int32_t* __restrict__ choice, int nchunk,
+                                                       int want_lp) {
+  fused_choice_body(blockIdx.x, blockIdx.y, out_ptr, out_dst, out_eid, group_of_node, G, B, N, fb, thr, lgt, uniform,
+                    pseed, pcounter, choice, nchunk, want_lp, nullptr);
 }
 
 // ---- Direction gather on the hot records (env-minor: lane = environment) ---------------------------------------------------
@@ -577,7 +595,7 @@ __device__ __forceinline__ bool fused_target(const FusedBufs& fb, int64_t b, int
   return room > 0;
 }
 
-__global__ __launch_bounds__(INSB) void k_fused_insert(int Nmax, int64_t B, int64_t N, FusedBufs fb,
+__device__ __forceinline__ void fused_insert_body(int64_t b, int Nmax, int64_t B, int64_t N, FusedBufs fb,
                                                        float* __restrict__ ag, int64_t A, int64_t a_bstride,
                                                        int use_cong, float t, int32_t* __restrict__ scratch,
                                                        const float* __restrict__ entropy_in,
@@ -588,7 +606,6 @@ __global__ __launch_bounds__(INSB) void k_fused_insert(int Nmax, int64_t B, int6
   __shared__ int32_t s_adm;
   __shared__ int32_t s_lo;
   __shared__ int32_t s_un_agent[INS_CAP], s_un_road[INS_CAP];
-  const int64_t b = blockIdx.x;
   float* agb = ag + b * a_bstride;
   int32_t* cand_agent = scratch + b * 2 * A;
   int32_t* cand_road = cand_agent + A;
@@ -786,6 +803,62 @@ __global__ __launch_bounds__(INSB) void k_fused_insert(int Nmax, int64_t B, int6
   }
 }
 
+__global__ __launch_bounds__(INSB) void k_fused_insert(int Nmax, int64_t B, int64_t N, FusedBufs fb,
+                                                       float* __restrict__ ag, int64_t A, int64_t a_bstride,
+                                                       int use_cong, float t, int32_t* __restrict__ scratch,
+                                                       const float* __restrict__ entropy_in,
+                                                       float* __restrict__ reward, float* __restrict__ counts,
+                                                       float* __restrict__ log_prob, float* __restrict__ entropy) {
+  fused_insert_body(blockIdx.x, Nmax, B, N, fb, ag, A, a_bstride, use_cong, t, scratch, entropy_in, reward, counts,
+                    log_prob, entropy);
+}
+
+// One launch, two roles (rollout steady state): the first B workgroups run frame t's insert (one wave each; the other
+// three waves of such a workgroup retire at once, so its barriers only count the live wave), the remaining
+// `choice_blocks` workgroups draw frame t+1's action into the OTHER half of the double-buffered SELECTED_ROAD / log-prob
+// accumulators.
+// The insert kernel is a latency chain that leaves the chip idle and the live policy's sample does not depend on the
+// state, so the choice work rides in its shadow — without the cross-stream events that made the two-stream variant
+// slower — and still completes right before the Direction kernel that consumes it (Infinity-Cache adjacency).
+struct ChoiceArgs {
+  const int32_t* out_ptr;
+  const int32_t* out_dst;
+  const int32_t* out_eid;
+  const int32_t* group_of_node;
+  int64_t G;
+  const float* thr;
+  const long long* lgt;
+  uint64_t pseed, pcounter;
+  int32_t* choice;
+  int nchunk, want_lp;
+  float* sel_next;
+  long long* acc_next;
+  const float* sel_cur;
+  unsigned gx;             // environment tiles (x extent of the choice grid)
+  unsigned choice_blocks;  // gx * node chunks
+};
+__global__ __launch_bounds__(TILE) void k_fused_insert_choice(ChoiceArgs C, int Nmax, int64_t B, int64_t N, FusedBufs fb,
+                                                              float* __restrict__ ag, int64_t A, int64_t a_bstride,
+                                                              int use_cong, float t, int32_t* __restrict__ scratch,
+                                                              const float* __restrict__ entropy_in,
+                                                              float* __restrict__ reward, float* __restrict__ counts,
+                                                              float* __restrict__ log_prob,
+                                                              float* __restrict__ entropy) {
+  // insert workgroups first: their dependent-load chains start at once and the choice workgroups fill the chip around them
+  if (blockIdx.x < (unsigned)B) {
+    if (threadIdx.x >= INSB) return;   // whole waves leave before any barrier
+    fused_insert_body((int64_t)blockIdx.x, Nmax, B, N, fb, ag, A, a_bstride, use_cong, t, scratch, entropy_in, reward,
+                      counts, log_prob, entropy);
+  } else {
+    const unsigned cb = blockIdx.x - (unsigned)B;
+    FusedBufs fc = fb;
+    fc.sel = C.sel_next;
+    fc.acc_lp = C.acc_next;
+    fused_choice_body(cb % C.gx, cb / C.gx, C.out_ptr, C.out_dst, C.out_eid, C.group_of_node, C.G, B, N, fc, C.thr,
+                      C.lgt, nullptr, C.pseed, C.pcounter, C.choice, C.nchunk, C.want_lp, C.sel_cur);
+  }
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------------------
 FusedBufs tarl_to_bufs(const tarl_fused* f) {
   return FusedBufs{(float4*)f->rec0,         (float2*)f->rec1, (float2*)f->post_a, f->post_b,
@@ -969,7 +1042,8 @@ extern "C" int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int6
 }
 
 // T consecutive frames with device noise: the collector loop in one foreign call. Each frame is choice -> direction ->
-// rows -> insert on the caller's stream, in place. (Two alternatives were measured and rejected, DESIGN.md §4.2: folding
+// rows -> insert on the caller's stream; with the scratch pair, frame t+1's choice shares the launch of frame t's insert
+// (k_fused_insert_choice). (Two alternatives were measured and rejected, DESIGN.md §4.2: folding
 // frame t+1's choice into the row pass, and running it on a side stream into double-buffered SELECTED_ROAD /
 // accumulators. Both lose the producer -> consumer adjacency that lets the Direction kernel read the 20 MB the choice
 // kernel just wrote from the Infinity Cache.)
@@ -978,8 +1052,9 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
                                   const float* entropy1, uint64_t policy_seed, uint64_t policy_counter0,
                                   float* agent_features, int64_t A, int64_t a_bstride, const float* edge_attr,
                                   const float* log_edge_attr, float log_eps, int use_cong, uint64_t seed,
-                                  uint64_t counter0, int32_t* ins_scratch, int32_t* choice, float* log_prob,
-                                  float* entropy, float* reward, float* counts, tarl_stream stream) {
+                                  uint64_t counter0, int32_t* ins_scratch, float* sel_scratch, int64_t* acc_scratch,
+                                  int32_t* choice, float* log_prob, float* entropy, float* reward, float* counts,
+                                  tarl_stream stream) {
   int rc = tarl_check_fused_core(plan, f, B, Nmax);
   if (rc) return rc;
   TARL_REQUIRE(T >= 1 && times_host, "bad frame count / times");
@@ -998,13 +1073,23 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
   const dim3 grid_c((unsigned)ceil_div(B, threads), (unsigned)ceil_div(N, nchunk_choice()));
   const dim3 grid_d((unsigned)ceil_div(B, threads), (unsigned)ceil_div(N, nchunk_dir()));
   const int want_lp = log_prob != nullptr ? 1 : 0;
-  const FusedBufs fb = tarl_to_bufs(f);
+  FusedBufs fb = tarl_to_bufs(f);
+  // steady state: frame t's insert and frame t+1's choice share ONE launch (k_fused_insert_choice); SELECTED_ROAD and
+  // the log-prob accumulator banks are double-buffered between f->sel / f->acc_lp and the scratch pair
+  const char* knob = getenv("TARL_ROLLOUT_MERGE");
+  const bool merge = sel_scratch && acc_scratch && T > 1 && !(knob && atoi(knob) == 0);
+  float* sel_buf[2] = {f->sel, merge ? sel_scratch : f->sel};
+  long long* acc_buf[2] = {(long long*)f->acc_lp, merge ? (long long*)acc_scratch : (long long*)f->acc_lp};
+  if (merge) TARL_CHECK_HIP(hipMemsetAsync(acc_scratch, 0, (size_t)(f->acc_slots * B) * sizeof(int64_t), s));
+  hipLaunchKernelGGL(k_fused_choice, grid_c, dim3(threads), 0, s, plan->out_ptr, plan->out_dst, plan->out_eid,
+                     plan->group_of_node, plan->G, B, N, fb, thresholds, (const long long*)log_probs,
+                     (const float*)nullptr, policy_seed, policy_counter0, choice, nchunk_choice(), want_lp);
+  TARL_LAUNCH_CHECK();
   for (int64_t t = 0; t < T; ++t) {
+    const int cur = merge ? (int)(t & 1) : 0;
     const float time = times_host[t];
-    hipLaunchKernelGGL(k_fused_choice, grid_c, dim3(threads), 0, s, plan->out_ptr, plan->out_dst, plan->out_eid,
-                       plan->group_of_node, plan->G, B, N, fb, thresholds, (const long long*)log_probs, (const float*)nullptr, policy_seed,
-                       policy_counter0 + (uint64_t)t, choice ? choice + t * NB : nullptr, nchunk_choice(), want_lp);
-    TARL_LAUNCH_CHECK();
+    fb.sel = sel_buf[cur];
+    fb.acc_lp = acc_buf[cur];
     const bool timed = tarl_prof_mark(s, 0) != nullptr;
     hipLaunchKernelGGL(k_fused_direction, grid_d, dim3(threads), 0, s, plan->in_ptr, plan->in_src, plan->in_eid,
                        plan->E, B, N, fb, edge_attr, log_edge_attr, log_eps, time, (const float*)nullptr, seed,
@@ -1016,10 +1101,32 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
                        agent_features, A, a_bstride, time, (uint8_t*)nullptr, (uint8_t*)nullptr, counts_t, nchunk());
     TARL_LAUNCH_CHECK();
     if (timed) (void)tarl_prof_mark(s, 2);
-    hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(INSB), 0, s, (int)Nmax, B, N, fb, agent_features, A,
-                       a_bstride, use_cong, time, ins_scratch, entropy1, reward ? reward + t * B : nullptr, counts_t,
-                       log_prob ? log_prob + t * B : nullptr, entropy ? entropy + t * B : nullptr);
-    TARL_LAUNCH_CHECK();
+    float* reward_t = reward ? reward + t * B : nullptr;
+    float* lp_t = log_prob ? log_prob + t * B : nullptr;
+    float* ent_t = entropy ? entropy + t * B : nullptr;
+    if (merge && t + 1 < T) {
+      const ChoiceArgs C{plan->out_ptr, plan->out_dst, plan->out_eid, plan->group_of_node, plan->G, thresholds,
+                         (const long long*)log_probs, policy_seed, policy_counter0 + (uint64_t)(t + 1),
+                         choice ? choice + (t + 1) * NB : nullptr, nchunk_choice(), want_lp, sel_buf[cur ^ 1],
+                         acc_buf[cur ^ 1], sel_buf[cur], grid_c.x, grid_c.x * grid_c.y};
+      hipLaunchKernelGGL(k_fused_insert_choice, dim3(C.choice_blocks + (unsigned)B), dim3(threads), 0, s, C, (int)Nmax,
+                         B, N, fb, agent_features, A, a_bstride, use_cong, time, ins_scratch, entropy1, reward_t,
+                         counts_t, lp_t, ent_t);
+      TARL_LAUNCH_CHECK();
+    } else {
+      hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(INSB), 0, s, (int)Nmax, B, N, fb, agent_features, A,
+                         a_bstride, use_cong, time, ins_scratch, entropy1, reward_t, counts_t, lp_t, ent_t);
+      TARL_LAUNCH_CHECK();
+      if (t + 1 < T) {   // unmerged: the next frame's choice in place
+        hipLaunchKernelGGL(k_fused_choice, grid_c, dim3(threads), 0, s, plan->out_ptr, plan->out_dst, plan->out_eid,
+                           plan->group_of_node, plan->G, B, N, fb, thresholds, (const long long*)log_probs,
+                           (const float*)nullptr, policy_seed, policy_counter0 + (uint64_t)(t + 1),
+                           choice ? choice + (t + 1) * NB : nullptr, nchunk_choice(), want_lp);
+        TARL_LAUNCH_CHECK();
+      }
+    }
   }
+  if (merge && ((T - 1) & 1) == 1)   // the last frame's SELECTED_ROAD lives in the scratch buffer: bring it home
+    TARL_CHECK_HIP(hipMemcpyAsync(f->sel, sel_scratch, (size_t)NB * sizeof(float), hipMemcpyDeviceToDevice, s));
   return TARL_OK;
 }

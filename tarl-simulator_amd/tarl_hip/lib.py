@@ -58,7 +58,7 @@ SIGNATURES = {
     "tarl_fused_frame": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _u64, _u64, _p, _i64, _i64, _p, _p, _f32, C.c_int,
                                    _f32, _p, _u64, _u64] + [_p] * 10),
     "tarl_fused_rollout": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _u64, _u64, _p, _i64, _i64, _p, _p, _f32,
-                                     C.c_int, _u64, _u64] + [_p] * 7),
+                                     C.c_int, _u64, _u64] + [_p] * 9),
     "tarl_rollout_env_supported": (C.c_int, [_p]),
     "tarl_rollout_env_scratch_bytes": (_i64, [_p]),
     "tarl_rollout_env": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _u64, _u64, _p, _i64, _i64, _p, _p, _f32,

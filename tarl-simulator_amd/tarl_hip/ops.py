@@ -623,13 +623,17 @@ def fused_rollout(plan: Plan, fs: FusedState, tables: PolicyTables, agent_featur
                                ("reward", reward, torch.float32, (T, B))):
         if tns is not None and (tns.dtype != dt or tuple(tns.shape) != shp or not tns.is_contiguous() or not tns.is_cuda):
             raise ValueError(f"{name} must be a contiguous cuda {dt} tensor of shape {shp}")
+    if getattr(fs, "sel_scratch", None) is None:     # double buffers of the merged insert + choice launch
+        fs.sel_scratch = torch.empty_like(fs.sel)
+        fs.acc_scratch = torch.zeros_like(fs.acc_lp)
     tarr = (C.c_float * T)(*[float(t) for t in times])
     _lib.check(L.tarl_fused_rollout(plan.handle, fs.ref, B, fs.Nmax, T, tarr, tables.thresholds.data_ptr(),
                                     tables.log_probs.data_ptr(), tables.entropy.data_ptr(), int(policy_seed),
                                     int(policy_counter0), agent_features.data_ptr(), A, abs_, ec.edge_attr.data_ptr(),
                                     ec.log_edge_attr.data_ptr(), ec.log_eps, 1 if use_cong else 0, int(seed),
-                                    int(counter0), scratch.data_ptr(), _lib.ptr(choice), _lib.ptr(log_prob),
-                                    _lib.ptr(entropy), _lib.ptr(reward), _lib.ptr(counts), _lib.current_stream()))
+                                    int(counter0), scratch.data_ptr(), fs.sel_scratch.data_ptr(),
+                                    fs.acc_scratch.data_ptr(), _lib.ptr(choice), _lib.ptr(log_prob), _lib.ptr(entropy),
+                                    _lib.ptr(reward), _lib.ptr(counts), _lib.current_stream()))
 
 
 # ---- MPNNValueNet (dormant message-passing critic) ---------------------------------------------------------------------------

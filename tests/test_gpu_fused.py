@@ -175,10 +175,14 @@ def test_critic_slab_mode_matches_row_major(ops):
     assert torch.equal(v_slab, v_rows)        # same tiles, same k order, same MFMA chain
 
 
-@pytest.mark.parametrize("B,T", [(5, 30), (70, 7), (3, 1), (130, 2)])
-def test_rollout_launcher_equals_frame_loop(ops, B, T):
-    """SimEngine.rollout_fused (tarl_fused_rollout: the whole collector loop in one foreign call) == T calls of
-    frame_fused; then a second rollout continues from the state the first left."""
+@pytest.mark.parametrize("B,T,merge", [(5, 30, "1"), (5, 30, "0"), (70, 7, "1"), (3, 1, "1"), (130, 2, "1"),
+                                       (130, 3, "1"), (300, 5, "1")])
+def test_rollout_launcher_equals_frame_loop(ops, monkeypatch, B, T, merge):
+    """SimEngine.rollout_fused (tarl_fused_rollout: the whole collector loop in one foreign call; with merge = 1 frame
+    t+1's choice shares a launch with frame t's insert, SELECTED_ROAD and the log-prob accumulators double-buffered)
+    == T calls of frame_fused; then a second rollout continues from the state the first left (odd and even T end in
+    different buffers)."""
+    monkeypatch.setenv("TARL_ROLLOUT_MERGE", merge)
     from tarl_hip import synth
     from tarl_hip.engine import SimEngine
     net = synth.torus_network(5, 5, heterogeneous=True, seed=3)
