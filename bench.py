@@ -8,18 +8,27 @@
 A *step* is one PPO iteration of the reference's ``ppo_train`` (src/rl/ppo_trainer.py:129-145) for every environment
 of a rank: a rollout of T frames (policy logits -> GraphDistribution sample/log_prob -> env step: choice,
 DirectionMPNN, ResponseMPNN, withdraw, insert, reward) followed by ``epochs`` x (critic over all frames, GAE,
-advantage normalisation, minibatch, clipped PPO loss, backward, gradient all-reduce, Adam). Nothing is skipped or cached.
+advantage normalisation, minibatch, clipped PPO loss, backward, gradient all-reduce, Adam).
+What is hoisted: the live policy's logits are state-independent (embedding of the target road), so its segment softmax,
+inverse-CDF thresholds, log-probabilities and entropy are evaluated once per parameter update, not per frame (bit-identical
+to evaluating them per frame; ``--policy edge_mlp`` runs the state-dependent head with per-frame logits instead).
 Workload: BASELINE.json config 4 — 10k-edge synthetic torus dual graph, 16k agents, rollout-steps 256 — with ``--envs``
 vectorised environments per GPU (weak scaling: per-GPU work is fixed). Inputs are resident in HBM before the timed
 region. The timed region is bracketed by barrier + synchronize on both sides; the slowest rank's time is used.
 
 Also reported on the same JSON line:
-  roofline      — the Direction message+aggregate kernel (the scatter kernel named by the north star): algorithmic bytes
-                  per launch / average launch duration measured live with HIP events on the launch stream (the T frames
-                  of the first timed iteration), vs 8 TB/s; roofline_row_pass: the same for the row pass (Direction
-                  update + Response + withdraw), the kernel with the largest share of a frame.
-  cpu_baseline  — the oracle (CPU restatement of the reference path, torch CPU) timed on this host's cores on a bounded
-                  sample of the same workload (rank 0, N=1 only). A reported baseline, not a target.
+  roofline            — the DOMINANT kernel of a frame, k_fused_rows (DirectionMPNN.update + ResponseMPNN message /
+                        aggregate / update + withdraw): HBM bytes per launch from the PMC counters (2*FETCH_SIZE +
+                        WRITE_SIZE, rocprofv3 --pmc passes of THIS script reduced by tools/pmc_bench.py over frames >= 200
+                        of an iteration and committed under profiles/) / the kernel's average launch duration over the
+                        same frames, measured live with HIP events on the launch stream, vs the 8 TB/s HBM peak.
+                        ``compulsory_*``: the same with the bytes the packed layout must move instead of
+                        the counter bytes; ``survey_8d_*``: SURVEY §8d's per-edge figure for the reference's AoS layout,
+                        kept for continuity only (it charges every record once per out-edge: not a fraction of peak).
+  roofline_direction  — the same for k_fused_direction (DirectionMPNN.message + aggregate, the scatter kernel the
+                        north star names); roofline_insert_choice — the insert(t) + choice(t+1) launch.
+  cpu_baseline        — the oracle (CPU restatement of the reference path, torch CPU) timed on this host's cores on a
+                        bounded sample of the same workload (rank 0, N=1 only). A reported baseline, not a target.
 """
 from __future__ import annotations
 
@@ -38,16 +47,22 @@ for p in (ROOT, os.path.join(ROOT, "tarl-simulator_amd")):
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy kernel achieves
-# Direction message+aggregate, algorithmic bytes per edge (DESIGN.md "Kernels"): int32 src,eid (8) + edge_attr (4) +
-# upstream id/arr/dep/max/n/ff/sel (28) + downstream max/n/road_index (12) = 52; + 4 when Gumbel noise is read from
-# HBM (parity mode) + 4 when delta_travel_time is materialised. The bench draws noise in-kernel and skips dtt -> 52.
-DIR_BYTES_PER_EDGE = 52.0
-DIR_BYTES_PER_NODE = 4.0  # chosen[] out
-# Row pass = DirectionMPNN.update (32 B/node: max, n, ff, cong in; id, arr, dep, n out) + ResponseMPNN message+aggregate
-# (24 B/edge: indices 8 + upstream n, head 8 + downstream n, tail 8); the per-pop FIFO movement (344 B/pop in the
-# reference's layout) is not counted (SURVEY 8d's per-unit figures).
-ROWS_BYTES_PER_EDGE = 24.0
-ROWS_BYTES_PER_NODE = 32.0
+LATE_FRAME = 200          # the roofline window: frames >= 200 of an iteration (traffic and live time alike)
+PMC_RECORD = os.path.join("profiles", "r02_pmc_traffic.json")   # written by tools/pmc_bench.py from --pmc passes of this script
+# Compulsory HBM bytes per (road, environment) and launch of the packed env-minor layout: what each kernel
+# must read and write once, neighbour gathers served by the XCD's L2, statics / topology / policy tables through the
+# scalar cache (shared by all environments, not counted).
+COMPULSORY = {
+    # rec0 16 + SELECTED_ROAD 4 in; post records 8 + 4 out
+    "k_fused_direction": {"per_node_env": 20.0 + 12.0},
+    # post records 12 + rec0 16 + rec1 8 in; rec0 16 + rec1 8 + count 4 out (slot store / agent rows only on events)
+    "k_fused_rows": {"per_node_env": 36.0 + 28.0},
+    # choice(t+1): SELECTED_ROAD 4 + action 4 out; insert(t): departure window, a few records per admitted agent
+    "k_fused_insert_choice": {"per_node_env": 8.0},
+}
+# SURVEY §8d's per-unit figures for the reference's AoS layout (kept as ``survey_8d_*`` keys only): Direction message +
+# aggregate 52 B/edge + 4 B/node; row pass = Direction update 32 B/node + Response message/aggregate 24 B/edge.
+SURVEY_8D = {"k_fused_direction": (52.0, 4.0), "k_fused_rows": (24.0, 32.0)}
 
 
 def parse():
@@ -147,7 +162,10 @@ def main():
         torch.set_num_threads(max(1, (os.cpu_count() or 1) // world))
     L = lib.load()
 
+    t_setup = time.perf_counter()
     net, engine, trainer = build_trainer(args, rank, device)
+    torch.cuda.synchronize()
+    setup_s = time.perf_counter() - t_setup
     E, B, T = engine.E, engine.B, args.rollout_steps
 
     for _ in range(args.warmup):
@@ -165,30 +183,50 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = dist_utils.allreduce_max_float(elapsed, device)
 
-    k_ms, r_ms, k_n = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_int64(0)
-    lib.check(L.tarl_prof_collect2(ctypes.byref(k_ms), ctypes.byref(r_ms), ctypes.byref(k_n)))
+    ms_all, ms_late, nfr = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int64 * 2)()
+    late0 = LATE_FRAME if T > LATE_FRAME else 0
+    lib.check(L.tarl_prof_collect(late0, ms_all, ms_late, nfr))
     L.tarl_prof_enable(0)
 
     if rank == 0:
         total_frames = frames * world
         value = total_frames / elapsed
-        avg_s = (k_ms.value / max(1, k_n.value)) * 1e-3
-        alg_bytes = DIR_BYTES_PER_EDGE * B * E + DIR_BYTES_PER_NODE * B * engine.N
-        achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
-        # HBM traffic per launch from the PMC counters (2*FETCH_SIZE + WRITE_SIZE, collected in separate rocprofv3 --pmc
-        # passes of the same kernels at the same sizes and committed under profiles/); null when no matching record.
-        traffic, traffic_rows, traffic_src = None, None, None
+        NB = B * engine.N
+        pmc = None
         try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", "r01_v5_pmc_traffic.json")))
-            if rec["config"] == {"edges": E, "agents": args.agents, "envs": B}:
-                traffic = rec["kernels"]["k_fused_direction"]["hbm_bytes_per_launch"]
-                traffic_rows = rec["kernels"]["k_fused_rows"]["hbm_bytes_per_launch"]
-                traffic_src = "profiles/r01_v5_pmc_traffic.json (rocprofv3 --pmc, 2*FETCH_SIZE + WRITE_SIZE)"
+            rec = json.load(open(os.path.join(ROOT, PMC_RECORD)))
+            if rec["config"] == {"edges": E, "agents": args.agents, "envs": B, "rollout_steps": T} and \
+                    rec.get("layout") == trainer.layout_tag:
+                pmc = rec
         except (OSError, KeyError, ValueError):
             pass
-        rows_s = (r_ms.value / max(1, k_n.value)) * 1e-3
-        rows_bytes = ROWS_BYTES_PER_EDGE * B * E + ROWS_BYTES_PER_NODE * B * engine.N
-        rows_achieved = rows_bytes / rows_s / 1e9 if rows_s > 0 else 0.0
+
+        def roofline(slot, kernel, what):
+            """achieved = HBM bytes per launch (PMC counters of this script's own rollout, frames >= LATE_FRAME) / the live
+            average launch duration over the same frames; without a matching PMC record: the compulsory bytes."""
+            n_late, n_all = max(1, nfr[1]), max(1, nfr[0])
+            late_s, all_s = ms_late[slot] / n_late * 1e-3, ms_all[slot] / n_all * 1e-3
+            comp = COMPULSORY[kernel]["per_node_env"] * NB
+            traffic = pmc["kernels"][kernel]["hbm_bytes_per_launch"] if pmc and kernel in pmc["kernels"] else None
+            byts = traffic if traffic is not None else comp
+            achieved = byts / late_s / 1e9 if late_s > 0 else 0.0
+            out = {"bound": "hbm", "kernel": f"{kernel} ({what})", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                   "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                   "traffic_source": (f"{PMC_RECORD}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, "
+                                      f"2*FETCH_SIZE + WRITE_SIZE, mean over frames >= {LATE_FRAME}") if traffic else None,
+                   "bytes_basis": "pmc_counters" if traffic is not None else "compulsory",
+                   "avg_launch_us": late_s * 1e6, "frames_timed": int(nfr[1]), "first_frame": late0,
+                   "avg_launch_us_all_frames": all_s * 1e6,
+                   "compulsory_bytes_per_launch": comp,
+                   "compulsory_frac": (comp / late_s / 1e9 / HBM_PEAK_GBS) if late_s > 0 else 0.0}
+            if kernel in SURVEY_8D:
+                pe, pn = SURVEY_8D[kernel]
+                out["survey_8d_bytes_per_launch"] = pe * B * E + pn * NB
+            return out, late_s
+
+        rf_rows, rows_s = roofline(1, "k_fused_rows", "DirectionMPNN.update + ResponseMPNN + withdraw; the dominant kernel")
+        rf_dir, dir_s = roofline(0, "k_fused_direction", "DirectionMPNN message + aggregate on the packed hot records")
+        rf_ic, _ = roofline(2, "k_fused_insert_choice", "insert(t) + GraphDistribution sample / log_prob of frame t+1")
         out = {
             "metric": "ppo_env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -198,21 +236,12 @@ def main():
                                    f"sub-batch {args.sub_batch}" +
                                    (" (BASELINE config 4)" if (E, args.agents) == (10000, 16384) else ""),
                        "envs_per_gpu": B, "env_steps_per_step": B * T, "parallelism": f"dp{world} (rollouts sharded, "
-                       "one gradient all-reduce per optimiser step)"},
+                       "one gradient all-reduce per optimiser step)", "rollout_kernels": trainer.rollout},
             "msgpass_edges_per_sec": value * E,
             # Direction + Response pair alone (SURVEY 8d's second metric): B*E edges per frame / the two kernels' live time
-            "msgpass_pair_edges_per_sec": (B * E) / (avg_s + rows_s) if (avg_s + rows_s) > 0 else None,
-            "roofline": {"bound": "hbm", "kernel": "k_fused_direction (DirectionMPNN message+aggregate on the packed hot records)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_us": avg_s * 1e6, "launches_timed": k_n.value},
-            # the kernel with the largest share of the frame (35 %): Direction update + Response + withdraw
-            "roofline_row_pass": {"bound": "hbm", "kernel": "k_fused_rows (DirectionMPNN.update + ResponseMPNN + withdraw)",
-                                  "achieved": rows_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": rows_achieved / HBM_PEAK_GBS, "traffic": traffic_rows,
-                                  "traffic_source": traffic_src, "algorithmic_bytes_per_launch": rows_bytes,
-                                  "avg_launch_us": rows_s * 1e6, "launches_timed": k_n.value},
+            "msgpass_pair_edges_per_sec": (B * E) / (dir_s + rows_s) if (dir_s + rows_s) > 0 else None,
+            "roofline": rf_rows, "roofline_direction": rf_dir, "roofline_insert_choice": rf_ic,
+            "setup_seconds": setup_s, "timed_seconds": elapsed,
         }
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args, net)

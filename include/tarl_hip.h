@@ -355,13 +355,13 @@ int tarl_select_next_hop(float* x, int64_t B, int64_t x_bstride, int64_t ldx, in
                          int64_t nh_bstride, tarl_stream stream);
 
 /* ---- measurement hook (bench.py roofline leg; nothing comparable in the reference) ------------------------------------
- * tarl_prof_enable(n > 0) brackets the next n launches of the Direction message+aggregate kernel with HIP events on
- * their launch stream; tarl_prof_enable(0) turns it off. tarl_prof_collect synchronises those events and returns the
- * summed kernel time (ms) and the number of timed launches. */
-int tarl_prof_enable(int64_t max_launches);
-int tarl_prof_collect(double* total_ms_host, int64_t* launches_host);
-/* the same, plus the summed time of the row pass (Direction update + Response + withdraw) of the timed fused frames */
-int tarl_prof_collect2(double* direction_ms_host, double* rows_ms_host, int64_t* launches_host);
+ * tarl_prof_enable(n > 0) brackets the frame kernels of the next n fused frames (Direction message+aggregate, the row
+ * pass, the insert [+ next frame's choice] launch) with HIP events on their launch stream; tarl_prof_enable(0) turns it
+ * off. tarl_prof_collect synchronises those events and returns, per kernel slot k = 0 (Direction gather), 1 (row pass),
+ * 2 (insert [+ choice]), the summed kernel time in ms over all timed frames (ms_all[3]) and over the timed frames with
+ * index >= first_late_frame (ms_late[3]); frames[0], frames[1] = the number of frames behind each sum. */
+int tarl_prof_enable(int64_t max_frames);
+int tarl_prof_collect(int64_t first_late_frame, double* ms_all_host, double* ms_late_host, int64_t* frames_host);
 
 #ifdef __cplusplus
 }

@@ -1038,6 +1038,7 @@ extern "C" int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int6
                      agent_features, A, a_bstride, use_cong, time, ins_scratch, entropy1, reward, counts, log_prob,
                      entropy);
   TARL_LAUNCH_CHECK();
+  if (timed) (void)tarl_prof_mark(s, 3);
   return TARL_OK;
 }
 
@@ -1125,6 +1126,7 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
         TARL_LAUNCH_CHECK();
       }
     }
+    if (timed) (void)tarl_prof_mark(s, 3);
   }
   if (merge && ((T - 1) & 1) == 1)   // the last frame's SELECTED_ROAD lives in the scratch buffer: bring it home
     TARL_CHECK_HIP(hipMemcpyAsync(f->sel, sel_scratch, (size_t)NB * sizeof(float), hipMemcpyDeviceToDevice, s));

@@ -20,7 +20,10 @@ __global__ __launch_bounds__(POL_BLOCK) void k_edge_logits_fwd(const int32_t* __
   logits[gid] = (idx >= 0 && idx < M) ? emb[idx] : 0.0f;
 }
 
-// one thread per (batch row, node n): sum the gradients of n's in-edges (ascending edge id), one atomic per (b, n)
+// one thread per node n: the gradients of n's in-edges (ascending edge id) summed over the batch rows in row order. Rows
+// that map n to the same embedding (always, while ROAD_INDEX is the static column it is) are accumulated in registers and
+// flushed with ONE add per (node, embedding) run: with a one-to-one ROAD_INDEX every embedding receives a single add, so
+// the gradient is bit-reproducible run to run (a per-(row, node) atomic was order-dependent in the last bit).
 __global__ __launch_bounds__(POL_BLOCK) void k_edge_logits_bwd(const int32_t* __restrict__ in_ptr,
                                                                const int32_t* __restrict__ in_eid,
                                                                const float* __restrict__ road_index,
@@ -28,17 +31,22 @@ __global__ __launch_bounds__(POL_BLOCK) void k_edge_logits_bwd(const int32_t* __
                                                                int64_t N, int64_t E,
                                                                const float* __restrict__ grad_logits,
                                                                float* __restrict__ grad_emb, int64_t M) {
-  const int64_t gid = (int64_t)blockIdx.x * POL_BLOCK + threadIdx.x;
-  if (gid >= B * N) return;
-  const int64_t b = gid / N;
-  const int32_t n = (int32_t)(gid - b * N);
+  const int64_t n = (int64_t)blockIdx.x * POL_BLOCK + threadIdx.x;
+  if (n >= N) return;
   const int32_t k0 = in_ptr[n], k1 = in_ptr[n + 1];
   if (k0 == k1) return;
-  const long long idx = (long long)road_index[b * ri_bstride + (int64_t)n * ri_nstride];
-  if (idx < 0 || idx >= M) return;
+  long long cur = -1;
   float s = 0.0f;
-  for (int32_t k = k0; k < k1; ++k) s += grad_logits[b * E + in_eid[k]];
-  atomicAdd(&grad_emb[idx], s);
+  for (int64_t b = 0; b < B; ++b) {
+    const long long idx = (long long)road_index[b * ri_bstride + n * ri_nstride];
+    if (idx != cur) {
+      if (cur >= 0 && cur < M) atomicAdd(&grad_emb[cur], s);
+      cur = idx;
+      s = 0.0f;
+    }
+    for (int32_t k = k0; k < k1; ++k) s += grad_logits[b * E + in_eid[k]];
+  }
+  if (cur >= 0 && cur < M) atomicAdd(&grad_emb[cur], s);
 }
 
 extern "C" int tarl_policy_edge_logits_fwd(const tarl_plan* plan, const float* road_index, int64_t ri_bstride,
@@ -59,7 +67,7 @@ extern "C" int tarl_policy_edge_logits_bwd(const tarl_plan* plan, const float* r
   TARL_REQUIRE(plan && road_index && grad_logits && grad_emb, "null argument");
   TARL_REQUIRE(B >= 1 && M >= 1, "bad sizes");
   if (plan->E == 0 || plan->N == 0) return TARL_OK;
-  hipLaunchKernelGGL(k_edge_logits_bwd, dim3((unsigned)ceil_div(B * plan->N, POL_BLOCK)), dim3(POL_BLOCK), 0,
+  hipLaunchKernelGGL(k_edge_logits_bwd, dim3((unsigned)ceil_div(plan->N, POL_BLOCK)), dim3(POL_BLOCK), 0,
                      (hipStream_t)stream, plan->in_ptr, plan->in_eid, road_index, ri_bstride, ri_nstride, B, plan->N,
                      plan->E, grad_logits, grad_emb, M);
   TARL_LAUNCH_CHECK();

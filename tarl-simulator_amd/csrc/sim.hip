@@ -175,22 +175,24 @@ __global__ __launch_bounds__(SIM_BLOCK) void k_response_update(float* __restrict
 }
 
 // ---- live kernel timing (bench.py's roofline leg) -------------------------------------------------------------------
-// When enabled, every launch of the Direction gather kernel (the message-passing scatter kernel the roofline is quoted
-// on) is bracketed by a pair of HIP events on the launch stream. Events come from a pre-created pool (no allocation in
-// the launch path); tarl_prof_collect() synchronises them after the timed region and returns the summed duration.
+// When enabled, the frame kernels are bracketed by HIP events on the launch stream: tag 0 before the Direction gather,
+// 1 after it, 2 after the row pass, 3 after the insert (+ next frame's choice) launch. Events come from a pre-created
+// pool (no allocation in the launch path); tarl_prof_collect() synchronises them after the timed region and returns the
+// summed duration of each kernel slot, over all timed frames and over the frames >= first_late_frame alone.
 #include <vector>
 static bool g_prof_on = false;
 static std::vector<hipEvent_t> g_prof_events;   // marks in launch order
-static std::vector<int> g_prof_tags;            // 0 = before Direction gather, 1 = after it, 2 = after the row pass
+static std::vector<int> g_prof_tags;
 static size_t g_prof_used = 0;
+#define PROF_MARKS_PER_FRAME 4
 
-extern "C" int tarl_prof_enable(int64_t max_launches) {
+extern "C" int tarl_prof_enable(int64_t max_frames) {
   for (hipEvent_t e : g_prof_events) (void)hipEventDestroy(e);
   g_prof_events.clear();
   g_prof_tags.clear();
   g_prof_used = 0;
-  g_prof_on = max_launches > 0;
-  for (int64_t i = 0; i < 3 * max_launches; ++i) {
+  g_prof_on = max_frames > 0;
+  for (int64_t i = 0; i < PROF_MARKS_PER_FRAME * max_frames; ++i) {
     hipEvent_t e;
     TARL_CHECK_HIP(hipEventCreate(&e));
     g_prof_events.push_back(e);
@@ -199,35 +201,33 @@ extern "C" int tarl_prof_enable(int64_t max_launches) {
   return TARL_OK;
 }
 
-// Summed durations of the two message-passing kernels and the number of timed frames; re-arms the pool.
-extern "C" int tarl_prof_collect2(double* direction_ms, double* rows_ms, int64_t* launches) {
-  TARL_REQUIRE(direction_ms && rows_ms && launches, "null argument");
-  double dir = 0.0, rows = 0.0;
-  int64_t n = 0;
+// ms_all[k] / ms_late[k]: summed duration of kernel slot k (0 Direction gather, 1 row pass, 2 insert [+ choice]) over
+// all timed frames / over the timed frames with index >= first_late_frame; frames[0..1] = how many frames each sum
+// covers. Re-arms the pool.
+extern "C" int tarl_prof_collect(int64_t first_late_frame, double* ms_all, double* ms_late, int64_t* frames) {
+  TARL_REQUIRE(ms_all && ms_late && frames, "null argument");
+  for (int k = 0; k < 3; ++k) ms_all[k] = ms_late[k] = 0.0;
+  int64_t frame = -1, n_all = 0, n_late = 0;
   for (size_t i = 0; i + 1 < g_prof_used; ++i) {
     const int ta = g_prof_tags[i], tb = g_prof_tags[i + 1];
-    if (!((ta == 0 && tb == 1) || (ta == 1 && tb == 2))) continue;
+    if (ta == 0) {
+      ++frame;
+      if (tb == 1) {
+        ++n_all;
+        if (frame >= first_late_frame) ++n_late;
+      }
+    }
+    if (tb != ta + 1 || ta < 0 || ta > 2) continue;
     TARL_CHECK_HIP(hipEventSynchronize(g_prof_events[i + 1]));
     float ms = 0.0f;
     TARL_CHECK_HIP(hipEventElapsedTime(&ms, g_prof_events[i], g_prof_events[i + 1]));
-    if (ta == 0) {
-      dir += ms;
-      ++n;
-    } else {
-      rows += ms;
-    }
+    ms_all[ta] += ms;
+    if (frame >= first_late_frame) ms_late[ta] += ms;
   }
-  *direction_ms = dir;
-  *rows_ms = rows;
-  *launches = n;
+  frames[0] = n_all;
+  frames[1] = n_late;
   g_prof_used = 0;
   return TARL_OK;
-}
-
-extern "C" int tarl_prof_collect(double* total_ms, int64_t* launches) {
-  TARL_REQUIRE(total_ms && launches, "null argument");
-  double rows = 0.0;
-  return tarl_prof_collect2(total_ms, &rows, launches);
 }
 
 hipEvent_t tarl_prof_mark(hipStream_t s, int tag) {

@@ -61,6 +61,7 @@ class VecPPOTrainer:
         elif mode == "env" and not engine.env_rollout_supported:
             raise ValueError("rollout='env' needs a graph whose hot records fit the LDS (tarl_rollout_env_supported)")
         self.rollout = mode
+        self.layout_tag = ops.FUSED_LAYOUT
         # rollout buffers, written directly by the kernels: ENV-MINOR ([frame][node][env]) for "frames"
         self.env_minor = mode == "frames"
         shp = (lambda t: (t, N, B)) if self.env_minor else (lambda t: (t, B, N))

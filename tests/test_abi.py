@@ -72,5 +72,5 @@ def test_entry_points_reject_bad_arguments_on_the_host():
                               null, null, null, null, null, null, null, null) == -1
     assert L.tarl_value_mpnn_fwd(null, null, 1, null, null, 0, null, null, null, null, null, null) == -1
     assert L.tarl_select_next_hop(null, 1, 0, 52, 15, 4, null, 1, 9, null, 0, null) == -1
-    d, r, n = C.c_double(), C.c_double(), C.c_int64()
-    assert L.tarl_prof_collect2(C.byref(d), C.byref(r), C.byref(n)) == 0 and n.value == 0
+    ms_all, ms_late, n = (C.c_double * 3)(), (C.c_double * 3)(), (C.c_int64 * 2)()
+    assert L.tarl_prof_collect(0, ms_all, ms_late, n) == 0 and n[0] == 0 and n[1] == 0
