@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TARL_ABI_VERSION 1
+#define TARL_ABI_VERSION 2
 
 typedef enum {
   TARL_OK = 0,
@@ -195,6 +195,19 @@ int tarl_critic_mlp_fwd_slabs(const float* counts, int64_t rows_per_slab, int64_
                               int64_t rows_per_time, const float* w1, const float* b1, const float* w2, const float* b2,
                               const float* w3, const float* b3, float* value, tarl_stream stream);
 
+/* the same two forwards on the rollout buffers' count bytes (uint8 NUMBER_OF_AGENT, widened to fp32 in the LDS staging:
+ *   identical values): tarl_critic_mlp_fwd_u8 reads counts uint8 [M][ldc] (the env-major buffer of tarl_rollout_env),
+ *   tarl_critic_mlp_fwd_slabs_u8 counts uint8 [M / rows_per_slab][N][rows_per_slab] (the env-minor buffer of
+ *   tarl_fused_rollout). */
+int tarl_critic_mlp_fwd_u8(const uint8_t* counts, int64_t ldc, int64_t M, int64_t N, const float* time_rows,
+                           int64_t rows_per_time, const float* w1, const float* b1, const float* w2, const float* b2,
+                           const float* w3, const float* b3, float* value, float* h1_out, float* h2_out,
+                           tarl_stream stream);
+int tarl_critic_mlp_fwd_slabs_u8(const uint8_t* counts, int64_t rows_per_slab, int64_t M, int64_t N,
+                                 const float* time_rows, int64_t rows_per_time, const float* w1, const float* b1,
+                                 const float* w2, const float* b2, const float* w3, const float* b3, float* value,
+                                 tarl_stream stream);
+
 /* ---- MPNNValueNet (src/agents/mpnn_agent.py:265-402; the message-passing critic the reference defines but never
  * instantiates) in evaluation mode (Dropout = identity), M samples:
  *   value[m] = W_f . [tanh(w_n * mean_{e=(u->v)} tanh(W_m . [node_features[m][v] (7), agent_rows[m][v] (9), edge_features[m][e]] + b_m) + b_n) for u, time_net(time[m])] + b_f
@@ -211,37 +224,55 @@ int tarl_value_mpnn_bwd(const tarl_plan* plan, const float* node_features, int64
                         const float* grad_value, const float* node_act, const float* agg, float* const* grads,
                         tarl_stream stream);
 
-/* ---- fused rollout frame (vectorised fast path; same results as the entry points above, 3 launches per frame) ----------
+/* ---- fused rollout frame (vectorised fast path; same results as the entry points above, 3-4 launches per frame) --------
  * ENV-MINOR layout: every per-(node, environment) buffer is stored [node][environment], so that a wavefront holds 64
  * environments of one node: topology / table loads are wave-uniform and record gathers are coalesced.
- * Caller-owned side buffers that mirror x / agent_features (all device memory, 16-byte aligned):
- *   rec0 [N][B][4] = {head_id, head_dep, n, tail_id}   rec1 [N][B][2] = {head_arr, pending-garbage n0 or -1}
- *   post_a [N][B][2] = {n', tail'} (state after the Direction update), post_b [N][B] = the agent the update enqueues (0: none)
- *   sel [N][B] = SELECTED_ROAD; acc_lp int64 [acc_slots][B], acc_n fp32 [acc_slots][B]: per-frame accumulator banks
- *   (zeroed by pack; acc_slots >= 1 banks spread the atomics of the many workgroups that serve one environment)
+ * Caller-owned side buffers that mirror x / agent_features (all device memory, 16-byte aligned). Packed words ("v6"):
+ *   hdp  uint32 [N][B][2] = {head_id << 8 | NUMBER_OF_AGENT, bits of the head's departure time}
+ *   tl   uint32 [N][B]    = tail_id << 8 | flags (bit 0: rec1 is authoritative for the last frame)
+ *   post uint32 [N][B]    = state after the Direction update: tail' << 8 | non-empty' << 1 | arrived
+ *   rec1 uint32 [N][B][2] = {bits of the head's arrival time, (pending-garbage count + 1) << 16 | ring-buffer head offset};
+ *                           touched only by rows where something moves in a frame
+ *   sel8 uint8  [N][B]    = SELECTED_ROAD as the rank of the chosen out-edge in the node's CSR list (bit 7: carried over
+ *                           from the previous frame; 0x7F: the fp32 value in sel [N][B] is authoritative)
+ *   in_rank uint8 [E]     = (built by pack, CSC order) the sel8 rank of the upstream node that heads for this road
  *   st0  [N][4]    = {MAX_NUMBER_OF_AGENT, FREE_FLOW_TIME_TRAVEL, ROAD_INDEX, congestion_constant} (static, shared)
  *   slots [N][B][ld_slots]: slot-interleaved FIFO store, slot s at floats 3s..3s+2 = {agent id, arrival, departure};
  *                  ld_slots >= 3*Nmax (pad to a multiple of 16 floats)
+ *   acc_lp int64 [acc_slots][B], acc_n / acc_w fp32 [acc_slots][B]: per-frame accumulator banks (log-prob in 2^-32 fixed
+ *   point, sum of counts, agents withdrawn; zeroed by pack; acc_slots >= 1 banks spread the atomics of the many
+ *   workgroups that serve one environment)
  *   a_origin / a_dest int32 [B][A], a_dep fp32 [B][A], a_status uint8 [B][A] (0 waiting, 1 on the way, 2 done);
  *   a_order int32 [B][A] (optional, may be NULL): each environment's agent ids sorted by DEPARTURE_TIME — with it the
  *   insert kernel scans a window of that order from the cursor cur_lo int32 [B] instead of every agent every frame;
  *   a_dep_sorted fp32 [B][A] (required with a_order): DEPARTURE_TIME in that order, so the scan reads departures
  *   sequentially and touches the per-agent arrays only for the few entries that are due.
+ *   flags int32 [1]: sticky device status word (cleared by pack): TARL_FLAG_COUNT_AT_NMAX = a FIFO count reached Nmax
+ *   (the reference raises IndexError there, src/direction_mpnn.py:172-191: the state is outside its defined domain),
+ *   TARL_FLAG_AMBIGUOUS_EDGES = two out-edges of a node lead to the same ROAD_INDEX, TARL_FLAG_PACK_RANGE = a packed
+ *   count above 255 / agent id at or above 2^24. The caller reads it at its next synchronisation point.
+ * Domain of the fused path: Nmax <= 255, out-degree <= 126, agent ids < 2^24 (refused / flagged otherwise).
  * tarl_fused_pack imports x / agent_features (call after construction, reset, or any external write to x); between
  * pack and export the packed state is authoritative for the FIFO columns, NUMBER_OF_AGENT and SELECTED_ROAD;
  * tarl_fused_export writes them back into x in the reference's column layout, bit-identical to the unfused path.
  * agent_features is updated in place by every call. */
+#define TARL_FLAG_COUNT_AT_NMAX 1
+#define TARL_FLAG_AMBIGUOUS_EDGES 2
+#define TARL_FLAG_PACK_RANGE 4
 typedef struct tarl_fused {
-  float* rec0;
-  float* rec1;
-  float* post_a;
-  float* post_b;
+  void* hdp;
+  void* tl;
+  void* rec1;
+  void* post;
   float* st0;
   float* slots;
   int64_t ld_slots;
+  uint8_t* sel8;
   float* sel;
+  uint8_t* in_rank;
   int64_t* acc_lp;
   float* acc_n;
+  float* acc_w;
   int32_t* a_origin;
   int32_t* a_dest;
   float* a_dep;
@@ -250,6 +281,7 @@ typedef struct tarl_fused {
   int32_t* cur_lo;
   const float* a_dep_sorted;
   int64_t acc_slots;
+  int32_t* flags;
 } tarl_fused;
 
 int tarl_fused_pack(const tarl_plan* plan, const tarl_fused* f, const float* x, int64_t B, int64_t x_bstride,
@@ -274,53 +306,80 @@ int tarl_fused_policy_prepare(const tarl_plan* plan, const tarl_fused* f, const 
                               float temperature, double* group_base, float* thresholds, int64_t* log_probs,
                               float* entropy1, tarl_stream stream);
 /* tarl_fused_frame == one collector frame for B environments: GraphDistribution.sample() + log_prob() (+ entropy) and
- *   the choice phase, then tarl_core_step + tarl_withdraw_step + tarl_insert_step, in three launches.
+ *   the choice phase, then tarl_core_step + tarl_withdraw_step + tarl_insert_step, in four launches.
  *   uniform [B][num_groups] or NULL (Philox keyed by policy_seed / policy_counter); gumbel [B][E] or NULL (Philox keyed
- *   by seed / counter). Nullable outputs: delta_travel_time [B][E], popped / withdrawn uint8 [B][N] (env-major, like the
- *   unfused entry points); choice int32 [N][B] and counts fp32 [N][B] (ENV-MINOR); log_prob, entropy, reward [B].
+ *   by seed / counter). prev_time: the clock of the previous frame on this state (an idle empty FIFO's head arrival, used
+ *   by delta_travel_time only). Nullable outputs: delta_travel_time [B][E], popped / withdrawn uint8 [B][N] (env-major,
+ *   like the unfused entry points); choice int32 [N][B] (chosen edge id, -1: none) and counts fp32 [N][B] (ENV-MINOR);
+ *   log_prob, entropy, reward [B].
+ *   thresholds == NULL skips the choice phase: SELECTED_ROAD is what tarl_fused_apply_choice (an externally sampled
+ *   action, e.g. of a state-dependent policy) left; choice / log_prob / entropy must then be NULL.
  *   log_prob sums the same terms as tarl_graphdist_logprob_entropy_fwd, accumulated in 2^-32 fixed point (order-
  *   independent, hence deterministic): equal to fp32 rounding, not bit-identical. use_cong = 0 reproduces a graph without congestion_constant in insert. */
 int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, const float* thresholds,
                      const int64_t* log_probs, const float* entropy1, const float* uniform, uint64_t policy_seed,
                      uint64_t policy_counter, float* agent_features, int64_t num_agents, int64_t a_bstride,
                      const float* edge_attr, const float* log_edge_attr, float log_eps, int use_cong, float time,
-                     const float* gumbel, uint64_t seed, uint64_t counter, float* delta_travel_time, uint8_t* popped,
-                     uint8_t* withdrawn, int32_t* ins_scratch, int32_t* choice, float* log_prob, float* entropy,
-                     float* reward, float* counts, tarl_stream stream);
+                     float prev_time, const float* gumbel, uint64_t seed, uint64_t counter, float* delta_travel_time,
+                     uint8_t* popped, uint8_t* withdrawn, int32_t* ins_scratch, int32_t* choice, float* log_prob,
+                     float* entropy, float* reward, float* counts, tarl_stream stream);
+/* tarl_fused_apply_choice == the choice phase of SimulatorEnv._step (src/reinforcement_learning.py:223-231) on the packed
+ *   state for an action sampled elsewhere: choice int32 [B][N] = chosen edge id per source node, -1 = none (the node keeps
+ *   its SELECTED_ROAD). */
+int tarl_fused_apply_choice(const tarl_plan* plan, const tarl_fused* f, int64_t B, const int32_t* choice,
+                            tarl_stream stream);
 
 /* tarl_fused_rollout == T consecutive tarl_fused_frame calls with device noise (uniform = gumbel = NULL), frame t at
- *   clock times_host[t] (HOST array of T floats) with policy counter policy_counter0 + t and noise counter counter0 + t —
- *   the collector loop of ppo_train (src/rl/ppo_trainer.py:129-133) in one call, same results as the frame-by-frame calls.
- *   Outputs, each frame-major: choice int32 [T][N][B], counts fp32 [T][N][B] (ENV-MINOR inside a frame), log_prob /
- *   entropy / reward fp32 [T][B]; choice, counts, log_prob, entropy, reward may be NULL.
- *   Scratch (device): ins_scratch int32 [B][2A]; optional sel_scratch fp32 [N][B] + acc_scratch int64 [acc_slots][B]
- *   (both or neither): with them frame t+1's choice work shares ONE launch with frame t's insert (a latency chain that
- *   leaves the chip idle), SELECTED_ROAD and the log-prob accumulator being double-buffered (TARL_ROLLOUT_MERGE=0
- *   disables it). */
+ *   clock times_host[t] (HOST array of T floats; prev_time = the clock of the frame before the first, if any) with policy
+ *   counter policy_counter0 + t and noise counter counter0 + t — the collector loop of ppo_train
+ *   (src/rl/ppo_trainer.py:129-133) in one call, same results as the frame-by-frame calls.
+ *   Outputs, each frame-major and nullable: choice uint8 [T][N][B] (the action: rank of the chosen out-edge in the source
+ *   node's CSR list = tarl_plan order; bit 7 set: the node drew nothing — the action is infeasible there / the node has no
+ *   out-edges), counts uint8 [T][N][B] (NUMBER_OF_AGENT after frame t; ENV-MINOR inside a frame), log_prob / entropy /
+ *   reward fp32 [T][B].
+ *   What SimulatorEnv._step logs per step (src/reinforcement_learning.py:278-294), device-side: leg int32 [T][B][2] =
+ *   {agents departed, agents arrived} per frame (the leg histogram's series); for the first metrics_envs environments the
+ *   per-node series dtt_node fp32 [T][N][metrics_envs] (delta_travel_time of the node's out-edges,
+ *   src/direction_mpnn.py:94-96) and events uint8 [T][N][metrics_envs] (bit 0: Response pop, bit 1: withdraw — the masks
+ *   of update_history / withdraw_history).
+ *   Scratch (device): ins_scratch int32 [B][2A]; sel_scratch uint8 [N][B] (only used without a choice buffer) +
+ *   acc_scratch int64 [acc_slots][B]: with acc_scratch and two distinct SELECTED_ROAD slices frame t+1's choice work
+ *   shares ONE launch with frame t's insert (a latency chain that leaves the chip idle); TARL_ROLLOUT_MERGE=0 disables it. */
 int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, int64_t T,
-                       const float* times_host, const float* thresholds, const int64_t* log_probs, const float* entropy1,
-                       uint64_t policy_seed, uint64_t policy_counter0, float* agent_features, int64_t num_agents,
-                       int64_t a_bstride, const float* edge_attr, const float* log_edge_attr, float log_eps, int use_cong,
-                       uint64_t seed, uint64_t counter0, int32_t* ins_scratch, float* sel_scratch, int64_t* acc_scratch,
-                       int32_t* choice, float* log_prob, float* entropy, float* reward, float* counts,
-                       tarl_stream stream);
+                       const float* times_host, float prev_time, const float* thresholds, const int64_t* log_probs,
+                       const float* entropy1, uint64_t policy_seed, uint64_t policy_counter0, float* agent_features,
+                       int64_t num_agents, int64_t a_bstride, const float* edge_attr, const float* log_edge_attr,
+                       float log_eps, int use_cong, uint64_t seed, uint64_t counter0, int32_t* ins_scratch,
+                       uint8_t* sel_scratch, int64_t* acc_scratch, uint8_t* choice, float* log_prob, float* entropy,
+                       float* reward, uint8_t* counts, int32_t metrics_envs, float* dtt_node, uint8_t* events,
+                       int32_t* leg, tarl_stream stream);
 
 /* tarl_rollout_env == tarl_fused_rollout with the other mapping: ONE workgroup per environment keeps that environment's
  *   hot records and static columns in LDS (56 B per road + 16 KB; tarl_rollout_env_supported(plan) tells whether the
  *   graph fits the CU's 160 KB, i.e. up to ~2 600 roads) and runs all T frames inside a single launch, with workgroup barriers where the env-minor path has kernel
  *   boundaries. Same packed state in / out (tarl_fused), same noise streams, identical states / agents / actions /
  *   rewards / counts / log-probs. Differences at the interface: times_dev is a DEVICE array of T floats, and the
- *   per-frame outputs are ENV-MAJOR: choice int32 [T][B][N], counts fp32 [T][B][N] (log_prob / entropy / reward [T][B]).
+ *   per-frame outputs are ENV-MAJOR: choice uint8 [T][B][N], counts uint8 [T][B][N], dtt_node fp32 [T][metrics_envs][N],
+ *   events uint8 [T][metrics_envs][N] (log_prob / entropy / reward [T][B], leg [T][B][2]).
  *   static_scratch: tarl_rollout_env_scratch_bytes(plan) bytes of 16-byte aligned device memory (the per-edge statics
  *   are packed into 16-byte records there by every call). */
 int tarl_rollout_env_supported(const tarl_plan* plan);
 int64_t tarl_rollout_env_scratch_bytes(const tarl_plan* plan);
 int tarl_rollout_env(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, int64_t T,
-                     const float* times_dev, const float* thresholds, const int64_t* log_probs, const float* entropy1,
-                     uint64_t policy_seed, uint64_t policy_counter0, float* agent_features, int64_t num_agents,
-                     int64_t a_bstride, const float* edge_attr, const float* log_edge_attr, float log_eps, int use_cong,
-                     uint64_t seed, uint64_t counter0, int32_t* ins_scratch, void* static_scratch, int32_t* choice,
-                     float* log_prob, float* entropy, float* reward, float* counts, tarl_stream stream);
+                     const float* times_dev, float prev_time, const float* thresholds, const int64_t* log_probs,
+                     const float* entropy1, uint64_t policy_seed, uint64_t policy_counter0, float* agent_features,
+                     int64_t num_agents, int64_t a_bstride, const float* edge_attr, const float* log_edge_attr,
+                     float log_eps, int use_cong, uint64_t seed, uint64_t counter0, int32_t* ins_scratch,
+                     void* static_scratch, uint8_t* choice, float* log_prob, float* entropy, float* reward,
+                     uint8_t* counts, int32_t metrics_envs, float* dtt_node, uint8_t* events, int32_t* leg,
+                     tarl_stream stream);
+/* the action / count bytes of a rollout back in the formats of the unfused entry points: choice_eid int32 [rows][N] =
+ *   chosen edge id (-1: none), counts_f fp32 [rows][N], for `rows` (frame, environment) pairs given as flat indices
+ *   idx int64 [rows] = t * B + b (NULL: all T * B pairs in order). env_minor != 0: the buffers are [T][N][B], else
+ *   [T][B][N]. Either output / input pair may be NULL. (The minibatch gather of ppo_train, src/rl/ppo_trainer.py:134.) */
+int tarl_rollout_gather(const tarl_plan* plan, const uint8_t* choice, const uint8_t* counts, int64_t T, int64_t B,
+                        int env_minor, const int64_t* idx, int64_t rows, int32_t* choice_eid, float* counts_f,
+                        tarl_stream stream);
 
 /* ---- shortest-path routing -----------------------------------------------------------------------
  * tarl_edge_travel_time == the edge weights of DijkstraAgents.choice (src/agents/base.py:541-550):

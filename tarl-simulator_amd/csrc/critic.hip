@@ -32,7 +32,9 @@ __device__ __forceinline__ int mfma_row(int reg, int lane) { return (reg & 3) + 
 // rps == 0: counts is row-major [M][ldc]. rps > 0 ("slab" mode, rps % CR_BM == 0): counts is [M / rps][N][rps] — the
 // env-minor rollout buffer [frame][node][env] — i.e. k-major inside each slab of rps rows, which is exactly the order
 // the LDS staging wants (lanes along rows => coalesced).
-__global__ __launch_bounds__(CR_THREADS) void k_critic_fwd(const float* __restrict__ counts, int64_t ldc, int64_t rps,
+// XT: float (observations as the reference holds them) or uint8_t (the rollout buffers' count bytes, widened in the staging).
+template <typename XT>
+__global__ __launch_bounds__(CR_THREADS) void k_critic_fwd(const XT* __restrict__ counts, int64_t ldc, int64_t rps,
                                                            int64_t M, int64_t N,
                                                            const float* __restrict__ time_rows,
                                                            int64_t rows_per_time, CriticParams P,
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_critic_fwd(const float* __restri
         const int idx = it * CR_THREADS + tid;
         const int r = idx >> 5, k = idx & 31;
         const int64_t gr = row0 + r, gk = k0 + k;
-        Xs[k * (CR_BM + 1) + r] = (gr < M && gk < N) ? counts[gr * ldc + gk] : 0.0f;
+        Xs[k * (CR_BM + 1) + r] = (gr < M && gk < N) ? (float)counts[gr * ldc + gk] : 0.0f;
       }
     } else {
       // slab input: lanes along rows => 256-B coalesced segments, conflict-free LDS stores
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_critic_fwd(const float* __restri
         const int idx = it * CR_THREADS + tid;
         const int r = idx & (CR_BM - 1), k = idx >> 7;
         const int64_t gr = row0 + r, gk = k0 + k;
-        Xs[k * (CR_BM + 1) + r] = (gr < M && gk < N) ? counts[slab_base + gk * rps + r] : 0.0f;
+        Xs[k * (CR_BM + 1) + r] = (gr < M && gk < N) ? (float)counts[slab_base + gk * rps + r] : 0.0f;
       }
     }
 #pragma unroll
@@ -166,7 +168,13 @@ __global__ __launch_bounds__(CR_THREADS) void k_critic_fwd(const float* __restri
 // fetched into registers (float4 along the row dimension for X) BEFORE the MFMAs of chunk c and stored into the other
 // LDS buffer after them, so global-memory latency hides behind the matrix work and there is one barrier per chunk.
 #define CRS_LDX (CR_BM + 4)   // X tile row stride (floats): keeps the float4 LDS stores 16-byte aligned
-__global__ __launch_bounds__(CR_THREADS) void k_critic_fwd_slab(const float* __restrict__ counts, int64_t rps, int64_t M,
+__device__ __forceinline__ float4 load_x4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 load_x4(const uint8_t* p) {   // four count bytes in one dword
+  const uint32_t w = *reinterpret_cast<const uint32_t*>(p);
+  return make_float4((float)(w & 255u), (float)((w >> 8) & 255u), (float)((w >> 16) & 255u), (float)(w >> 24));
+}
+template <typename XT>
+__global__ __launch_bounds__(CR_THREADS) void k_critic_fwd_slab(const XT* __restrict__ counts, int64_t rps, int64_t M,
                                                                 int64_t N, const float* __restrict__ time_rows,
                                                                 int64_t rows_per_time, CriticParams P,
                                                                 float* __restrict__ value) {
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_critic_fwd_slab(const float* __r
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t row0 = (int64_t)blockIdx.x * CR_BM;
   const int64_t ldw = N + 1;
-  const float* xbase = counts + (row0 / rps) * (N * rps) + (row0 % rps);   // element (r, k) at xbase[k * rps + r]
+  const XT* xbase = counts + (row0 / rps) * (N * rps) + (row0 % rps);   // element (r, k) at xbase[k * rps + r]
 
   float4 xr[4];
   float wr[8];
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_critic_fwd_slab(const float* __r
       const int idx = it * CR_THREADS + tid;
       const int r4 = (idx & 31) * 4, k = idx >> 5;
       const int64_t gk = k0 + k;
-      xr[it] = (gk < N) ? *reinterpret_cast<const float4*>(xbase + gk * rps + r4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      xr[it] = (gk < N) ? load_x4(xbase + gk * rps + r4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
@@ -370,7 +378,8 @@ __global__ __launch_bounds__(CR_THREADS) void k_critic_bwd_w1(int64_t M, int64_t
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
-static int critic_fwd(const float* counts, int64_t ldc, int64_t rps, int64_t M, int64_t N, const float* time_rows,
+template <typename XT>
+static int critic_fwd(const XT* counts, int64_t ldc, int64_t rps, int64_t M, int64_t N, const float* time_rows,
                       int64_t rows_per_time, const float* w1, const float* b1, const float* w2, const float* b2,
                       const float* w3, const float* b3, float* value, float* h1_out, float* h2_out,
                       tarl_stream stream) {
@@ -378,8 +387,8 @@ static int critic_fwd(const float* counts, int64_t ldc, int64_t rps, int64_t M, 
   TARL_REQUIRE(M >= 1 && N >= 1 && rows_per_time >= 1, "bad sizes");
   TARL_REQUIRE(ceil_div(M, CR_BM) < ((int64_t)1 << 31), "too many rows");
   const CriticParams P{w1, b1, w2, b2, w3, b3};
-  hipLaunchKernelGGL(k_critic_fwd, dim3((unsigned)ceil_div(M, CR_BM)), dim3(CR_THREADS), 0, (hipStream_t)stream, counts,
-                     ldc, rps, M, N, time_rows, rows_per_time, P, value, h1_out, h2_out);
+  hipLaunchKernelGGL(k_critic_fwd<XT>, dim3((unsigned)ceil_div(M, CR_BM)), dim3(CR_THREADS), 0, (hipStream_t)stream,
+                     counts, ldc, rps, M, N, time_rows, rows_per_time, P, value, h1_out, h2_out);
   TARL_LAUNCH_CHECK();
   return TARL_OK;
 }
@@ -393,20 +402,43 @@ extern "C" int tarl_critic_mlp_fwd(const float* counts, int64_t ldc, int64_t M, 
                     stream);
 }
 
-extern "C" int tarl_critic_mlp_fwd_slabs(const float* counts, int64_t rows_per_slab, int64_t M, int64_t N,
-                                         const float* time_rows, int64_t rows_per_time, const float* w1,
-                                         const float* b1, const float* w2, const float* b2, const float* w3,
-                                         const float* b3, float* value, tarl_stream stream) {
+extern "C" int tarl_critic_mlp_fwd_u8(const uint8_t* counts, int64_t ldc, int64_t M, int64_t N, const float* time_rows,
+                                      int64_t rows_per_time, const float* w1, const float* b1, const float* w2,
+                                      const float* b2, const float* w3, const float* b3, float* value, float* h1_out,
+                                      float* h2_out, tarl_stream stream) {
+  TARL_REQUIRE(ldc >= N, "row stride smaller than N");
+  return critic_fwd(counts, ldc, 0, M, N, time_rows, rows_per_time, w1, b1, w2, b2, w3, b3, value, h1_out, h2_out,
+                    stream);
+}
+
+template <typename XT>
+static int critic_fwd_slabs(const XT* counts, int64_t rows_per_slab, int64_t M, int64_t N, const float* time_rows,
+                            int64_t rows_per_time, const float* w1, const float* b1, const float* w2, const float* b2,
+                            const float* w3, const float* b3, float* value, tarl_stream stream) {
   TARL_REQUIRE(rows_per_slab >= CR_BM && rows_per_slab % CR_BM == 0, "rows_per_slab must be a multiple of 128");
   TARL_REQUIRE(M % rows_per_slab == 0, "M must be a whole number of slabs");
   TARL_REQUIRE(counts && time_rows && w1 && b1 && w2 && b2 && w3 && b3 && value, "null argument");
   TARL_REQUIRE(M >= 1 && N >= 1 && rows_per_time >= 1, "bad sizes");
   TARL_REQUIRE(((uintptr_t)counts) % 16 == 0, "counts must be 16-byte aligned");
   const CriticParams P{w1, b1, w2, b2, w3, b3};
-  hipLaunchKernelGGL(k_critic_fwd_slab, dim3((unsigned)(M / CR_BM)), dim3(CR_THREADS), 0, (hipStream_t)stream, counts,
+  hipLaunchKernelGGL(k_critic_fwd_slab<XT>, dim3((unsigned)(M / CR_BM)), dim3(CR_THREADS), 0, (hipStream_t)stream, counts,
                      rows_per_slab, M, N, time_rows, rows_per_time, P, value);
   TARL_LAUNCH_CHECK();
   return TARL_OK;
+}
+
+extern "C" int tarl_critic_mlp_fwd_slabs(const float* counts, int64_t rows_per_slab, int64_t M, int64_t N,
+                                         const float* time_rows, int64_t rows_per_time, const float* w1,
+                                         const float* b1, const float* w2, const float* b2, const float* w3,
+                                         const float* b3, float* value, tarl_stream stream) {
+  return critic_fwd_slabs(counts, rows_per_slab, M, N, time_rows, rows_per_time, w1, b1, w2, b2, w3, b3, value, stream);
+}
+
+extern "C" int tarl_critic_mlp_fwd_slabs_u8(const uint8_t* counts, int64_t rows_per_slab, int64_t M, int64_t N,
+                                            const float* time_rows, int64_t rows_per_time, const float* w1,
+                                            const float* b1, const float* w2, const float* b2, const float* w3,
+                                            const float* b3, float* value, tarl_stream stream) {
+  return critic_fwd_slabs(counts, rows_per_slab, M, N, time_rows, rows_per_time, w1, b1, w2, b2, w3, b3, value, stream);
 }
 
 extern "C" int tarl_critic_mlp_bwd(const float* counts, int64_t ldc, int64_t M, int64_t N, const float* time_rows,

@@ -1,28 +1,33 @@
-// fused.hip — the vectorised rollout frame in 4 launches, bit-identical (state, agents, actions, rewards) to the unfused
+// fused.hip — the vectorised rollout frame in 3-4 launches, bit-identical (state, agents, actions, rewards) to the unfused
 // kernels and therefore to the reference.
 //
 // Why: the reference's AoS row (F = 3*Nmax+7 floats, 208 B at Nmax = 15) scatters the ~10 scalars a message needs over
 // 2-3 cache lines, and eleven separate launches per frame each re-stream the whole state. Here
-//   * a packed per-(node, env) HOT RECORD  rec0 = {head_id, head_dep, n, tail_id} (+ sel [node][env], and the cold half
-//     rec1 = {head_arr, pending-garbage n0}) and a per-node STATIC record st0 = {maxn, ff, road_index, cong} (shared by
-//     all environments) mirror the row: the gather kernel reads 20 B per neighbour and never touches the FIFO storage;
 //   * ENV-MINOR LAYOUT: every per-(node, env) array is stored [node][env]. A workgroup owns a tile of consecutive
 //     environments (one per lane) and walks a chunk of nodes: all topology / table / static loads are wave-uniform
-//     (scalar loads through the constant cache) and every record gather is a fully coalesced 16 B x 64 = 1 KiB load —
-//     there is no dependent index -> address -> data chain left in the vector memory path;
-//   * the Direction gather also emits postA = {n', tail'} / postB = chosen agent: the state every row will have after
-//     the Direction update, from which the Response "accepted" test is evaluated (8-B gathers of postA) without a second
-//     pass over the FIFOs;
+//     (scalar loads through the constant cache) and every record gather is fully coalesced — there is no dependent
+//     index -> address -> data chain left in the vector memory path;
+//   * DENSE WORDS (fused_common.h): what every row reads and rewrites every frame is 12 bytes — hdp = {head_id << 8 | n,
+//     head_dep} and tl = tail_id << 8 | flags — plus a per-node STATIC record st0 = {maxn, ff, road_index, cong} shared by
+//     all environments. The Direction gather reads 8 B (+ 1 B of SELECTED_ROAD) per neighbour and never touches the FIFOs;
+//   * the Direction gather emits ONE post word per row (tail' << 8 | non-empty' | arrived): the state the row will have
+//     after the Direction update. The enqueued agent, the new count and the Response "accepted" test (tail of the
+//     downstream row == my head, both non-empty) all follow from it — no second pass over the FIFOs, no extra arrays;
+//   * SELECTED_ROAD and the action are the same byte: the rank of the chosen out-edge in the node's CSR list (sel8). In a
+//     rollout the action buffer's slice of frame t IS the SELECTED_ROAD column the Direction gather of frame t reads;
 //   * the live policy's sample is state-independent (see k_policy_tables): the choice phase is a table walk per
 //     (node, env) with Philox blocks shared across consecutive nodes;
-//   * ONE row pass applies Direction update + Response pop + withdraw and refreshes the hot record;
+//   * ONE row pass applies Direction update + Response pop + withdraw. A row where nothing moves (nobody enqueued, no pop,
+//     head not due) touches nothing but its dense words; the EVENT-ONLY word rec1 = {head_arr, pending-garbage count,
+//     ring offset} and the FIFO store are read / written only by the rows that move something;
 //   * the FIFO contents live in a slot-interleaved store  slots[node][env][s] = {id, arrival, departure}: the Direction
 //     update's per-row write is ONE 12-byte store instead of three dwords in three DRAM sectors (+ counter);
 //   * LAZY GARBAGE SLOT: a row that receives nobody still gets (0, t, t + tt) written into its first dead slot by the
 //     reference. That value is never read by the simulation, is overwritten by the next frame's update (or
-//     by an insertion) before anything can move it, and only shows in x. The row pass just records {flag, n0} in rec1 and
-//     the export kernel materialises it (same fp32 expression, same slot). The one case where the pop's "last slot keeps
-//     its value" rule would duplicate it (count == Nmax-1) is written eagerly;
+//     by an insertion) before anything can move it, and only shows in x. It is never stored: for a row that was idle in
+//     the last frame the count at the write is its count, otherwise rec1 holds it (TLF_AUTH), and the export kernel
+//     materialises the triple (same fp32 expression, same slot). The one case where the pop's "last slot keeps its value"
+//     rule would duplicate it (count == Nmax-1) is written eagerly;
 //   * RING-BUFFER FIFOs: the reference pops by shifting all Nmax slots (and withdraws with a zero-filled shift). Here a
 //     per-row head offset makes the pop one triple copy (the slot that falls off the front receives the old last slot,
 //     which is exactly the reference's "last slot keeps its value") and a withdraw of c agents c zero-writes; the dead
@@ -32,13 +37,20 @@
 // bit-identical to what the unfused kernels (and the reference) produce after every frame (tests/test_gpu_fused.py).
 //
 // Domain: the plan is built on the same node set as x (plan nodes == rows of x): pure road graphs and MATSim graphs
-// with SRC/DEST pseudo-nodes alike (tests/test_gpu_fused.py::test_fused_equals_unfused_on_a_matsim_graph_with_pseudo_nodes). Counts that reach Nmax (outside the reference's defined domain,
-// DESIGN.md Q25) are not supported by this path.
+// with SRC/DEST pseudo-nodes alike. Nmax <= 255, out-degree <= 126, agent ids < 2^24 (checked). A count that reaches Nmax
+// leaves the reference's defined domain (it raises IndexError one or two steps later): the kernels set
+// FLAG_COUNT_AT_NMAX in the device status word and the host raises when it reads it.
 #include "fused_common.h"
 
-// ---- pack: build the hot / static records, the slot store and the agent SoA from x / agent_features ------------------
+struct PlanOut {   // CSR by source
+  const int32_t* out_ptr;
+  const int32_t* out_dst;
+};
+
+// ---- pack: build the dense / static words, the slot store and the agent SoA from x / agent_features -------------------
 __global__ __launch_bounds__(FB) void k_pack_nodes(const float* __restrict__ x, Layout L, int64_t B, int64_t N,
-                                                   const float* __restrict__ cong, FusedBufs fb, float4* st0_out) {
+                                                   const float* __restrict__ cong, FusedBufs fb, float4* st0_out,
+                                                   PlanOut P) {
   const int64_t gid = (int64_t)blockIdx.x * FB + threadIdx.x;  // gid = i * B + b  (env-minor)
   if (gid >= B * N) return;
   const int64_t i = gid / B;
@@ -48,15 +60,26 @@ __global__ __launch_bounds__(FB) void k_pack_nodes(const float* __restrict__ x, 
   const float n = xi[L.col_n()];
   const int q = (int)n;
   const float tail = (q >= 1 && q <= Nmax) ? xi[q - 1] : 0.0f;
-  fb.rec0[gid] = make_float4(xi[0], xi[2 * Nmax], n, tail);
-  fb.rec1[gid] = make_float2(xi[Nmax], r1_code(-1.0f, 0));
-  fb.postA[gid] = make_float2(n, tail);
-  fb.postB[gid] = 0.0f;
-  fb.sel[gid] = xi[L.col_sel()];
+  const float head = xi[0];
+  if (q < 0 || q > 255 || !(head >= 0.0f && head < 16777216.0f) || !(tail >= 0.0f && tail < 16777216.0f))
+    atomicOr(fb.flags, FLAG_PACK_RANGE);
+  fb.hdp[gid] = make_uint2(((uint32_t)head << 8) | (uint32_t)(q & 255), __float_as_uint(xi[2 * Nmax]));
+  fb.tl[gid] = ((uint32_t)tail << 8) | TLF_AUTH;
+  fb.rec1[gid] = make_uint2(__float_as_uint(xi[Nmax]), r1_code(-1, 0));
+  fb.post[gid] = ((uint32_t)tail << 8) | (q > 0 ? PF_NONEMPTY : 0u);
+  // SELECTED_ROAD: the rank of the out-edge it names, or the raw value when it names none of them
+  const float sv = xi[L.col_sel()];
+  fb.sel[gid] = sv;
+  uint32_t code = SEL_RAW;
+  const int32_t k0 = P.out_ptr[i], k1 = P.out_ptr[i + 1];
+  for (int32_t k = k1 - 1; k >= k0; --k)
+    if ((float)P.out_dst[k] == sv && k - k0 < (int32_t)SEL_RAW) code = (uint32_t)(k - k0);
+  fb.sel8[gid] = (uint8_t)code;
   if (i == 0) {
     for (int64_t sl_ = 0; sl_ < fb.acc_slots; ++sl_) {
       fb.acc_lp[sl_ * B + b] = 0;
       fb.acc_n[sl_ * B + b] = 0.0f;
+      fb.acc_w[sl_ * B + b] = 0.0f;
     }
   }
   float* sl = fb.slots + gid * fb.lds;
@@ -78,6 +101,34 @@ __global__ __launch_bounds__(FB) void k_pack_nodes(const float* __restrict__ x, 
   }
 }
 
+// in_rank[k] for in-edge k = (j -> i): the rank r of j's out-edges with (float)out_dst == ROAD_INDEX(i), i.e. the sel8
+// code of j that makes "SELECTED_ROAD(j) == ROAD_INDEX(i)" (src/direction_mpnn.py:77-79) true; INRANK_NONE when no
+// out-edge of j does. Two matching out-edges (parallel dual edges) have no unique rank: FLAG_AMBIGUOUS_EDGES.
+__global__ __launch_bounds__(FB) void k_pack_inrank(const float* __restrict__ x, Layout L, int64_t N,
+                                                    const int32_t* __restrict__ in_ptr,
+                                                    const int32_t* __restrict__ in_src, PlanOut P, uint8_t* in_rank,
+                                                    int32_t* flags) {
+  const int64_t i = (int64_t)blockIdx.x * FB + threadIdx.x;
+  if (i >= N) return;
+  const float road_i = x[i * L.ldx + L.col_road()];   // static column: environment 0 speaks for all
+  const int32_t a1 = in_ptr[i + 1];
+  for (int32_t k = in_ptr[i]; k < a1; ++k) {
+    const int32_t j = in_src[k];
+    const int32_t k0 = P.out_ptr[j], k1 = P.out_ptr[j + 1];
+    int cnt = 0, r = (int)INRANK_NONE;
+    for (int32_t kk = k0; kk < k1; ++kk)
+      if ((float)P.out_dst[kk] == road_i) {
+        if (cnt == 0) r = kk - k0;
+        ++cnt;
+      }
+    if (cnt > 1 || (cnt == 1 && r >= (int)SEL_RAW)) {
+      atomicOr(flags, FLAG_AMBIGUOUS_EDGES);
+      r = (int)INRANK_NONE;
+    }
+    in_rank[k] = (uint8_t)r;
+  }
+}
+
 __global__ __launch_bounds__(FB) void k_pack_agents(const float* __restrict__ ag, int64_t B, int64_t A,
                                                     int64_t a_bstride, FusedBufs fb) {
   const int64_t gid = (int64_t)blockIdx.x * FB + threadIdx.x;
@@ -95,14 +146,15 @@ __global__ __launch_bounds__(FB) void k_pack_agents(const float* __restrict__ ag
 __global__ __launch_bounds__(FB) void k_fused_reset_nodes(int64_t B, int64_t N, FusedBufs fb) {
   const int64_t gid = (int64_t)blockIdx.x * FB + threadIdx.x;
   if (gid >= B * N) return;
-  fb.rec0[gid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  fb.rec1[gid] = make_float2(0.0f, r1_code(-1.0f, 0));
-  fb.postA[gid] = make_float2(0.0f, 0.0f);
-  fb.postB[gid] = 0.0f;
+  fb.hdp[gid] = make_uint2(0u, 0u);
+  fb.tl[gid] = TLF_AUTH;
+  fb.rec1[gid] = make_uint2(0u, r1_code(-1, 0));
+  fb.post[gid] = 0u;
   if (gid < B) {
     for (int64_t sl_ = 0; sl_ < fb.acc_slots; ++sl_) {
       fb.acc_lp[sl_ * B + gid] = 0;
       fb.acc_n[sl_ * B + gid] = 0.0f;
+      fb.acc_w[sl_ * B + gid] = 0.0f;
     }
     if (fb.cur_lo) fb.cur_lo[gid] = 0;
   }
@@ -124,7 +176,7 @@ __global__ __launch_bounds__(FB) void k_fused_reset_agents(float* __restrict__ a
 
 // ---- export: rebuild the reference's x layout (three FIFO column blocks + NUMBER_OF_AGENT + SELECTED_ROAD) ----------
 __global__ __launch_bounds__(FB) void k_export_rows(float* __restrict__ x, Layout L, int64_t B, int64_t N, FusedBufs fb,
-                                                    float t_last) {
+                                                    float t_last, PlanOut P) {
   const int64_t gid = (int64_t)blockIdx.x * FB + threadIdx.x;
   const int Nmax = L.Nmax;
   if (gid >= B * N * Nmax) return;
@@ -132,14 +184,13 @@ __global__ __launch_bounds__(FB) void k_export_rows(float* __restrict__ x, Layou
   const int sidx = (int)(gid - row * Nmax);
   const int64_t i = row / B, b = row - i * B;
   float* xi = x + b * L.bstride + i * L.ldx;
-  const float4 r0 = fb.rec0[row];
-  const float2 r1 = fb.rec1[row];
-  const float g = r1_g(r1.y);
-  const float* sl = fb.slots + row * fb.lds + 3 * phys(r1_hoff(r1.y), sidx, Nmax);  // un-rotate the ring buffer
-  if (g >= 0.0f && sidx == (int)r0.z) {  // pending garbage write of the last Direction update -> first dead slot
-    const float4 st = fb.st0[i];
-    const float t_cong = st.w / (st.x + 10.0f - g);
-    const float tt = (t_cong != t_cong) ? t_cong : fmaxf(st.y, t_cong);
+  const uint32_t hd = fb.hdp[row].x;
+  const uint32_t code = fb.rec1[row].y;
+  const int n = (int)(hd & 255u);
+  const int g = pending_g(fb.tl[row], n, code, Nmax);
+  const float* sl = fb.slots + row * fb.lds + 3 * phys(r1_hoff(code), sidx, Nmax);  // un-rotate the ring buffer
+  if (g >= 0 && sidx == n) {  // pending garbage write of the last Direction update -> first dead slot
+    const float tt = entry_tt(fb.st0[i], (float)g);
     xi[sidx] = 0.0f;
     xi[Nmax + sidx] = t_last;
     xi[2 * Nmax + sidx] = t_last + tt;
@@ -149,8 +200,10 @@ __global__ __launch_bounds__(FB) void k_export_rows(float* __restrict__ x, Layou
     xi[2 * Nmax + sidx] = sl[2];
   }
   if (sidx == 0) {
-    xi[L.col_n()] = r0.z;
-    xi[L.col_sel()] = fb.sel[row];
+    xi[L.col_n()] = (float)n;
+    const float sv = sel_value(fb, P.out_ptr, P.out_dst, i, row);
+    xi[L.col_sel()] = sv;
+    fb.sel[row] = sv;
   }
 }
 
@@ -251,33 +304,19 @@ __global__ __launch_bounds__(ENVB) void k_policy_tables(const int32_t* __restric
   if (tid == 0) entropy_out[0] = ent_t;
 }
 
-// CSR position of the edge node j picks in this frame: the first out-edge (plan order) whose threshold exceeds j's
-// uniform draw; -1 when none does (u >= last threshold through rounding: the action is then infeasible).
-__device__ __forceinline__ int32_t sample_node(const int32_t* __restrict__ out_ptr, const float* __restrict__ thr,
-                                               int32_t j, float u) {
-  const int32_t k1 = out_ptr[j + 1];
-  for (int32_t k = out_ptr[j]; k < k1; ++k)
-    if (u < thr[k]) return k;
-  return -1;
-}
-
-__device__ __forceinline__ float node_uniform(const float* __restrict__ uniform, uint64_t seed, uint64_t counter,
-                                              int64_t b, int64_t G, int32_t g) {
-  return uniform ? uniform[b * G + g] : philox_uniform(seed, counter, (uint64_t)(b * G + g));
-}
-
 // ---- choice phase (env-minor: lane = environment, a workgroup walks a chunk of nodes) --------------------------------
 // Consecutive nodes of one environment share Philox blocks (index = b*G + g), so a chunk costs ~nchunk/4 + 1 Philox
-// evaluations per lane instead of one per node.
+// evaluations per lane instead of one per node. The action AND the new SELECTED_ROAD are one byte per (node, env): the
+// rank of the chosen out-edge (sel_out); a node that draws nothing (no out-edges, or u beyond the last threshold through
+// rounding) carries its previous code over from sel_prev with SEL_CARRIED set.
 __device__ __forceinline__ void fused_choice_body(unsigned bx, unsigned by, const int32_t* __restrict__ out_ptr,
-                                                       const int32_t* __restrict__ out_dst,
-                                                       const int32_t* __restrict__ out_eid,
-                                                       const int32_t* __restrict__ group_of_node, int64_t G, int64_t B,
-                                                       int64_t N, FusedBufs fb, const float* __restrict__ thr,
-                                                       const long long* __restrict__ lgt,
-                                                       const float* __restrict__ uniform, uint64_t pseed,
-                                                       uint64_t pcounter, int32_t* __restrict__ choice, int nchunk,
-                                                       int want_lp, const float* __restrict__ sel_prev) {
+                                                  const int32_t* __restrict__ out_eid,
+                                                  const int32_t* __restrict__ group_of_node, int64_t G, int64_t B,
+                                                  int64_t N, long long* __restrict__ acc_lp, int64_t acc_slots,
+                                                  const float* __restrict__ thr, const long long* __restrict__ lgt,
+                                                  const float* __restrict__ uniform, uint64_t pseed, uint64_t pcounter,
+                                                  uint8_t* __restrict__ sel_out, const uint8_t* __restrict__ sel_prev,
+                                                  int32_t* __restrict__ choice, int nchunk, int want_lp) {
   const int64_t b = (int64_t)bx * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const int32_t i0 = by * nchunk;
@@ -288,109 +327,122 @@ __device__ __forceinline__ void fused_choice_body(unsigned bx, unsigned by, cons
   for (int32_t i = i0; i < i1; ++i) {
     const int64_t row = (int64_t)i * B + b;
     int32_t ch = -1;
+    uint32_t code = SEL_RAW;
+    bool found = false;
     const int32_t gi = group_of_node[i];
     if (gi >= 0) {
       const float u = uniform ? uniform[b * G + gi] : rng.uniform(pseed, pcounter, (uint64_t)(b * G + gi));
       // first out-edge (plan order) whose threshold exceeds u. Every table operand is wave-uniform (scalar loads), the
       // per-lane part is compare + select: no dependent vector gathers
-      bool found = false;
-      float selv = 0.0f;
       long long lpn = 0;
-      const int32_t k1 = out_ptr[i + 1];
-      for (int32_t k = out_ptr[i]; k < k1; ++k) {
+      const int32_t k0 = out_ptr[i], k1 = out_ptr[i + 1];
+      for (int32_t k = k0; k < k1; ++k) {
         const bool hit = !found && (u < thr[k]);
         const long long lgk = lgt[k];
-        selv = hit ? (float)out_dst[k] : selv;
+        code = hit ? (uint32_t)(k - k0) : code;
         ch = hit ? out_eid[k] : ch;
         lpn = hit ? lgk : lpn;
         found = found || hit;
       }
-      // a node that picks nothing keeps its previous SELECTED_ROAD (sel_prev = the other buffer when the rollout
-      // double-buffers sel: the value is carried over)
-      if (found) {
-        fb.sel[row] = selv;
-        lp += lpn;
-      } else {
-        bad = true;
-        if (sel_prev) fb.sel[row] = sel_prev[row];
-      }
-    } else if (sel_prev) {
-      fb.sel[row] = sel_prev[row];
+      if (found) lp += lpn; else bad = true;
     }
-    if (choice) __builtin_nontemporal_store(ch, &choice[row]);  // write-once stream: keep it out of the caches
+    if (!found) code = (sel_prev[row] & 0x7Fu) | SEL_CARRIED;   // keeps its previous SELECTED_ROAD
+    sel_out[row] = (uint8_t)code;
+    if (choice) __builtin_nontemporal_store(ch, &choice[row]);  // frame API: the action as an edge id (-1: none)
   }
   // infeasible action (some node picked nothing): poison the accumulator far beyond any legitimate sum
   if (want_lp)
-    atomicAdd((unsigned long long*)&fb.acc_lp[(int64_t)(by % (unsigned)fb.acc_slots) * B + b], (unsigned long long)(bad ? -(1ll << 50) : lp));  // up to 2^13 chunks cannot wrap
+    atomicAdd((unsigned long long*)&acc_lp[(int64_t)(by % (unsigned)acc_slots) * B + b],
+              (unsigned long long)(bad ? -(1ll << 50) : lp));  // up to 2^13 chunks cannot wrap
 }
 
 __global__ __launch_bounds__(TILE) void k_fused_choice(const int32_t* __restrict__ out_ptr,
-                                                       const int32_t* __restrict__ out_dst,
                                                        const int32_t* __restrict__ out_eid,
                                                        const int32_t* __restrict__ group_of_node, int64_t G, int64_t B,
-                                                       int64_t N, FusedBufs fb, const float* __restrict__ thr,
+                                                       int64_t N, long long* __restrict__ acc_lp, int64_t acc_slots,
+                                                       const float* __restrict__ thr,
                                                        const long long* __restrict__ lgt,
                                                        const float* __restrict__ uniform, uint64_t pseed,
-                                                       uint64_t pcounter, int32_t* __restrict__ choice, int nchunk,
-                                                       int want_lp) {
-  fused_choice_body(blockIdx.x, blockIdx.y, out_ptr, out_dst, out_eid, group_of_node, G, B, N, fb, thr, lgt, uniform,
-                    pseed, pcounter, choice, nchunk, want_lp, nullptr);
+                                                       uint64_t pcounter, uint8_t* __restrict__ sel_out,
+                                                       const uint8_t* __restrict__ sel_prev,
+                                                       int32_t* __restrict__ choice, int nchunk, int want_lp) {
+  fused_choice_body(blockIdx.x, blockIdx.y, out_ptr, out_eid, group_of_node, G, B, N, acc_lp, acc_slots, thr, lgt,
+                    uniform, pseed, pcounter, sel_out, sel_prev, choice, nchunk, want_lp);
 }
 
-// ---- Direction gather on the hot records (env-minor: lane = environment) ---------------------------------------------------
+// ---- Direction gather on the dense words (env-minor: lane = environment) ---------------------------------------------------
 // Two passes inside the workgroup. Pass 1 (every (node, environment) pair of the chunk): admissibility masks and the
-// summed turn probability P — no random numbers — and the default post record (nobody chosen). A pair needs the Gumbel
+// summed turn probability P — no random numbers — and the default post word (nobody chosen). A pair needs the Gumbel
 // race only when P > 0, i.e. when some in-edge is admissible; that is a few percent of the pairs, but scattered over all
 // lanes, so every wave would still pay for the Philox block and the two logs per edge. The pairs with P > 0 are
 // therefore appended to an LDS list and pass 2 walks that list densely (one lane per pair), re-evaluating the pair with
 // its noise — same Philox indices, same expressions: the result is bit-identical to evaluating everything.
 #define DIR_LIST (TILE * 8)
-__global__ __launch_bounds__(TILE) void k_fused_direction(const int32_t* __restrict__ in_ptr,
-                                                          const int32_t* __restrict__ in_src,
-                                                          const int32_t* __restrict__ in_eid, int64_t E, int64_t B,
-                                                          int64_t N, FusedBufs fb, const float* __restrict__ edge_attr,
-                                                          const float* __restrict__ log_edge_attr, float log_eps,
-                                                          float t, const float* __restrict__ gumbel, uint64_t seed,
-                                                          uint64_t counter, float* __restrict__ dtt, int nchunk) {
+struct DirIn {
+  const int32_t* in_ptr;
+  const int32_t* in_src;
+  const int32_t* in_eid;
+  const float* edge_attr;
+  const float* log_edge_attr;
+  const float* gumbel;   // [B][E] or NULL (device Philox)
+  float* dtt;            // [B][E] or NULL (frame API)
+  float log_eps, t, t_prev;
+  uint64_t seed, counter;
+};
+
+// does upstream row j (dense words hj, SELECTED_ROAD code cj) send its head to the row behind in-edge k?
+__device__ __forceinline__ bool edge_admissible(const FusedBufs& fb, int32_t k, int64_t jrow, uint2 hj, float max_j,
+                                                float road_i, float n_i, float max_i, float t, const uint8_t* sel8) {
+  const uint32_t cj = sel8[jrow] & 0x7Fu;
+  const bool heads_here = (cj == SEL_RAW) ? (fb.sel[jrow] == road_i) : (cj == (uint32_t)fb.in_rank[k]);
+  const float dep = __uint_as_float(hj.y), n_j = (float)(hj.x & 255u);
+  const bool m1 = (dep <= t) && (n_i < max_i - TARL_CONGESTION_FILE) && heads_here && (n_j > 0.0f);
+  const bool m2 = ((dep - t) < -10.0f) && ((max_j - TARL_CONGESTION_FILE) <= n_j) && ((max_j - n_j) <= (max_i - n_i)) &&
+                  heads_here;
+  return m1 || m2;
+}
+
+__global__ __launch_bounds__(TILE) void k_fused_direction(DirIn D, int64_t E, int64_t B, int64_t N, FusedBufs fb,
+                                                          const uint8_t* __restrict__ sel8, FrameOut out, int nchunk) {
   __shared__ int32_t s_n;
   __shared__ uint16_t s_item[DIR_LIST];   // (node offset in the chunk) * TILE + lane
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = b < B;
   const int32_t i0 = blockIdx.y * nchunk;
   const int32_t i1 = (i0 + nchunk < N) ? i0 + nchunk : (int32_t)N;
+  const float t = D.t;
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
   if (valid) {
     for (int32_t i = i0; i < i1; ++i) {  // i, and everything indexed by it alone, is wave-uniform
       const int64_t row = (int64_t)i * B + b;
-      const float4 me = fb.rec0[row];
+      const uint2 me = fb.hdp[row];
+      const uint32_t tlw = fb.tl[row];
       const float4 sti = fb.st0[i];
-      const float max_i = sti.x, n_i = me.z, road_i = sti.z;
-      const float room_i = max_i - n_i;
-      const bool has_room = n_i < max_i - TARL_CONGESTION_FILE;
+      const float max_i = sti.x, n_i = (float)(me.x & 255u), road_i = sti.z;
       float P = 0.0f;
-      const int32_t k1 = in_ptr[i + 1];
-      for (int32_t k = in_ptr[i]; k < k1; ++k) {
-        const int32_t j = in_src[k];
-        const int32_t e = in_eid[k];
+      const int32_t k1 = D.in_ptr[i + 1];
+      for (int32_t k = D.in_ptr[i]; k < k1; ++k) {
+        const int32_t j = D.in_src[k];
         const int64_t jrow = (int64_t)j * B + b;
-        const float4 rj = fb.rec0[jrow];
-        const float sel_j = fb.sel[jrow];  // road selected by upstream j in THIS frame's choice phase
+        const uint2 hj = fb.hdp[jrow];
         const float4 stj = fb.st0[j];
-        const float dep = rj.y, n_j = rj.z, max_j = stj.x;
-        const bool heads_here = sel_j == road_i;
-        const bool m1 = (dep <= t) && has_room && heads_here && (n_j > 0.0f);
-        const bool m2 = ((dep - t) < -10.0f) && ((max_j - TARL_CONGESTION_FILE) <= n_j) && ((max_j - n_j) <= room_i) &&
-                        heads_here;
-        const float prob = edge_attr[e] * ((m1 || m2) ? 1.0f : 0.0f);
-        P = P + prob;
-        if (dtt) {
-          const float d = (dep - fb.rec1[jrow].x) - stj.y;
-          dtt[b * E + e] = d > 0.0f ? d : (d != d ? d : 0.0f);
+        const bool m = edge_admissible(fb, k, jrow, hj, stj.x, road_i, n_i, max_i, t, sel8);
+        P = P + D.edge_attr[D.in_eid[k]] * (m ? 1.0f : 0.0f);
+        if (D.dtt) {   // per-edge side output of DirectionMPNN.message (src/direction_mpnn.py:94-96): a property of j
+          const uint32_t tlj = fb.tl[jrow];
+          const float arr_j = ((hj.x & 255u) == 0u && !(tlj & TLF_AUTH)) ? D.t_prev : __uint_as_float(fb.rec1[jrow].x);
+          const float d = (__uint_as_float(hj.y) - arr_j) - stj.y;
+          D.dtt[b * E + D.in_eid[k]] = d > 0.0f ? d : (d != d ? d : 0.0f);
         }
       }
-      fb.postA[row] = make_float2(n_i, me.w);   // nobody chosen; overwritten by pass 2 where P > 0
-      fb.postB[row] = 0.0f;
+      if (out.dtt_node && b < out.m_env) {   // the same value, once per upstream node, for the metric environments
+        const float arr_i = ((me.x & 255u) == 0u && !(tlw & TLF_AUTH)) ? D.t_prev : __uint_as_float(fb.rec1[row].x);
+        const float d = (__uint_as_float(me.y) - arr_i) - sti.y;
+        out.dtt_node[(int64_t)i * out.m_env + b] = d > 0.0f ? d : (d != d ? d : 0.0f);
+      }
+      // nobody chosen; overwritten by pass 2 where P > 0
+      fb.post[row] = (tlw & ~0xFFu) | ((me.x & 255u) ? PF_NONEMPTY : 0u);
       if (P > 0.0f) s_item[atomicAdd(&s_n, 1)] = (uint16_t)((i - i0) * TILE + threadIdx.x);
     }
   }
@@ -401,104 +453,107 @@ __global__ __launch_bounds__(TILE) void k_fused_direction(const int32_t* __restr
     const int32_t i = i0 + item / TILE;
     const int64_t bb = (int64_t)blockIdx.x * blockDim.x + (item % TILE);
     const int64_t row = (int64_t)i * B + bb;
-    const float4 me = fb.rec0[row];
+    const uint2 me = fb.hdp[row];
     const float4 sti = fb.st0[i];
-    const float max_i = sti.x, n_i = me.z, road_i = sti.z;
-    const float room_i = max_i - n_i;
-    const bool has_room = n_i < max_i - TARL_CONGESTION_FILE;
-    float P = 0.0f, best = -FLT_MAX, best_id = 0.0f;
+    const float max_i = sti.x, n_i = (float)(me.x & 255u), road_i = sti.z;
+    float P = 0.0f, best = -FLT_MAX;
+    uint32_t best_id = 0u;
     PhiloxRun rng;
-    const int32_t k1 = in_ptr[i + 1];
-    for (int32_t k = in_ptr[i]; k < k1; ++k) {
-      const int32_t j = in_src[k];
-      const int32_t e = in_eid[k];
+    const int32_t k1 = D.in_ptr[i + 1];
+    for (int32_t k = D.in_ptr[i]; k < k1; ++k) {
+      const int32_t j = D.in_src[k];
+      const int32_t e = D.in_eid[k];
       const int64_t jrow = (int64_t)j * B + bb;
-      const float4 rj = fb.rec0[jrow];
-      const float sel_j = fb.sel[jrow];
-      const float id = rj.x, dep = rj.y, n_j = rj.z, max_j = fb.st0[j].x;
-      const bool heads_here = sel_j == road_i;
-      const bool m1 = (dep <= t) && has_room && heads_here && (n_j > 0.0f);
-      const bool m2 = ((dep - t) < -10.0f) && ((max_j - TARL_CONGESTION_FILE) <= n_j) && ((max_j - n_j) <= room_i) &&
-                      heads_here;
-      const bool m = m1 || m2;
-      const float prob = edge_attr[e] * (m ? 1.0f : 0.0f);
-      P = P + prob;
+      const uint2 hj = fb.hdp[jrow];
+      const bool m = edge_admissible(fb, k, jrow, hj, fb.st0[j].x, road_i, n_i, max_i, t, sel8);
+      P = P + D.edge_attr[e] * (m ? 1.0f : 0.0f);
       float g;
-      if (gumbel) {
-        g = gumbel[bb * E + e];
+      if (D.gumbel) {
+        g = D.gumbel[bb * E + e];
       } else {
-        const float u = rng.uniform(seed, counter, (uint64_t)(bb * E + k));
+        const float u = rng.uniform(D.seed, D.counter, (uint64_t)(bb * E + k));
         g = gumbel_from_u01(u);
       }
-      const float score = (m ? log_edge_attr[e] : log_eps) + g;
+      const float score = (m ? D.log_edge_attr[e] : D.log_eps) + g;
       if (score > best) {
         best = score;
-        best_id = id;
+        best_id = hj.x >> 8;
       }
     }
-    const float who = (P > 0.0f) ? best_id : 0.0f;
-    fb.postA[row] = make_float2(who != 0.0f ? n_i + 1.0f : n_i, who != 0.0f ? who : me.w);
-    fb.postB[row] = who;
+    const uint32_t who = (P > 0.0f) ? best_id : 0u;
+    if (who != 0u) fb.post[row] = (who << 8) | PF_NONEMPTY | PF_ARRIVED;
   }
 }
 
-// ---- the row pass: Direction update + Response pop + withdraw on the slot store, then refresh the hot record -------------
-__global__ __launch_bounds__(TILE) void k_fused_rows(const int32_t* __restrict__ out_ptr,
-                                                     const int32_t* __restrict__ out_dst, int Nmax, int64_t B,
-                                                     int64_t N, FusedBufs fb, float* __restrict__ ag, int64_t A,
-                                                     int64_t a_bstride, float t, uint8_t* __restrict__ popped_out,
-                                                     uint8_t* __restrict__ withdrawn_out, float* __restrict__ counts,
-                                                     int nchunk) {
+// ---- the row pass: Direction update + Response pop + withdraw on the slot store, then refresh the dense words -----------
+__global__ __launch_bounds__(TILE) void k_fused_rows(PlanOut P, int Nmax, int64_t B, int64_t N, FusedBufs fb,
+                                                     float* __restrict__ ag, int64_t A, int64_t a_bstride, float t,
+                                                     FrameOut out, int nchunk) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const int32_t i0 = blockIdx.y * nchunk;
   const int32_t i1 = (i0 + nchunk < N) ? i0 + nchunk : (int32_t)N;
-  float nsum = 0.0f;
+  float nsum = 0.0f, wsum = 0.0f;
   for (int32_t i = i0; i < i1; ++i) {
     const int64_t row = (int64_t)i * B + b;
-    float* sl = fb.slots + row * fb.lds;  // slot s = sl[3s .. 3s+2] = {id, arrival, departure}
-    const float2 pa = fb.postA[row];   // {n', tail'}
-    const float who = fb.postB[row];   // chosen
-    const float4 r0 = fb.rec0[row];
-    const float2 r1 = fb.rec1[row];
+    const uint32_t pa = fb.post[row];
+    const uint2 hp = fb.hdp[row];
+    const uint32_t tlw = fb.tl[row];
     const float4 st = fb.st0[i];
-    const float n0 = r0.z;
-    const int32_t k0 = out_ptr[i], k1 = out_ptr[i + 1];
+    const uint32_t n0i = hp.x & 255u, head_id0 = hp.x >> 8, tail0 = tlw >> 8;
+    const uint32_t arrived = pa & PF_ARRIVED;
+    const uint32_t who = arrived ? (pa >> 8) : 0u;   // the agent the Direction update enqueues
+    const int32_t k0 = P.out_ptr[i], k1 = P.out_ptr[i + 1];
 
-    // Response message + max-aggregate from the post records (state after the Direction update of every row)
+    // Response message + max-aggregate from the post words (state after the Direction update of every row)
     bool pop = false;
     {
-      const long long head = (long long)((n0 == 0.0f) ? who : r0.x);   // head after the Direction update
-      const bool up = (long long)pa.x > 0;
+      const uint32_t head = (n0i == 0u) ? who : head_id0;   // head after the Direction update
+      const bool up = (n0i + arrived) > 0u;
       for (int32_t k = k0; k < k1; ++k) {  // uniform trip count: the post gathers stay coalesced and unconditional
-        const float2 pj = fb.postA[(int64_t)out_dst[k] * B + b];
-        pop = pop || (up && (long long)pj.x > 0 && (long long)pj.y == head);
+        const uint32_t pj = fb.post[(int64_t)P.out_dst[k] * B + b];
+        pop = pop || (up && (pj & PF_NONEMPTY) && (pj >> 8) == head);
       }
     }
-    if (popped_out) popped_out[b * N + i] = pop ? 1 : 0;
 
     // Direction update (every row, also when nothing was chosen): one 12-byte store — or, for a row that received
-    // nobody, a note in the hot record (lazy garbage slot, see the file header). The FIFO is a ring buffer: logical
-    // slot s lives at physical slot (hoff + s) mod Nmax.
+    // nobody, nothing at all (lazy garbage slot, see the file header).
+    const float n0 = (float)n0i;
+    const int q = (int)n0i;
+    const float dep_new = t + entry_tt(st, n0);
+    const bool lazy = (who == 0u) && (q < Nmax - 1);
+    const uint32_t ni = n0i + arrived;   // count after the Direction update
+    if ((int)ni >= Nmax) atomicOr(fb.flags, FLAG_COUNT_AT_NMAX);
+    uint32_t head_id = (n0i == 0u) ? who : head_id0;
+    float head_dep = (n0i == 0u) ? dep_new : __uint_as_float(hp.y);
+    // is the (unpopped) head a withdraw candidate? (the first two tests of the withdraw scan, on registers)
+    const bool due = !pop && ni > 0u && (int64_t)head_id < A && (head_dep <= t);
+    if (lazy && !pop && !due) {
+      // IDLE ROW: nothing moves. Only the dense words are refreshed (an empty row's head is this frame's garbage triple).
+      fb.hdp[row] = make_uint2((head_id << 8) | ni, __float_as_uint(head_dep));
+      fb.tl[row] = tail0 << 8;
+      if (out.counts8) __builtin_nontemporal_store((uint8_t)ni, &out.counts8[row]);
+      if (out.countsf) __builtin_nontemporal_store((float)ni, &out.countsf[row]);
+      if (out.popped) out.popped[b * N + i] = 0;
+      if (out.withdrawn) out.withdrawn[b * N + i] = 0;
+      if (out.events && b < out.m_env) out.events[(int64_t)i * out.m_env + b] = 0;
+      nsum += (float)ni;
+      continue;
+    }
+
+    // EVENT ROW. The FIFO is a ring buffer: logical slot s lives at physical slot (hoff + s) mod Nmax.
+    float* sl = fb.slots + row * fb.lds;  // slot s = sl[3s .. 3s+2] = {id, arrival, departure}
+    const uint2 r1 = fb.rec1[row];
     int hoff = r1_hoff(r1.y);
-    const int q = (int)n0;
-    const float t_cong = st.w / (st.x + 10.0f - n0);
-    const float tt = (t_cong != t_cong) ? t_cong : fmaxf(st.y, t_cong);
-    const float dep_new = t + tt;
-    const bool lazy = (who == 0.0f) && (q >= 0) && (q < Nmax - 1);
-    if (!lazy && q >= 0 && q < Nmax) {
+    if (!lazy && q < Nmax) {
       float* w = sl + 3 * phys(hoff, q, Nmax);
-      w[0] = who;
+      w[0] = (float)who;
       w[1] = t;
       w[2] = dep_new;
     }
-    float n = pa.x;  // count after the Direction update
-
-    // head / tail of the row after the Direction update (no memory reads needed)
-    float head_id = (n0 == 0.0f) ? who : r0.x;
-    float head_dep = (n0 == 0.0f) ? dep_new : r0.y;
-    float head_arr = (n0 == 0.0f) ? t : r1.x;
-    float tail_id = pa.y;
+    int n = (int)ni;
+    float head_arr = (n0i == 0u) ? t : __uint_as_float(r1.x);
+    uint32_t tail_id = arrived ? who : tail0;
 
     // Response pop: logical shift by one where the LAST slot keeps its value. Ring form: the slot that falls off the
     // front becomes the new logical last slot, so it receives a copy of the old last slot; then the head advances.
@@ -512,21 +567,21 @@ __global__ __launch_bounds__(TILE) void k_fused_rows(const int32_t* __restrict__
       front[2] = l2;
       hoff = phys(hoff, 1, Nmax);
       shift = 1;
-      n = n - 1.0f;
+      n = n - 1;
     }
     // withdraw: leading run of the (popped) row
     int c = 0;
-    if (n > 0.0f) {
+    if (n > 0) {
       const long long road = (long long)st.z;
       int32_t w0 = 0, w1 = 0;
       if (road >= 0 && road < N) {
-        w0 = out_ptr[road];
-        w1 = out_ptr[road + 1];
+        w0 = P.out_ptr[road];
+        w1 = P.out_ptr[road + 1];
       }
-      for (int sx = 0; sx < Nmax && (float)sx < n; ++sx) {
+      for (int sx = 0; sx < Nmax && sx < n; ++sx) {
         float idf, depf;
         if (sx == 0 && shift == 0) {   // the head is in registers unless the pop just exposed a new one
-          idf = head_id;
+          idf = (float)head_id;
           depf = head_dep;
         } else {
           const float* rd = sl + 3 * phys(hoff, sx, Nmax);
@@ -538,7 +593,7 @@ __global__ __launch_bounds__(TILE) void k_fused_rows(const int32_t* __restrict__
         if (!(depf <= t)) break;  // tested first: most heads are still travelling, and the lookup below is a gather
         const long long dest = (long long)fb.a_dest[b * A + id];
         bool conn = false;
-        for (int32_t k = w0; k < w1; ++k) conn = conn || ((long long)out_dst[k] == dest);
+        for (int32_t k = w0; k < w1; ++k) conn = conn || ((long long)P.out_dst[k] == dest);
         if (!conn) break;
         float* a = ag + b * a_bstride + id * AG_COLS;
         a[AG_DONE] = 1.0f;
@@ -548,7 +603,6 @@ __global__ __launch_bounds__(TILE) void k_fused_rows(const int32_t* __restrict__
         ++c;
       }
     }
-    if (withdrawn_out) withdrawn_out[b * N + i] = c > 0 ? 1 : 0;
     // withdraw = logical shift by c with zero fill: the c slots that fall off the front become the zeroed tail
     for (int k = 0; k < c; ++k) {
       float* z = sl + 3 * phys(hoff, k, Nmax);
@@ -558,49 +612,59 @@ __global__ __launch_bounds__(TILE) void k_fused_rows(const int32_t* __restrict__
     }
     if (c > 0) {
       hoff = phys(hoff, c, Nmax);   // c <= Nmax
-      n = n - (float)c;
+      n = n - c;
     }
     if (shift + c > 0) {
-      if (lazy && n == 0.0f) {  // the row emptied: its head slot is the (unmaterialised) garbage slot
-        head_id = 0.0f;
+      if (lazy && n == 0) {  // the row emptied: its head slot is the (unmaterialised) garbage slot
+        head_id = 0u;
         head_arr = t;
         head_dep = dep_new;
       } else {
         const float* hd = sl + 3 * hoff;
-        head_id = hd[0];
+        head_id = (uint32_t)(long long)hd[0];
         head_arr = hd[1];
         head_dep = hd[2];
       }
-      const int qn = (int)n;
-      tail_id = (qn >= 1 && qn <= Nmax) ? sl[3 * phys(hoff, qn - 1, Nmax)] : 0.0f;
+      tail_id = (n >= 1 && n <= Nmax) ? (uint32_t)(long long)sl[3 * phys(hoff, n - 1, Nmax)] : 0u;
     }
-    fb.rec0[row] = make_float4(head_id, head_dep, n, tail_id);
-    fb.rec1[row] = make_float2(head_arr, r1_code(lazy ? n0 : -1.0f, hoff));
+    fb.hdp[row] = make_uint2((head_id << 8) | (uint32_t)n, __float_as_uint(head_dep));
+    fb.tl[row] = (tail_id << 8) | TLF_AUTH;
+    const uint2 r1n = make_uint2(__float_as_uint(head_arr), r1_code(lazy ? q : -1, hoff));
+    if (r1n.x != r1.x || r1n.y != r1.y) fb.rec1[row] = r1n;
     // per-node count before insertion (the insert kernel adds this frame's arrivals); write-once stream
-    if (counts) __builtin_nontemporal_store(n, &counts[row]);
-    nsum += n;
+    if (out.counts8) __builtin_nontemporal_store((uint8_t)n, &out.counts8[row]);
+    if (out.countsf) __builtin_nontemporal_store((float)n, &out.countsf[row]);
+    if (out.popped) out.popped[b * N + i] = pop ? 1 : 0;
+    if (out.withdrawn) out.withdrawn[b * N + i] = c > 0 ? 1 : 0;
+    if (out.events && b < out.m_env) out.events[(int64_t)i * out.m_env + b] = (uint8_t)((pop ? 1 : 0) | (c > 0 ? 2 : 0));
+    nsum += (float)n;
+    wsum += (float)c;
   }
-  atomicAdd(&fb.acc_n[(int64_t)(blockIdx.y % (unsigned)fb.acc_slots) * B + b], nsum);
+  const int64_t bank = (int64_t)(blockIdx.y % (unsigned)fb.acc_slots) * B + b;
+  atomicAdd(&fb.acc_n[bank], nsum);
+  if (wsum != 0.0f) atomicAdd(&fb.acc_w[bank], wsum);
 }
 
-// ---- insert + reward + log-prob reduction (one workgroup per environment) ----------------------------------------------
-__device__ __forceinline__ bool fused_target(const FusedBufs& fb, int64_t b, int64_t B, int64_t N, int32_t origin,
-                                             int32_t* road, int32_t* cap) {
+// ---- insert + reward + log-prob reduction (one wave per environment) -----------------------------------------------------
+__device__ __forceinline__ bool fused_target(const FusedBufs& fb, PlanOut P, const uint8_t* __restrict__ sel8, int64_t b,
+                                             int64_t B, int64_t N, int32_t origin, int32_t* road, int32_t* cap) {
   if (origin < 0 || origin >= N) return false;
-  const long long r = (long long)fb.sel[(int64_t)origin * B + b];
+  const int64_t orow = (int64_t)origin * B + b;
+  const uint32_t c = sel8[orow] & 0x7Fu;
+  const long long r = (long long)(c == SEL_RAW ? fb.sel[orow] : (float)P.out_dst[P.out_ptr[origin] + (int32_t)c]);
   if (r < 0 || r >= N) return false;
-  const long long room = (long long)(fb.st0[r].x - TARL_CONGESTION_FILE - fb.rec0[r * B + b].z);
+  const long long room = (long long)(fb.st0[r].x - TARL_CONGESTION_FILE - (float)(fb.hdp[r * B + b].x & 255u));
   *road = (int32_t)r;
   *cap = (int32_t)(room > 0x7fffffff ? 0x7fffffff : room);
   return room > 0;
 }
 
-__device__ __forceinline__ void fused_insert_body(int64_t b, int Nmax, int64_t B, int64_t N, FusedBufs fb,
-                                                       float* __restrict__ ag, int64_t A, int64_t a_bstride,
-                                                       int use_cong, float t, int32_t* __restrict__ scratch,
-                                                       const float* __restrict__ entropy_in,
-                                                       float* __restrict__ reward, float* __restrict__ counts,
-                                                       float* __restrict__ log_prob, float* __restrict__ entropy) {
+__device__ __forceinline__ void fused_insert_body(int64_t b, int Nmax, int64_t B, int64_t N, FusedBufs fb, PlanOut P,
+                                                  const uint8_t* __restrict__ sel8, float* __restrict__ ag, int64_t A,
+                                                  int64_t a_bstride, int use_cong, float t,
+                                                  int32_t* __restrict__ scratch, const float* __restrict__ entropy_in,
+                                                  float* __restrict__ reward, FrameOut out,
+                                                  float* __restrict__ log_prob, float* __restrict__ entropy) {
   __shared__ int32_t s_wave[INSB / 64];
   __shared__ int32_t s_cnt;
   __shared__ int32_t s_adm;
@@ -641,7 +705,7 @@ __device__ __forceinline__ void fused_insert_body(int64_t b, int Nmax, int64_t B
           if (fb.a_status[b * A + a] == 0) {
             atomicMin(&s_lo, (int32_t)k);
             int32_t road = 0, cap = 0;
-            if (fused_target(fb, b, B, N, fb.a_origin[b * A + a], &road, &cap)) {
+            if (fused_target(fb, P, sel8, b, B, N, fb.a_origin[b * A + a], &road, &cap)) {
               const int32_t pos = atomicAdd(&s_cnt, 1);
               if (pos < INS_CAP) {
                 s_un_agent[pos] = a;
@@ -670,7 +734,7 @@ __device__ __forceinline__ void fused_insert_body(int64_t b, int Nmax, int64_t B
         if (stt[j] == 0 && dp[j] <= t) {
           const int64_t a = a0 + (int64_t)j * INSB;
           int32_t road = 0, cap = 0;
-          if (fused_target(fb, b, B, N, fb.a_origin[b * A + a], &road, &cap)) {
+          if (fused_target(fb, P, sel8, b, B, N, fb.a_origin[b * A + a], &road, &cap)) {
             const int32_t pos = atomicAdd(&s_cnt, 1);
             if (pos < INS_CAP) {
               s_un_agent[pos] = (int32_t)a;
@@ -700,7 +764,7 @@ __device__ __forceinline__ void fused_insert_body(int64_t b, int Nmax, int64_t B
       bool cnd = false;
       int32_t road = 0, cap = 0;
       if (a < A && fb.a_status[b * A + a] == 0 && fb.a_dep[b * A + a] <= t)
-        cnd = fused_target(fb, b, B, N, fb.a_origin[b * A + a], &road, &cap);
+        cnd = fused_target(fb, P, sel8, b, B, N, fb.a_origin[b * A + a], &road, &cap);
       const unsigned long long bal = __ballot(cnd);
       const int lane_off = __popcll(bal & ((1ull << lane) - 1ull));
       if (lane == 0) s_wave[wid] = __popcll(bal);
@@ -723,7 +787,9 @@ __device__ __forceinline__ void fused_insert_body(int64_t b, int Nmax, int64_t B
     __syncthreads();
   }
 
-  // phase 2: rank within road (stable), admit the first min(count, capacity), write slots / hot records
+  // phase 2: rank within road (stable), admit the first min(count, capacity), write slots / dense words.
+  // Per admitted road: the rank-0 candidate owns hdp / rec1 (the count's byte of hd is committed after the barrier), the
+  // last admitted candidate owns tl. Everybody else only READS the count byte, which nobody changes in this phase.
   for (int32_t idx = tid; idx < Lc; idx += INSB) {
     const int32_t r = cand_road[idx];
     const int32_t a = cand_agent[idx];
@@ -735,48 +801,46 @@ __device__ __forceinline__ void fused_insert_body(int64_t b, int Nmax, int64_t B
     }
     const int64_t rrow = (int64_t)r * B + b;
     const float4 str = fb.st0[r];
-    const float n0 = fb.rec0[rrow].z;
+    const uint32_t hd = fb.hdp[rrow].x;
+    const uint32_t n0i = hd & 255u;
+    const float n0 = (float)n0i;
     const long long cap = (long long)(str.x - TARL_CONGESTION_FILE - n0);
     int32_t commit = 0;
-    bool pend_clear = false;
     if (rank < cap) {
       const long long m = total < cap ? total : cap;  // arrivals admitted on this road
-      const long long slot = (long long)n0 + rank;
-      const float t_cong = use_cong ? str.w / (str.x + 10.0f - (float)(long long)n0) : 0.0f;
+      const long long slot = (long long)n0i + rank;
+      const float t_cong = use_cong ? str.w / (str.x + 10.0f - n0) : 0.0f;
       const float tt = (t_cong != t_cong) ? t_cong : fmaxf(str.y, t_cong);
-      const float code = fb.rec1[rrow].y;   // nobody writes rec1.y before the barrier below
+      const uint32_t code = fb.rec1[rrow].y;   // nobody writes rec1.y before the barrier below
       if (slot >= 0 && slot < Nmax) {
         float* sr = fb.slots + rrow * fb.lds + 3 * phys(r1_hoff(code), (int)slot, Nmax);
         sr[0] = (float)a;
         sr[1] = t;
         sr[2] = t + tt;
       }
-      if (rank == 0) pend_clear = true;
       agb[(int64_t)a * AG_COLS + AG_ON_WAY] = 1.0f;
       fb.a_status[b * A + a] = 1;
-      // hot record: only fields nobody reads in this phase (n is committed after the barrier)
-      if (rank == 0 && n0 == 0.0f) {
-        fb.rec0[rrow].x = (float)a;
-        fb.rec0[rrow].y = t + tt;
-        fb.rec1[rrow].x = t;
+      if (rank == 0 && n0i == 0u) {   // new head: id + departure (count byte unchanged), arrival
+        fb.hdp[rrow] = make_uint2(((uint32_t)a << 8) | n0i, __float_as_uint(t + tt));
+        fb.rec1[rrow].x = __float_as_uint(t);
       }
-      if (rank == m - 1) fb.rec0[rrow].w = (float)a;  // new tail
+      if (rank == m - 1) fb.tl[rrow] = ((uint32_t)a << 8) | TLF_AUTH;  // new tail; rec1 is authoritative from here on
       if (rank == 0) commit = (int32_t)m;
     }
     cand_agent[idx] = commit;
-    (void)pend_clear;
   }
   __threadfence_block();
   __syncthreads();
-  // phase 3: commit the counters; the arrivals overwrote a pending garbage slot: clear the flag, keep the head offset
+  // phase 3: commit the counters; the arrivals overwrote a pending garbage slot: no garbage pending, keep the head offset
   for (int32_t idx = tid; idx < Lc; idx += INSB) {
     const int32_t cmt = cand_agent[idx];
     if (cmt > 0) {
       const int64_t rrow = (int64_t)cand_road[idx] * B + b;
-      fb.rec1[rrow].y = r1_code(-1.0f, r1_hoff(fb.rec1[rrow].y));
-      const float nn = fb.rec0[rrow].z + (float)cmt;
-      fb.rec0[rrow].z = nn;
-      if (counts) counts[rrow] = nn;
+      fb.rec1[rrow].y = r1_code(-1, r1_hoff(fb.rec1[rrow].y));
+      const uint32_t hd = fb.hdp[rrow].x + (uint32_t)cmt;   // count byte: n0 + cmt <= MAX - 3 < 255
+      fb.hdp[rrow].x = hd;
+      if (out.counts8) out.counts8[rrow] = (uint8_t)(hd & 255u);
+      if (out.countsf) out.countsf[rrow] = (float)(hd & 255u);
       atomicAdd(&s_adm, cmt);
     }
   }
@@ -784,88 +848,91 @@ __device__ __forceinline__ void fused_insert_body(int64_t b, int Nmax, int64_t B
   // phase 4: the frame's accumulator banks (filled by the choice kernel and the row pass) -> reward, log-prob; re-arm
   if (wid == 0) {
     long long lpf = 0;
-    float nf = 0.0f;
+    float nf = 0.0f, wf = 0.0f;
     for (int64_t sl_ = lane; sl_ < fb.acc_slots; sl_ += 64) {
       lpf += fb.acc_lp[sl_ * B + b];
       nf += fb.acc_n[sl_ * B + b];
+      wf += fb.acc_w[sl_ * B + b];
       fb.acc_lp[sl_ * B + b] = 0;
       fb.acc_n[sl_ * B + b] = 0.0f;
+      fb.acc_w[sl_ * B + b] = 0.0f;
     }
     for (int off = 32; off > 0; off >>= 1) {
       lpf += __shfl_down(lpf, off);
       nf += __shfl_down(nf, off);      // sums of small integers: exact in fp32 in any order
+      wf += __shfl_down(wf, off);
     }
     if (lane == 0) {
       if (reward) reward[b] = -(nf + (float)s_adm);
       if (log_prob) log_prob[b] = (lpf < -(1ll << 49)) ? -INFINITY : (float)((double)lpf / LP_FIX);
       if (entropy) entropy[b] = entropy_in[0];
+      if (out.leg) {
+        out.leg[2 * b + 0] = s_adm;
+        out.leg[2 * b + 1] = (int32_t)wf;
+      }
     }
   }
 }
 
-__global__ __launch_bounds__(INSB) void k_fused_insert(int Nmax, int64_t B, int64_t N, FusedBufs fb,
-                                                       float* __restrict__ ag, int64_t A, int64_t a_bstride,
-                                                       int use_cong, float t, int32_t* __restrict__ scratch,
+__global__ __launch_bounds__(INSB) void k_fused_insert(int Nmax, int64_t B, int64_t N, FusedBufs fb, PlanOut P,
+                                                       const uint8_t* __restrict__ sel8, float* __restrict__ ag,
+                                                       int64_t A, int64_t a_bstride, int use_cong, float t,
+                                                       int32_t* __restrict__ scratch,
                                                        const float* __restrict__ entropy_in,
-                                                       float* __restrict__ reward, float* __restrict__ counts,
+                                                       float* __restrict__ reward, FrameOut out,
                                                        float* __restrict__ log_prob, float* __restrict__ entropy) {
-  fused_insert_body(blockIdx.x, Nmax, B, N, fb, ag, A, a_bstride, use_cong, t, scratch, entropy_in, reward, counts,
+  fused_insert_body(blockIdx.x, Nmax, B, N, fb, P, sel8, ag, A, a_bstride, use_cong, t, scratch, entropy_in, reward, out,
                     log_prob, entropy);
 }
 
 // One launch, two roles (rollout steady state): the first B workgroups run frame t's insert (one wave each; the other
 // three waves of such a workgroup retire at once, so its barriers only count the live wave), the remaining
-// `choice_blocks` workgroups draw frame t+1's action into the OTHER half of the double-buffered SELECTED_ROAD / log-prob
-// accumulators.
+// `choice_blocks` workgroups draw frame t+1's action into the NEXT slice of the action buffer and the other half of the
+// double-buffered log-prob accumulators.
 // The insert kernel is a latency chain that leaves the chip idle and the live policy's sample does not depend on the
-// state, so the choice work rides in its shadow — without the cross-stream events that made the two-stream variant
+// state, so the choice work rides in its shadow — without the cross-stream events that made a two-stream variant
 // slower — and still completes right before the Direction kernel that consumes it (Infinity-Cache adjacency).
 struct ChoiceArgs {
   const int32_t* out_ptr;
-  const int32_t* out_dst;
   const int32_t* out_eid;
   const int32_t* group_of_node;
   int64_t G;
   const float* thr;
   const long long* lgt;
   uint64_t pseed, pcounter;
-  int32_t* choice;
   int nchunk, want_lp;
-  float* sel_next;
+  uint8_t* sel_next;       // frame t+1's action / SELECTED_ROAD slice
   long long* acc_next;
-  const float* sel_cur;
   unsigned gx;             // environment tiles (x extent of the choice grid)
   unsigned choice_blocks;  // gx * node chunks
 };
 __global__ __launch_bounds__(TILE) void k_fused_insert_choice(ChoiceArgs C, int Nmax, int64_t B, int64_t N, FusedBufs fb,
+                                                              PlanOut P, const uint8_t* __restrict__ sel8,
                                                               float* __restrict__ ag, int64_t A, int64_t a_bstride,
                                                               int use_cong, float t, int32_t* __restrict__ scratch,
                                                               const float* __restrict__ entropy_in,
-                                                              float* __restrict__ reward, float* __restrict__ counts,
+                                                              float* __restrict__ reward, FrameOut out,
                                                               float* __restrict__ log_prob,
                                                               float* __restrict__ entropy) {
   // insert workgroups first: their dependent-load chains start at once and the choice workgroups fill the chip around them
   if (blockIdx.x < (unsigned)B) {
     if (threadIdx.x >= INSB) return;   // whole waves leave before any barrier
-    fused_insert_body((int64_t)blockIdx.x, Nmax, B, N, fb, ag, A, a_bstride, use_cong, t, scratch, entropy_in, reward,
-                      counts, log_prob, entropy);
+    fused_insert_body((int64_t)blockIdx.x, Nmax, B, N, fb, P, sel8, ag, A, a_bstride, use_cong, t, scratch, entropy_in,
+                      reward, out, log_prob, entropy);
   } else {
     const unsigned cb = blockIdx.x - (unsigned)B;
-    FusedBufs fc = fb;
-    fc.sel = C.sel_next;
-    fc.acc_lp = C.acc_next;
-    fused_choice_body(cb % C.gx, cb / C.gx, C.out_ptr, C.out_dst, C.out_eid, C.group_of_node, C.G, B, N, fc, C.thr,
-                      C.lgt, nullptr, C.pseed, C.pcounter, C.choice, C.nchunk, C.want_lp, C.sel_cur);
+    fused_choice_body(cb % C.gx, cb / C.gx, C.out_ptr, C.out_eid, C.group_of_node, C.G, B, N, C.acc_next, fb.acc_slots,
+                      C.thr, C.lgt, nullptr, C.pseed, C.pcounter, C.sel_next, sel8, nullptr, C.nchunk, C.want_lp);
   }
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
 FusedBufs tarl_to_bufs(const tarl_fused* f) {
-  return FusedBufs{(float4*)f->rec0,         (float2*)f->rec1, (float2*)f->post_a, f->post_b,
-                   (const float4*)f->st0,    f->slots,         f->ld_slots,        f->sel,
-                   (long long*)f->acc_lp,    f->acc_n,         f->a_origin,        f->a_dest,
-                   f->a_dep,                 f->a_status,      f->a_order,         f->cur_lo,
-                   f->a_dep_sorted,          f->acc_slots};
+  return FusedBufs{(uint2*)f->hdp,        (uint32_t*)f->tl, (uint2*)f->rec1, (uint32_t*)f->post, (const float4*)f->st0,
+                   f->slots,              f->ld_slots,      f->sel8,         f->sel,             f->in_rank,
+                   (long long*)f->acc_lp, f->acc_n,         f->acc_w,        f->a_origin,        f->a_dest,
+                   f->a_dep,              f->a_status,      f->a_order,      f->cur_lo,          f->a_dep_sorted,
+                   f->acc_slots,          f->flags};
 }
 
 // nodes walked by one workgroup of the env-minor kernels (tunable: TARL_NCHUNK)
@@ -879,9 +946,9 @@ static int nchunk() {
   return v;
 }
 static int64_t num_chunks(const tarl_plan* plan) { return ceil_div(plan->N, nchunk()); }
-// nodes per workgroup pass of the Direction kernel (measured: 1 -> 53.5 us, 2 -> 48.2, 3 -> 49.9, 4 -> 64, 8 -> 85 per
-// launch at B = 2048): two give the dense second pass ~25 pairs per workgroup without starving the chip of workgroups;
-// at most 8 (capacity of the LDS list and of the 16-bit item code)
+// nodes per workgroup pass of the Direction kernel (measured on the v5 layout: 1 -> 53.5 us, 2 -> 48.2, 3 -> 49.9,
+// 4 -> 64, 8 -> 85 per launch at B = 2048): two give the dense second pass ~25 pairs per workgroup without starving the
+// chip of workgroups; at most 8 (capacity of the LDS list and of the 16-bit item code)
 static int nchunk_dir() {
   static int v = 0;
   if (v == 0) {
@@ -905,16 +972,20 @@ static int nchunk_choice() {
 
 int tarl_check_fused_core(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax) {
   TARL_REQUIRE(plan && f, "null argument");
-  TARL_REQUIRE(f->rec0 && f->rec1 && f->post_a && f->post_b && f->st0 && f->slots && f->sel && f->acc_lp && f->acc_n,
+  TARL_REQUIRE(f->hdp && f->tl && f->rec1 && f->post && f->st0 && f->slots && f->sel8 && f->sel && f->acc_lp &&
+                   f->acc_n && f->acc_w && f->flags && (f->in_rank || plan->E == 0),
                "fused node buffers missing");
   TARL_REQUIRE(B >= 1 && B < ((int64_t)1 << 31) && Nmax >= 2, "bad sizes");
+  TARL_REQUIRE(Nmax <= 255, "the fused path packs NUMBER_OF_AGENT into one byte: Nmax must be <= 255 (use the unfused "
+                            "entry points for longer FIFOs)");
+  TARL_REQUIRE(plan->max_out <= 126, "the fused path packs the chosen out-edge's rank into 7 bits: out-degree must be <= 126");
   TARL_REQUIRE(f->acc_slots >= 1 && f->acc_slots <= 4096, "acc_slots out of range");
   TARL_REQUIRE(f->ld_slots >= 3 * (int64_t)Nmax, "slot row stride smaller than 3*Nmax");
   TARL_REQUIRE(num_chunks(plan) < 65536 && ceil_div(plan->N, nchunk_choice()) < 65536 &&
                    ceil_div(plan->N, nchunk_dir()) < 65536,
                "too many node chunks for one launch");
-  TARL_REQUIRE(((uintptr_t)f->rec0 | (uintptr_t)f->rec1 | (uintptr_t)f->post_a | (uintptr_t)f->post_b |
-                (uintptr_t)f->st0) % 16 == 0,
+  TARL_REQUIRE(((uintptr_t)f->hdp | (uintptr_t)f->rec1 | (uintptr_t)f->st0) % 16 == 0 &&
+                   ((uintptr_t)f->tl | (uintptr_t)f->post) % 4 == 0,
                "fused records must be 16-byte aligned");
   return TARL_OK;
 }
@@ -938,14 +1009,22 @@ extern "C" int tarl_fused_pack(const tarl_plan* plan, const tarl_fused* f, const
   if (rc) return rc;
   const Layout L{Nmax, ldx, x_bstride};
   const FusedBufs fb = tarl_to_bufs(f);
+  const PlanOut P{plan->out_ptr, plan->out_dst};
   hipStream_t s = (hipStream_t)stream;
+  TARL_CHECK_HIP(hipMemsetAsync(f->flags, 0, sizeof(int32_t), s));
   if (plan->N > 0) {
     hipLaunchKernelGGL(k_pack_nodes, dim3((unsigned)ceil_div(B * plan->N, FB)), dim3(FB), 0, s, x, L, B, plan->N, cong,
-                       fb, (float4*)f->st0);
+                       fb, (float4*)f->st0, P);
     TARL_LAUNCH_CHECK();
+    if (plan->E > 0) {
+      hipLaunchKernelGGL(k_pack_inrank, dim3((unsigned)ceil_div(plan->N, FB)), dim3(FB), 0, s, x, L, plan->N,
+                         plan->in_ptr, plan->in_src, P, f->in_rank, f->flags);
+      TARL_LAUNCH_CHECK();
+    }
   }
   if (agent_features) {
     TARL_REQUIRE(f->a_origin && f->a_dest && f->a_dep && f->a_status && A >= 1, "fused agent buffers missing");
+    TARL_REQUIRE(A <= ((int64_t)1 << 24), "agent ids must stay below 2^24 (they are exact fp32 integers in the reference)");
     hipLaunchKernelGGL(k_pack_agents, dim3((unsigned)ceil_div(B * A, FB)), dim3(FB), 0, s, agent_features, B, A,
                        a_bstride, fb);
     TARL_LAUNCH_CHECK();
@@ -977,8 +1056,9 @@ extern "C" int tarl_fused_export(const tarl_plan* plan, const tarl_fused* f, flo
   if (rc) return rc;
   if (plan->N == 0) return TARL_OK;
   const Layout L{Nmax, ldx, x_bstride};
+  const PlanOut P{plan->out_ptr, plan->out_dst};
   hipLaunchKernelGGL(k_export_rows, dim3((unsigned)ceil_div(B * plan->N * Nmax, FB)), dim3(FB), 0, (hipStream_t)stream,
-                     x, L, B, plan->N, tarl_to_bufs(f), last_step_time);
+                     x, L, B, plan->N, tarl_to_bufs(f), last_step_time, P);
   TARL_LAUNCH_CHECK();
   return TARL_OK;
 }
@@ -996,76 +1076,120 @@ extern "C" int tarl_fused_policy_prepare(const tarl_plan* plan, const tarl_fused
   return TARL_OK;
 }
 
-extern "C" int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax,
-                                const float* thresholds, const int64_t* log_probs, const float* entropy1,
-                                const float* uniform, uint64_t policy_seed, uint64_t policy_counter,
-                                float* agent_features, int64_t A, int64_t a_bstride, const float* edge_attr,
-                                const float* log_edge_attr, float log_eps, int use_cong, float time, const float* gumbel,
-                                uint64_t seed, uint64_t counter, float* delta_travel_time, uint8_t* popped,
-                                uint8_t* withdrawn, int32_t* ins_scratch, int32_t* choice, float* log_prob,
-                                float* entropy, float* reward, float* counts, tarl_stream stream) {
-  int rc = tarl_check_fused_core(plan, f, B, Nmax);
-  if (rc) return rc;
-  TARL_REQUIRE(thresholds && log_probs && entropy1, "policy tables missing (call tarl_fused_policy_prepare)");
+static int check_frame_args(const tarl_plan* plan, const tarl_fused* f, int64_t B, const float* agent_features, int64_t A,
+                            int64_t a_bstride, const int32_t* ins_scratch, const float* edge_attr,
+                            const float* log_edge_attr) {
   TARL_REQUIRE(agent_features && A >= 1 && ins_scratch, "agents / scratch missing");
   TARL_REQUIRE(f->a_origin && f->a_dest && f->a_dep && f->a_status, "fused agent buffers missing");
   TARL_REQUIRE(f->a_order == nullptr || (f->cur_lo != nullptr && f->a_dep_sorted != nullptr),
                "a_order needs cur_lo and a_dep_sorted");
   TARL_REQUIRE(B == 1 || a_bstride >= A * AG_COLS, "agent stride smaller than one population");
   TARL_REQUIRE(plan->E == 0 || (edge_attr && log_edge_attr), "edge constants missing");
+  return TARL_OK;
+}
+
+extern "C" int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax,
+                                const float* thresholds, const int64_t* log_probs, const float* entropy1,
+                                const float* uniform, uint64_t policy_seed, uint64_t policy_counter,
+                                float* agent_features, int64_t A, int64_t a_bstride, const float* edge_attr,
+                                const float* log_edge_attr, float log_eps, int use_cong, float time, float prev_time,
+                                const float* gumbel, uint64_t seed, uint64_t counter, float* delta_travel_time,
+                                uint8_t* popped, uint8_t* withdrawn, int32_t* ins_scratch, int32_t* choice,
+                                float* log_prob, float* entropy, float* reward, float* counts, tarl_stream stream) {
+  int rc = tarl_check_fused_core(plan, f, B, Nmax);
+  if (rc) return rc;
+  // thresholds == NULL: SELECTED_ROAD was set by the caller (tarl_fused_apply_choice); no sample / log-prob in this call
+  TARL_REQUIRE((thresholds && log_probs && entropy1) || (!thresholds && !log_prob && !entropy && !choice),
+               "policy tables missing (call tarl_fused_policy_prepare), or outputs of the skipped choice phase requested");
+  rc = check_frame_args(plan, f, B, agent_features, A, a_bstride, ins_scratch, edge_attr, log_edge_attr);
+  if (rc) return rc;
   if (plan->N == 0) return TARL_OK;
   const FusedBufs fb = tarl_to_bufs(f);
+  const PlanOut P{plan->out_ptr, plan->out_dst};
   hipStream_t s = (hipStream_t)stream;
   const unsigned threads = tile_threads(B);
   const dim3 grid((unsigned)ceil_div(B, threads), (unsigned)num_chunks(plan));
   const dim3 grid_c((unsigned)ceil_div(B, threads), (unsigned)ceil_div(plan->N, nchunk_choice()));
-  hipLaunchKernelGGL(k_fused_choice, grid_c, dim3(threads), 0, s, plan->out_ptr, plan->out_dst, plan->out_eid,
-                     plan->group_of_node, plan->G, B, plan->N, fb, thresholds, (const long long*)log_probs, uniform, policy_seed,
-                     policy_counter, choice, nchunk_choice(), log_prob != nullptr ? 1 : 0);
-  TARL_LAUNCH_CHECK();
+  if (thresholds) {
+    hipLaunchKernelGGL(k_fused_choice, grid_c, dim3(threads), 0, s, plan->out_ptr, plan->out_eid, plan->group_of_node,
+                       plan->G, B, plan->N, fb.acc_lp, fb.acc_slots, thresholds, (const long long*)log_probs, uniform,
+                       policy_seed, policy_counter, f->sel8, (const uint8_t*)f->sel8, choice, nchunk_choice(),
+                       log_prob != nullptr ? 1 : 0);
+    TARL_LAUNCH_CHECK();
+  }
   const bool timed = tarl_prof_mark(s, 0) != nullptr;
   const dim3 grid_d((unsigned)ceil_div(B, threads), (unsigned)ceil_div(plan->N, nchunk_dir()));
-  hipLaunchKernelGGL(k_fused_direction, grid_d, dim3(threads), 0, s, plan->in_ptr, plan->in_src, plan->in_eid, plan->E,
-                     B, plan->N, fb, edge_attr, log_edge_attr, log_eps, time, gumbel, seed, counter, delta_travel_time,
-                     nchunk_dir());
+  const DirIn D{plan->in_ptr, plan->in_src, plan->in_eid, edge_attr, log_edge_attr, gumbel, delta_travel_time,
+                log_eps,      time,         prev_time,    seed,      counter};
+  const FrameOut out{nullptr, counts, popped, withdrawn, nullptr, nullptr, 0, nullptr};
+  hipLaunchKernelGGL(k_fused_direction, grid_d, dim3(threads), 0, s, D, plan->E, B, plan->N, fb,
+                     (const uint8_t*)f->sel8, out, nchunk_dir());
   TARL_LAUNCH_CHECK();
   if (timed) (void)tarl_prof_mark(s, 1);
-  hipLaunchKernelGGL(k_fused_rows, grid, dim3(threads), 0, s, plan->out_ptr, plan->out_dst, (int)Nmax, B, plan->N, fb,
-                     agent_features, A, a_bstride, time, popped, withdrawn, counts, nchunk());
+  hipLaunchKernelGGL(k_fused_rows, grid, dim3(threads), 0, s, P, (int)Nmax, B, plan->N, fb, agent_features, A, a_bstride,
+                     time, out, nchunk());
   TARL_LAUNCH_CHECK();
   if (timed) (void)tarl_prof_mark(s, 2);
-  hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(INSB), 0, s, (int)Nmax, B, plan->N, fb,
-                     agent_features, A, a_bstride, use_cong, time, ins_scratch, entropy1, reward, counts, log_prob,
-                     entropy);
+  hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(INSB), 0, s, (int)Nmax, B, plan->N, fb, P,
+                     (const uint8_t*)f->sel8, agent_features, A, a_bstride, use_cong, time, ins_scratch, entropy1, reward,
+                     out, log_prob, entropy);
   TARL_LAUNCH_CHECK();
   if (timed) (void)tarl_prof_mark(s, 3);
   return TARL_OK;
 }
 
+// x[b, src(e), SELECTED_ROAD] = dst(e) for the chosen edge of every node, on the packed state (the choice phase of
+// SimulatorEnv._step for an externally sampled action): choice int32 [B][N] = chosen edge id per node, -1 = none.
+__global__ __launch_bounds__(FB) void k_apply_choice8(const int32_t* __restrict__ choice, const int32_t* __restrict__ out_ptr,
+                                                      const int32_t* __restrict__ out_eid, int64_t B, int64_t N,
+                                                      uint8_t* __restrict__ sel8) {
+  const int64_t gid = (int64_t)blockIdx.x * FB + threadIdx.x;  // gid = i * B + b
+  if (gid >= B * N) return;
+  const int64_t i = gid / B, b = gid - i * B;
+  const int32_t e = choice[b * N + i];
+  uint32_t code = (sel8[gid] & 0x7Fu) | SEL_CARRIED;
+  if (e >= 0) {
+    const int32_t k0 = out_ptr[i], k1 = out_ptr[i + 1];
+    for (int32_t k = k0; k < k1; ++k)
+      if (out_eid[k] == e) code = (uint32_t)(k - k0);
+  }
+  sel8[gid] = (uint8_t)code;
+}
+
+extern "C" int tarl_fused_apply_choice(const tarl_plan* plan, const tarl_fused* f, int64_t B, const int32_t* choice,
+                                       tarl_stream stream) {
+  TARL_REQUIRE(plan && f && f->sel8 && choice && B >= 1, "null argument");
+  if (plan->N == 0) return TARL_OK;
+  hipLaunchKernelGGL(k_apply_choice8, dim3((unsigned)ceil_div(B * plan->N, FB)), dim3(FB), 0, (hipStream_t)stream, choice,
+                     plan->out_ptr, plan->out_eid, B, plan->N, f->sel8);
+  TARL_LAUNCH_CHECK();
+  return TARL_OK;
+}
+
 // T consecutive frames with device noise: the collector loop in one foreign call. Each frame is choice -> direction ->
-// rows -> insert on the caller's stream; with the scratch pair, frame t+1's choice shares the launch of frame t's insert
-// (k_fused_insert_choice). (Two alternatives were measured and rejected, DESIGN.md §4.2: folding
-// frame t+1's choice into the row pass, and running it on a side stream into double-buffered SELECTED_ROAD /
-// accumulators. Both lose the producer -> consumer adjacency that lets the Direction kernel read the 20 MB the choice
-// kernel just wrote from the Infinity Cache.)
+// rows -> insert on the caller's stream; frame t+1's choice shares the launch of frame t's insert
+// (k_fused_insert_choice). The action of frame t is written into slice t of the action buffer, which is also the
+// SELECTED_ROAD column that frame's Direction gather and insert read. (Two alternatives were measured and rejected,
+// folding frame t+1's choice into the row pass, and running it on a side stream. Both lose the
+// producer -> consumer adjacency that lets the Direction kernel read what the choice kernel just wrote from the
+// Infinity Cache.)
 extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, int64_t T,
-                                  const float* times_host, const float* thresholds, const int64_t* log_probs,
-                                  const float* entropy1, uint64_t policy_seed, uint64_t policy_counter0,
-                                  float* agent_features, int64_t A, int64_t a_bstride, const float* edge_attr,
-                                  const float* log_edge_attr, float log_eps, int use_cong, uint64_t seed,
-                                  uint64_t counter0, int32_t* ins_scratch, float* sel_scratch, int64_t* acc_scratch,
-                                  int32_t* choice, float* log_prob, float* entropy, float* reward, float* counts,
+                                  const float* times_host, float prev_time, const float* thresholds,
+                                  const int64_t* log_probs, const float* entropy1, uint64_t policy_seed,
+                                  uint64_t policy_counter0, float* agent_features, int64_t A, int64_t a_bstride,
+                                  const float* edge_attr, const float* log_edge_attr, float log_eps, int use_cong,
+                                  uint64_t seed, uint64_t counter0, int32_t* ins_scratch, uint8_t* sel_scratch,
+                                  int64_t* acc_scratch, uint8_t* choice, float* log_prob, float* entropy, float* reward,
+                                  uint8_t* counts, int32_t metrics_envs, float* dtt_node, uint8_t* events, int32_t* leg,
                                   tarl_stream stream) {
   int rc = tarl_check_fused_core(plan, f, B, Nmax);
   if (rc) return rc;
   TARL_REQUIRE(T >= 1 && times_host, "bad frame count / times");
   TARL_REQUIRE(thresholds && log_probs && entropy1, "policy tables missing (call tarl_fused_policy_prepare)");
-  TARL_REQUIRE(agent_features && A >= 1 && ins_scratch, "agents / scratch missing");
-  TARL_REQUIRE(f->a_origin && f->a_dest && f->a_dep && f->a_status, "fused agent buffers missing");
-  TARL_REQUIRE(f->a_order == nullptr || (f->cur_lo != nullptr && f->a_dep_sorted != nullptr),
-               "a_order needs cur_lo and a_dep_sorted");
-  TARL_REQUIRE(B == 1 || a_bstride >= A * AG_COLS, "agent stride smaller than one population");
-  TARL_REQUIRE(plan->E == 0 || (edge_attr && log_edge_attr), "edge constants missing");
+  rc = check_frame_args(plan, f, B, agent_features, A, a_bstride, ins_scratch, edge_attr, log_edge_attr);
+  if (rc) return rc;
+  TARL_REQUIRE(metrics_envs >= 0 && metrics_envs <= B, "metrics_envs out of range");
+  TARL_REQUIRE(metrics_envs > 0 || (!dtt_node && !events), "per-node series need metrics_envs > 0");
   if (plan->N == 0) return TARL_OK;
   hipStream_t s = (hipStream_t)stream;
   const int64_t N = plan->N, NB = N * B;
@@ -1074,61 +1198,110 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
   const dim3 grid_c((unsigned)ceil_div(B, threads), (unsigned)ceil_div(N, nchunk_choice()));
   const dim3 grid_d((unsigned)ceil_div(B, threads), (unsigned)ceil_div(N, nchunk_dir()));
   const int want_lp = log_prob != nullptr ? 1 : 0;
-  FusedBufs fb = tarl_to_bufs(f);
-  // steady state: frame t's insert and frame t+1's choice share ONE launch (k_fused_insert_choice); SELECTED_ROAD and
-  // the log-prob accumulator banks are double-buffered between f->sel / f->acc_lp and the scratch pair
+  const FusedBufs fb = tarl_to_bufs(f);
+  const PlanOut P{plan->out_ptr, plan->out_dst};
+  // slice t of the action buffer (or, without one, the ping-pong pair f->sel8 / sel_scratch)
+  auto slice = [&](int64_t t) -> uint8_t* {
+    if (choice) return choice + t * NB;
+    return (sel_scratch && (t & 1)) ? sel_scratch : f->sel8;
+  };
+  // steady state: frame t's insert and frame t+1's choice share ONE launch (k_fused_insert_choice); needs two distinct
+  // SELECTED_ROAD slices and double-buffered log-prob accumulator banks
   const char* knob = getenv("TARL_ROLLOUT_MERGE");
-  const bool merge = sel_scratch && acc_scratch && T > 1 && !(knob && atoi(knob) == 0);
-  float* sel_buf[2] = {f->sel, merge ? sel_scratch : f->sel};
+  const bool merge = (choice || sel_scratch) && acc_scratch && T > 1 && !(knob && atoi(knob) == 0);
   long long* acc_buf[2] = {(long long*)f->acc_lp, merge ? (long long*)acc_scratch : (long long*)f->acc_lp};
   if (merge) TARL_CHECK_HIP(hipMemsetAsync(acc_scratch, 0, (size_t)(f->acc_slots * B) * sizeof(int64_t), s));
-  hipLaunchKernelGGL(k_fused_choice, grid_c, dim3(threads), 0, s, plan->out_ptr, plan->out_dst, plan->out_eid,
-                     plan->group_of_node, plan->G, B, N, fb, thresholds, (const long long*)log_probs,
-                     (const float*)nullptr, policy_seed, policy_counter0, choice, nchunk_choice(), want_lp);
+  hipLaunchKernelGGL(k_fused_choice, grid_c, dim3(threads), 0, s, plan->out_ptr, plan->out_eid, plan->group_of_node,
+                     plan->G, B, N, acc_buf[0], fb.acc_slots, thresholds, (const long long*)log_probs,
+                     (const float*)nullptr, policy_seed, policy_counter0, slice(0), (const uint8_t*)f->sel8,
+                     (int32_t*)nullptr, nchunk_choice(), want_lp);
   TARL_LAUNCH_CHECK();
   for (int64_t t = 0; t < T; ++t) {
     const int cur = merge ? (int)(t & 1) : 0;
     const float time = times_host[t];
-    fb.sel = sel_buf[cur];
-    fb.acc_lp = acc_buf[cur];
+    FusedBufs fbt = fb;
+    fbt.acc_lp = acc_buf[cur];
+    const uint8_t* sel_t = slice(t);
+    const int64_t m = metrics_envs;
+    const FrameOut out{counts ? counts + t * NB : nullptr,
+                       nullptr,
+                       nullptr,
+                       nullptr,
+                       events ? events + t * N * m : nullptr,
+                       dtt_node ? dtt_node + t * N * m : nullptr,
+                       metrics_envs,
+                       leg ? leg + t * 2 * B : nullptr};
+    const DirIn D{plan->in_ptr, plan->in_src, plan->in_eid, edge_attr, log_edge_attr, nullptr, nullptr,
+                  log_eps,      time,         t > 0 ? times_host[t - 1] : prev_time, seed, counter0 + (uint64_t)t};
     const bool timed = tarl_prof_mark(s, 0) != nullptr;
-    hipLaunchKernelGGL(k_fused_direction, grid_d, dim3(threads), 0, s, plan->in_ptr, plan->in_src, plan->in_eid,
-                       plan->E, B, N, fb, edge_attr, log_edge_attr, log_eps, time, (const float*)nullptr, seed,
-                       counter0 + (uint64_t)t, (float*)nullptr, nchunk_dir());
+    hipLaunchKernelGGL(k_fused_direction, grid_d, dim3(threads), 0, s, D, plan->E, B, N, fbt, sel_t, out, nchunk_dir());
     TARL_LAUNCH_CHECK();
     if (timed) (void)tarl_prof_mark(s, 1);
-    float* counts_t = counts ? counts + t * NB : nullptr;
-    hipLaunchKernelGGL(k_fused_rows, grid, dim3(threads), 0, s, plan->out_ptr, plan->out_dst, (int)Nmax, B, N, fb,
-                       agent_features, A, a_bstride, time, (uint8_t*)nullptr, (uint8_t*)nullptr, counts_t, nchunk());
+    hipLaunchKernelGGL(k_fused_rows, grid, dim3(threads), 0, s, P, (int)Nmax, B, N, fbt, agent_features, A, a_bstride,
+                       time, out, nchunk());
     TARL_LAUNCH_CHECK();
     if (timed) (void)tarl_prof_mark(s, 2);
     float* reward_t = reward ? reward + t * B : nullptr;
     float* lp_t = log_prob ? log_prob + t * B : nullptr;
     float* ent_t = entropy ? entropy + t * B : nullptr;
     if (merge && t + 1 < T) {
-      const ChoiceArgs C{plan->out_ptr, plan->out_dst, plan->out_eid, plan->group_of_node, plan->G, thresholds,
-                         (const long long*)log_probs, policy_seed, policy_counter0 + (uint64_t)(t + 1),
-                         choice ? choice + (t + 1) * NB : nullptr, nchunk_choice(), want_lp, sel_buf[cur ^ 1],
-                         acc_buf[cur ^ 1], sel_buf[cur], grid_c.x, grid_c.x * grid_c.y};
+      const ChoiceArgs C{plan->out_ptr, plan->out_eid, plan->group_of_node, plan->G, thresholds,
+                         (const long long*)log_probs, policy_seed, policy_counter0 + (uint64_t)(t + 1), nchunk_choice(),
+                         want_lp, slice(t + 1), acc_buf[cur ^ 1], grid_c.x, grid_c.x * grid_c.y};
       hipLaunchKernelGGL(k_fused_insert_choice, dim3(C.choice_blocks + (unsigned)B), dim3(threads), 0, s, C, (int)Nmax,
-                         B, N, fb, agent_features, A, a_bstride, use_cong, time, ins_scratch, entropy1, reward_t,
-                         counts_t, lp_t, ent_t);
+                         B, N, fbt, P, sel_t, agent_features, A, a_bstride, use_cong, time, ins_scratch, entropy1,
+                         reward_t, out, lp_t, ent_t);
       TARL_LAUNCH_CHECK();
     } else {
-      hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(INSB), 0, s, (int)Nmax, B, N, fb, agent_features, A,
-                         a_bstride, use_cong, time, ins_scratch, entropy1, reward_t, counts_t, lp_t, ent_t);
+      hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(INSB), 0, s, (int)Nmax, B, N, fbt, P, sel_t,
+                         agent_features, A, a_bstride, use_cong, time, ins_scratch, entropy1, reward_t, out, lp_t, ent_t);
       TARL_LAUNCH_CHECK();
-      if (t + 1 < T) {   // unmerged: the next frame's choice in place
-        hipLaunchKernelGGL(k_fused_choice, grid_c, dim3(threads), 0, s, plan->out_ptr, plan->out_dst, plan->out_eid,
-                           plan->group_of_node, plan->G, B, N, fb, thresholds, (const long long*)log_probs,
-                           (const float*)nullptr, policy_seed, policy_counter0 + (uint64_t)(t + 1),
-                           choice ? choice + (t + 1) * NB : nullptr, nchunk_choice(), want_lp);
+      if (t + 1 < T) {   // unmerged: the next frame's choice as its own launch
+        hipLaunchKernelGGL(k_fused_choice, grid_c, dim3(threads), 0, s, plan->out_ptr, plan->out_eid,
+                           plan->group_of_node, plan->G, B, N, fbt.acc_lp, fb.acc_slots, thresholds,
+                           (const long long*)log_probs, (const float*)nullptr, policy_seed,
+                           policy_counter0 + (uint64_t)(t + 1), slice(t + 1), sel_t, (int32_t*)nullptr, nchunk_choice(),
+                           want_lp);
         TARL_LAUNCH_CHECK();
       }
     }
     if (timed) (void)tarl_prof_mark(s, 3);
   }
-  if (merge && ((T - 1) & 1) == 1)   // the last frame's SELECTED_ROAD lives in the scratch buffer: bring it home
-    TARL_CHECK_HIP(hipMemcpyAsync(f->sel, sel_scratch, (size_t)NB * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (slice(T - 1) != f->sel8)   // the last frame's SELECTED_ROAD lives in the action buffer / scratch: bring it home
+    TARL_CHECK_HIP(hipMemcpyAsync(f->sel8, slice(T - 1), (size_t)NB, hipMemcpyDeviceToDevice, s));
+  return TARL_OK;
+}
+
+// ---- rollout bytes -> the formats of the unfused entry points (minibatch gather of the PPO update) ------------------------
+__global__ __launch_bounds__(FB) void k_rollout_gather(const uint8_t* __restrict__ choice, const uint8_t* __restrict__ counts,
+                                                       int64_t B, int64_t N, int env_minor,
+                                                       const int64_t* __restrict__ idx, int64_t rows,
+                                                       const int32_t* __restrict__ out_ptr,
+                                                       const int32_t* __restrict__ out_eid,
+                                                       int32_t* __restrict__ choice_eid, float* __restrict__ counts_f) {
+  const int64_t gid = (int64_t)blockIdx.x * FB + threadIdx.x;
+  if (gid >= rows * N) return;
+  const int64_t r = gid / N, i = gid - r * N;
+  const int64_t tb = idx ? idx[r] : r;
+  const int64_t t = tb / B, b = tb - t * B;
+  const int64_t src = env_minor ? ((t * N + i) * B + b) : ((t * B + b) * N + i);
+  if (choice_eid) {
+    const uint32_t c = choice[src];
+    choice_eid[gid] = (c & SEL_CARRIED) ? -1 : out_eid[out_ptr[i] + (int32_t)c];
+  }
+  if (counts_f) counts_f[gid] = (float)counts[src];
+}
+
+extern "C" int tarl_rollout_gather(const tarl_plan* plan, const uint8_t* choice, const uint8_t* counts, int64_t T,
+                                   int64_t B, int env_minor, const int64_t* idx, int64_t rows, int32_t* choice_eid,
+                                   float* counts_f, tarl_stream stream) {
+  TARL_REQUIRE(plan && T >= 1 && B >= 1 && rows >= 0, "bad arguments");
+  TARL_REQUIRE((choice != nullptr) == (choice_eid != nullptr) && (counts != nullptr) == (counts_f != nullptr),
+               "each output needs its input");
+  TARL_REQUIRE(idx || rows == T * B, "without an index list all T * B rows are converted");
+  if (rows == 0 || plan->N == 0) return TARL_OK;
+  hipLaunchKernelGGL(k_rollout_gather, dim3((unsigned)ceil_div(rows * plan->N, FB)), dim3(FB), 0, (hipStream_t)stream,
+                     choice, counts, B, plan->N, env_minor, idx, rows, plan->out_ptr, plan->out_eid, choice_eid, counts_f);
+  TARL_LAUNCH_CHECK();
   return TARL_OK;
 }

@@ -1,4 +1,4 @@
-// fused_common.h — definitions shared by the two rollout implementations: fused.hip (env-minor, four launches per frame)
+// fused_common.h — definitions shared by the two rollout implementations: fused.hip (env-minor, launches per frame)
 // and rollout_env.hip (one workgroup per environment, LDS-resident records, all T frames in one launch).
 #pragma once
 
@@ -15,17 +15,47 @@
 #define INS_CAP 2048    // LDS candidate list of the insert kernel (entries)
 #define INSB 64         // insert kernel: one wave per environment (all resident at once, 3/4 of the wave slots left free)
 
+// ---- packed per-(node, environment) words (layout "v6") ------------------------------------------------------------------
+// Dense words, read and rewritten by every row every frame (12 + 4 + 1 bytes):
+//   hdp  uint2  {hd = head_id << 8 | n, bits of head_dep}   n = NUMBER_OF_AGENT (<= 255: the fused path requires Nmax <= 255),
+//                                                            ids < 2^24 (the reference keeps them in fp32: exact below 2^24)
+//   tl   u32    tail_id << 8 | flags                         TLF_AUTH: rec1 (head_arr, pending-garbage count) is
+//                                                            authoritative for the last frame; clear = the row was idle in
+//                                                            the last frame: the pending garbage count is n itself and an
+//                                                            empty row's head arrival is the last frame's clock
+//   post u32    tail' << 8 | PF_NONEMPTY | PF_ARRIVED        the row's state after the Direction update: tail' = the agent
+//                                                            it enqueues (PF_ARRIVED) or its old tail; written by the
+//                                                            Direction gather, gathered by the upstream rows' Response test
+//   sel8 u8     SELECTED_ROAD as the rank of the chosen out-edge in the node's CSR list (| SEL_CARRIED when the node drew
+//               nothing in this frame and keeps its previous value); SEL_RAW: the fp32 value in `sel` is authoritative
+// Event-only word, read / written by the rows that move something in a frame (a few percent):
+//   rec1 uint2  {bits of head_arr, (g + 1) << 16 | hoff}     g = count at the pending (unmaterialised) garbage write or -1,
+//                                                            hoff = physical slot of logical slot 0 (ring buffer)
+#define TLF_AUTH 1u
+#define PF_ARRIVED 1u
+#define PF_NONEMPTY 2u
+#define SEL_RAW 0x7Fu
+#define SEL_CARRIED 0x80u
+#define INRANK_NONE 0xFEu
+// device status word (tarl_fused.flags): sticky bits, read by the host at its next synchronisation point
+#define FLAG_COUNT_AT_NMAX 1      // a FIFO count reached Nmax: outside the reference's defined domain (it raises IndexError)
+#define FLAG_AMBIGUOUS_EDGES 2    // two out-edges of one node lead to the same ROAD_INDEX: SELECTED_ROAD has no unique rank
+#define FLAG_PACK_RANGE 4         // pack: a count above 255 / an agent id at or above 2^24
+
 struct FusedBufs {
-  float4* rec0;         // [N][B] {head_id, head_dep, n, tail_id}
-  float2* rec1;         // [N][B] {head_arr, pending-garbage n0 (or -1 when nothing is pending)}
-  float2* postA;        // [N][B] {n', tail'}   state after the Direction update, gathered by the upstream rows
-  float* postB;         // [N][B] chosen: the agent the Direction update enqueues (0: nobody); read by the row itself only
+  uint2* hdp;           // [N][B]
+  uint32_t* tl;         // [N][B]
+  uint2* rec1;          // [N][B]
+  uint32_t* post;       // [N][B]
   const float4* st0;    // [N]    {maxn, ff, road_index, cong}
   float* slots;         // [N][B][lds] slot-interleaved FIFO store: slot s at floats 3s..3s+2 = {id, arrival, departure}
   int64_t lds;          // row stride of slots in floats (>= 3*Nmax, multiple of 16)
-  float* sel;           // [N][B] SELECTED_ROAD
+  uint8_t* sel8;        // [N][B] SELECTED_ROAD code
+  float* sel;           // [N][B] SELECTED_ROAD as fp32 (authoritative where sel8 == SEL_RAW; refreshed by export)
+  const uint8_t* in_rank;  // [E] CSC order: the sel8 rank of the upstream node that means "heads for this road"
   long long* acc_lp;    // [S][B] log-prob of this frame's action, 2^-32 fixed point (order-independent => deterministic)
   float* acc_n;         // [S][B] sum of the per-node counts after the row pass (small integers: exact in any order)
+  float* acc_w;         // [S][B] agents withdrawn (arrived at their destination) in this frame
                         // S = acc_slots banks spread the atomics of the N/chunk workgroups that serve one environment
   int32_t* a_origin;    // [B][A]
   int32_t* a_dest;      // [B][A]
@@ -34,24 +64,49 @@ struct FusedBufs {
   const int32_t* a_order;  // [B][A] agent ids sorted by departure time (static), or NULL: scan all agents every frame
   int32_t* cur_lo;      // [B] first position of a_order that may still hold a waiting agent
   const float* a_dep_sorted;  // [B][A] departure times in a_order's order (sequential scan instead of a gather)
-  int64_t acc_slots;    // accumulator banks: acc_lp / acc_n are [acc_slots][B]; a workgroup adds into bank (chunk % slots)
+  int64_t acc_slots;    // accumulator banks: acc_* are [acc_slots][B]; a workgroup adds into bank (chunk % slots)
+  int32_t* flags;       // [1] device status word
+};
+
+// per-frame side outputs (all optional)
+struct FrameOut {
+  uint8_t* counts8;     // [N][B] NUMBER_OF_AGENT after the frame (rollout buffers)
+  float* countsf;       // [N][B] the same as fp32 (frame API)
+  uint8_t* popped;      // [B][N] Response pop mask      (frame API, env-major like the unfused entry points)
+  uint8_t* withdrawn;   // [B][N] withdraw mask
+  uint8_t* events;      // [N][m_env] metric environments: bit 0 popped, bit 1 withdrawn
+  float* dtt_node;      // [N][m_env] metric environments: delta_travel_time of the node's out-edges
+  int32_t m_env;        // environments 0 .. m_env-1 keep the per-node series
+  int32_t* leg;         // [B][2] {agents departed (inserted), agents arrived (withdrawn)} in this frame
 };
 
 #define LP_FIX 4294967296.0  // 2^32
 
-// rec1.y packs two small integers exactly in fp32: code = (g + 1) * 1024 + hoff, where g = count at the pending
-// (unmaterialised) garbage write or -1 when nothing is pending, and hoff = physical slot of logical slot 0 (ring buffer).
-__device__ __forceinline__ float r1_code(float g, int hoff) { return (g + 1.0f) * 1024.0f + (float)hoff; }
-__device__ __forceinline__ int r1_hoff(float code) { return ((int)code) & 1023; }
-__device__ __forceinline__ float r1_g(float code) { return (float)(((int)code) >> 10) - 1.0f; }
+__device__ __forceinline__ uint32_t r1_code(int g, int hoff) { return ((uint32_t)(g + 1) << 16) | (uint32_t)hoff; }
+__device__ __forceinline__ int r1_hoff(uint32_t code) { return (int)(code & 0xffffu); }
+__device__ __forceinline__ int r1_g(uint32_t code) { return (int)(code >> 16) - 1; }
+// pending garbage count of a row from its dense words (+ rec1 when it is authoritative)
+__device__ __forceinline__ int pending_g(uint32_t tlw, int n, uint32_t code, int Nmax) {
+  return (tlw & TLF_AUTH) ? r1_g(code) : (n < Nmax - 1 ? n : -1);
+}
 // physical slot of logical slot s
 __device__ __forceinline__ int phys(int hoff, int s, int Nmax) {
   int p = hoff + s;
   return p >= Nmax ? p - Nmax : p;
 }
-
+// SELECTED_ROAD value of a sel8 code (node i)
+__device__ __forceinline__ float sel_value(const FusedBufs& fb, const int32_t* __restrict__ out_ptr,
+                                           const int32_t* __restrict__ out_dst, int64_t i, int64_t row) {
+  const uint32_t c = fb.sel8[row] & 0x7Fu;
+  return c == SEL_RAW ? fb.sel[row] : (float)out_dst[out_ptr[i] + (int32_t)c];
+}
+// travel time assigned to an agent entering a row that holds n agents (src/direction_mpnn.py:176-187)
+__device__ __forceinline__ float entry_tt(const float4 st, float n) {
+  const float t_cong = st.w / (st.x + 10.0f - n);
+  return (t_cong != t_cong) ? t_cong : fmaxf(st.y, t_cong);
+}
 
 // fused.hip
 FusedBufs tarl_to_bufs(const tarl_fused* f);
 int tarl_check_fused_core(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax);
-hipEvent_t tarl_prof_mark(hipStream_t s, int tag);  // sim.hip: live timing of the message-passing kernels (tag 0/1/2)
+hipEvent_t tarl_prof_mark(hipStream_t s, int tag);  // sim.hip: live timing of the frame kernels (tags 0..3)

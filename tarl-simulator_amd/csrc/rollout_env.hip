@@ -25,6 +25,13 @@
 #define RE_LAST 0x80000000u
 #define RE_NPT_MAX 4        // roads per thread: N <= 4 * block size (the LDS budget allows < 3 * 1024 roads anyway)
 
+// Inside the workgroup the records keep an unpacked fp32 form (r0 = {head_id, head_dep, n, tail_id}, r1 = {head_arr,
+// code}); code packs the pending-garbage count g (or -1) and the ring-buffer head offset as an exact fp32 integer. They
+// are converted from / to the packed HBM words of fused_common.h when the rollout starts / ends.
+__device__ __forceinline__ float l1_code(float g, int hoff) { return (g + 1.0f) * 1024.0f + (float)hoff; }
+__device__ __forceinline__ int l1_hoff(float code) { return ((int)code) & 1023; }
+__device__ __forceinline__ float l1_g(float code) { return (float)(((int)code) >> 10) - 1.0f; }
+
 struct EnvPlanPtrs {
   const int32_t* in_ptr;
   const int32_t* in_src;
@@ -51,8 +58,8 @@ struct __align__(16) OutEdge {
 // what the choice needs of the edge it picked
 struct __align__(16) OutPick {
   long long lg;     // log-prob in 2^-32 fixed point
-  int32_t eid;      // original edge id (the action)
-  int32_t pad;
+  int32_t eid;      // original edge id
+  int32_t rank;     // rank in the source node's CSR list (the action byte)
 };
 
 __global__ __launch_bounds__(256) void k_pack_static(EnvPlanPtrs P, int64_t N, const float* __restrict__ edge_attr,
@@ -71,16 +78,20 @@ __global__ __launch_bounds__(256) void k_pack_static(EnvPlanPtrs P, int64_t N, c
   const int32_t gi = P.group_of_node[i];
   for (int32_t k = P.out_ptr[i]; k < b1; ++k) {
     oe[k] = OutEdge{(int32_t)i, (uint32_t)P.out_dst[k] | (k == b1 - 1 ? RE_LAST : 0u), thr[k], gi};
-    op[k] = OutPick{lgt[k], P.out_eid[k], 0};
+    op[k] = OutPick{lgt[k], P.out_eid[k], k - P.out_ptr[i]};
   }
 }
 
 struct EnvOut {
-  int32_t* choice;   // [T][B][N] or NULL
+  uint8_t* choice;   // [T][B][N] or NULL: rank of the chosen out-edge (bit 7: nothing drawn)
   float* log_prob;   // [T][B] or NULL
   float* entropy;    // [T][B] or NULL
   float* reward;     // [T][B] or NULL
-  float* counts;     // [T][B][N] or NULL
+  uint8_t* counts;   // [T][B][N] or NULL
+  int32_t m_env;     // environments 0 .. m_env-1 keep the per-node series
+  float* dtt_node;   // [T][m_env][N] or NULL
+  uint8_t* events;   // [T][m_env][N] or NULL: bit 0 popped, bit 1 withdrawn
+  int32_t* leg;      // [T][B][2] or NULL: {departed, arrived}
 };
 
 struct EnvPlan {
@@ -131,7 +142,8 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
                                                             const float* __restrict__ log_edge_attr, float log_eps,
                                                             int use_cong, uint64_t pseed, uint64_t pcounter0,
                                                             uint64_t seed, uint64_t counter0, int64_t T,
-                                                            const float* __restrict__ times, float* __restrict__ ag,
+                                                            const float* __restrict__ times, float prev_time,
+                                                            float* __restrict__ ag,
                                                             int64_t A, int64_t a_bstride,
                                                             int32_t* __restrict__ scratch, EnvOut out) {
   extern __shared__ float4 re_lds[];
@@ -151,7 +163,7 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
   __shared__ float s_red_f[RE_MAX_WAVES];
   __shared__ long long s_red_ll[RE_MAX_WAVES];
   __shared__ int32_t s_wave[RE_MAX_WAVES];
-  __shared__ int32_t s_cnt, s_lo, s_bad, s_cur;
+  __shared__ int32_t s_cnt, s_lo, s_bad, s_cur, s_dep, s_arr;
 
   const int64_t b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -162,13 +174,26 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
   int32_t* cand_agent = scratch + b * 2 * A;
   int32_t* cand_road = cand_agent + A;
 
+  uint32_t prevcode[RE_NPT_MAX];   // SELECTED_ROAD code of each own road in the previous frame (carried when nothing is drawn)
+#pragma unroll
+  for (int z = 0; z < RE_NPT_MAX; ++z) prevcode[z] = SEL_RAW;
   for (int32_t i = i0; i < i1; ++i) {
     const int64_t row = (int64_t)i * B + b;
-    r0[i] = fb.rec0[row];
-    r1[i] = fb.rec1[row];
-    pA[i] = fb.postA[row];
-    who_l[i] = fb.postB[row];
-    sel_l[i] = fb.sel[row];
+    const uint2 hp = fb.hdp[row];
+    const uint32_t tlw = fb.tl[row];
+    const uint2 q1 = fb.rec1[row];
+    const uint32_t pw = fb.post[row];
+    const int n = (int)(hp.x & 255u);
+    r0[i] = make_float4((float)(hp.x >> 8), __uint_as_float(hp.y), (float)n, (float)(tlw >> 8));
+    // an idle empty row's head arrival is the previous frame's clock; its pending garbage count is its count
+    const float arr = (n == 0 && !(tlw & TLF_AUTH)) ? prev_time : __uint_as_float(q1.x);
+    r1[i] = make_float2(arr, l1_code((float)pending_g(tlw, n, q1.y, Nmax), r1_hoff(q1.y)));
+    const bool arrived = (pw & PF_ARRIVED) != 0u;
+    pA[i] = make_float2(arrived ? (float)(n + 1) : (float)n, (float)(pw >> 8));
+    who_l[i] = arrived ? (float)(pw >> 8) : 0.0f;
+    sel_l[i] = sel_value(fb, P.out_ptr, P.out_dst, i, row);
+#pragma unroll
+    for (int z = 0; z < RE_NPT_MAX; ++z) prevcode[z] = (z == i - i0) ? (uint32_t)(fb.sel8[row] & 0x7Fu) : prevcode[z];
     const float4 st = fb.st0[i];
     maxn_l[i] = st.x;
     ff_l[i] = st.y;
@@ -233,7 +258,9 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
         const int32_t i = i0 + z;
         if (i < i1) {
           if (pick[z] >= 0) lp += pk[z].lg;
-          if (out.choice) __builtin_nontemporal_store(pick[z] >= 0 ? pk[z].eid : -1, &out.choice[(f * B + b) * N + i]);
+          const uint32_t code = pick[z] >= 0 ? (uint32_t)pk[z].rank : (prevcode[z] | SEL_CARRIED);
+          prevcode[z] = code & 0x7Fu;
+          if (out.choice) __builtin_nontemporal_store((uint8_t)code, &out.choice[(f * B + b) * N + i]);
         }
       }
     }
@@ -241,6 +268,8 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
       s_cnt = 0;
       s_lo = 0x7fffffff;
       s_bad = 0;
+      s_dep = 0;
+      s_arr = 0;
     }
     __syncthreads();
     if (bad) atomicOr(&s_bad, 1);
@@ -255,6 +284,10 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
         const float4 me = r0[i];
         pA[i] = make_float2(me.z, me.w);
         who_l[i] = 0.0f;
+        if (out.dtt_node && b < out.m_env) {   // delta_travel_time of this road's out-edges (src/direction_mpnn.py:94-96)
+          const float d = (me.y - r1[i].x) - ff_l[i];
+          out.dtt_node[(f * out.m_env + b) * N + i] = d > 0.0f ? d : (d != d ? d : 0.0f);
+        }
       }
       float Psum = 0.0f;
       for (int32_t k4 = ka0; k4 < ka1; k4 += 4) {
@@ -356,12 +389,13 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
       const float4 st = make_float4(maxn_l[i], ff_l[i], road_l[i], cong_l[i]);
       const float n0 = q0.z;
       const bool pop = ((popbits >> (i - i0)) & 1ull) != 0ull;
-      int hoff = r1_hoff(q1.y);
+      int hoff = l1_hoff(q1.y);
       const int q = (int)n0;
       const float t_cong = st.w / (st.x + 10.0f - n0);
       const float tt = (t_cong != t_cong) ? t_cong : fmaxf(st.y, t_cong);
       const float dep_new = t + tt;
       const bool lazy = (who == 0.0f) && (q >= 0) && (q < Nmax - 1);
+      if ((int)pa.x >= Nmax) atomicOr(fb.flags, FLAG_COUNT_AT_NMAX);
       if (!lazy && q >= 0 && q < Nmax) {
         float* w = sl + 3 * phys(hoff, q, Nmax);
         w[0] = who;
@@ -446,7 +480,10 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
         tail_id = (qn >= 1 && qn <= Nmax) ? sl[3 * phys(hoff, qn - 1, Nmax)] : 0.0f;
       }
       r0[i] = make_float4(head_id, head_dep, n, tail_id);
-      r1[i] = make_float2(head_arr, r1_code(lazy ? n0 : -1.0f, hoff));
+      r1[i] = make_float2(head_arr, l1_code(lazy ? n0 : -1.0f, hoff));
+      if (out.events && b < out.m_env)
+        out.events[(f * out.m_env + b) * N + i] = (uint8_t)((pop ? 1 : 0) | (c > 0 ? 2 : 0));
+      if (c > 0) atomicAdd(&s_arr, c);
     }
     __threadfence_block();   // the slot-store writes above are read by this workgroup's insert / later frames
     __syncthreads();
@@ -568,7 +605,7 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
           const float tt = (t_cong != t_cong) ? t_cong : fmaxf(str.y, t_cong);
           const float code = r1[r].y;   // nobody writes r1.y before the barrier below
           if (slot >= 0 && slot < Nmax) {
-            float* sr = fb.slots + rrow * fb.lds + 3 * phys(r1_hoff(code), (int)slot, Nmax);
+            float* sr = fb.slots + rrow * fb.lds + 3 * phys(l1_hoff(code), (int)slot, Nmax);
             sr[0] = (float)a;
             sr[1] = t;
             sr[2] = t + tt;
@@ -591,8 +628,9 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
         const int32_t cmt = cand_agent[idx];
         if (cmt > 0) {
           const int32_t r = cand_road[idx];
-          r1[r].y = r1_code(-1.0f, r1_hoff(r1[r].y));
+          r1[r].y = l1_code(-1.0f, l1_hoff(r1[r].y));
           r0[r].z = r0[r].z + (float)cmt;
+          atomicAdd(&s_dep, cmt);
         }
       }
       __threadfence_block();
@@ -603,7 +641,7 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
     float nsum = 0.0f;
     for (int32_t i = i0; i < i1; ++i) {
       const float n = r0[i].z;
-      if (out.counts) __builtin_nontemporal_store(n, &out.counts[(f * B + b) * N + i]);
+      if (out.counts) __builtin_nontemporal_store((uint8_t)n, &out.counts[(f * B + b) * N + i]);
       nsum += n;
     }
     const float ntot = re_block_sum_f<RE_WAVES>(nsum, s_red_f);          // sums of small integers: exact in fp32 in any order
@@ -612,17 +650,31 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
       if (out.reward) out.reward[f * B + b] = -ntot;
       if (out.log_prob) out.log_prob[f * B + b] = (s_bad & 1) ? -INFINITY : (float)((double)lptot / LP_FIX);
       if (out.entropy) out.entropy[f * B + b] = entropy1[0];
+      if (out.leg) {
+        out.leg[(f * B + b) * 2 + 0] = s_dep;
+        out.leg[(f * B + b) * 2 + 1] = s_arr;
+      }
     }
     __syncthreads();
   }
 
   for (int32_t i = i0; i < i1; ++i) {
     const int64_t row = (int64_t)i * B + b;
-    fb.rec0[row] = r0[i];
-    fb.rec1[row] = r1[i];
-    fb.postA[row] = pA[i];
-    fb.postB[row] = who_l[i];
-    fb.sel[row] = sel_l[i];
+    const float4 q0 = r0[i];
+    const float2 q1 = r1[i];
+    fb.hdp[row] = make_uint2(((uint32_t)q0.x << 8) | (uint32_t)q0.z, __float_as_uint(q0.y));
+    fb.tl[row] = ((uint32_t)q0.w << 8) | TLF_AUTH;
+    fb.rec1[row] = make_uint2(__float_as_uint(q1.x), r1_code((int)l1_g(q1.y), l1_hoff(q1.y)));
+    const float who = who_l[i];
+    fb.post[row] = ((uint32_t)pA[i].y << 8) | (pA[i].x > 0.0f ? PF_NONEMPTY : 0u) | (who != 0.0f ? PF_ARRIVED : 0u);
+    // SELECTED_ROAD back as a rank of this road's out-list (the raw value where it names none of them, as pack does)
+    const float sv = sel_l[i];
+    uint32_t code = SEL_RAW;
+    const int32_t k0 = P.out_ptr[i], k1 = P.out_ptr[i + 1];
+    for (int32_t k = k1 - 1; k >= k0; --k)
+      if ((float)P.out_dst[k] == sv && k - k0 < (int32_t)SEL_RAW) code = (uint32_t)(k - k0);
+    fb.sel8[row] = (uint8_t)code;
+    fb.sel[row] = sv;
   }
   if (tid == 0 && fb.cur_lo) fb.cur_lo[b] = s_cur;
 }
@@ -640,12 +692,14 @@ extern "C" int64_t tarl_rollout_env_scratch_bytes(const tarl_plan* plan) {
 }
 
 extern "C" int tarl_rollout_env(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, int64_t T,
-                                const float* times_dev, const float* thresholds, const int64_t* log_probs,
-                                const float* entropy1, uint64_t policy_seed, uint64_t policy_counter0,
-                                float* agent_features, int64_t A, int64_t a_bstride, const float* edge_attr,
-                                const float* log_edge_attr, float log_eps, int use_cong, uint64_t seed,
-                                uint64_t counter0, int32_t* ins_scratch, void* static_scratch, int32_t* choice,
-                                float* log_prob, float* entropy, float* reward, float* counts, tarl_stream stream) {
+                                const float* times_dev, float prev_time, const float* thresholds,
+                                const int64_t* log_probs, const float* entropy1, uint64_t policy_seed,
+                                uint64_t policy_counter0, float* agent_features, int64_t A, int64_t a_bstride,
+                                const float* edge_attr, const float* log_edge_attr, float log_eps, int use_cong,
+                                uint64_t seed, uint64_t counter0, int32_t* ins_scratch, void* static_scratch,
+                                uint8_t* choice, float* log_prob, float* entropy, float* reward, uint8_t* counts,
+                                int32_t metrics_envs, float* dtt_node, uint8_t* events, int32_t* leg,
+                                tarl_stream stream) {
   int rc = tarl_check_fused_core(plan, f, B, Nmax);
   if (rc) return rc;
   TARL_REQUIRE(T >= 1 && times_dev, "bad frame count / times");
@@ -660,6 +714,8 @@ extern "C" int tarl_rollout_env(const tarl_plan* plan, const tarl_fused* f, int6
   TARL_REQUIRE(plan->N <= (plan->N <= 512 ? 256 : 1024) * RE_NPT_MAX, "too many roads per thread");
   TARL_REQUIRE(tarl_rollout_env_supported(plan), "graph too large for the LDS-resident rollout (tarl_rollout_env_supported)");
   TARL_REQUIRE(B < 65536ll * 32768ll, "too many environments for one launch");
+  TARL_REQUIRE(metrics_envs >= 0 && metrics_envs <= B, "metrics_envs out of range");
+  TARL_REQUIRE(metrics_envs > 0 || (!dtt_node && !events), "per-node series need metrics_envs > 0");
   if (plan->N == 0) return TARL_OK;
   const size_t lds = re_lds_bytes(plan->N);
   const int64_t Ecap = plan->E > 0 ? plan->E : 1;
@@ -673,23 +729,27 @@ extern "C" int tarl_rollout_env(const tarl_plan* plan, const tarl_fused* f, int6
   TARL_LAUNCH_CHECK();
   const EnvPlan P{plan->in_ptr, plan->in_src, plan->in_eid, plan->out_ptr, plan->out_dst, plan->out_eid,
                   plan->group_of_node, plan->N, plan->E, plan->G, ie, oe, op};
-  const EnvOut out{choice, log_prob, entropy, reward, counts};
+  const EnvOut out{choice, log_prob, entropy, reward, counts, metrics_envs, dtt_node, events, leg};
   if (plan->N <= 512) {
     hipLaunchKernelGGL(k_rollout_env<256>, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, P, B, (int)Nmax,
                        tarl_to_bufs(f), thresholds, (const long long*)log_probs, entropy1, edge_attr, log_edge_attr, log_eps, use_cong,
-                       policy_seed, policy_counter0, seed, counter0, T, times_dev, agent_features, A, a_bstride,
-                       ins_scratch, out);
+                       policy_seed, policy_counter0, seed, counter0, T, times_dev, prev_time, agent_features, A,
+                       a_bstride, ins_scratch, out);
   } else {
-    static size_t lds_set = 0;
-    if (lds > 64 * 1024 && lds > lds_set) {
+    // the opt-in to > 64 KB of dynamic LDS is a per-device attribute of the function
+    static size_t lds_set[64] = {0};
+    int devid = 0;
+    TARL_CHECK_HIP(hipGetDevice(&devid));
+    size_t* set = &lds_set[devid & 63];
+    if (lds > 64 * 1024 && lds > *set) {
       TARL_CHECK_HIP(hipFuncSetAttribute((const void*)k_rollout_env<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds));
-      lds_set = lds;
+      *set = lds;
     }
     hipLaunchKernelGGL(k_rollout_env<1024>, dim3((unsigned)B), dim3(1024), lds, (hipStream_t)stream, P, B, (int)Nmax,
                        tarl_to_bufs(f), thresholds, (const long long*)log_probs, entropy1, edge_attr, log_edge_attr, log_eps, use_cong,
-                       policy_seed, policy_counter0, seed, counter0, T, times_dev, agent_features, A, a_bstride,
-                       ins_scratch, out);
+                       policy_seed, policy_counter0, seed, counter0, T, times_dev, prev_time, agent_features, A,
+                       a_bstride, ins_scratch, out);
   }
   TARL_LAUNCH_CHECK();
   return TARL_OK;

@@ -76,6 +76,7 @@ class SimEngine:
         if self.fs is not None:
             ops.fused_pack(self.plan, self.fs, self.x, self.Nmax, self.agents, self.cc)
             self._packed_stale = False
+            self.fs.check_flags()
 
     # -- observation -------------------------------------------------------------------------------------------------
     @property
@@ -128,17 +129,28 @@ class SimEngine:
         """Evaluate the live policy's distribution tables; call once per parameter update."""
         self.tables = ops.fused_policy_prepare(self.plan, self.fs, emb, temperature, getattr(self, "tables", None))
 
+    def check_flags(self):
+        """Raise :class:`TarlError` if a kernel flagged a domain exit since the last pack (one host synchronisation)."""
+        if self.fs is not None:
+            self.fs.check_flags()
+
     def frame_fused(self, *, choice=None, log_prob=None, entropy=None, reward=None, counts=None, uniform=None,
-                    gumbel=None, dtt=None, popped=None, withdrawn=None):
-        """One collector frame (sample + log_prob + choice phase + env step) for all B environments in 3 launches.
-        ``choice`` (N, B) int32 and ``counts`` (N, B) are env-minor. Returns done (bool)."""
+                    gumbel=None, dtt=None, popped=None, withdrawn=None, action=None):
+        """One collector frame (sample + log_prob + choice phase + env step) for all B environments in 4 launches.
+        ``choice`` (N, B) int32 and ``counts`` (N, B) fp32 are env-minor. ``action``: an externally sampled action (B, N)
+        int32 edge ids (-1: none) instead of the live policy's own sample (state-dependent policies). Returns done."""
         if self._packed_stale:
             self.resync()
         self.sample_counter += 1
         self.noise_counter += 1
         self._x_stale = True
+        prev = self._last_step_time
         self._last_step_time = float(self.time)
-        ops.fused_frame(self.plan, self.fs, self.tables, self.agents, self.ec, float(self.time),
+        tables = self.tables
+        if action is not None:
+            ops.fused_apply_choice(self.plan, self.fs, action)
+            tables = None
+        ops.fused_frame(self.plan, self.fs, tables, self.agents, self.ec, float(self.time), prev_time=prev,
                         use_cong=self.cc is not None, uniform=uniform, policy_seed=self.seed ^ 0x5DEECE66D,
                         policy_counter=self.sample_counter, gumbel=gumbel, seed=self.seed, counter=self.noise_counter,
                         dtt=dtt, popped=popped, withdrawn=withdrawn, scratch=self.ins_scratch, choice=choice,
@@ -152,59 +164,60 @@ class SimEngine:
         """True when one environment's hot records fit a CU's LDS (tarl_rollout_env)."""
         return self.fs is not None and ops.rollout_env_supported(self.plan)
 
-    def rollout_env(self, T, *, choice, log_prob, reward, counts):
-        """Same frames as :meth:`rollout_fused` through ``tarl_rollout_env`` (one workgroup per environment, LDS-resident
-        records, a single launch); the buffers are ENV-MAJOR: ``choice`` (T,B,N) int32, ``counts`` (T+1,B,N) fp32 with
-        counts[t + 1] = the counts after frame t; ``log_prob`` (T,B) or None; ``reward`` (T,B)."""
+    def _rollout(self, fn, env_minor, T, choice, log_prob, reward, counts, metrics_envs, dtt_node, events, leg, check):
         if self._packed_stale:
             self.resync()
-        if tuple(counts.shape) != (T + 1, self.B, self.N) or not counts.is_contiguous():
-            raise ValueError(f"counts must be a contiguous (T + 1, B, N) = {(T + 1, self.B, self.N)} tensor")
+        shp = (T + 1, self.N, self.B) if env_minor else (T + 1, self.B, self.N)
+        if counts.dtype != torch.uint8 or tuple(counts.shape) != shp or not counts.is_contiguous():
+            raise ValueError(f"counts must be a contiguous uint8 {shp} tensor")
         times = []
         t_clock = self.time
         for _ in range(T):
             times.append(float(t_clock))
             t_clock += self.timestep
         self._x_stale = True
-        self._times_dev = ops.rollout_env(self.plan, self.fs, self.tables, self.agents, self.ec, times,
-                                          use_cong=self.cc is not None, policy_seed=self.seed ^ 0x5DEECE66D,
-                                          policy_counter0=self.sample_counter + 1, seed=self.seed,
-                                          counter0=self.noise_counter + 1, scratch=self.ins_scratch, choice=choice,
-                                          log_prob=log_prob, reward=reward, counts=counts[1:])
+        self._times_dev = fn(self.plan, self.fs, self.tables, self.agents, self.ec, times, use_cong=self.cc is not None,
+                             prev_time=self._last_step_time, policy_seed=self.seed ^ 0x5DEECE66D,
+                             policy_counter0=self.sample_counter + 1, seed=self.seed, counter0=self.noise_counter + 1,
+                             scratch=self.ins_scratch, choice=choice, log_prob=log_prob, reward=reward,
+                             counts=counts[1:], metrics_envs=metrics_envs, dtt_node=dtt_node, events=events, leg=leg)
         self.sample_counter += T
         self.noise_counter += T
         self._last_step_time = times[-1]
         self.time = t_clock
         times.append(float(self.time))
+        if check:
+            self.check_flags()
         return times
 
-    def rollout_fused(self, T, *, choice, log_prob, reward, counts):
-        """``T`` consecutive frames with the outputs of frame t written to ``choice[t]`` (T,N,B) int32, ``log_prob[t]``
-        (T,B) or None, ``reward[t]`` (T,B), ``counts[t + 1]`` (T+1,N,B). Same as T calls of :meth:`frame_fused` with the
-        per-frame Python overhead removed (arguments marshalled once). Returns the list of clock values."""
-        if self._packed_stale:
-            self.resync()
-        for n, t_, dt, shp in (("choice", choice, torch.int32, (T, self.N, self.B)),
-                               ("reward", reward, torch.float32, (T, self.B)),
-                               ("counts", counts, torch.float32, (T + 1, self.N, self.B))):
-            if t_.dtype != dt or tuple(t_.shape) != shp or not t_.is_contiguous() or not t_.is_cuda:
-                raise ValueError(f"{n} must be a contiguous cuda {dt} tensor of shape {shp}")
-        if log_prob is not None and (log_prob.dtype != torch.float32 or tuple(log_prob.shape) != (T, self.B)
-                                     or not log_prob.is_contiguous()):
-            raise ValueError("log_prob must be a contiguous float32 (T, B) tensor")
-        times = []
-        t_clock = self.time
-        for _ in range(T):
-            times.append(float(t_clock))
-            t_clock += self.timestep
-        self._x_stale = True
-        ops.fused_rollout(self.plan, self.fs, self.tables, self.agents, self.ec, times, use_cong=self.cc is not None,
-                          policy_seed=self.seed ^ 0x5DEECE66D, policy_counter0=self.sample_counter + 1, seed=self.seed,
-                          counter0=self.noise_counter + 1, scratch=self.ins_scratch, choice=choice, log_prob=log_prob,
-                          reward=reward, counts=counts[1:])
-        self.sample_counter += T
-        self.noise_counter += T
-        self._last_step_time = times[-1]
-        self.time = t_clock
-        times.append(float(self.time))
-        return times
+    def decode_rollout(self, env_minor, *, choice=None, counts=None):
+        """The rollout's byte buffers in the formats of the unfused entry points, ENV-MAJOR: ``choice`` (T,N,B) / (T,B,N)
+        uint8 -> (T,B,N) int32 edge ids (-1: none); ``counts`` (T',N,B) / (T',B,N) uint8 -> (T',B,N) fp32."""
+        out = []
+        for buf, key in ((choice, "choice"), (counts, "counts")):
+            if buf is None:
+                out.append(None)
+                continue
+            Tn = buf.size(0)
+            r = ops.rollout_gather(self.plan, Tn, self.B, env_minor, **{key: buf})[0 if key == "choice" else 1]
+            out.append(r.view(Tn, self.B, self.N))
+        return out
+
+    def rollout_env(self, T, *, choice, log_prob, reward, counts, metrics_envs=0, dtt_node=None, events=None, leg=None,
+                    check=True):
+        """Same frames as :meth:`rollout_fused` through ``tarl_rollout_env`` (one workgroup per environment, LDS-resident
+        records, a single launch); the buffers are ENV-MAJOR: ``choice`` (T,B,N) uint8, ``counts`` (T+1,B,N) uint8 with
+        counts[t + 1] = the counts after frame t; ``log_prob`` (T,B) or None; ``reward`` (T,B)."""
+        return self._rollout(ops.rollout_env, False, T, choice, log_prob, reward, counts, metrics_envs, dtt_node, events,
+                             leg, check)
+
+    def rollout_fused(self, T, *, choice, log_prob, reward, counts, metrics_envs=0, dtt_node=None, events=None, leg=None,
+                      check=True):
+        """``T`` consecutive frames with the outputs of frame t written to ``choice[t]`` (T,N,B) uint8 (rank of the chosen
+        out-edge; ``ops.rollout_gather`` turns it into edge ids), ``log_prob[t]`` (T,B) or None, ``reward[t]`` (T,B),
+        ``counts[t + 1]`` (T+1,N,B) uint8; optional per-step logs: ``leg`` (T,B,2) int32 {departed, arrived}, and for the
+        first ``metrics_envs`` environments ``dtt_node`` (T,N,m) fp32 / ``events`` (T,N,m) uint8. Same as T calls of
+        :meth:`frame_fused` with the per-frame Python overhead removed. ``check``: read the device status word afterwards
+        (one synchronisation) and raise on a domain exit. Returns the list of clock values."""
+        return self._rollout(ops.fused_rollout, True, T, choice, log_prob, reward, counts, metrics_envs, dtt_node, events,
+                             leg, check)

@@ -51,18 +51,22 @@ SIGNATURES = {
     "tarl_ppo_loss": (C.c_int, [_p] * 6 + [_i64, _f32, _f32, _f32, _f32, _p, _p, _p, _p, _p]),
     "tarl_adam_step": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _f64, _f64, _f64, _f64, _f32, _p]),
     "tarl_critic_mlp_fwd_slabs": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64] + [_p] * 6 + [_p, _p]),
+    "tarl_critic_mlp_fwd_u8": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64] + [_p] * 6 + [_p, _p, _p, _p]),
+    "tarl_critic_mlp_fwd_slabs_u8": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64] + [_p] * 6 + [_p, _p]),
     "tarl_fused_pack": (C.c_int, [_p, _p] + _STATE + [_p, _p, _i64, _i64, _p]),
     "tarl_fused_reset": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _i64, _p]),
     "tarl_fused_export": (C.c_int, [_p, _p] + _STATE + [_f32, _p]),
     "tarl_fused_policy_prepare": (C.c_int, [_p, _p, _p, _i64, _f32, _p, _p, _p, _p, _p]),
     "tarl_fused_frame": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _p, _u64, _u64, _p, _i64, _i64, _p, _p, _f32, C.c_int,
-                                   _f32, _p, _u64, _u64] + [_p] * 10),
-    "tarl_fused_rollout": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _u64, _u64, _p, _i64, _i64, _p, _p, _f32,
-                                     C.c_int, _u64, _u64] + [_p] * 9),
+                                   _f32, _f32, _p, _u64, _u64] + [_p] * 10),
+    "tarl_fused_apply_choice": (C.c_int, [_p, _p, _i64, _p, _p]),
+    "tarl_fused_rollout": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _f32, _p, _p, _p, _u64, _u64, _p, _i64, _i64, _p, _p,
+                                     _f32, C.c_int, _u64, _u64] + [_p] * 8 + [_i32, _p, _p, _p, _p]),
+    "tarl_rollout_gather": (C.c_int, [_p, _p, _p, _i64, _i64, C.c_int, _p, _i64, _p, _p, _p]),
     "tarl_rollout_env_supported": (C.c_int, [_p]),
     "tarl_rollout_env_scratch_bytes": (_i64, [_p]),
-    "tarl_rollout_env": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _p, _p, _p, _u64, _u64, _p, _i64, _i64, _p, _p, _f32,
-                                   C.c_int, _u64, _u64] + [_p] * 8),
+    "tarl_rollout_env": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _f32, _p, _p, _p, _u64, _u64, _p, _i64, _i64, _p, _p,
+                                   _f32, C.c_int, _u64, _u64] + [_p] * 7 + [_i32, _p, _p, _p, _p]),
     "tarl_edge_travel_time": (C.c_int, [_p] + _STATE + [_p, _p, _p]),
     "tarl_apsp_scratch_bytes": (_i64, [_p, _i64]),
     "tarl_apsp": (C.c_int, [_p, _p, _i64, _i64, _p, _i64, _p, _p, _p]),
@@ -77,11 +81,14 @@ SIGNATURES = {
 
 class FusedStruct(C.Structure):
     """``tarl_fused`` of include/tarl_hip.h."""
-    _fields_ = ([(n, C.c_void_p) for n in ("rec0", "rec1", "post_a", "post_b", "st0", "slots")] +
+    _fields_ = ([(n, C.c_void_p) for n in ("hdp", "tl", "rec1", "post", "st0", "slots")] +
                 [("ld_slots", C.c_int64)] +
-                [(n, C.c_void_p) for n in ("sel", "acc_lp", "acc_n", "a_origin", "a_dest", "a_dep", "a_status", "a_order",
-                                           "cur_lo", "a_dep_sorted")] +
-                [("acc_slots", C.c_int64)])
+                [(n, C.c_void_p) for n in ("sel8", "sel", "in_rank", "acc_lp", "acc_n", "acc_w", "a_origin", "a_dest",
+                                           "a_dep", "a_status", "a_order", "cur_lo", "a_dep_sorted")] +
+                [("acc_slots", C.c_int64), ("flags", C.c_void_p)])
+
+
+FLAG_COUNT_AT_NMAX, FLAG_AMBIGUOUS_EDGES, FLAG_PACK_RANGE = 1, 2, 4
 
 
 _lib = None

@@ -16,7 +16,7 @@ from . import lib as _lib
 EPS_GUMBEL = 1e-12   # src/direction_mpnn.py:136
 # revision of the fused path's packed HBM layout / kernel set: a PMC traffic record (profiles/*_pmc_traffic.json) only
 # applies to the revision it was measured on
-FUSED_LAYOUT = "v5"
+FUSED_LAYOUT = "v6"
 
 
 def _check_dev(t: torch.Tensor, dtype, name: str):
@@ -392,7 +392,8 @@ class CriticWeights:
 def critic_forward(cw: CriticWeights, counts, time_rows, rows_per_time=1, *, keep_hidden=False):
     """counts (M, N) fp32 with contiguous last dim (row stride free); time_rows (ceil(M / rows_per_time),)."""
     L = _lib.load()
-    _check_dev(counts, torch.float32, "counts")
+    u8 = counts.dtype == torch.uint8           # the rollout buffers' count bytes (widened inside the kernel)
+    _check_dev(counts, torch.uint8 if u8 else torch.float32, "counts")
     if counts.dim() != 2 or counts.stride(1) != 1 or counts.size(1) != cw.N:
         raise ValueError(f"counts must be (M, {cw.N}) with a contiguous last dim")
     _contig(time_rows, torch.float32, "time_rows")
@@ -402,10 +403,11 @@ def critic_forward(cw: CriticWeights, counts, time_rows, rows_per_time=1, *, kee
     value = torch.empty(M, dtype=torch.float32, device=counts.device)
     h1 = torch.empty((M, 64), dtype=torch.float32, device=counts.device) if keep_hidden else None
     h2 = torch.empty((M, 64), dtype=torch.float32, device=counts.device) if keep_hidden else None
-    _lib.check(L.tarl_critic_mlp_fwd(counts.data_ptr(), counts.stride(0), M, cw.N, time_rows.data_ptr(), rows_per_time,
-                                     cw.w1.data_ptr(), cw.b1.data_ptr(), cw.w2.data_ptr(), cw.b2.data_ptr(),
-                                     cw.w3.data_ptr(), cw.b3.data_ptr(), value.data_ptr(), _lib.ptr(h1), _lib.ptr(h2),
-                                     _lib.current_stream()))
+    fn = L.tarl_critic_mlp_fwd_u8 if u8 else L.tarl_critic_mlp_fwd
+    _lib.check(fn(counts.data_ptr(), counts.stride(0), M, cw.N, time_rows.data_ptr(), rows_per_time,
+                  cw.w1.data_ptr(), cw.b1.data_ptr(), cw.w2.data_ptr(), cw.b2.data_ptr(),
+                  cw.w3.data_ptr(), cw.b3.data_ptr(), value.data_ptr(), _lib.ptr(h1), _lib.ptr(h2),
+                  _lib.current_stream()))
     return value, h1, h2
 
 
@@ -481,40 +483,66 @@ def adam_step_(param, grad, exp_avg, exp_avg_sq, step, *, lr=1e-3, beta1=0.9, be
 
 # ---- fused rollout frame ----------------------------------------------------------------------------------------------
 class FusedState:
-    """Side buffers of the fused path (``tarl_fused`` in include/tarl_hip.h), ENV-MINOR ([node][env]): packed hot /
-    post / static node records, the slot-interleaved FIFO store and the agent SoA. They hold the state between
-    :func:`fused_pack` and :func:`fused_export`."""
+    """Side buffers of the fused path (``tarl_fused`` in include/tarl_hip.h), ENV-MINOR ([node][env]): the packed dense
+    words (hdp, tl, post, sel8), the event-only word rec1, static node records, the slot-interleaved FIFO store and the
+    agent SoA. They hold the state between :func:`fused_pack` and :func:`fused_export`."""
 
     def __init__(self, plan: Plan, B: int, A: int, device, Nmax: int = 15):
         L = _lib.load()
-        N = plan.num_nodes
+        N, E = plan.num_nodes, plan.num_edges
+        if Nmax > 255 or plan.max_out > 126:
+            raise _lib.TarlError(f"the fused path needs Nmax <= 255 and out-degree <= 126 (got Nmax={Nmax}, max out-degree="
+                                 f"{plan.max_out}); construct SimEngine(..., fused=False) for this graph")
         f32 = dict(dtype=torch.float32, device=device)
+        i32 = dict(dtype=torch.int32, device=device)
         self.ld_slots = ((3 * Nmax + 15) // 16) * 16
         self.slots = torch.zeros((N, B, self.ld_slots), **f32)
-        self.rec0 = torch.zeros((N, B, 4), **f32)
-        self.rec1 = torch.zeros((N, B, 2), **f32)
-        self.post_a = torch.zeros((N, B, 2), **f32)
-        self.post_b = torch.zeros((N, B), **f32)
+        self.hdp = torch.zeros((N, B, 2), **i32)
+        self.tl = torch.zeros((N, B), **i32)
+        self.rec1 = torch.zeros((N, B, 2), **i32)
+        self.post = torch.zeros((N, B), **i32)
         self.st0 = torch.zeros((N, 4), **f32)
+        self.sel8 = torch.zeros((N, B), dtype=torch.uint8, device=device)
         self.sel = torch.zeros((N, B), **f32)
+        self.in_rank = torch.zeros(max(E, 1), dtype=torch.uint8, device=device)
         self.acc_slots = 32      # accumulator banks (spread the per-environment atomics of the N/chunk workgroups)
         self.acc_lp = torch.zeros((self.acc_slots, B), dtype=torch.int64, device=device)
         self.acc_n = torch.zeros((self.acc_slots, B), **f32)
-        self.a_origin = torch.zeros((B, A), dtype=torch.int32, device=device)
-        self.a_dest = torch.zeros((B, A), dtype=torch.int32, device=device)
+        self.acc_w = torch.zeros((self.acc_slots, B), **f32)
+        self.a_origin = torch.zeros((B, A), **i32)
+        self.a_dest = torch.zeros((B, A), **i32)
         self.a_dep = torch.zeros((B, A), **f32)
         self.a_status = torch.zeros((B, A), dtype=torch.uint8, device=device)
-        self.a_order = torch.zeros((B, A), dtype=torch.int32, device=device)
+        self.a_order = torch.zeros((B, A), **i32)
         self.a_dep_sorted = torch.zeros((B, A), **f32)
-        self.cur_lo = torch.zeros(B, dtype=torch.int32, device=device)
+        self.cur_lo = torch.zeros(B, **i32)
+        self.flags = torch.zeros(1, **i32)
         self.order_valid = False
-        self.struct = _lib.FusedStruct(self.rec0.data_ptr(), self.rec1.data_ptr(), self.post_a.data_ptr(),
-                                       self.post_b.data_ptr(), self.st0.data_ptr(), self.slots.data_ptr(),
-                                       self.ld_slots, self.sel.data_ptr(), self.acc_lp.data_ptr(),
-                                       self.acc_n.data_ptr(), self.a_origin.data_ptr(), self.a_dest.data_ptr(),
-                                       self.a_dep.data_ptr(), self.a_status.data_ptr(), None,
-                                       self.cur_lo.data_ptr(), None, self.acc_slots)
+        self.struct = _lib.FusedStruct(self.hdp.data_ptr(), self.tl.data_ptr(), self.rec1.data_ptr(),
+                                       self.post.data_ptr(), self.st0.data_ptr(), self.slots.data_ptr(), self.ld_slots,
+                                       self.sel8.data_ptr(), self.sel.data_ptr(), self.in_rank.data_ptr(),
+                                       self.acc_lp.data_ptr(), self.acc_n.data_ptr(), self.acc_w.data_ptr(),
+                                       self.a_origin.data_ptr(), self.a_dest.data_ptr(), self.a_dep.data_ptr(),
+                                       self.a_status.data_ptr(), None, self.cur_lo.data_ptr(), None, self.acc_slots,
+                                       self.flags.data_ptr())
         self.B, self.N, self.A, self.Nmax = B, N, A, Nmax
+
+    # -- unpacked views of the dense words (tests / debugging; torch plumbing, never on a hot path) ----------------------
+    @property
+    def count(self):
+        return (self.hdp[..., 0] & 255).to(torch.float32)
+
+    @property
+    def head_id(self):
+        return ((self.hdp[..., 0] >> 8) & 0xFFFFFF).to(torch.float32)
+
+    @property
+    def head_dep(self):
+        return self.hdp[..., 1].contiguous().view(torch.float32)
+
+    @property
+    def tail_id(self):
+        return ((self.tl >> 8) & 0xFFFFFF).to(torch.float32)
 
     def sort_agents(self, agent_features):
         """Departure-time order of every environment's population (static while DEPARTURE_TIME is not edited): lets the
@@ -526,6 +554,18 @@ class FusedState:
         self.struct.a_order = self.a_order.data_ptr()
         self.struct.a_dep_sorted = self.a_dep_sorted.data_ptr()
         self.order_valid = True
+
+    def check_flags(self):
+        """Read the device status word (one host synchronisation) and raise on a domain exit."""
+        v = int(self.flags.item())
+        if v & _lib.FLAG_COUNT_AT_NMAX:
+            raise _lib.TarlError("a FIFO count reached Nmax: the state left the reference's defined domain (its "
+                                 "DirectionMPNN.update raises IndexError there, src/direction_mpnn.py:172-191)")
+        if v & _lib.FLAG_AMBIGUOUS_EDGES:
+            raise _lib.TarlError("two out-edges of one node lead to the same ROAD_INDEX: SELECTED_ROAD has no unique rank "
+                                 "on this graph; construct SimEngine(..., fused=False)")
+        if v & _lib.FLAG_PACK_RANGE:
+            raise _lib.TarlError("pack: a FIFO count above 255 or an agent id at / above 2^24 does not fit the packed words")
 
     @property
     def ref(self):
@@ -582,13 +622,24 @@ def fused_policy_prepare(plan: Plan, fs: FusedState, emb, temperature=1.0, table
     return tables
 
 
-def fused_frame(plan: Plan, fs: FusedState, tables: PolicyTables, agent_features, ec: EdgeConst, t, *, use_cong=True,
-                uniform=None, policy_seed=0, policy_counter=0, gumbel=None, seed=0, counter=0, dtt=None, popped=None,
-                withdrawn=None, scratch=None, choice=None, log_prob=None, entropy=None, reward=None, counts=None):
-    """One collector frame for all B environments (3 launches): sample + log_prob + choice phase, core step, withdraw,
-    insert, reward. ``choice`` (N, B) int32 and ``counts`` (N, B) fp32 are ENV-MINOR; ``dtt`` (B, E), ``popped`` /
-    ``withdrawn`` (B, N) uint8, ``log_prob`` / ``entropy`` / ``reward`` (B,). Outputs are written into the tensors
-    passed in (e.g. slices of the rollout buffers)."""
+def fused_apply_choice(plan: Plan, fs: FusedState, choice):
+    """SELECTED_ROAD of the packed state <- an externally sampled action: ``choice`` (B, N) int32 edge ids (-1: none)."""
+    L = _lib.load()
+    _contig(choice, torch.int32, "choice")
+    if tuple(choice.shape) != (fs.B, fs.N):
+        raise ValueError("choice must be (B, N)")
+    _lib.check(L.tarl_fused_apply_choice(plan.handle, fs.ref, fs.B, choice.data_ptr(), _lib.current_stream()))
+
+
+def fused_frame(plan: Plan, fs: FusedState, tables: PolicyTables | None, agent_features, ec: EdgeConst, t, *,
+                use_cong=True, prev_time=None, uniform=None, policy_seed=0, policy_counter=0, gumbel=None, seed=0,
+                counter=0, dtt=None, popped=None, withdrawn=None, scratch=None, choice=None, log_prob=None, entropy=None,
+                reward=None, counts=None):
+    """One collector frame for all B environments: sample + log_prob + choice phase, core step, withdraw, insert, reward.
+    ``tables=None`` skips the choice phase (the action was written by :func:`fused_apply_choice`).
+    ``choice`` (N, B) int32 and ``counts`` (N, B) fp32 are ENV-MINOR; ``dtt`` (B, E), ``popped`` / ``withdrawn`` (B, N)
+    uint8, ``log_prob`` / ``entropy`` / ``reward`` (B,). Outputs are written into the tensors passed in.
+    ``prev_time``: the previous frame's clock (default ``t - 1``; only ``dtt`` reads it)."""
     L = _lib.load()
     B, Nmax = fs.B, fs.Nmax
     A, abs_ = _agents(agent_features, B)
@@ -601,42 +652,79 @@ def fused_frame(plan: Plan, fs: FusedState, tables: PolicyTables, agent_features
                       ("entropy", entropy, torch.float32)):
         if tt is not None:
             _contig(tt, dt, n)
-    _lib.check(L.tarl_fused_frame(plan.handle, fs.ref, B, Nmax, tables.thresholds.data_ptr(),
-                                  tables.log_probs.data_ptr(), tables.entropy.data_ptr(), _lib.ptr(uniform),
+    th, lg, en = ((tables.thresholds.data_ptr(), tables.log_probs.data_ptr(), tables.entropy.data_ptr())
+                  if tables is not None else (None, None, None))
+    _lib.check(L.tarl_fused_frame(plan.handle, fs.ref, B, Nmax, th, lg, en, _lib.ptr(uniform),
                                   int(policy_seed), int(policy_counter), agent_features.data_ptr(), A, abs_,
                                   ec.edge_attr.data_ptr(), ec.log_edge_attr.data_ptr(), ec.log_eps,
-                                  1 if use_cong else 0, float(t), _lib.ptr(gumbel), int(seed), int(counter),
+                                  1 if use_cong else 0, float(t), float(t - 1 if prev_time is None else prev_time),
+                                  _lib.ptr(gumbel), int(seed), int(counter),
                                   _lib.ptr(dtt), _lib.ptr(popped), _lib.ptr(withdrawn), scratch.data_ptr(),
                                   _lib.ptr(choice), _lib.ptr(log_prob), _lib.ptr(entropy), _lib.ptr(reward),
                                   _lib.ptr(counts), _lib.current_stream()))
 
 
+def _check_rollout_outputs(T, B, N, env_minor, m_env, choice, counts, log_prob, entropy, reward, dtt_node, events, leg):
+    nb = (lambda t_, k: (t_, N, k)) if env_minor else (lambda t_, k: (t_, k, N))
+    for name, tns, dt, shp in (("choice", choice, torch.uint8, nb(T, B)), ("counts", counts, torch.uint8, nb(T, B)),
+                               ("log_prob", log_prob, torch.float32, (T, B)), ("entropy", entropy, torch.float32, (T, B)),
+                               ("reward", reward, torch.float32, (T, B)),
+                               ("dtt_node", dtt_node, torch.float32, nb(T, m_env)),
+                               ("events", events, torch.uint8, nb(T, m_env)), ("leg", leg, torch.int32, (T, B, 2))):
+        if tns is not None and (tns.dtype != dt or tuple(tns.shape) != shp or not tns.is_contiguous() or not tns.is_cuda):
+            raise ValueError(f"{name} must be a contiguous cuda {dt} tensor of shape {shp}")
+
+
 def fused_rollout(plan: Plan, fs: FusedState, tables: PolicyTables, agent_features, ec: EdgeConst, times, *, use_cong,
-                  policy_seed, policy_counter0, seed, counter0, scratch, choice=None, log_prob=None, entropy=None,
-                  reward=None, counts=None):
-    """``T = len(times)`` frames in one foreign call (tarl_fused_rollout). ``choice`` (T,N,B) int32, ``counts`` (T,N,B)
-    fp32 (counts[t] = per-node counts after frame t), ``log_prob`` / ``entropy`` / ``reward`` (T,B) fp32 — all optional,
-    contiguous device tensors. Frame t uses policy counter ``policy_counter0 + t`` and noise counter ``counter0 + t``."""
+                  policy_seed, policy_counter0, seed, counter0, scratch, prev_time=None, choice=None, log_prob=None,
+                  entropy=None, reward=None, counts=None, metrics_envs=0, dtt_node=None, events=None, leg=None):
+    """``T = len(times)`` frames in one foreign call (tarl_fused_rollout). ``choice`` (T,N,B) uint8 (rank of the chosen
+    out-edge, bit 7: none), ``counts`` (T,N,B) uint8 (counts[t] = per-node counts after frame t), ``log_prob`` / ``entropy``
+    / ``reward`` (T,B) fp32, ``leg`` (T,B,2) int32, ``dtt_node`` (T,N,metrics_envs) fp32, ``events`` (T,N,metrics_envs)
+    uint8 — all optional, contiguous device tensors. Frame t uses policy counter ``policy_counter0 + t`` and noise counter
+    ``counter0 + t``."""
     L = _lib.load()
     T, B, N = len(times), fs.B, fs.N
     A, abs_ = _agents(agent_features, B)
     _contig(scratch, torch.int32, "scratch")
-    for name, tns, dt, shp in (("choice", choice, torch.int32, (T, N, B)), ("counts", counts, torch.float32, (T, N, B)),
-                               ("log_prob", log_prob, torch.float32, (T, B)), ("entropy", entropy, torch.float32, (T, B)),
-                               ("reward", reward, torch.float32, (T, B))):
-        if tns is not None and (tns.dtype != dt or tuple(tns.shape) != shp or not tns.is_contiguous() or not tns.is_cuda):
-            raise ValueError(f"{name} must be a contiguous cuda {dt} tensor of shape {shp}")
-    if getattr(fs, "sel_scratch", None) is None:     # double buffers of the merged insert + choice launch
-        fs.sel_scratch = torch.empty_like(fs.sel)
+    _check_rollout_outputs(T, B, N, True, metrics_envs, choice, counts, log_prob, entropy, reward, dtt_node, events, leg)
+    if getattr(fs, "acc_scratch", None) is None:     # double buffers of the merged insert + choice launch
         fs.acc_scratch = torch.zeros_like(fs.acc_lp)
+    if choice is None and getattr(fs, "sel_scratch", None) is None:
+        fs.sel_scratch = torch.empty_like(fs.sel8)
     tarr = (C.c_float * T)(*[float(t) for t in times])
-    _lib.check(L.tarl_fused_rollout(plan.handle, fs.ref, B, fs.Nmax, T, tarr, tables.thresholds.data_ptr(),
+    _lib.check(L.tarl_fused_rollout(plan.handle, fs.ref, B, fs.Nmax, T, tarr,
+                                    float(times[0] - 1 if prev_time is None else prev_time), tables.thresholds.data_ptr(),
                                     tables.log_probs.data_ptr(), tables.entropy.data_ptr(), int(policy_seed),
                                     int(policy_counter0), agent_features.data_ptr(), A, abs_, ec.edge_attr.data_ptr(),
                                     ec.log_edge_attr.data_ptr(), ec.log_eps, 1 if use_cong else 0, int(seed),
-                                    int(counter0), scratch.data_ptr(), fs.sel_scratch.data_ptr(),
+                                    int(counter0), scratch.data_ptr(),
+                                    _lib.ptr(getattr(fs, "sel_scratch", None)) if choice is None else None,
                                     fs.acc_scratch.data_ptr(), _lib.ptr(choice), _lib.ptr(log_prob), _lib.ptr(entropy),
-                                    _lib.ptr(reward), _lib.ptr(counts), _lib.current_stream()))
+                                    _lib.ptr(reward), _lib.ptr(counts), int(metrics_envs), _lib.ptr(dtt_node),
+                                    _lib.ptr(events), _lib.ptr(leg), _lib.current_stream()))
+
+
+def rollout_gather(plan: Plan, T, B, env_minor, idx=None, *, choice=None, counts=None):
+    """Rollout bytes -> (choice_eid int32 (rows, N) | None, counts_f fp32 (rows, N) | None) for the (frame, env) pairs
+    ``idx`` (int64 flat indices t * B + b; None = all ``T * B`` in order). ``choice`` / ``counts``: the uint8 buffers
+    ((T,N,B) when ``env_minor`` else (T,B,N)); ``T`` is the buffers' leading extent."""
+    L = _lib.load()
+    N = plan.num_nodes
+    some = choice if choice is not None else counts
+    rows = T * B if idx is None else idx.numel()
+    for nm, t_ in (("choice", choice), ("counts", counts)):
+        if t_ is not None:
+            _contig(t_, torch.uint8, nm)
+            if t_.numel() != T * B * N:
+                raise ValueError(f"{nm} must hold T*B*N bytes")
+    if idx is not None:
+        _contig(idx, torch.int64, "idx")
+    ce = torch.empty((rows, N), dtype=torch.int32, device=some.device) if choice is not None else None
+    cf = torch.empty((rows, N), dtype=torch.float32, device=some.device) if counts is not None else None
+    _lib.check(L.tarl_rollout_gather(plan.handle, _lib.ptr(choice), _lib.ptr(counts), T, B, 1 if env_minor else 0,
+                                     _lib.ptr(idx), rows, _lib.ptr(ce), _lib.ptr(cf), _lib.current_stream()))
+    return ce, cf
 
 
 # ---- MPNNValueNet (dormant message-passing critic) ---------------------------------------------------------------------------
@@ -689,44 +777,45 @@ def rollout_env_supported(plan: Plan) -> bool:
 
 
 def rollout_env(plan: Plan, fs: FusedState, tables: PolicyTables, agent_features, ec: EdgeConst, times, *, use_cong,
-                policy_seed, policy_counter0, seed, counter0, scratch, choice=None, log_prob=None, entropy=None,
-                reward=None, counts=None):
+                policy_seed, policy_counter0, seed, counter0, scratch, prev_time=None, choice=None, log_prob=None,
+                entropy=None, reward=None, counts=None, metrics_envs=0, dtt_node=None, events=None, leg=None):
     """Same contract as :func:`fused_rollout` through ``tarl_rollout_env`` (one workgroup per environment, LDS-resident
-    records, one launch for all frames); ``choice`` / ``counts`` are ENV-MAJOR (T, B, N)."""
+    records, one launch for all frames); the per-node buffers are ENV-MAJOR: ``choice`` / ``counts`` (T, B, N),
+    ``dtt_node`` / ``events`` (T, metrics_envs, N)."""
     L = _lib.load()
     T, B, N = len(times), fs.B, fs.N
     A, abs_ = _agents(agent_features, B)
     _contig(scratch, torch.int32, "scratch")
-    for name, tns, dt, shp in (("choice", choice, torch.int32, (T, B, N)), ("counts", counts, torch.float32, (T, B, N)),
-                               ("log_prob", log_prob, torch.float32, (T, B)), ("entropy", entropy, torch.float32, (T, B)),
-                               ("reward", reward, torch.float32, (T, B))):
-        if tns is not None and (tns.dtype != dt or tuple(tns.shape) != shp or not tns.is_contiguous() or not tns.is_cuda):
-            raise ValueError(f"{name} must be a contiguous cuda {dt} tensor of shape {shp}")
+    _check_rollout_outputs(T, B, N, False, metrics_envs, choice, counts, log_prob, entropy, reward, dtt_node, events, leg)
     tdev = torch.tensor([float(t) for t in times], dtype=torch.float32).to(fs.sel.device, non_blocking=True)
     if getattr(fs, "env_scratch", None) is None:
         fs.env_scratch = torch.empty(int(L.tarl_rollout_env_scratch_bytes(plan.handle)), dtype=torch.uint8,
                                      device=fs.sel.device)
-    _lib.check(L.tarl_rollout_env(plan.handle, fs.ref, B, fs.Nmax, T, tdev.data_ptr(), tables.thresholds.data_ptr(),
+    _lib.check(L.tarl_rollout_env(plan.handle, fs.ref, B, fs.Nmax, T, tdev.data_ptr(),
+                                  float(times[0] - 1 if prev_time is None else prev_time), tables.thresholds.data_ptr(),
                                   tables.log_probs.data_ptr(), tables.entropy.data_ptr(), int(policy_seed),
                                   int(policy_counter0), agent_features.data_ptr(), A, abs_, ec.edge_attr.data_ptr(),
                                   ec.log_edge_attr.data_ptr(), ec.log_eps, 1 if use_cong else 0, int(seed),
                                   int(counter0), scratch.data_ptr(), fs.env_scratch.data_ptr(), _lib.ptr(choice),
                                   _lib.ptr(log_prob), _lib.ptr(entropy), _lib.ptr(reward), _lib.ptr(counts),
+                                  int(metrics_envs), _lib.ptr(dtt_node), _lib.ptr(events), _lib.ptr(leg),
                                   _lib.current_stream()))
     return tdev
 
 
 def critic_forward_slabs(cw: CriticWeights, counts, time_rows):
-    """counts (S, N, R) fp32 contiguous = [frame][node][env] with R % 128 == 0 -> value (S*R,) in (frame, env) order;
-    ``time_rows`` (S,) is each frame's clock."""
+    """counts (S, N, R) fp32 or uint8 contiguous = [frame][node][env] with R % 128 == 0 -> value (S*R,) in (frame, env)
+    order; ``time_rows`` (S,) is each frame's clock."""
     L = _lib.load()
-    _contig(counts, torch.float32, "counts")
+    u8 = counts.dtype == torch.uint8
+    _contig(counts, torch.uint8 if u8 else torch.float32, "counts")
     _contig(time_rows, torch.float32, "time_rows")
     S, N, R = counts.shape
     if N != cw.N or R % 128 or time_rows.numel() < S:
         raise ValueError("counts must be (S, N, R) with R a multiple of 128 and one time per slab")
     value = torch.empty(S * R, dtype=torch.float32, device=counts.device)
-    _lib.check(L.tarl_critic_mlp_fwd_slabs(counts.data_ptr(), R, S * R, N, time_rows.data_ptr(), R, cw.w1.data_ptr(),
-                                           cw.b1.data_ptr(), cw.w2.data_ptr(), cw.b2.data_ptr(), cw.w3.data_ptr(),
-                                           cw.b3.data_ptr(), value.data_ptr(), _lib.current_stream()))
+    fn = L.tarl_critic_mlp_fwd_slabs_u8 if u8 else L.tarl_critic_mlp_fwd_slabs
+    _lib.check(fn(counts.data_ptr(), R, S * R, N, time_rows.data_ptr(), R, cw.w1.data_ptr(), cw.b1.data_ptr(),
+                  cw.w2.data_ptr(), cw.b2.data_ptr(), cw.w3.data_ptr(), cw.b3.data_ptr(), value.data_ptr(),
+                  _lib.current_stream()))
     return value

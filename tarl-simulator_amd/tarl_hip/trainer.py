@@ -22,7 +22,7 @@ from .flatparams import FlatParams
 class VecPPOTrainer:
     def __init__(self, engine, emb_param, critic_params, *, rollout_steps, num_epochs=1, sub_batch_size=32, lr=1e-3,
                  gamma=0.99, lmbda=0.95, clip_epsilon=0.2, entropy_coef=0.01, critic_coef=1.0, temperature=1.0,
-                 extra_params=(), seed=0, lazy_log_prob=False, rank_offset=True, rollout=None):
+                 extra_params=(), seed=0, lazy_log_prob=False, rank_offset=True, rollout=None, metrics_envs=1):
         """``emb_param``: nn.Parameter (num_nodes, 1) — MPNNPolicyNet.nodes_embedding.weight;
         ``critic_params``: [w1 (64,N+1), b1, w2 (64,64), b2, w3 (1,64), b3] — MPNNValueNetSimple.final_mlp.{0,2,4};
         ``extra_params``: further actor/critic parameters that never receive gradient on the live path (the dormant
@@ -65,8 +65,21 @@ class VecPPOTrainer:
         # rollout buffers, written directly by the kernels: ENV-MINOR ([frame][node][env]) for "frames"
         self.env_minor = mode == "frames"
         shp = (lambda t: (t, N, B)) if self.env_minor else (lambda t: (t, B, N))
-        self.counts = torch.zeros(shp(self.T + 1), dtype=torch.float32, device=dev)
-        self.choice = torch.zeros(shp(self.T), dtype=torch.int32, device=dev)
+        # fused rollouts write one BYTE per (frame, node, env): the count and the rank of the chosen out-edge
+        byte = mode in ("frames", "env")
+        self.counts = torch.zeros(shp(self.T + 1), dtype=torch.uint8 if byte else torch.float32, device=dev)
+        self.choice = torch.zeros(shp(self.T), dtype=torch.uint8 if byte else torch.int32, device=dev)
+        # per-step logs of SimulatorEnv._step, accumulated on the device by the rollout kernels: the leg histogram's
+        # (departed, arrived) per frame for every environment, delta_travel_time / pop + withdraw masks per node for the
+        # first ``metrics_envs`` environments (the reference logs them for its single environment)
+        self.metrics_envs = min(int(metrics_envs), B) if byte else 0
+        m = self.metrics_envs
+        self.leg = torch.zeros((self.T, B, 2), dtype=torch.int32, device=dev) if byte else None
+        self.dtt_node = torch.zeros(shp(self.T)[:1] + ((N, m) if self.env_minor else (m, N)), dtype=torch.float32,
+                                    device=dev) if m else None
+        self.events = torch.zeros_like(self.dtt_node, dtype=torch.uint8) if m else None
+        self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory() if byte else None
+        self._flag_event = None
         self.logp = torch.zeros((self.T, B), dtype=torch.float32, device=dev)
         self.reward = torch.zeros((self.T, B), dtype=torch.float32, device=dev)
         self.times = torch.zeros(self.T + 1, dtype=torch.float32, device=dev)
@@ -102,9 +115,16 @@ class VecPPOTrainer:
             # sample_log_prob is only ever read for the <= sub_batch_size frames of each minibatch: keep the behaviour
             # policy's parameters and evaluate it (exactly, with the unfused kernel) for those frames at update time
             self.emb_rollout = emb.clone()
+            self.poll_flags()
             run = eng.rollout_env if self.rollout == "env" else eng.rollout_fused
             host_times = run(self.T, choice=self.choice, log_prob=None if self.lazy_log_prob else self.logp,
-                             reward=self.reward, counts=self.counts)
+                             reward=self.reward, counts=self.counts, metrics_envs=self.metrics_envs,
+                             dtt_node=self.dtt_node, events=self.events, leg=self.leg, check=False)
+            # the device status word travels to pinned host memory behind the rollout; it is looked at when it has
+            # arrived (no stall of the launch pipeline) and by check_flags() at the caller's synchronisation points
+            self._flag_host.copy_(eng.fs.flags, non_blocking=True)
+            self._flag_event = torch.cuda.Event()
+            self._flag_event.record()
             self.times.copy_(torch.tensor(host_times, dtype=torch.float32))
             return self.T * eng.B
         for t in range(self.T):
@@ -125,6 +145,18 @@ class VecPPOTrainer:
         self.times.copy_(torch.tensor(host_times, dtype=torch.float32))
         return self.T * eng.B
 
+    def poll_flags(self):
+        """Raise if a finished rollout flagged a domain exit (non-blocking)."""
+        if self._flag_event is not None and self._flag_event.query():
+            self._flag_event = None
+            if int(self._flag_host[0]) != 0:
+                self.eng.check_flags()
+
+    def check_flags(self):
+        """Blocking form of :meth:`poll_flags` (call at a synchronisation point, e.g. the end of training)."""
+        self._flag_event = None
+        self.eng.check_flags()
+
     # -- HOT LOOP B -------------------------------------------------------------------------------------------------------
     def advantages(self):
         """GAE(gamma, lmbda, average_gae=True) with the current critic over all (T+1)*B observations."""
@@ -132,10 +164,12 @@ class VecPPOTrainer:
         T, B, N = self.T, eng.B, eng.N
         cw = self._critic()
         if self.env_minor and B % 128 == 0:
-            v = ops.critic_forward_slabs(cw, self.counts, self.times)           # reads [frame][node][env] as is
+            v = ops.critic_forward_slabs(cw, self.counts, self.times)           # reads [frame][node][env] bytes as is
+        elif self.env_minor:    # odd batch sizes: the count bytes as fp32 rows first
+            _, rows = ops.rollout_gather(eng.plan, T + 1, B, True, counts=self.counts)
+            v, _, _ = ops.critic_forward(cw, rows, self.times, rows_per_time=B)
         else:
-            rows = self.counts.permute(0, 2, 1).contiguous() if self.env_minor else self.counts
-            v, _, _ = ops.critic_forward(cw, rows.view((T + 1) * B, N), self.times, rows_per_time=B)
+            v, _, _ = ops.critic_forward(cw, self.counts.view((T + 1) * B, N), self.times, rows_per_time=B)
         self.values = v.view(T + 1, B)
         adv, target = ops.gae(self.reward, self.values[:T], self.values[1:], gamma=self.gamma, lmbda=self.lmbda)
         stats = ops.advantage_stats(adv)
@@ -153,13 +187,12 @@ class VecPPOTrainer:
         else:
             idx = idx.to(eng.device)
             M = idx.numel()
-        if self.env_minor:
-            t_idx, b_idx = torch.div(idx, B, rounding_mode="floor"), idx % B
-            counts_mb = self.counts[t_idx, :, b_idx].contiguous()               # (M, N) rows of the sampled frames
-            choice_mb = self.choice[t_idx, :, b_idx].contiguous()
-        else:
+        if self.rollout == "unfused":
             counts_mb = self.counts[:T].view(T * B, N).index_select(0, idx)
             choice_mb = self.choice.view(T * B, N).index_select(0, idx)
+        else:   # one launch: the sampled frames' action bytes -> edge ids, count bytes -> fp32 rows
+            choice_mb, counts_mb = ops.rollout_gather(eng.plan, T, B, self.env_minor, idx, choice=self.choice,
+                                                      counts=self.counts[:T])
         nf = eng.static_node_features[:1].expand(M, N, 7)
         if eng.fs is not None and self.lazy_log_prob:   # behaviour log-prob of the sampled frames, rollout-time parameters
             p_old = ops.graphdist_softmax(eng.plan, ops.policy_edge_logits(eng.plan, nf, self.emb_rollout),

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     # the ctypes table binds exactly the declared entry points
     assert sorted(lib.SIGNATURES) == names
     L = lib.load()
-    assert L.tarl_abi_version() == 1
+    assert L.tarl_abi_version() == 2
 
 
 def test_plan_create_rejects_bad_input_without_gpu_compute():
@@ -66,10 +66,12 @@ def test_entry_points_reject_bad_arguments_on_the_host():
     assert L.tarl_apsp_scratch_bytes(null, 1) == -1
     assert L.tarl_apsp(null, null, 1, 0, null, 0, null, null, null) == -1
     assert b"null" in L.tarl_last_error()
-    assert L.tarl_fused_rollout(null, null, 1, 15, 1, null, null, null, null, 0, 0, null, 1, 9, null, null, 0.0, 0, 0, 0,
-                                null, null, null, null, null, null, null, null, null) == -1
-    assert L.tarl_rollout_env(null, null, 1, 15, 1, null, null, null, null, 0, 0, null, 1, 9, null, null, 0.0, 0, 0, 0,
-                              null, null, null, null, null, null, null, null) == -1
+    assert L.tarl_fused_rollout(null, null, 1, 15, 1, null, 0.0, null, null, null, 0, 0, null, 1, 9, null, null, 0.0, 0, 0,
+                                0, null, null, null, null, null, null, null, null, 0, null, null, null, null) == -1
+    assert L.tarl_rollout_env(null, null, 1, 15, 1, null, 0.0, null, null, null, 0, 0, null, 1, 9, null, null, 0.0, 0, 0, 0,
+                              null, null, null, null, null, null, null, 0, null, null, null, null) == -1
+    assert L.tarl_rollout_gather(null, null, null, 1, 1, 1, null, 0, null, null, null) == -1
+    assert L.tarl_fused_apply_choice(null, null, 1, null, null) == -1
     assert L.tarl_value_mpnn_fwd(null, null, 1, null, null, 0, null, null, null, null, null, null) == -1
     assert L.tarl_select_next_hop(null, 1, 0, 52, 15, 4, null, 1, 9, null, 0, null) == -1
     ms_all, ms_late, n = (C.c_double * 3)(), (C.c_double * 3)(), (C.c_int64 * 2)()

@@ -73,18 +73,19 @@ def test_config5_rollout_launcher_equals_frame_loop():
     emb = torch.randn(N, generator=torch.Generator().manual_seed(4)).cuda()
     e1.prepare_policy(emb)
     e2.prepare_policy(emb)
-    ch = torch.zeros((T, N, B), dtype=torch.int32, device="cuda")
-    ct = torch.zeros((T + 1, N, B), device="cuda")
+    ch = torch.zeros((T, N, B), dtype=torch.uint8, device="cuda")
+    ct = torch.zeros((T + 1, N, B), dtype=torch.uint8, device="cuda")
     lp, rw = torch.zeros((T, B), device="cuda"), torch.zeros((T, B), device="cuda")
     e1.rollout_fused(T, choice=ch, log_prob=lp, reward=rw, counts=ct)
+    ch, ct = e1.decode_rollout(True, choice=ch, counts=ct)          # (T, B, N) edge ids / fp32 counts
     ch2 = torch.empty((N, B), dtype=torch.int32, device="cuda")
     lp2, rw2, c2 = torch.empty(B, device="cuda"), torch.empty(B, device="cuda"), torch.empty((N, B), device="cuda")
     for s in range(T):
         e2.frame_fused(choice=ch2, log_prob=lp2, reward=rw2, counts=c2)
-        assert torch.equal(ch[s], ch2) and torch.equal(lp[s], lp2) and torch.equal(rw[s], rw2), f"frame {s}"
-        assert torch.equal(ct[s + 1], c2), f"counts frame {s}"
+        assert torch.equal(ch[s], ch2.t()) and torch.equal(lp[s], lp2) and torch.equal(rw[s], rw2), f"frame {s}"
+        assert torch.equal(ct[s + 1], c2.t()), f"counts frame {s}"
     assert torch.equal(e1.x, e2.x) and torch.equal(e1.agents, e2.agents)
-    _check_invariants(net, e1, rw, ct.permute(0, 2, 1))
+    _check_invariants(net, e1, rw, ct)
 
 
 def test_too_many_node_chunks_is_refused():

@@ -25,15 +25,18 @@ def check_records(ops, plan, fs, x, Nmax, ag, cc):
     """The maintained hot records equal a fresh pack of the exported x / agents (tail only where the FIFO is non-empty)."""
     ref = ops.FusedState(plan, fs.B, fs.A, x.device, Nmax)
     ops.fused_pack(plan, ref, x, Nmax, ag, cc)
-    assert torch.equal(fs.rec0[..., :3], ref.rec0[..., :3]) and torch.equal(fs.sel, ref.sel)
-    nz = (ref.rec0[..., 2] > 0)
-    assert torch.equal(fs.rec0[..., 3][nz], ref.rec0[..., 3][nz]) and torch.equal(fs.rec1[..., 0], ref.rec1[..., 0])
+    assert torch.equal(fs.hdp, ref.hdp) and torch.equal(fs.sel, ref.sel)      # head id, count, head departure
+    assert torch.equal(fs.sel8 & 0x7F, ref.sel8 & 0x7F) and torch.equal(fs.in_rank, ref.in_rank)
+    nz = ref.count > 0
+    assert torch.equal(fs.tail_id[nz], ref.tail_id[nz])
+    assert torch.equal(fs.rec1[..., 0][nz], ref.rec1[..., 0][nz])              # head arrival (event-only word)
     assert torch.equal(fs.a_status, ref.a_status) and torch.equal(fs.st0, ref.st0)
     # insert cursor: nobody before it is still waiting
     pos = torch.arange(fs.A, device=x.device).unsqueeze(0)
     st_sorted = torch.gather(fs.a_status, 1, fs.a_order.long())
     assert not bool(((pos < fs.cur_lo.unsqueeze(1)) & (st_sorted == 0)).any())
-    assert int((fs.rec1[..., 1] >= 0).sum()) > 0   # some rows carry a pending (lazy) garbage slot
+    # some rows carry a pending (lazy, never stored) garbage slot: idle in the last frame, or an event row that received nobody
+    assert int((((fs.tl & 1) == 0) | ((fs.rec1[..., 1] >> 16) > 0)).sum()) > 0
 
 
 @pytest.mark.parametrize("W,H,het,B,A,frames,with_cc,Nmax", [(3, 3, True, 3, 1500, 60, True, None),
@@ -193,10 +196,11 @@ def test_rollout_launcher_equals_frame_loop(ops, monkeypatch, B, T, merge):
                            dev(pops.clone()), congestion_constant=net.congestion_constant, seed=9)
     e1, e2 = mk(), mk()
     emb = torch.randn(N, generator=torch.Generator().manual_seed(5)).cuda()
-    bufs = lambda: (torch.zeros((T, N, B), dtype=torch.int32, device="cuda"), torch.zeros((T, B), device="cuda"),
-                    torch.zeros((T, B), device="cuda"), torch.zeros((T + 1, N, B), device="cuda"))
-    ch1, lp1, rw1, ct1 = bufs()
-    ch2, lp2, rw2, ct2 = bufs()
+    # frame API: edge ids / fp32 counts; rollout API: one byte each (rank of the chosen out-edge, count)
+    ch1, lp1, rw1, ct1 = (torch.zeros((T, N, B), dtype=torch.int32, device="cuda"), torch.zeros((T, B), device="cuda"),
+                          torch.zeros((T, B), device="cuda"), torch.zeros((T + 1, N, B), device="cuda"))
+    ch2, lp2, rw2, ct2 = (torch.zeros((T, N, B), dtype=torch.uint8, device="cuda"), torch.zeros((T, B), device="cuda"),
+                          torch.zeros((T, B), device="cuda"), torch.zeros((T + 1, N, B), dtype=torch.uint8, device="cuda"))
     for e in (e1, e2):
         e.reset()
         e.prepare_policy(emb)
@@ -204,13 +208,17 @@ def test_rollout_launcher_equals_frame_loop(ops, monkeypatch, B, T, merge):
         e1.frame_fused(choice=ch1[t], log_prob=lp1[t], reward=rw1[t], counts=ct1[t + 1])
     times = e2.rollout_fused(T, choice=ch2, log_prob=lp2, reward=rw2, counts=ct2)
     assert len(times) == T + 1 and times[0] == 21540.0 and e1.time == e2.time
-    assert torch.equal(ch1, ch2) and torch.equal(lp1, lp2) and torch.equal(rw1, rw2) and torch.equal(ct1, ct2)
+    ch2d, ct2d = e2.decode_rollout(True, choice=ch2, counts=ct2)
+    assert torch.equal(ch1.permute(0, 2, 1), ch2d) and torch.equal(lp1, lp2) and torch.equal(rw1, rw2)
+    assert torch.equal(ct1.permute(0, 2, 1), ct2d)
     assert torch.equal(e1.x, e2.x) and torch.equal(e1.agents, e2.agents)
     # continue: the packed state (incl. the SELECTED_ROAD of the last frame) is where the frame loop left it
     for t in range(T):
         e1.frame_fused(choice=ch1[t], log_prob=lp1[t], reward=rw1[t], counts=ct1[t + 1])
     e2.rollout_fused(T, choice=ch2, log_prob=lp2, reward=rw2, counts=ct2)
-    assert torch.equal(ch1, ch2) and torch.equal(lp1, lp2) and torch.equal(rw1, rw2) and torch.equal(ct1[1:], ct2[1:])
+    ch2d, ct2d = e2.decode_rollout(True, choice=ch2, counts=ct2)
+    assert torch.equal(ch1.permute(0, 2, 1), ch2d) and torch.equal(lp1, lp2) and torch.equal(rw1, rw2)
+    assert torch.equal(ct1[1:].permute(0, 2, 1), ct2d[1:])
     assert torch.equal(e1.x, e2.x) and torch.equal(e1.agents, e2.agents) and e1.time == e2.time
     assert float(rw1.abs().sum()) > 0 or T < 5
 
@@ -234,9 +242,9 @@ def test_env_rollout_equals_frame_loop(ops, W, H, B, T, A):
     ch1, lp1, rw1 = (torch.zeros((T, N, B), dtype=torch.int32, device="cuda"), torch.zeros((T, B), device="cuda"),
                      torch.zeros((T, B), device="cuda"))
     ct1 = torch.zeros((T + 1, N, B), device="cuda")
-    ch2, lp2, rw2 = (torch.zeros((T, B, N), dtype=torch.int32, device="cuda"), torch.zeros((T, B), device="cuda"),
+    ch2, lp2, rw2 = (torch.zeros((T, B, N), dtype=torch.uint8, device="cuda"), torch.zeros((T, B), device="cuda"),
                      torch.zeros((T, B), device="cuda"))
-    ct2 = torch.zeros((T + 1, B, N), device="cuda")
+    ct2 = torch.zeros((T + 1, B, N), dtype=torch.uint8, device="cuda")
     for e in (e1, e2):
         e.reset()
         e.prepare_policy(emb)
@@ -245,9 +253,10 @@ def test_env_rollout_equals_frame_loop(ops, W, H, B, T, A):
             e1.frame_fused(choice=ch1[t], log_prob=lp1[t], reward=rw1[t], counts=ct1[t + 1])
         times = e2.rollout_env(T, choice=ch2, log_prob=lp2, reward=rw2, counts=ct2)
         assert len(times) == T + 1 and e1.time == e2.time
-        assert torch.equal(ch1.permute(0, 2, 1), ch2), f"actions (rollout {rep})"
+        ch2d, ct2d = e2.decode_rollout(False, choice=ch2, counts=ct2)
+        assert torch.equal(ch1.permute(0, 2, 1), ch2d), f"actions (rollout {rep})"
         assert torch.equal(lp1, lp2) and torch.equal(rw1, rw2), f"log-prob / reward (rollout {rep})"
-        assert torch.equal(ct1[1:].permute(0, 2, 1), ct2[1:]), f"counts (rollout {rep})"
+        assert torch.equal(ct1[1:].permute(0, 2, 1), ct2d[1:]), f"counts (rollout {rep})"
         assert torch.equal(e1.x, e2.x) and torch.equal(e1.agents, e2.agents), f"state / agents (rollout {rep})"
     assert float(rw1.abs().sum()) > 0
     ca, cb = torch.zeros_like(ch1[0]), torch.zeros_like(ch1[0])
@@ -285,10 +294,11 @@ def test_fused_equals_unfused_on_a_matsim_graph_with_pseudo_nodes(ops, tmp_path)
     e3.prepare_policy(emb)
     ch2 = torch.empty((N, B), dtype=torch.int32, device="cuda")
     r2 = torch.empty(B, device="cuda")
-    ch3 = torch.zeros((T, B, N), dtype=torch.int32, device="cuda")
-    rw3, ct3 = torch.zeros((T, B), device="cuda"), torch.zeros((T + 1, B, N), device="cuda")
+    ch3 = torch.zeros((T, B, N), dtype=torch.uint8, device="cuda")
+    rw3, ct3 = torch.zeros((T, B), device="cuda"), torch.zeros((T + 1, B, N), dtype=torch.uint8, device="cuda")
     assert e3.env_rollout_supported
     e3.rollout_env(T, choice=ch3, log_prob=None, reward=rw3, counts=ct3)
+    ch3 = e3.decode_rollout(False, choice=ch3)[0]
     for s in range(T):
         logits = ops.policy_edge_logits(e1.plan, e1.node_features, emb)
         p = ops.graphdist_softmax(e1.plan, logits)

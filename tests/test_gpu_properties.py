@@ -28,18 +28,12 @@ def _engine(B, seeds, seed=11):
 
 def _rollout(eng, T, mode):
     N, B = eng.N, eng.B
-    if mode == "env":
-        ch = torch.zeros((T, B, N), dtype=torch.int32, device="cuda")
-        ct = torch.zeros((T + 1, B, N), device="cuda")
-        run = eng.rollout_env
-    else:
-        ch = torch.zeros((T, N, B), dtype=torch.int32, device="cuda")
-        ct = torch.zeros((T + 1, N, B), device="cuda")
-        run = eng.rollout_fused
+    shp = (lambda t: (t, B, N)) if mode == "env" else (lambda t: (t, N, B))
+    ch = torch.zeros(shp(T), dtype=torch.uint8, device="cuda")
+    ct = torch.zeros(shp(T + 1), dtype=torch.uint8, device="cuda")
     lp, rw = torch.zeros((T, B), device="cuda"), torch.zeros((T, B), device="cuda")
-    run(T, choice=ch, log_prob=lp, reward=rw, counts=ct)
-    if mode != "env":
-        ch, ct = ch.permute(0, 2, 1).contiguous(), ct.permute(0, 2, 1).contiguous()
+    (eng.rollout_env if mode == "env" else eng.rollout_fused)(T, choice=ch, log_prob=lp, reward=rw, counts=ct)
+    ch, ct = eng.decode_rollout(mode != "env", choice=ch, counts=ct)     # (T, B, N) edge ids / fp32 counts
     return ch, lp, rw, ct
 
 

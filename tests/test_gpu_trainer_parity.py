@@ -45,8 +45,10 @@ def test_ppo_update_matches_oracle_autograd(fused, lazy, rollout):
     # ---- snapshot everything the update reads (CPU copies, reference (frame, env, node) order) ----
     emb0 = pol.nodes_embedding.weight.detach().cpu().clone()
     crit0 = [p.detach().cpu().clone() for p in crit]
-    counts = tr.counts.permute(0, 2, 1).cpu() if tr.env_minor else tr.counts.cpu()          # (T+1, B, N)
-    choice = tr.choice.permute(0, 2, 1).cpu() if tr.env_minor else tr.choice.cpu()          # (T, B, N) edge ids
+    if fused:   # the rollout's byte buffers (count, rank of the chosen out-edge) in the reference's terms
+        choice, counts = (t_.cpu() for t_ in eng.decode_rollout(tr.env_minor, choice=tr.choice, counts=tr.counts))
+    else:
+        counts, choice = tr.counts.cpu(), tr.choice.cpu()                                    # (T+1, B, N), (T, B, N) edge ids
     reward, times = tr.reward.cpu(), tr.times.cpu()
     assert float(reward.abs().sum()) > 0
     idx = torch.randperm(T * B, generator=torch.Generator().manual_seed(4))[:M]
