@@ -53,12 +53,14 @@ PMC_RECORD = os.path.join("profiles", "r02_pmc_traffic.json")   # written by too
 # must read and write once, neighbour gathers served by the XCD's L2, statics / topology / policy tables through the
 # scalar cache (shared by all environments, not counted).
 COMPULSORY = {
-    # rec0 16 + SELECTED_ROAD 4 in; post records 8 + 4 out
-    "k_fused_direction": {"per_node_env": 20.0 + 12.0},
-    # post records 12 + rec0 16 + rec1 8 in; rec0 16 + rec1 8 + count 4 out (slot store / agent rows only on events)
-    "k_fused_rows": {"per_node_env": 36.0 + 28.0},
-    # choice(t+1): SELECTED_ROAD 4 + action 4 out; insert(t): departure window, a few records per admitted agent
-    "k_fused_insert_choice": {"per_node_env": 8.0},
+    # head words 8 + tail word 4 + SELECTED_ROAD byte 1 in; post word 4 out
+    "k_fused_direction": {"per_node_env": 13.0 + 4.0},
+    # post word 4 + head words 8 + tail word 4 in; head words 8 + tail word 4 + count byte 1 out (event word, slot store
+    # and agent rows only where something moves)
+    "k_fused_rows": {"per_node_env": 16.0 + 13.0},
+    # choice(t+1): the action byte (= SELECTED_ROAD of frame t+1) out; insert(t): departure window, a few words per
+    # admitted agent
+    "k_fused_insert_choice": {"per_node_env": 1.0},
 }
 # SURVEY §8d's per-unit figures for the reference's AoS layout (kept as ``survey_8d_*`` keys only): Direction message +
 # aggregate 52 B/edge + 4 B/node; row pass = Direction update 32 B/node + Response message/aggregate 24 B/edge.

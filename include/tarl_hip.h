@@ -235,7 +235,10 @@ int tarl_value_mpnn_bwd(const tarl_plan* plan, const float* node_features, int64
  *                           touched only by rows where something moves in a frame
  *   sel8 uint8  [N][B]    = SELECTED_ROAD as the rank of the chosen out-edge in the node's CSR list (bit 7: carried over
  *                           from the previous frame; 0x7F: the fp32 value in sel [N][B] is authoritative)
- *   in_rank uint8 [E]     = (built by pack, CSC order) the sel8 rank of the upstream node that heads for this road
+ *   static records built by pack and shared by all environments (read through the scalar cache): node_rec int32/fp32
+ *   [N][8] = {CSC start, in-degree, CSR start, out-degree, MAX_NUMBER_OF_AGENT, FREE_FLOW, ROAD_INDEX, congestion_constant};
+ *   in_rec [E + 4][4] (CSC order) = {upstream row, the sel8 rank of that row which heads for this road (0xFE: none),
+ *   edge_attr, MAX_NUMBER_OF_AGENT of the upstream row}; out_pad int32 [E + 4] (CSR order) = target row of each out-edge
  *   st0  [N][4]    = {MAX_NUMBER_OF_AGENT, FREE_FLOW_TIME_TRAVEL, ROAD_INDEX, congestion_constant} (static, shared)
  *   slots [N][B][ld_slots]: slot-interleaved FIFO store, slot s at floats 3s..3s+2 = {agent id, arrival, departure};
  *                  ld_slots >= 3*Nmax (pad to a multiple of 16 floats)
@@ -269,7 +272,9 @@ typedef struct tarl_fused {
   int64_t ld_slots;
   uint8_t* sel8;
   float* sel;
-  uint8_t* in_rank;
+  void* node_rec;
+  void* in_rec;
+  int32_t* out_pad;
   int64_t* acc_lp;
   float* acc_n;
   float* acc_w;
@@ -285,8 +290,8 @@ typedef struct tarl_fused {
 } tarl_fused;
 
 int tarl_fused_pack(const tarl_plan* plan, const tarl_fused* f, const float* x, int64_t B, int64_t x_bstride,
-                    int64_t ldx, int32_t Nmax, const float* congestion_constant, const float* agent_features,
-                    int64_t num_agents, int64_t a_bstride, tarl_stream stream);
+                    int64_t ldx, int32_t Nmax, const float* congestion_constant, const float* edge_attr,
+                    const float* agent_features, int64_t num_agents, int64_t a_bstride, tarl_stream stream);
 /* tarl_fused_reset == tarl_reset_state applied to the packed state (SimulatorEnv._reset): zero the FIFO store and the
  *   counters, keep SELECTED_ROAD, clear ON_WAY / DONE in agent_features (for the agents the status SoA marks as on the
  *   way / done, i.e. everything that changed since tarl_fused_pack) and the status SoA, re-arm the insert cursor. */

@@ -101,23 +101,32 @@ __global__ __launch_bounds__(FB) void k_pack_nodes(const float* __restrict__ x, 
   }
 }
 
-// in_rank[k] for in-edge k = (j -> i): the rank r of j's out-edges with (float)out_dst == ROAD_INDEX(i), i.e. the sel8
-// code of j that makes "SELECTED_ROAD(j) == ROAD_INDEX(i)" (src/direction_mpnn.py:77-79) true; INRANK_NONE when no
-// out-edge of j does. Two matching out-edges (parallel dual edges) have no unique rank: FLAG_AMBIGUOUS_EDGES.
-__global__ __launch_bounds__(FB) void k_pack_inrank(const float* __restrict__ x, Layout L, int64_t N,
-                                                    const int32_t* __restrict__ in_ptr,
-                                                    const int32_t* __restrict__ in_src, PlanOut P, uint8_t* in_rank,
-                                                    int32_t* flags) {
+// Static records (fused_common.h). in_rec[k].rank for in-edge k = (j -> i): the rank r of j's out-edges with
+// (float)out_dst == ROAD_INDEX(i), i.e. the sel8 code of j that makes "SELECTED_ROAD(j) == ROAD_INDEX(i)"
+// (src/direction_mpnn.py:77-79) true; INRANK_NONE when no out-edge of j does. Two matching out-edges (parallel dual
+// edges) have no unique rank: FLAG_AMBIGUOUS_EDGES. Runs after k_pack_nodes (reads st0).
+__global__ __launch_bounds__(FB) void k_pack_static(int64_t N, int64_t E, const int32_t* __restrict__ in_ptr,
+                                                    const int32_t* __restrict__ in_src,
+                                                    const int32_t* __restrict__ in_eid, PlanOut P,
+                                                    const float* __restrict__ edge_attr,
+                                                    const float4* __restrict__ st0, NodeRec* nodes, InRec* in_rec,
+                                                    int32_t* out_pad, int32_t* flags) {
   const int64_t i = (int64_t)blockIdx.x * FB + threadIdx.x;
+  if (i < 4) {   // padding entries: any valid row, never used
+    in_rec[E + i] = InRec{0, (int32_t)INRANK_NONE, 0.0f, 0.0f};
+    out_pad[E + i] = 0;
+  }
   if (i >= N) return;
-  const float road_i = x[i * L.ldx + L.col_road()];   // static column: environment 0 speaks for all
-  const int32_t a1 = in_ptr[i + 1];
-  for (int32_t k = in_ptr[i]; k < a1; ++k) {
+  const float4 sti = st0[i];
+  const int32_t a0 = in_ptr[i], a1 = in_ptr[i + 1], o0 = P.out_ptr[i], o1 = P.out_ptr[i + 1];
+  nodes[i] = NodeRec{a0, a1 - a0, o0, o1 - o0, sti.x, sti.y, sti.z, sti.w};
+  for (int32_t k = o0; k < o1; ++k) out_pad[k] = P.out_dst[k];
+  for (int32_t k = a0; k < a1; ++k) {
     const int32_t j = in_src[k];
     const int32_t k0 = P.out_ptr[j], k1 = P.out_ptr[j + 1];
     int cnt = 0, r = (int)INRANK_NONE;
     for (int32_t kk = k0; kk < k1; ++kk)
-      if ((float)P.out_dst[kk] == road_i) {
+      if ((float)P.out_dst[kk] == sti.z) {
         if (cnt == 0) r = kk - k0;
         ++cnt;
       }
@@ -125,7 +134,7 @@ __global__ __launch_bounds__(FB) void k_pack_inrank(const float* __restrict__ x,
       atomicOr(flags, FLAG_AMBIGUOUS_EDGES);
       r = (int)INRANK_NONE;
     }
-    in_rank[k] = (uint8_t)r;
+    in_rec[k] = InRec{j, r, edge_attr ? edge_attr[in_eid[k]] : 0.0f, st0[j].x};
   }
 }
 
@@ -378,23 +387,13 @@ __global__ __launch_bounds__(TILE) void k_fused_choice(const int32_t* __restrict
 // therefore appended to an LDS list and pass 2 walks that list densely (one lane per pair), re-evaluating the pair with
 // its noise — same Philox indices, same expressions: the result is bit-identical to evaluating everything.
 #define DIR_LIST (TILE * 8)
-struct DirIn {
-  const int32_t* in_ptr;
-  const int32_t* in_src;
-  const int32_t* in_eid;
-  const float* edge_attr;
-  const float* log_edge_attr;
-  const float* gumbel;   // [B][E] or NULL (device Philox)
-  float* dtt;            // [B][E] or NULL (frame API)
-  float log_eps, t, t_prev;
-  uint64_t seed, counter;
-};
-
-// does upstream row j (dense words hj, SELECTED_ROAD code cj) send its head to the row behind in-edge k?
-__device__ __forceinline__ bool edge_admissible(const FusedBufs& fb, int32_t k, int64_t jrow, uint2 hj, float max_j,
-                                                float road_i, float n_i, float max_i, float t, const uint8_t* sel8) {
-  const uint32_t cj = sel8[jrow] & 0x7Fu;
-  const bool heads_here = (cj == SEL_RAW) ? (fb.sel[jrow] == road_i) : (cj == (uint32_t)fb.in_rank[k]);
+// does upstream row j (dense words hj, SELECTED_ROAD code cj) send its head to the row behind an in-edge of rank code rk?
+// EXACT: a raw SELECTED_ROAD (cj == SEL_RAW: a value pack found among none of j's out-edges) is compared as a value.
+template <bool EXACT>
+__device__ __forceinline__ bool edge_admissible(uint32_t cj, int32_t rk, const float* __restrict__ sel_raw, int64_t jrow,
+                                                uint2 hj, float max_j, float road_i, float n_i, float max_i, float t) {
+  bool heads_here = cj == (uint32_t)rk;   // ranks are < SEL_RAW: a raw code never matches here
+  if (EXACT && cj == SEL_RAW) heads_here = sel_raw[jrow] == road_i;
   const float dep = __uint_as_float(hj.y), n_j = (float)(hj.x & 255u);
   const bool m1 = (dep <= t) && (n_i < max_i - TARL_CONGESTION_FILE) && heads_here && (n_j > 0.0f);
   const bool m2 = ((dep - t) < -10.0f) && ((max_j - TARL_CONGESTION_FILE) <= n_j) && ((max_j - n_j) <= (max_i - n_i)) &&
@@ -402,116 +401,183 @@ __device__ __forceinline__ bool edge_admissible(const FusedBufs& fb, int32_t k, 
   return m1 || m2;
 }
 
-__global__ __launch_bounds__(TILE) void k_fused_direction(DirIn D, int64_t E, int64_t B, int64_t N, FusedBufs fb,
-                                                          const uint8_t* __restrict__ sel8, FrameOut out, int nchunk) {
+// Every read-only array is its own `const __restrict__` kernel argument: topology, statics and edge constants are
+// wave-uniform and must compile to SCALAR loads (through a struct member the compiler has to assume they alias the post
+// stores and falls back to dependent vector loads — measured: 48 -> 85 us per launch).
+template <int NCH>
+__global__ __launch_bounds__(TILE) void k_fused_direction(
+    const NodeRec* __restrict__ nodes, const InRec* __restrict__ in_rec, const int32_t* __restrict__ in_eid,
+    const float* __restrict__ log_edge_attr, const uint2* __restrict__ hdp, const uint32_t* __restrict__ tl,
+    const uint2* __restrict__ rec1, const uint8_t* __restrict__ sel8, const float* __restrict__ sel_raw,
+    const float* __restrict__ gumbel, float* __restrict__ dtt, uint32_t* __restrict__ post, float log_eps, float t,
+    float t_prev, uint64_t seed, uint64_t counter, uint32_t E, uint32_t B, uint32_t N, FrameOut out) {
   __shared__ int32_t s_n;
   __shared__ uint16_t s_item[DIR_LIST];   // (node offset in the chunk) * TILE + lane
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;   // row indices are 32-bit: N * B < 2^31 (host check)
   const bool valid = b < B;
-  const int32_t i0 = blockIdx.y * nchunk;
-  const int32_t i1 = (i0 + nchunk < N) ? i0 + nchunk : (int32_t)N;
-  const float t = D.t;
+  const uint32_t i0 = blockIdx.y * NCH;
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
+  // pass 1, branch-free form: a raw SELECTED_ROAD code is only noted; if any lane of the workgroup saw one (never in a
+  // rollout: every node with out-edges draws an action in every frame) the pass is repeated in its exact form.
+  // NCH rows per lane, ALL their loads (own words + the first four in-edges' gathers) issued before anything is used:
+  // the pass is bound by memory latency and by scalar-instruction issue, so requests in flight per wave and address
+  // arithmetic per request are what counts: one node record + one base address fetch a row's statics.
+  bool raw_seen = false;
   if (valid) {
-    for (int32_t i = i0; i < i1; ++i) {  // i, and everything indexed by it alone, is wave-uniform
-      const int64_t row = (int64_t)i * B + b;
-      const uint2 me = fb.hdp[row];
-      const uint32_t tlw = fb.tl[row];
-      const float4 sti = fb.st0[i];
-      const float max_i = sti.x, n_i = (float)(me.x & 255u), road_i = sti.z;
-      float P = 0.0f;
-      const int32_t k1 = D.in_ptr[i + 1];
-      for (int32_t k = D.in_ptr[i]; k < k1; ++k) {
-        const int32_t j = D.in_src[k];
-        const int64_t jrow = (int64_t)j * B + b;
-        const uint2 hj = fb.hdp[jrow];
-        const float4 stj = fb.st0[j];
-        const bool m = edge_admissible(fb, k, jrow, hj, stj.x, road_i, n_i, max_i, t, sel8);
-        P = P + D.edge_attr[D.in_eid[k]] * (m ? 1.0f : 0.0f);
-        if (D.dtt) {   // per-edge side output of DirectionMPNN.message (src/direction_mpnn.py:94-96): a property of j
-          const uint32_t tlj = fb.tl[jrow];
-          const float arr_j = ((hj.x & 255u) == 0u && !(tlj & TLF_AUTH)) ? D.t_prev : __uint_as_float(fb.rec1[jrow].x);
-          const float d = (__uint_as_float(hj.y) - arr_j) - stj.y;
-          D.dtt[b * E + D.in_eid[k]] = d > 0.0f ? d : (d != d ? d : 0.0f);
+    uint2 me[NCH], hj[NCH][4];
+    uint32_t tlw[NCH], cj[NCH][4];
+#pragma unroll
+    for (int r = 0; r < NCH; ++r) {
+      const uint32_t i = (i0 + r < N) ? i0 + r : N - 1;
+      const uint32_t row = i * B + b;
+      me[r] = hdp[row];
+      tlw[r] = tl[row];
+      const InRec* ir = in_rec + nodes[i].in0;   // four records from consecutive addresses (padded array)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t jrow = (uint32_t)ir[q].src * B + b;
+        hj[r][q] = hdp[jrow];
+        cj[r][q] = sel8[jrow] & 0x7Fu;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < NCH; ++r) {
+      const uint32_t i = i0 + r;   // i, and everything indexed by it alone, is wave-uniform
+      if (i < N) {
+        const uint32_t row = i * B + b;
+        const NodeRec nr = nodes[i];
+        const InRec* ir = in_rec + nr.in0;
+        const float max_i = nr.maxn, n_i = (float)(me[r].x & 255u), road_i = nr.road;
+        float P = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (q < nr.in_deg) {   // wave-uniform
+            raw_seen = raw_seen || (cj[r][q] == SEL_RAW);
+            const bool m = edge_admissible<false>(cj[r][q], ir[q].rank, sel_raw, 0, hj[r][q], ir[q].max_src, road_i, n_i,
+                                                  max_i, t);
+            P = P + ir[q].ea * (m ? 1.0f : 0.0f);
+          }
         }
+        for (int32_t q = 4; q < nr.in_deg; ++q) {   // in-degree above four: the rest one by one
+          const uint32_t jrow = (uint32_t)ir[q].src * B + b;
+          const uint2 hx = hdp[jrow];
+          const uint32_t cx = sel8[jrow] & 0x7Fu;
+          raw_seen = raw_seen || (cx == SEL_RAW);
+          const bool m = edge_admissible<false>(cx, ir[q].rank, sel_raw, 0, hx, ir[q].max_src, road_i, n_i, max_i, t);
+          P = P + ir[q].ea * (m ? 1.0f : 0.0f);
+        }
+        post[row] = (tlw[r] & ~0xFFu) | ((me[r].x & 255u) ? PF_NONEMPTY : 0u);   // nobody chosen; pass 2 overwrites
+        if (P > 0.0f) s_item[atomicAdd(&s_n, 1)] = (uint16_t)(r * TILE + threadIdx.x);
       }
-      if (out.dtt_node && b < out.m_env) {   // the same value, once per upstream node, for the metric environments
-        const float arr_i = ((me.x & 255u) == 0u && !(tlw & TLF_AUTH)) ? D.t_prev : __uint_as_float(fb.rec1[row].x);
-        const float d = (__uint_as_float(me.y) - arr_i) - sti.y;
-        out.dtt_node[(int64_t)i * out.m_env + b] = d > 0.0f ? d : (d != d ? d : 0.0f);
-      }
-      // nobody chosen; overwritten by pass 2 where P > 0
-      fb.post[row] = (tlw & ~0xFFu) | ((me.x & 255u) ? PF_NONEMPTY : 0u);
-      if (P > 0.0f) s_item[atomicAdd(&s_n, 1)] = (uint16_t)((i - i0) * TILE + threadIdx.x);
     }
   }
-  __syncthreads();
+  const bool redo = __syncthreads_or(raw_seen ? 1 : 0) != 0;
+  if (out.dtt_node && valid && b < (uint32_t)out.m_env) {   // metric environments: delta_travel_time once per upstream node
+    for (uint32_t i = i0; i < i0 + NCH && i < N; ++i) {
+      const uint32_t row = i * B + b;
+      const uint2 mw = hdp[row];
+      const float arr_i = ((mw.x & 255u) == 0u && !(tl[row] & TLF_AUTH)) ? t_prev : __uint_as_float(rec1[row].x);
+      const float d = (__uint_as_float(mw.y) - arr_i) - nodes[i].ff;
+      out.dtt_node[(int64_t)i * out.m_env + b] = d > 0.0f ? d : (d != d ? d : 0.0f);
+    }
+  }
+  if (redo || dtt) {   // exact form and / or the per-edge delta_travel_time of the frame API (uniform branch)
+    if (redo && threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    if (valid) {
+      for (uint32_t i = i0; i < i0 + NCH && i < N; ++i) {
+        const uint32_t row = i * B + b;
+        const uint2 mw = hdp[row];
+        const NodeRec nr = nodes[i];
+        const InRec* ir = in_rec + nr.in0;
+        const float max_i = nr.maxn, n_i = (float)(mw.x & 255u), road_i = nr.road;
+        float P = 0.0f;
+        for (int32_t q = 0; q < nr.in_deg; ++q) {
+          const int32_t j = ir[q].src;
+          const uint32_t jrow = (uint32_t)j * B + b;
+          const uint2 hx = hdp[jrow];
+          if (redo) {
+            const bool m = edge_admissible<true>(sel8[jrow] & 0x7Fu, ir[q].rank, sel_raw, jrow, hx, ir[q].max_src, road_i,
+                                                 n_i, max_i, t);
+            P = P + ir[q].ea * (m ? 1.0f : 0.0f);
+          }
+          if (dtt) {   // per-edge side output of DirectionMPNN.message (src/direction_mpnn.py:94-96): a property of j
+            const float arr_j = ((hx.x & 255u) == 0u && !(tl[jrow] & TLF_AUTH)) ? t_prev : __uint_as_float(rec1[jrow].x);
+            const float d = (__uint_as_float(hx.y) - arr_j) - nodes[j].ff;
+            dtt[(int64_t)b * E + in_eid[nr.in0 + q]] = d > 0.0f ? d : (d != d ? d : 0.0f);
+          }
+        }
+        if (redo && P > 0.0f) s_item[atomicAdd(&s_n, 1)] = (uint16_t)((i - i0) * TILE + threadIdx.x);
+      }
+    }
+    __syncthreads();
+  }
   const int32_t cnt = s_n;
   for (int32_t idx = threadIdx.x; idx < cnt; idx += blockDim.x) {
     const int32_t item = s_item[idx];
-    const int32_t i = i0 + item / TILE;
-    const int64_t bb = (int64_t)blockIdx.x * blockDim.x + (item % TILE);
-    const int64_t row = (int64_t)i * B + bb;
-    const uint2 me = fb.hdp[row];
-    const float4 sti = fb.st0[i];
-    const float max_i = sti.x, n_i = (float)(me.x & 255u), road_i = sti.z;
+    const uint32_t i = i0 + item / TILE;
+    const uint32_t bb = blockIdx.x * blockDim.x + (item % TILE);
+    const uint32_t row = i * B + bb;
+    const uint2 mw = hdp[row];
+    const NodeRec nr = nodes[i];
+    const InRec* ir = in_rec + nr.in0;
+    const float max_i = nr.maxn, n_i = (float)(mw.x & 255u), road_i = nr.road;
     float P = 0.0f, best = -FLT_MAX;
     uint32_t best_id = 0u;
     PhiloxRun rng;
-    const int32_t k1 = D.in_ptr[i + 1];
-    for (int32_t k = D.in_ptr[i]; k < k1; ++k) {
-      const int32_t j = D.in_src[k];
-      const int32_t e = D.in_eid[k];
-      const int64_t jrow = (int64_t)j * B + bb;
-      const uint2 hj = fb.hdp[jrow];
-      const bool m = edge_admissible(fb, k, jrow, hj, fb.st0[j].x, road_i, n_i, max_i, t, sel8);
-      P = P + D.edge_attr[e] * (m ? 1.0f : 0.0f);
+    for (int32_t q = 0; q < nr.in_deg; ++q) {
+      const int32_t k = nr.in0 + q;
+      const int32_t e = in_eid[k];
+      const uint32_t jrow = (uint32_t)ir[q].src * B + bb;
+      const uint2 hx = hdp[jrow];
+      const bool m = edge_admissible<true>(sel8[jrow] & 0x7Fu, ir[q].rank, sel_raw, jrow, hx, ir[q].max_src, road_i, n_i,
+                                           max_i, t);
+      P = P + ir[q].ea * (m ? 1.0f : 0.0f);
       float g;
-      if (D.gumbel) {
-        g = D.gumbel[bb * E + e];
+      if (gumbel) {
+        g = gumbel[(int64_t)bb * E + e];
       } else {
-        const float u = rng.uniform(D.seed, D.counter, (uint64_t)(bb * E + k));
+        const float u = rng.uniform(seed, counter, (uint64_t)bb * E + (uint64_t)k);
         g = gumbel_from_u01(u);
       }
-      const float score = (m ? D.log_edge_attr[e] : D.log_eps) + g;
+      const float score = (m ? log_edge_attr[e] : log_eps) + g;
       if (score > best) {
         best = score;
-        best_id = hj.x >> 8;
+        best_id = hx.x >> 8;
       }
     }
     const uint32_t who = (P > 0.0f) ? best_id : 0u;
-    if (who != 0u) fb.post[row] = (who << 8) | PF_NONEMPTY | PF_ARRIVED;
+    if (who != 0u) post[row] = (who << 8) | PF_NONEMPTY | PF_ARRIVED;
   }
 }
 
 // ---- the row pass: Direction update + Response pop + withdraw on the slot store, then refresh the dense words -----------
-__global__ __launch_bounds__(TILE) void k_fused_rows(PlanOut P, int Nmax, int64_t B, int64_t N, FusedBufs fb,
-                                                     float* __restrict__ ag, int64_t A, int64_t a_bstride, float t,
-                                                     FrameOut out, int nchunk) {
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  const int32_t i0 = blockIdx.y * nchunk;
-  const int32_t i1 = (i0 + nchunk < N) ? i0 + nchunk : (int32_t)N;
-  float nsum = 0.0f, wsum = 0.0f;
-  for (int32_t i = i0; i < i1; ++i) {
-    const int64_t row = (int64_t)i * B + b;
-    const uint32_t pa = fb.post[row];
-    const uint2 hp = fb.hdp[row];
-    const uint32_t tlw = fb.tl[row];
-    const float4 st = fb.st0[i];
+// One row of the pass, its dense words and the first four downstream post words already in registers.
+__device__ __forceinline__ float2 fused_row(uint32_t i, uint32_t b, const NodeRec nr, const int32_t* __restrict__ out_ptr,
+                                            const int32_t* __restrict__ out_dst, const uint32_t* __restrict__ post,
+                                            uint32_t pa, uint2 hp, uint32_t tlw, const uint32_t (&pj4)[4], int Nmax,
+                                            uint32_t B, uint32_t N, const FusedBufs& fb, float* __restrict__ ag,
+                                            int64_t A, int64_t a_bstride, float t,
+                                            const FrameOut& out) {   // -> {count after the pass, agents withdrawn}
+  const PlanOut P{out_ptr, out_dst};
+  {
+    const uint32_t row = i * B + b;   // 32-bit row indices: N * B < 2^31 (host check)
+    const float4 st = make_float4(nr.maxn, nr.ff, nr.road, nr.cong);
     const uint32_t n0i = hp.x & 255u, head_id0 = hp.x >> 8, tail0 = tlw >> 8;
     const uint32_t arrived = pa & PF_ARRIVED;
     const uint32_t who = arrived ? (pa >> 8) : 0u;   // the agent the Direction update enqueues
-    const int32_t k0 = P.out_ptr[i], k1 = P.out_ptr[i + 1];
 
     // Response message + max-aggregate from the post words (state after the Direction update of every row)
     bool pop = false;
     {
       const uint32_t head = (n0i == 0u) ? who : head_id0;   // head after the Direction update
       const bool up = (n0i + arrived) > 0u;
-      for (int32_t k = k0; k < k1; ++k) {  // uniform trip count: the post gathers stay coalesced and unconditional
-        const uint32_t pj = fb.post[(int64_t)P.out_dst[k] * B + b];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        pop = pop || (q < nr.out_deg && up && (pj4[q] & PF_NONEMPTY) && (pj4[q] >> 8) == head);
+      for (int32_t q = 4; q < nr.out_deg; ++q) {   // out-degree above four: the rest one by one
+        const uint32_t pj = post[(uint32_t)fb.out_pad[nr.out0 + q] * B + b];
         pop = pop || (up && (pj & PF_NONEMPTY) && (pj >> 8) == head);
       }
     }
@@ -534,15 +600,14 @@ __global__ __launch_bounds__(TILE) void k_fused_rows(PlanOut P, int Nmax, int64_
       fb.tl[row] = tail0 << 8;
       if (out.counts8) __builtin_nontemporal_store((uint8_t)ni, &out.counts8[row]);
       if (out.countsf) __builtin_nontemporal_store((float)ni, &out.countsf[row]);
-      if (out.popped) out.popped[b * N + i] = 0;
-      if (out.withdrawn) out.withdrawn[b * N + i] = 0;
+      if (out.popped) out.popped[(int64_t)b * N + i] = 0;
+      if (out.withdrawn) out.withdrawn[(int64_t)b * N + i] = 0;
       if (out.events && b < out.m_env) out.events[(int64_t)i * out.m_env + b] = 0;
-      nsum += (float)ni;
-      continue;
+      return make_float2((float)ni, 0.0f);
     }
 
     // EVENT ROW. The FIFO is a ring buffer: logical slot s lives at physical slot (hoff + s) mod Nmax.
-    float* sl = fb.slots + row * fb.lds;  // slot s = sl[3s .. 3s+2] = {id, arrival, departure}
+    float* sl = fb.slots + (int64_t)row * fb.lds;  // slot s = sl[3s .. 3s+2] = {id, arrival, departure}
     const uint2 r1 = fb.rec1[row];
     int hoff = r1_hoff(r1.y);
     if (!lazy && q < Nmax) {
@@ -591,15 +656,15 @@ __global__ __launch_bounds__(TILE) void k_fused_rows(PlanOut P, int Nmax, int64_
         const long long id = (long long)idf;
         if (id < 0 || id >= A) break;
         if (!(depf <= t)) break;  // tested first: most heads are still travelling, and the lookup below is a gather
-        const long long dest = (long long)fb.a_dest[b * A + id];
+        const long long dest = (long long)fb.a_dest[(int64_t)b * A + id];
         bool conn = false;
         for (int32_t k = w0; k < w1; ++k) conn = conn || ((long long)P.out_dst[k] == dest);
         if (!conn) break;
-        float* a = ag + b * a_bstride + id * AG_COLS;
+        float* a = ag + (int64_t)b * a_bstride + id * AG_COLS;
         a[AG_DONE] = 1.0f;
         a[AG_ON_WAY] = 0.0f;
         a[AG_ARR] = t;
-        fb.a_status[b * A + id] = 2;
+        fb.a_status[(int64_t)b * A + id] = 2;
         ++c;
       }
     }
@@ -634,12 +699,49 @@ __global__ __launch_bounds__(TILE) void k_fused_rows(PlanOut P, int Nmax, int64_
     // per-node count before insertion (the insert kernel adds this frame's arrivals); write-once stream
     if (out.counts8) __builtin_nontemporal_store((uint8_t)n, &out.counts8[row]);
     if (out.countsf) __builtin_nontemporal_store((float)n, &out.countsf[row]);
-    if (out.popped) out.popped[b * N + i] = pop ? 1 : 0;
-    if (out.withdrawn) out.withdrawn[b * N + i] = c > 0 ? 1 : 0;
+    if (out.popped) out.popped[(int64_t)b * N + i] = pop ? 1 : 0;
+    if (out.withdrawn) out.withdrawn[(int64_t)b * N + i] = c > 0 ? 1 : 0;
     if (out.events && b < out.m_env) out.events[(int64_t)i * out.m_env + b] = (uint8_t)((pop ? 1 : 0) | (c > 0 ? 2 : 0));
-    nsum += (float)n;
-    wsum += (float)c;
+    return make_float2((float)n, (float)c);
   }
+}
+
+// NCH rows per lane: ALL their loads (dense words, downstream post words) are issued before the first row is processed,
+// so a wave keeps 8 * NCH independent requests in flight instead of one row's dependent phases (the pass is bound by
+// memory latency, not bytes: 66 % of the wave cycles were waits with one row at a time).
+template <int NCH>
+__global__ __launch_bounds__(TILE) void k_fused_rows(const NodeRec* __restrict__ nodes,
+                                                     const int32_t* __restrict__ out_pad,
+                                                     const int32_t* __restrict__ out_ptr,
+                                                     const int32_t* __restrict__ out_dst,
+                                                     const uint32_t* __restrict__ post, int Nmax, uint32_t B, uint32_t N,
+                                                     FusedBufs fb, float* __restrict__ ag, int64_t A, int64_t a_bstride,
+                                                     float t, FrameOut out) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const uint32_t i0 = blockIdx.y * NCH;
+  uint32_t pa[NCH], tlw[NCH], pj[NCH][4];
+  uint2 hp[NCH];
+#pragma unroll
+  for (int r = 0; r < NCH; ++r) {
+    const uint32_t i = (i0 + r < N) ? i0 + r : N - 1;   // clamped: the tail rows are loaded twice, used once
+    const uint32_t row = i * B + b;
+    pa[r] = post[row];
+    hp[r] = fb.hdp[row];
+    tlw[r] = fb.tl[row];
+    const int32_t* od = out_pad + nodes[i].out0;   // four targets from consecutive addresses (padded array)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pj[r][q] = post[(uint32_t)od[q] * B + b];
+  }
+  float nsum = 0.0f, wsum = 0.0f;
+#pragma unroll
+  for (int r = 0; r < NCH; ++r)
+    if (i0 + r < N) {
+      const float2 nc = fused_row(i0 + r, b, nodes[i0 + r], out_ptr, out_dst, post, pa[r], hp[r], tlw[r], pj[r], Nmax, B,
+                                  N, fb, ag, A, a_bstride, t, out);
+      nsum += nc.x;
+      wsum += nc.y;
+    }
   const int64_t bank = (int64_t)(blockIdx.y % (unsigned)fb.acc_slots) * B + b;
   atomicAdd(&fb.acc_n[bank], nsum);
   if (wsum != 0.0f) atomicAdd(&fb.acc_w[bank], wsum);
@@ -929,33 +1031,32 @@ __global__ __launch_bounds__(TILE) void k_fused_insert_choice(ChoiceArgs C, int 
 // ---- host side -------------------------------------------------------------------------------------------------------------
 FusedBufs tarl_to_bufs(const tarl_fused* f) {
   return FusedBufs{(uint2*)f->hdp,        (uint32_t*)f->tl, (uint2*)f->rec1, (uint32_t*)f->post, (const float4*)f->st0,
-                   f->slots,              f->ld_slots,      f->sel8,         f->sel,             f->in_rank,
+                   f->slots,              f->ld_slots,      f->sel8,         f->sel,             (const NodeRec*)f->node_rec,
+                   (const InRec*)f->in_rec, f->out_pad,
                    (long long*)f->acc_lp, f->acc_n,         f->acc_w,        f->a_origin,        f->a_dest,
                    f->a_dep,              f->a_status,      f->a_order,      f->cur_lo,          f->a_dep_sorted,
                    f->acc_slots,          f->flags};
 }
 
-// nodes walked by one workgroup of the env-minor kernels (tunable: TARL_NCHUNK)
+// rows per lane of the row pass (tunable: TARL_NCHUNK = 1, 2 or 4; measured 63.7 / 57.8 / 56.0 us per launch)
 static int nchunk() {
   static int v = 0;
   if (v == 0) {
     const char* e = getenv("TARL_NCHUNK");
-    v = e ? atoi(e) : 2;
-    if (v < 1) v = 1;
+    v = e ? atoi(e) : 4;
+    v = v >= 4 ? 4 : (v >= 2 ? 2 : 1);
   }
   return v;
 }
 static int64_t num_chunks(const tarl_plan* plan) { return ceil_div(plan->N, nchunk()); }
-// nodes per workgroup pass of the Direction kernel (measured on the v5 layout: 1 -> 53.5 us, 2 -> 48.2, 3 -> 49.9,
-// 4 -> 64, 8 -> 85 per launch at B = 2048): two give the dense second pass ~25 pairs per workgroup without starving the
-// chip of workgroups; at most 8 (capacity of the LDS list and of the 16-bit item code)
+// rows per lane of the Direction gather: 1, 2 or 4, all their gathers in flight together (measured at B = 2048, config 4:
+// 1 -> 65.7 us, 2 -> 42.4, 4 -> 39.8 per launch)
 static int nchunk_dir() {
   static int v = 0;
   if (v == 0) {
     const char* e = getenv("TARL_NCHUNK_DIR");
-    v = e ? atoi(e) : 2;
-    if (v < 1) v = 1;
-    if (v > 8) v = 8;
+    v = e ? atoi(e) : 4;
+    v = v >= 4 ? 4 : (v >= 2 ? 2 : 1);
   }
   return v;
 }
@@ -973,9 +1074,10 @@ static int nchunk_choice() {
 int tarl_check_fused_core(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax) {
   TARL_REQUIRE(plan && f, "null argument");
   TARL_REQUIRE(f->hdp && f->tl && f->rec1 && f->post && f->st0 && f->slots && f->sel8 && f->sel && f->acc_lp &&
-                   f->acc_n && f->acc_w && f->flags && (f->in_rank || plan->E == 0),
+                   f->acc_n && f->acc_w && f->flags && f->node_rec && f->in_rec && f->out_pad,
                "fused node buffers missing");
   TARL_REQUIRE(B >= 1 && B < ((int64_t)1 << 31) && Nmax >= 2, "bad sizes");
+  TARL_REQUIRE(plan->N * B < ((int64_t)1 << 31), "N * B must stay below 2^31 (32-bit row indices in the frame kernels)");
   TARL_REQUIRE(Nmax <= 255, "the fused path packs NUMBER_OF_AGENT into one byte: Nmax must be <= 255 (use the unfused "
                             "entry points for longer FIFOs)");
   TARL_REQUIRE(plan->max_out <= 126, "the fused path packs the chosen out-edge's rank into 7 bits: out-degree must be <= 126");
@@ -1003,10 +1105,11 @@ static int check_fused(const tarl_plan* plan, const tarl_fused* f, const float* 
 static unsigned tile_threads(int64_t B) { return B >= TILE ? TILE : (unsigned)(ceil_div(B, 64) * 64); }
 
 extern "C" int tarl_fused_pack(const tarl_plan* plan, const tarl_fused* f, const float* x, int64_t B, int64_t x_bstride,
-                               int64_t ldx, int32_t Nmax, const float* cong, const float* agent_features, int64_t A,
-                               int64_t a_bstride, tarl_stream stream) {
+                               int64_t ldx, int32_t Nmax, const float* cong, const float* edge_attr,
+                               const float* agent_features, int64_t A, int64_t a_bstride, tarl_stream stream) {
   int rc = check_fused(plan, f, x, B, x_bstride, ldx, Nmax);
   if (rc) return rc;
+  TARL_REQUIRE(plan->E == 0 || edge_attr, "edge_attr is null");
   const Layout L{Nmax, ldx, x_bstride};
   const FusedBufs fb = tarl_to_bufs(f);
   const PlanOut P{plan->out_ptr, plan->out_dst};
@@ -1016,11 +1119,10 @@ extern "C" int tarl_fused_pack(const tarl_plan* plan, const tarl_fused* f, const
     hipLaunchKernelGGL(k_pack_nodes, dim3((unsigned)ceil_div(B * plan->N, FB)), dim3(FB), 0, s, x, L, B, plan->N, cong,
                        fb, (float4*)f->st0, P);
     TARL_LAUNCH_CHECK();
-    if (plan->E > 0) {
-      hipLaunchKernelGGL(k_pack_inrank, dim3((unsigned)ceil_div(plan->N, FB)), dim3(FB), 0, s, x, L, plan->N,
-                         plan->in_ptr, plan->in_src, P, f->in_rank, f->flags);
-      TARL_LAUNCH_CHECK();
-    }
+    hipLaunchKernelGGL(k_pack_static, dim3((unsigned)ceil_div(plan->N > 4 ? plan->N : 4, FB)), dim3(FB), 0, s, plan->N,
+                       plan->E, plan->in_ptr, plan->in_src, plan->in_eid, P, edge_attr, (const float4*)f->st0,
+                       (NodeRec*)f->node_rec, (InRec*)f->in_rec, f->out_pad, f->flags);
+    TARL_LAUNCH_CHECK();
   }
   if (agent_features) {
     TARL_REQUIRE(f->a_origin && f->a_dest && f->a_dep && f->a_status && A >= 1, "fused agent buffers missing");
@@ -1076,6 +1178,44 @@ extern "C" int tarl_fused_policy_prepare(const tarl_plan* plan, const tarl_fused
   return TARL_OK;
 }
 
+// rows per lane of the Direction gather (TARL_NCHUNK_DIR = 1, 2 or 4)
+static int launch_direction(dim3 grid, unsigned threads, hipStream_t s, const tarl_plan* plan, const tarl_fused* f,
+                            const float* edge_attr, const float* log_edge_attr, const uint8_t* sel8, const float* gumbel,
+                            float* dtt, float log_eps, float time, float prev_time, uint64_t seed, uint64_t counter,
+                            int64_t B, const FrameOut& out) {
+#define DIR_LAUNCH(NCH)                                                                                                   \
+  hipLaunchKernelGGL(k_fused_direction<NCH>, grid, dim3(threads), 0, s, (const NodeRec*)f->node_rec,                    \
+                     (const InRec*)f->in_rec, plan->in_eid, log_edge_attr, (const uint2*)f->hdp, (const uint32_t*)f->tl,  \
+                     (const uint2*)f->rec1, sel8, (const float*)f->sel, gumbel, dtt, (uint32_t*)f->post, log_eps, time,   \
+                     prev_time, seed, counter, (uint32_t)plan->E, (uint32_t)B, (uint32_t)plan->N, out)
+  switch (nchunk_dir()) {
+    case 1: DIR_LAUNCH(1); break;
+    case 2: DIR_LAUNCH(2); break;
+    default: DIR_LAUNCH(4); break;
+  }
+#undef DIR_LAUNCH
+  TARL_LAUNCH_CHECK();
+  return TARL_OK;
+}
+
+// rows per lane of the row pass (TARL_NCHUNK = 1, 2 or 4)
+static int launch_rows(dim3 grid, unsigned threads, hipStream_t s, const tarl_plan* plan, const tarl_fused* f,
+                       const FusedBufs& fb, int Nmax, int64_t B, float* agent_features, int64_t A, int64_t a_bstride,
+                       float time, const FrameOut& out) {
+#define ROWS_LAUNCH(NCH)                                                                                              \
+  hipLaunchKernelGGL(k_fused_rows<NCH>, grid, dim3(threads), 0, s, (const NodeRec*)f->node_rec,                          \
+                     (const int32_t*)f->out_pad, plan->out_ptr, plan->out_dst, (const uint32_t*)f->post, Nmax,            \
+                     (uint32_t)B, (uint32_t)plan->N, fb, agent_features, A, a_bstride, time, out)
+  switch (nchunk()) {
+    case 1: ROWS_LAUNCH(1); break;
+    case 2: ROWS_LAUNCH(2); break;
+    default: ROWS_LAUNCH(4); break;
+  }
+#undef ROWS_LAUNCH
+  TARL_LAUNCH_CHECK();
+  return TARL_OK;
+}
+
 static int check_frame_args(const tarl_plan* plan, const tarl_fused* f, int64_t B, const float* agent_features, int64_t A,
                             int64_t a_bstride, const int32_t* ins_scratch, const float* edge_attr,
                             const float* log_edge_attr) {
@@ -1119,16 +1259,13 @@ extern "C" int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int6
   }
   const bool timed = tarl_prof_mark(s, 0) != nullptr;
   const dim3 grid_d((unsigned)ceil_div(B, threads), (unsigned)ceil_div(plan->N, nchunk_dir()));
-  const DirIn D{plan->in_ptr, plan->in_src, plan->in_eid, edge_attr, log_edge_attr, gumbel, delta_travel_time,
-                log_eps,      time,         prev_time,    seed,      counter};
   const FrameOut out{nullptr, counts, popped, withdrawn, nullptr, nullptr, 0, nullptr};
-  hipLaunchKernelGGL(k_fused_direction, grid_d, dim3(threads), 0, s, D, plan->E, B, plan->N, fb,
-                     (const uint8_t*)f->sel8, out, nchunk_dir());
-  TARL_LAUNCH_CHECK();
+  rc = launch_direction(grid_d, threads, s, plan, f, edge_attr, log_edge_attr, (const uint8_t*)f->sel8, gumbel,
+                        delta_travel_time, log_eps, time, prev_time, seed, counter, B, out);
+  if (rc) return rc;
   if (timed) (void)tarl_prof_mark(s, 1);
-  hipLaunchKernelGGL(k_fused_rows, grid, dim3(threads), 0, s, P, (int)Nmax, B, plan->N, fb, agent_features, A, a_bstride,
-                     time, out, nchunk());
-  TARL_LAUNCH_CHECK();
+  rc = launch_rows(grid, threads, s, plan, f, fb, (int)Nmax, B, agent_features, A, a_bstride, time, out);
+  if (rc) return rc;
   if (timed) (void)tarl_prof_mark(s, 2);
   hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(INSB), 0, s, (int)Nmax, B, plan->N, fb, P,
                      (const uint8_t*)f->sel8, agent_features, A, a_bstride, use_cong, time, ins_scratch, entropy1, reward,
@@ -1231,15 +1368,13 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
                        dtt_node ? dtt_node + t * N * m : nullptr,
                        metrics_envs,
                        leg ? leg + t * 2 * B : nullptr};
-    const DirIn D{plan->in_ptr, plan->in_src, plan->in_eid, edge_attr, log_edge_attr, nullptr, nullptr,
-                  log_eps,      time,         t > 0 ? times_host[t - 1] : prev_time, seed, counter0 + (uint64_t)t};
     const bool timed = tarl_prof_mark(s, 0) != nullptr;
-    hipLaunchKernelGGL(k_fused_direction, grid_d, dim3(threads), 0, s, D, plan->E, B, N, fbt, sel_t, out, nchunk_dir());
-    TARL_LAUNCH_CHECK();
+    rc = launch_direction(grid_d, threads, s, plan, f, edge_attr, log_edge_attr, sel_t, nullptr, nullptr, log_eps, time,
+                          t > 0 ? times_host[t - 1] : prev_time, seed, counter0 + (uint64_t)t, B, out);
+    if (rc) return rc;
     if (timed) (void)tarl_prof_mark(s, 1);
-    hipLaunchKernelGGL(k_fused_rows, grid, dim3(threads), 0, s, P, (int)Nmax, B, N, fbt, agent_features, A, a_bstride,
-                       time, out, nchunk());
-    TARL_LAUNCH_CHECK();
+    rc = launch_rows(grid, threads, s, plan, f, fbt, (int)Nmax, B, agent_features, A, a_bstride, time, out);
+    if (rc) return rc;
     if (timed) (void)tarl_prof_mark(s, 2);
     float* reward_t = reward ? reward + t * B : nullptr;
     float* lp_t = log_prob ? log_prob + t * B : nullptr;

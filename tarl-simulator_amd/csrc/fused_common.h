@@ -42,6 +42,22 @@
 #define FLAG_AMBIGUOUS_EDGES 2    // two out-edges of one node lead to the same ROAD_INDEX: SELECTED_ROAD has no unique rank
 #define FLAG_PACK_RANGE 4         // pack: a count above 255 / an agent id at or above 2^24
 
+// Static per-graph records (built by pack; shared by all environments, read through the scalar cache). One node record
+// and ONE base address per row give the hot kernels everything static they need: a row's in-edge records and out-edge
+// targets are contiguous (CSC / CSR), so four of them are fetched from consecutive addresses without per-edge index
+// chains (the arrays are padded by four entries: a row with fewer edges reads its successors' and ignores them).
+struct __attribute__((aligned(4))) NodeRec {
+  int32_t in0, in_deg;      // CSC range of the row's in-edges
+  int32_t out0, out_deg;    // CSR range of its out-edges
+  float maxn, ff, road, cong;   // = st0
+};
+struct __attribute__((aligned(4))) InRec {
+  int32_t src;      // upstream row
+  int32_t rank;     // sel8 rank of src that heads for this row (INRANK_NONE: none)
+  float ea;         // turn probability edge_attr[eid]
+  float max_src;    // MAX_NUMBER_OF_AGENT of src
+};
+
 struct FusedBufs {
   uint2* hdp;           // [N][B]
   uint32_t* tl;         // [N][B]
@@ -52,7 +68,9 @@ struct FusedBufs {
   int64_t lds;          // row stride of slots in floats (>= 3*Nmax, multiple of 16)
   uint8_t* sel8;        // [N][B] SELECTED_ROAD code
   float* sel;           // [N][B] SELECTED_ROAD as fp32 (authoritative where sel8 == SEL_RAW; refreshed by export)
-  const uint8_t* in_rank;  // [E] CSC order: the sel8 rank of the upstream node that means "heads for this road"
+  const NodeRec* nodes;    // [N]
+  const InRec* in_rec;     // [E + 4] CSC order
+  const int32_t* out_pad;  // [E + 4] CSR order: target row of every out-edge (= plan out_dst, padded)
   long long* acc_lp;    // [S][B] log-prob of this frame's action, 2^-32 fixed point (order-independent => deterministic)
   float* acc_n;         // [S][B] sum of the per-node counts after the row pass (small integers: exact in any order)
   float* acc_w;         // [S][B] agents withdrawn (arrived at their destination) in this frame

@@ -74,7 +74,7 @@ class SimEngine:
     def resync(self):
         """Rebuild the fused side buffers from ``x`` / ``agents`` (after construction, reset, or external writes)."""
         if self.fs is not None:
-            ops.fused_pack(self.plan, self.fs, self.x, self.Nmax, self.agents, self.cc)
+            ops.fused_pack(self.plan, self.fs, self.x, self.Nmax, self.agents, self.cc, ec=self.ec)
             self._packed_stale = False
             self.fs.check_flags()
 

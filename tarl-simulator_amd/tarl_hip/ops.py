@@ -504,7 +504,9 @@ class FusedState:
         self.st0 = torch.zeros((N, 4), **f32)
         self.sel8 = torch.zeros((N, B), dtype=torch.uint8, device=device)
         self.sel = torch.zeros((N, B), **f32)
-        self.in_rank = torch.zeros(max(E, 1), dtype=torch.uint8, device=device)
+        self.node_rec = torch.zeros((N, 8), **i32)           # static records (fused_common.h: NodeRec / InRec)
+        self.in_rec = torch.zeros((E + 4, 4), **i32)
+        self.out_pad = torch.zeros(E + 4, **i32)
         self.acc_slots = 32      # accumulator banks (spread the per-environment atomics of the N/chunk workgroups)
         self.acc_lp = torch.zeros((self.acc_slots, B), dtype=torch.int64, device=device)
         self.acc_n = torch.zeros((self.acc_slots, B), **f32)
@@ -520,7 +522,8 @@ class FusedState:
         self.order_valid = False
         self.struct = _lib.FusedStruct(self.hdp.data_ptr(), self.tl.data_ptr(), self.rec1.data_ptr(),
                                        self.post.data_ptr(), self.st0.data_ptr(), self.slots.data_ptr(), self.ld_slots,
-                                       self.sel8.data_ptr(), self.sel.data_ptr(), self.in_rank.data_ptr(),
+                                       self.sel8.data_ptr(), self.sel.data_ptr(), self.node_rec.data_ptr(),
+                                       self.in_rec.data_ptr(), self.out_pad.data_ptr(),
                                        self.acc_lp.data_ptr(), self.acc_n.data_ptr(), self.acc_w.data_ptr(),
                                        self.a_origin.data_ptr(), self.a_dest.data_ptr(), self.a_dep.data_ptr(),
                                        self.a_status.data_ptr(), None, self.cur_lo.data_ptr(), None, self.acc_slots,
@@ -572,15 +575,17 @@ class FusedState:
         return C.byref(self.struct)
 
 
-def fused_pack(plan: Plan, fs: FusedState, x, Nmax, agent_features, congestion_constant=None, sort_agents=None):
-    """``sort_agents``: True = (re)build the departure-time order, None = build it once, False = never."""
+def fused_pack(plan: Plan, fs: FusedState, x, Nmax, agent_features, congestion_constant=None, sort_agents=None, *,
+               ec: EdgeConst):
+    """``ec``: the graph's edge constants (the turn probabilities go into the static in-edge records);
+    ``sort_agents``: True = (re)build the departure-time order, None = build it once, False = never."""
     L = _lib.load()
     B, N, bs, ldx = _state(x, Nmax)
     A, abs_ = _agents(agent_features, B)
     if sort_agents or (sort_agents is None and not fs.order_valid):
         fs.sort_agents(agent_features)
     _lib.check(L.tarl_fused_pack(plan.handle, fs.ref, x.data_ptr(), B, bs, ldx, Nmax, _lib.ptr(congestion_constant),
-                                 agent_features.data_ptr(), A, abs_, _lib.current_stream()))
+                                 ec.edge_attr.data_ptr(), agent_features.data_ptr(), A, abs_, _lib.current_stream()))
 
 
 def fused_reset(plan: Plan, fs: FusedState, agent_features):

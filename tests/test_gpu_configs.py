@@ -89,17 +89,19 @@ def test_config5_rollout_launcher_equals_frame_loop():
 
 
 def test_too_many_node_chunks_is_refused():
-    """A ring of 140 000 roads = 70 000 node chunks > the 65 535 a grid's y extent holds: tarl_check_fused_core says so."""
+    """A ring of 300 000 roads = 75 000 node chunks (four rows per workgroup) > the 65 535 a grid's y extent holds:
+    tarl_check_fused_core says so."""
     from tarl_hip import lib, ops
-    N = 140_000
+    N = 300_000
     src = torch.arange(N)
     ei = torch.stack([src, (src + 1) % N])
     plan = ops.Plan(ei, N)
     fs = ops.FusedState(plan, 1, 2, "cuda", 3)
     x = torch.zeros((1, N, 3 * 3 + 7), device="cuda")
     ag = torch.zeros((1, 2, 9), device="cuda")
+    ec = ops.EdgeConst(torch.full((N, 1), 1.0), "cuda")
     with pytest.raises(lib.TarlError, match="node chunks"):
-        ops.fused_pack(plan, fs, x, 3, ag)
+        ops.fused_pack(plan, fs, x, 3, ag, ec=ec)
 
 
 @pytest.mark.parametrize("num_envs", [1, 3])

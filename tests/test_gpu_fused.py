@@ -21,12 +21,12 @@ def dev(t):
     return t.cuda()
 
 
-def check_records(ops, plan, fs, x, Nmax, ag, cc):
+def check_records(ops, plan, fs, x, Nmax, ag, cc, ec):
     """The maintained hot records equal a fresh pack of the exported x / agents (tail only where the FIFO is non-empty)."""
     ref = ops.FusedState(plan, fs.B, fs.A, x.device, Nmax)
-    ops.fused_pack(plan, ref, x, Nmax, ag, cc)
+    ops.fused_pack(plan, ref, x, Nmax, ag, cc, ec=ec)
     assert torch.equal(fs.hdp, ref.hdp) and torch.equal(fs.sel, ref.sel)      # head id, count, head departure
-    assert torch.equal(fs.sel8 & 0x7F, ref.sel8 & 0x7F) and torch.equal(fs.in_rank, ref.in_rank)
+    assert torch.equal(fs.sel8 & 0x7F, ref.sel8 & 0x7F) and torch.equal(fs.in_rec, ref.in_rec) and torch.equal(fs.node_rec, ref.node_rec)
     nz = ref.count > 0
     assert torch.equal(fs.tail_id[nz], ref.tail_id[nz])
     assert torch.equal(fs.rec1[..., 0][nz], ref.rec1[..., 0][nz])              # head arrival (event-only word)
@@ -55,7 +55,7 @@ def test_fused_equals_unfused_frame_by_frame(ops, W, H, het, B, A, frames, with_
     x1, a1 = dev(net.x.unsqueeze(0).repeat(B, 1, 1)), dev(pops.clone())
     x2, a2 = x1.clone(), a1.clone()
     fs = ops.FusedState(plan, B, A + 1, "cuda", Nmax)
-    ops.fused_pack(plan, fs, x2, Nmax, a2, cc)
+    ops.fused_pack(plan, fs, x2, Nmax, a2, cc, ec=ec)
     emb = torch.randn(N, generator=torch.Generator().manual_seed(1)).cuda()
     tables = ops.fused_policy_prepare(plan, fs, emb, 0.9)
     gen = torch.Generator().manual_seed(2)
@@ -92,7 +92,7 @@ def test_fused_equals_unfused_frame_by_frame(ops, W, H, het, B, A, frames, with_
         assert torch.equal(r1, r2) and torch.equal(c1, c2.t())
         events += int(pop1.sum()) + int(wd1.sum())
         if s % 10 == 0 or s == frames - 1:
-            check_records(ops, plan, fs, x2, Nmax, a2, cc)
+            check_records(ops, plan, fs, x2, Nmax, a2, cc, ec)
     assert events > 0 and float(a1[:, :, 8].sum()) > 0
 
 
@@ -109,7 +109,7 @@ def test_fused_golden_rollout(ops):
     x, ag = dev(g["x_init"].clone()).unsqueeze(0), dev(g["agents0"].clone()).unsqueeze(0)
     ops.reset_state(x, Nmax, ag)
     fs = ops.FusedState(plan, 1, A, "cuda", Nmax)
-    ops.fused_pack(plan, fs, x, Nmax, ag, cc)
+    ops.fused_pack(plan, fs, x, Nmax, ag, cc, ec=ec)
     tables = ops.fused_policy_prepare(plan, fs, dev(g["w_emb"]))
     choice = torch.empty((N, 1), dtype=torch.int32, device="cuda")
     lp, reward = torch.empty(1, device="cuda"), torch.empty(1, device="cuda")

@@ -22,6 +22,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -45,7 +46,8 @@ def per_kernel(dirname, counter):
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     per = {}
     for r in rows:
-        name = r["Kernel_Name"].split("(")[0].split()[-1]
+        m = re.search(r"\b(k_[A-Za-z0-9_]+)", r["Kernel_Name"])     # template kernels: "void k_fused_rows<4>(...)"
+        name = m.group(1) if m else r["Kernel_Name"].split("(")[0].split()[-1]
         per.setdefault(name, []).append(float(r["Counter_Value"]))
     return per
 

@@ -1,7 +1,10 @@
 #!/bin/bash
 # Developer tool: bench the fused path under different chunk knobs (each run is its own process: knobs are read once).
+# usage: tools/sweep_knobs.sh "TARL_NCHUNK=1 TARL_NCHUNK_DIR=2" "TARL_NCHUNK=4" ...
 cd "$(dirname "$0")/.."
-for kv in "TARL_NCHUNK_CHOICE=8" "TARL_NCHUNK_CHOICE=4" "TARL_NCHUNK_CHOICE=16" "TARL_NCHUNK_CHOICE=32" "TARL_NCHUNK_CHOICE=64" "TARL_NCHUNK=1" "TARL_NCHUNK=4" "TARL_NCHUNK_DIR=2"; do
-  v=$(env $kv python bench.py --steps 2 --warmup 1 --cpu-seconds 0 2>/dev/null | grep -o '"value": [0-9.]*' | head -1)
-  echo "$kv $v"
+for kv in "$@"; do
+  env $kv python bench.py --steps 3 --warmup 1 --cpu-seconds 0 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$kv', 'value %.3fM' % (d['value']/1e6), 'rows %.1f dir %.1f ic %.1f us' % (d['roofline']['avg_launch_us'], d['roofline_direction']['avg_launch_us'], d['roofline_insert_choice']['avg_launch_us']))"
 done
