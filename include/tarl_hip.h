@@ -37,6 +37,11 @@ typedef enum {
   TARL_ERR_UNSUPPORTED = -4
 } tarl_status;
 
+/* bits of a device status word (sticky; the caller reads it at its next synchronisation point) */
+#define TARL_FLAG_COUNT_AT_NMAX 1
+#define TARL_FLAG_AMBIGUOUS_EDGES 2
+#define TARL_FLAG_PACK_RANGE 4
+
 typedef struct tarl_plan tarl_plan; /* opaque static per-graph plan */
 typedef void* tarl_stream;          /* hipStream_t */
 
@@ -61,11 +66,13 @@ int tarl_plan_info(const tarl_plan* plan, int64_t* info6_host);
  *   (so the Gumbel scores are bit-identical to the reference's fp32 ones); congestion_constant [R] or NULL
  *   (then recomputed from x as src/simulation_core_model.py:55-67 does); gumbel [B][E] or NULL (device Philox);
  *   delta_travel_time [B][E] or NULL (side output, src/direction_mpnn.py:94-96); chosen [B][R] scratch/out.
- *   x is updated in place (every row, also when nothing was chosen). */
+ *   x is updated in place (every row, also when nothing was chosen).
+ *   status: int32[1] device status word or NULL: TARL_FLAG_COUNT_AT_NMAX is OR-ed in when a count reaches Nmax (a
+ *   gridlock-relief move into a full FIFO): the reference raises IndexError at its next update (:172-191). */
 int tarl_direction_step(const tarl_plan* plan, float* x, int64_t B, int64_t x_bstride, int64_t ldx, int32_t Nmax,
                         int64_t num_roads, const float* edge_attr, const float* log_edge_attr, float log_eps,
                         const float* congestion_constant, float time, const float* gumbel, uint64_t seed,
-                        uint64_t counter, float* delta_travel_time, float* chosen, tarl_stream stream);
+                        uint64_t counter, float* delta_travel_time, float* chosen, int32_t* status, tarl_stream stream);
 
 /* tarl_response_step == ResponseMPNN.forward: message + max-aggregate + update (src/response_mpnn.py:25-127).
  *   popped [B][R] uint8 out (the update mask appended to update_history, :125); any_popped: int32[1] or NULL,
@@ -78,7 +85,8 @@ int tarl_response_step(const tarl_plan* plan, float* x, int64_t B, int64_t x_bst
 int tarl_core_step(const tarl_plan* plan, float* x, int64_t B, int64_t x_bstride, int64_t ldx, int32_t Nmax,
                    int64_t num_roads, const float* edge_attr, const float* log_edge_attr, float log_eps,
                    const float* congestion_constant, float time, const float* gumbel, uint64_t seed, uint64_t counter,
-                   float* delta_travel_time, float* chosen, uint8_t* popped, int32_t* any_popped, tarl_stream stream);
+                   float* delta_travel_time, float* chosen, uint8_t* popped, int32_t* any_popped, int32_t* status,
+                   tarl_stream stream);
 
 /* ---- environment step around the core (src/reinforcement_learning.py:222-309, src/agents/base.py:244-403) -------
  * tarl_apply_action: x[b, src(e), SELECTED_ROAD] = dst(e) for every edge with action[b][e] != 0 (:223-231).
@@ -259,9 +267,6 @@ int tarl_value_mpnn_bwd(const tarl_plan* plan, const float* node_features, int64
  * pack and export the packed state is authoritative for the FIFO columns, NUMBER_OF_AGENT and SELECTED_ROAD;
  * tarl_fused_export writes them back into x in the reference's column layout, bit-identical to the unfused path.
  * agent_features is updated in place by every call. */
-#define TARL_FLAG_COUNT_AT_NMAX 1
-#define TARL_FLAG_AMBIGUOUS_EDGES 2
-#define TARL_FLAG_PACK_RANGE 4
 typedef struct tarl_fused {
   void* hdp;
   void* tl;

@@ -93,7 +93,8 @@ __global__ __launch_bounds__(SIM_BLOCK) void k_direction_gather(PlanView pv, con
 // ---- Direction: update (S5). Every row, also when nothing was chosen ----------------------------------
 __global__ __launch_bounds__(SIM_BLOCK) void k_direction_update(float* __restrict__ x, Layout L, int64_t B, int64_t R,
                                                                 const float* __restrict__ cong, float t,
-                                                                const float* __restrict__ chosen) {
+                                                                const float* __restrict__ chosen,
+                                                                int32_t* __restrict__ status) {
   const int64_t gid = (int64_t)blockIdx.x * SIM_BLOCK + threadIdx.x;
   if (gid >= B * R) return;
   const int64_t b = gid / R;
@@ -122,7 +123,12 @@ __global__ __launch_bounds__(SIM_BLOCK) void k_direction_update(float* __restric
   const float t_cong = c / (maxn + 10.0f - n0);
   const float tt = (t_cong != t_cong) ? t_cong : fmaxf(ff, t_cong);  // torch.maximum propagates NaN
   if (q >= 0 && 2 * Nmax + q < F) xi[2 * Nmax + q] = t + tt;
-  if (who != 0.0f) xi[L.col_n()] = xi[L.col_n()] + 1.0f;
+  if (who != 0.0f) {
+    const float n1 = xi[L.col_n()] + 1.0f;
+    xi[L.col_n()] = n1;
+    // a count that reaches Nmax leaves the reference's defined domain (its next update raises IndexError)
+    if (status && n1 >= (float)Nmax) atomicOr(status, TARL_FLAG_COUNT_AT_NMAX);
+  }
 }
 
 // ---- Response: message + max-aggregate (src-centric gather; S6-S8) -------------------------------------------------
@@ -255,7 +261,7 @@ static int check_state(const tarl_plan* plan, const float* x, int64_t B, int64_t
 extern "C" int tarl_direction_step(const tarl_plan* plan, float* x, int64_t B, int64_t x_bstride, int64_t ldx,
                                    int32_t Nmax, int64_t R, const float* edge_attr, const float* log_edge_attr,
                                    float log_eps, const float* cong, float time, const float* gumbel, uint64_t seed,
-                                   uint64_t counter, float* dtt, float* chosen, tarl_stream stream) {
+                                   uint64_t counter, float* dtt, float* chosen, int32_t* status, tarl_stream stream) {
   int rc = check_state(plan, x, B, x_bstride, ldx, Nmax, R);
   if (rc) return rc;
   TARL_REQUIRE(chosen != nullptr, "chosen scratch is null");
@@ -269,7 +275,7 @@ extern "C" int tarl_direction_step(const tarl_plan* plan, float* x, int64_t B, i
                      log_edge_attr, log_eps, time, gumbel, seed, counter, dtt, chosen);
   TARL_LAUNCH_CHECK();
   if (timed) (void)tarl_prof_mark(s, 1);
-  hipLaunchKernelGGL(k_direction_update, dim3(grid), dim3(SIM_BLOCK), 0, s, x, L, B, R, cong, time, chosen);
+  hipLaunchKernelGGL(k_direction_update, dim3(grid), dim3(SIM_BLOCK), 0, s, x, L, B, R, cong, time, chosen, status);
   TARL_LAUNCH_CHECK();
   return TARL_OK;
 }
@@ -294,9 +300,10 @@ extern "C" int tarl_response_step(const tarl_plan* plan, float* x, int64_t B, in
 extern "C" int tarl_core_step(const tarl_plan* plan, float* x, int64_t B, int64_t x_bstride, int64_t ldx, int32_t Nmax,
                               int64_t R, const float* edge_attr, const float* log_edge_attr, float log_eps,
                               const float* cong, float time, const float* gumbel, uint64_t seed, uint64_t counter,
-                              float* dtt, float* chosen, uint8_t* popped, int32_t* any_popped, tarl_stream stream) {
+                              float* dtt, float* chosen, uint8_t* popped, int32_t* any_popped, int32_t* status,
+                              tarl_stream stream) {
   int rc = tarl_direction_step(plan, x, B, x_bstride, ldx, Nmax, R, edge_attr, log_edge_attr, log_eps, cong, time,
-                               gumbel, seed, counter, dtt, chosen, stream);
+                               gumbel, seed, counter, dtt, chosen, status, stream);
   if (rc) return rc;
   return tarl_response_step(plan, x, B, x_bstride, ldx, Nmax, R, popped, any_popped, stream);
 }

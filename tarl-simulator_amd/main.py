@@ -40,12 +40,18 @@ def build_parser() -> argparse.ArgumentParser:
 
 
 def main(argv=None):
+    """Under ``torchrun --nproc-per-node N main.py --algo mpnn+ppo --mode train ...`` every rank joins the process group
+    (RCCL), binds its own GPU, trains on its own rollouts (engine seed + rank) with averaged gradients, and only rank 0
+    writes logs / checkpoints / metric tables."""
     ns = build_parser().parse_args(argv)
-    runner = Runner(RunnerArgs(**vars(ns)))
-    runner.setup()
-    if ns.mode == "train":
-        runner.train()
-    runner.eval()
+    runner = Runner(RunnerArgs(**vars(ns)))       # joins the process group when launched by torchrun
+    try:
+        runner.setup()
+        if ns.mode == "train":
+            runner.train()
+        runner.eval()
+    finally:
+        runner.close()
 
 
 if __name__ == "__main__":

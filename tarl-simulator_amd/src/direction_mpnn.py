@@ -24,6 +24,7 @@ class DirectionMPNN(MessagePassingBase, FeatureHelpers):
         self.noise_seed = None               # device Philox seed; None -> torch.initial_seed()
         self._noise_counter = 0
         self._uniform = None                 # one-shot injected noise (parity runs)
+        self._status = None                  # device status word: a count reached Nmax in an earlier forward
 
     def set_time(self, time):
         self.time = time
@@ -40,6 +41,13 @@ class DirectionMPNN(MessagePassingBase, FeatureHelpers):
         require_cuda(x, "x")
         plan = cached_plan(edge_index, x.size(0))
         ec = cached_edge_const(edge_attr, x.device)
+        # A gridlock-relief move into a full FIFO makes the reference's next update index past the row (IndexError,
+        # src/direction_mpnn.py:172-191); the kernel flags it on the device and the next forward raises the same error.
+        if self._status is None or self._status.device != x.device:
+            self._status = torch.zeros(1, dtype=torch.int32, device=x.device)
+        elif int(self._status.item()) != 0:
+            self._status.zero_()
+            raise IndexError("DirectionMPNN: a FIFO count reached Nmax (index out of range in the reference's update)")
         gumbel = None
         if self._uniform is not None:
             gumbel = ops.gumbel_from_uniform_cpu(self._uniform).to(x.device)
@@ -48,6 +56,6 @@ class DirectionMPNN(MessagePassingBase, FeatureHelpers):
         seed = torch.initial_seed() if self.noise_seed is None else self.noise_seed
         cc = None if congestion_constant is None else congestion_constant.to(torch.float32).contiguous()
         dtt, _ = ops.direction_step(plan, x, self.Nmax, ec, self.time, congestion_constant=cc, gumbel=gumbel,
-                                    seed=seed & 0x7FFFFFFFFFFFFFFF, counter=self._noise_counter)
+                                    seed=seed & 0x7FFFFFFFFFFFFFFF, counter=self._noise_counter, status=self._status)
         self.road_optimality_data = {"delta_travel_time": dtt.view(-1)}
         return x

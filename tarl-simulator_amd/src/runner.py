@@ -30,9 +30,26 @@ class RunnerArgs:
 class Runner:
     def __init__(self, args: RunnerArgs):
         self.args = args
+        # one process per GPU under torchrun: join the process group (backend nccl = RCCL) and bind this rank's device
+        # BEFORE any GPU work; a single process (WORLD_SIZE unset) skips all of it
+        from tarl_hip import dist_utils
+        self.rank, self.world, local = dist_utils.init_from_env()
         # the path runs on the GPU only: "cuda" on ROCm is the HIP device
-        self.device = torch.device("cuda" if torch.cuda.is_available() else args.device)
-        torch.manual_seed(args.seed)
+        if torch.cuda.is_available():
+            local = local % torch.cuda.device_count()
+            torch.cuda.set_device(local)
+            self.device = torch.device("cuda", local)
+        else:
+            self.device = torch.device(args.device)
+        torch.manual_seed(args.seed)          # identical initial weights on every rank (also broadcast by the trainer)
+
+    def close(self):
+        """Leave the process group (if this process joined one)."""
+        import torch.distributed as dist
+        from tarl_hip import dist_utils
+        if self.world > 1 and dist.is_initialized():
+            dist_utils.barrier()
+            dist.destroy_process_group()
 
     def setup(self):
         from .reinforcement_learning import SimulatorEnv
@@ -81,12 +98,21 @@ class Runner:
                                                       in_keys=["node_features", "edge_features", "agent_index", "time"],
                                                       out_keys=["value"]),
                                      in_keys=["node_features", "edge_features", "agent_index", "time"])
+        # the evaluation environment of the reference's Runner.train (src/runner.py:111-118): a second SimulatorEnv that
+        # shares the policy (= the population store)
+        from .reinforcement_learning import SimulatorEnv
+        eval_env = SimulatorEnv(device=str(self.device), timestep_size=a.timestep_size, start_time=a.start_end_time[0],
+                                scenario=a.scenario, torch_compile=a.torch_compile)
+        eval_env.simulator.agent = self.policy_net
         out = Path(a.output_dir)
-        out.mkdir(parents=True, exist_ok=True)
+        if self.rank == 0:
+            out.mkdir(parents=True, exist_ok=True)
+        # rank 0 alone writes the checkpoint and the logs; every rank takes part in the training collectives
         ppo_train(self.env, policy_module, value_module, total_frames=a.rollout_steps,
                   frames_per_batch=a.rollout_steps, num_epochs=a.epochs, device=self.device,
-                  checkpoint_path=out / "policy.pt", log_dir=str(out), eval_interval=1, num_envs=a.num_envs,
-                  seed=a.seed)
+                  checkpoint_path=(out / "policy.pt") if self.rank == 0 else None,
+                  log_dir=str(out) if self.rank == 0 else None, eval_env=eval_env, eval_interval=1,
+                  num_envs=a.num_envs, seed=a.seed)
 
     def eval(self):
         a = self.args
@@ -103,6 +129,8 @@ class Runner:
         tt = agent.agent_features[mask, agent.ARRIVAL_TIME] - agent.agent_features[mask, agent.DEPARTURE_TIME]
         avg = float(tt.mean()) if bool(mask.any()) else float("nan")
         total = sim.inserting_time + sim.choice_time + sim.core_time + sim.withdraw_time
+        if self.rank != 0:      # every rank evaluated its replica; one summary / one set of metric tables
+            return {"steps": n, "arrived": int(mask.sum()), "avg_travel_time": avg}
         print("\n=== Simulation Summary ===")
         print(f"{'Steps:':25} {n:10d}")
         print(f"{'Agents arrived:':25} {int(mask.sum()):10d}")

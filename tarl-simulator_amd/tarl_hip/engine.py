@@ -56,6 +56,7 @@ class SimEngine:
         self.reward = torch.zeros(self.B, dtype=torch.float32, device=self.device)
         self.counts = torch.zeros((self.B, self.N), dtype=torch.float32, device=self.device)
         self.dtt = None
+        self.status = torch.zeros(1, dtype=torch.int32, device=self.device)    # status word of the unfused kernels
         # fused fast path (csrc/fused.hip): packed hot records + agent SoA mirroring x / agents
         self.fs = ops.FusedState(self.plan, self.B, self.A, self.device, self.Nmax) if fused else None
         self.sample_counter = 0
@@ -117,7 +118,7 @@ class SimEngine:
         self.noise_counter += 1
         self.dtt, _ = ops.core_step(self.plan, self.x, self.Nmax, self.ec, t, congestion_constant=self.cc, gumbel=gumbel,
                                     seed=self.seed, counter=self.noise_counter, want_dtt=want_dtt, chosen=self.chosen,
-                                    popped=self.popped)
+                                    popped=self.popped, status=self.status)
         ops.withdraw_step(self.plan, self.x, self.Nmax, self.agents, t, want_mask=False)
         ops.insert_step(self.x, self.Nmax, self.agents, t, congestion_constant=self.cc, scratch=self.ins_scratch,
                         reward=self.reward, counts=self.counts)
@@ -131,6 +132,7 @@ class SimEngine:
 
     def check_flags(self):
         """Raise :class:`TarlError` if a kernel flagged a domain exit since the last pack (one host synchronisation)."""
+        ops.raise_on_flags(int(self.status.item()))
         if self.fs is not None:
             self.fs.check_flags()
 

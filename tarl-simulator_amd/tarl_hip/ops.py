@@ -110,7 +110,7 @@ def gumbel_from_uniform_cpu(u: torch.Tensor) -> torch.Tensor:
 
 
 def direction_step(plan: Plan, x, Nmax, ec: EdgeConst, t, *, congestion_constant=None, gumbel=None, seed=0, counter=0,
-                   want_dtt=True, chosen=None):
+                   want_dtt=True, chosen=None, status=None):
     """DirectionMPNN.forward on B environments. Returns (delta_travel_time (B,E) or None, chosen (B,R))."""
     L = _lib.load()
     B, R, bs, ldx = _state(x, Nmax)
@@ -129,7 +129,7 @@ def direction_step(plan: Plan, x, Nmax, ec: EdgeConst, t, *, congestion_constant
     _lib.check(L.tarl_direction_step(plan.handle, x.data_ptr(), B, bs, ldx, Nmax, R, ec.edge_attr.data_ptr(),
                                      ec.log_edge_attr.data_ptr(), ec.log_eps, _lib.ptr(congestion_constant), float(t),
                                      _lib.ptr(gumbel), int(seed), int(counter), _lib.ptr(dtt), chosen.data_ptr(),
-                                     _lib.current_stream()))
+                                     _lib.ptr(status), _lib.current_stream()))
     return dtt, chosen
 
 
@@ -145,7 +145,7 @@ def response_step(plan: Plan, x, Nmax, *, popped=None, any_flag=None):
 
 
 def core_step(plan: Plan, x, Nmax, ec: EdgeConst, t, *, congestion_constant=None, gumbel=None, seed=0, counter=0,
-              want_dtt=True, chosen=None, popped=None, any_flag=None):
+              want_dtt=True, chosen=None, popped=None, any_flag=None, status=None):
     """SimulationCoreModel.forward (both rounds). Returns (dtt or None, popped)."""
     L = _lib.load()
     B, R, bs, ldx = _state(x, Nmax)
@@ -160,7 +160,7 @@ def core_step(plan: Plan, x, Nmax, ec: EdgeConst, t, *, congestion_constant=None
     _lib.check(L.tarl_core_step(plan.handle, x.data_ptr(), B, bs, ldx, Nmax, R, ec.edge_attr.data_ptr(),
                                 ec.log_edge_attr.data_ptr(), ec.log_eps, _lib.ptr(congestion_constant), float(t),
                                 _lib.ptr(gumbel), int(seed), int(counter), _lib.ptr(dtt), chosen.data_ptr(),
-                                popped.data_ptr(), _lib.ptr(any_flag), _lib.current_stream()))
+                                popped.data_ptr(), _lib.ptr(any_flag), _lib.ptr(status), _lib.current_stream()))
     return dtt, popped
 
 
@@ -560,19 +560,23 @@ class FusedState:
 
     def check_flags(self):
         """Read the device status word (one host synchronisation) and raise on a domain exit."""
-        v = int(self.flags.item())
-        if v & _lib.FLAG_COUNT_AT_NMAX:
-            raise _lib.TarlError("a FIFO count reached Nmax: the state left the reference's defined domain (its "
-                                 "DirectionMPNN.update raises IndexError there, src/direction_mpnn.py:172-191)")
-        if v & _lib.FLAG_AMBIGUOUS_EDGES:
-            raise _lib.TarlError("two out-edges of one node lead to the same ROAD_INDEX: SELECTED_ROAD has no unique rank "
-                                 "on this graph; construct SimEngine(..., fused=False)")
-        if v & _lib.FLAG_PACK_RANGE:
-            raise _lib.TarlError("pack: a FIFO count above 255 or an agent id at / above 2^24 does not fit the packed words")
+        raise_on_flags(int(self.flags.item()))
 
     @property
     def ref(self):
         return C.byref(self.struct)
+
+
+def raise_on_flags(v: int):
+    """Turn the bits of a device status word (include/tarl_hip.h: TARL_FLAG_*) into a :class:`TarlError`."""
+    if v & _lib.FLAG_COUNT_AT_NMAX:
+        raise _lib.TarlError("a FIFO count reached Nmax: the state left the reference's defined domain (its "
+                             "DirectionMPNN.update raises IndexError there, src/direction_mpnn.py:172-191)")
+    if v & _lib.FLAG_AMBIGUOUS_EDGES:
+        raise _lib.TarlError("two out-edges of one node lead to the same ROAD_INDEX: SELECTED_ROAD has no unique rank "
+                             "on this graph; construct SimEngine(..., fused=False)")
+    if v & _lib.FLAG_PACK_RANGE:
+        raise _lib.TarlError("pack: a FIFO count above 255 or an agent id at / above 2^24 does not fit the packed words")
 
 
 def fused_pack(plan: Plan, fs: FusedState, x, Nmax, agent_features, congestion_constant=None, sort_agents=None, *,

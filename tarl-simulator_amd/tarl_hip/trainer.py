@@ -91,6 +91,8 @@ class VecPPOTrainer:
         self.seed = int(seed) + off
         self.sample_counter = 0
         self.last = {}
+        self.done_frames = torch.zeros(self.T, dtype=torch.bool)
+        self.done_mask = None
 
     # -- views of the live parameters -----------------------------------------------------------------------------------
     def _emb(self):
@@ -103,13 +105,18 @@ class VecPPOTrainer:
     # -- HOT LOOP A -------------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def collect(self):
-        """T frames for all B environments (SyncDataCollector with reset_at_each_iter=True, ExplorationType.RANDOM)."""
+        """T frames for all B environments (SyncDataCollector with reset_at_each_iter=True, ExplorationType.RANDOM).
+        An episode that ends inside the batch (clock past 7 h: ``done = terminated``, src/reinforcement_learning.py:273-276)
+        is followed by a reset, like the collector's auto-reset: the rollout is split at that frame, the reset observation
+        becomes the next frame's observation and ``done_frames`` marks the frame for GAE."""
+        from .engine import EPISODE_END
         eng = self.eng
         eng.reset()
         emb = self._emb()
-        host_times = []
+        T = self.T
+        host_times, done = [], [False] * T
         if eng.fs is not None:
-            # fused path: 4 launches per frame, every output lands directly in the rollout buffers (no copies)
+            # fused path: every output lands directly in the rollout buffers (no copies)
             self.counts[0].zero_()
             eng.prepare_policy(emb, self.temperature)      # once per parameter update, not per frame
             # sample_log_prob is only ever read for the <= sub_batch_size frames of each minibatch: keep the behaviour
@@ -117,33 +124,56 @@ class VecPPOTrainer:
             self.emb_rollout = emb.clone()
             self.poll_flags()
             run = eng.rollout_env if self.rollout == "env" else eng.rollout_fused
-            host_times = run(self.T, choice=self.choice, log_prob=None if self.lazy_log_prob else self.logp,
-                             reward=self.reward, counts=self.counts, metrics_envs=self.metrics_envs,
-                             dtt_node=self.dtt_node, events=self.events, leg=self.leg, check=False)
+            t = 0
+            while t < T:
+                # frames until the episode ends (the frame whose step pushes the clock past EPISODE_END is the last)
+                left = (EPISODE_END - eng.time) // eng.timestep + 1
+                n = int(min(T - t, max(1, left)))
+                sl = slice(t, t + n)
+                host_times += run(n, choice=self.choice[sl], log_prob=None if self.lazy_log_prob else self.logp[sl],
+                                  reward=self.reward[sl], counts=self.counts[t:t + n + 1],
+                                  metrics_envs=self.metrics_envs,
+                                  dtt_node=None if self.dtt_node is None else self.dtt_node[sl],
+                                  events=None if self.events is None else self.events[sl], leg=self.leg[sl],
+                                  check=False)[:-1]
+                t += n
+                if eng.time > EPISODE_END:
+                    done[t - 1] = True
+                    if t < T:
+                        eng.reset()
+                        self.counts[t].zero_()         # the reset observation is frame t's observation
+            host_times.append(float(eng.time))
             # the device status word travels to pinned host memory behind the rollout; it is looked at when it has
             # arrived (no stall of the launch pipeline) and by check_flags() at the caller's synchronisation points
             self._flag_host.copy_(eng.fs.flags, non_blocking=True)
             self._flag_event = torch.cuda.Event()
             self._flag_event.record()
-            self.times.copy_(torch.tensor(host_times, dtype=torch.float32))
-            return self.T * eng.B
-        for t in range(self.T):
-            self.counts[t].copy_(eng.counts)
+        else:
+            for t in range(T):
+                self.counts[t].copy_(eng.counts)
+                host_times.append(float(eng.time))
+                logits = ops.policy_edge_logits(eng.plan, eng.node_features, emb)
+                proba = ops.graphdist_softmax(eng.plan, logits, self.temperature)
+                self.sample_counter += 1
+                _, choice = ops.graphdist_sample(eng.plan, proba, seed=self.seed ^ 0x5DEECE66D,
+                                                 counter=self.sample_counter, want_onehot=False, want_choice=True)
+                lp, _ = ops.graphdist_logprob_entropy(eng.plan, proba, choice=choice, want_entropy=False)
+                self.choice[t].copy_(choice)
+                self.logp[t].copy_(lp)
+                reward, is_done = eng.step(choice=choice)
+                self.reward[t].copy_(reward)
+                if is_done:
+                    done[t] = True
+                    if t + 1 < T:
+                        eng.reset()
+            self.counts[T].copy_(eng.counts)
             host_times.append(float(eng.time))
-            logits = ops.policy_edge_logits(eng.plan, eng.node_features, emb)
-            proba = ops.graphdist_softmax(eng.plan, logits, self.temperature)
-            self.sample_counter += 1
-            _, choice = ops.graphdist_sample(eng.plan, proba, seed=self.seed ^ 0x5DEECE66D, counter=self.sample_counter,
-                                             want_onehot=False, want_choice=True)
-            lp, _ = ops.graphdist_logprob_entropy(eng.plan, proba, choice=choice, want_entropy=False)
-            self.choice[t].copy_(choice)
-            self.logp[t].copy_(lp)
-            reward, _done = eng.step(choice=choice)
-            self.reward[t].copy_(reward)
-        self.counts[self.T].copy_(eng.counts)
-        host_times.append(float(eng.time))
         self.times.copy_(torch.tensor(host_times, dtype=torch.float32))
-        return self.T * eng.B
+        self.done_frames = torch.tensor(done, dtype=torch.bool)
+        # (T, B) mask for tarl_gae, only when an episode actually ended inside the batch
+        self.done_mask = (self.done_frames.to(eng.device, torch.uint8).view(T, 1).expand(T, eng.B).contiguous()
+                          if any(done) else None)
+        return T * eng.B
 
     def poll_flags(self):
         """Raise if a finished rollout flagged a domain exit (non-blocking)."""
@@ -171,7 +201,9 @@ class VecPPOTrainer:
         else:
             v, _, _ = ops.critic_forward(cw, self.counts.view((T + 1) * B, N), self.times, rows_per_time=B)
         self.values = v.view(T + 1, B)
-        adv, target = ops.gae(self.reward, self.values[:T], self.values[1:], gamma=self.gamma, lmbda=self.lmbda)
+        # done = terminated (src/reinforcement_learning.py:296): no bootstrap across an episode end
+        adv, target = ops.gae(self.reward, self.values[:T], self.values[1:], done=self.done_mask,
+                              terminated=self.done_mask, gamma=self.gamma, lmbda=self.lmbda)
         stats = ops.advantage_stats(adv)
         dist_utils.allreduce_sum_(stats)          # global mean / std over all ranks' frames
         ops.advantage_normalize_(adv, stats)

@@ -104,3 +104,47 @@ def test_ranks_with_their_own_rollouts_average_gradients():
     assert not torch.equal(a0, a1)                               # different rollouts, normalised with GLOBAL statistics
     both = torch.cat([a0.view(-1), a1.view(-1)]).double()
     assert abs(float(both.mean())) < 1e-4 and abs(float(both.std()) - 1.0) < 1e-3
+
+
+def _main_worker(rank, world, port, out_dir, q):
+    import sys
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", TARL_DIST_BACKEND="gloo")
+    os.chdir(out_dir)
+    import importlib
+    main = importlib.import_module("main").main
+    from src.rl.ppo_trainer import ppo_train
+    main(["--algo", "mpnn+ppo", "--mode", "train", "--scenario", "synthetic-1024-1024", "--rollout-steps", "32",
+          "--epochs", "2", "--steps", "5", "--num-envs", "4", "--output-dir", os.path.join(out_dir, "run"), "--seed", "2"])
+    tr = ppo_train.last_trainer
+    import torch.distributed as dist
+    # numpy arrays pickle by value (torch tensors travel as file descriptors that die with this process)
+    q.put((rank, tr.world, tr.flat.flat.detach().cpu().numpy(), tr.reward.cpu().numpy(), tr.choice.cpu().numpy(),
+           dist.is_initialized()))
+
+
+def test_main_under_torchrun_trains_data_parallel(tmp_path):
+    """`torchrun --nproc-per-node 2 main.py --algo mpnn+ppo --mode train` (2 ranks, here sharing the card over gloo): the
+    ranks join the process group, roll out DIFFERENT trajectories, apply the same averaged update (identical weights), only
+    rank 0 writes the checkpoint / logs, and the group is torn down at exit."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_main_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, w0, f0, r0, c0, init0), (_, w1, f1, r1, c1, init1) = res
+    assert w0 == w1 == 2 and not init0 and not init1            # joined, and left again in main()'s finally
+    assert (f0 == f1).all()                                        # replicas stay identical
+    assert (c0 != c1).any()                                        # but every rank rolled out its own trajectories
+    import json
+    logs = [json.loads(l) for l in open(tmp_path / "run" / "train_log.jsonl")]
+    assert len(logs) == 1                                          # one writer
+    assert (tmp_path / "run" / "policy.pt").exists()

@@ -226,11 +226,27 @@ def test_ppo_train_and_runner_end_to_end(tmp_path, monkeypatch, capsys):
     assert any(k.endswith("nodes_embedding.weight") for k in ckpt) and any("edge_mlp.0.weight" in k for k in ckpt)
     import json
     logs = [json.loads(l) for l in open(tmp_path / "run" / "train_log.jsonl")]
-    assert logs and all(math.isfinite(v) for v in logs[-1].values())
+    assert logs and all(math.isfinite(v) for v in logs[-1].values() if not isinstance(v, list))
     for tag in ("PPO/avg_episode_return", "loss/objective", "loss/value", "loss/entropy", "loss/total", "approx_kl",
                 "clip_fraction", "grad_global_norm", "transport/avg_vc_ratio", "transport/std_vc_ratio"):
         assert tag in logs[-1], tag                       # the scalar tags of the reference's _log_training (:60-88)
     assert logs[-1]["grad_global_norm"] > 0
+    # periodic evaluation (reference src/rl/ppo_trainer.py:89-127,147-151): MODE rollout on the eval environment
+    for tag in ("eval/avg_return", "eval/episode_len", "eval/computation_time_ms", "eval/nodes_metrics/avg_vc",
+                "eval/nodes_metrics/std_vc", "eval/leg_histogram"):
+        assert tag in logs[-1], tag
+    assert logs[-1]["eval/episode_len"] == 48 and logs[-1]["eval/avg_return"] <= 0
+    assert len(logs[-1]["eval/nodes_metrics/avg_vc"]) == r.policy_net.num_nodes
+    from src.reinforcement_learning import GraphDistribution
+    from src.rl.ppo_trainer import ppo_train
+    frames = ppo_train.last_eval["eval"]
+    assert len(frames) == 48
+    for td in (frames[0], frames[-1]):      # ExplorationType.MODE: the action IS GraphDistribution.mode
+        mode = GraphDistribution(td["logits"], r.policy_net.edge_index).mode
+        assert torch.equal(td["action"], mode.to(torch.int64)) and int(td["action"].sum()) == r.policy_net.num_nodes
+    # the checkpoint: torchrl's key names, parameters only (not the flat training buffer they are views of)
+    assert "module.0.module.nodes_embedding.weight" in ckpt
+    assert ckpt["module.0.module.nodes_embedding.weight"].untyped_storage().nbytes() == 4 * r.policy_net.num_nodes
     torch.manual_seed(1)
     from src.agents.mpnn_agent import MPNNPolicyNet
     fresh = MPNNPolicyNet(r.policy_net.edge_index, r.policy_net.num_nodes, None, device="cuda")

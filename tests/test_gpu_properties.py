@@ -90,3 +90,50 @@ def test_full_size_both_rollout_kernels_agree():
         assert torch.equal(u, v), what
     assert torch.equal(e1.x, e2.x) and torch.equal(e1.agents, e2.agents)
     _check_invariants(net, e2, b[2], b[3])
+
+
+def _gridlocked_engine(fused):
+    """Every FIFO full (count == MAX == Nmax - 1) with an overdue head: the gridlock-relief rule (src/direction_mpnn.py:87-89)
+    moves heads into full rows, so counts reach Nmax in the first frame — outside the reference's defined domain."""
+    from tarl_hip import synth
+    from tarl_hip.engine import SimEngine
+    net = synth.torus_network(2, 2)
+    N, Nmax = net.num_roads, net.Nmax
+    x = net.x.clone()
+    ids = torch.arange(1, N * (Nmax - 1) + 1, dtype=torch.float32).view(N, Nmax - 1)
+    x[:, :Nmax - 1] = ids
+    x[:, Nmax:2 * Nmax - 1] = 100.0            # arrivals
+    x[:, 2 * Nmax:3 * Nmax - 1] = 200.0        # departures: long overdue at the episode clock
+    x[:, 3 * Nmax + 1] = Nmax - 1
+    ag = synth.population(N * (Nmax - 1), N, seed=0)
+    ag[1:, 7] = 1.0                            # everybody is on the way
+    eng = SimEngine(x.cuda().unsqueeze(0).contiguous(), net.edge_index, net.edge_attr, Nmax, ag.cuda().unsqueeze(0),
+                    congestion_constant=net.congestion_constant, seed=1, fused=fused)
+    if fused:
+        eng.prepare_policy(torch.zeros(N, device="cuda"))
+    return eng
+
+
+@pytest.mark.parametrize("mode", ["frames", "env", "frame_api", "unfused"])
+def test_count_reaching_nmax_is_flagged_and_raises(mode):
+    """The reference raises IndexError when a count reaches Nmax (DESIGN Q25); every kernel family sets the device status
+    word and the host raises TarlError when it reads it."""
+    from tarl_hip import lib, ops
+    eng = _gridlocked_engine(mode != "unfused")
+    N, B, T = eng.N, 1, 3
+    if mode == "unfused":
+        p = ops.graphdist_softmax(eng.plan, torch.zeros((1, eng.E), device="cuda"))
+        _, ch = ops.graphdist_sample(eng.plan, p, seed=1, counter=1, want_onehot=False, want_choice=True)
+        eng.step(choice=ch)
+    elif mode == "frame_api":
+        eng.frame_fused()
+    else:
+        shp = (lambda t: (t, N, B)) if mode == "frames" else (lambda t: (t, B, N))
+        ch, ct = torch.zeros(shp(T), dtype=torch.uint8, device="cuda"), torch.zeros(shp(T + 1), dtype=torch.uint8, device="cuda")
+        rw = torch.zeros((T, B), device="cuda")
+        run = eng.rollout_fused if mode == "frames" else eng.rollout_env
+        with pytest.raises(lib.TarlError, match="reached Nmax"):
+            run(T, choice=ch, log_prob=None, reward=rw, counts=ct)
+        return
+    with pytest.raises(lib.TarlError, match="reached Nmax"):
+        eng.check_flags()

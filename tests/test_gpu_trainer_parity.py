@@ -15,9 +15,14 @@ def close(a, b, what):
     assert err <= TOL * scale, f"{what}: max abs err {err:.3e} vs scale {scale:.3e}"
 
 
-@pytest.mark.parametrize("fused,lazy,rollout", [(True, False, "frames"), (True, True, "frames"), (True, False, "env"),
-                                                (True, True, "env"), (False, False, None)])
-def test_ppo_update_matches_oracle_autograd(fused, lazy, rollout):
+@pytest.mark.parametrize("fused,lazy,rollout,timestep", [(True, False, "frames", 1), (True, True, "frames", 1),
+                                                         (True, False, "env", 1), (True, True, "env", 1),
+                                                         (False, False, None, 1),
+                                                         # 300-s steps: the episode ends at frame 13 of 24 -> reset inside
+                                                         # the batch, done / terminated masks in GAE
+                                                         (True, False, "frames", 300), (True, False, "env", 300),
+                                                         (False, False, None, 300)])
+def test_ppo_update_matches_oracle_autograd(fused, lazy, rollout, timestep):
     assert torch.cuda.is_available()
     from oracle import dist, nets, ppo
     from src.agents.mpnn_agent import MPNNPolicyNet, MPNNValueNetSimple
@@ -30,7 +35,7 @@ def test_ppo_update_matches_oracle_autograd(fused, lazy, rollout):
     B, A, T, M = 128 if fused else 5, 300, 24, 16
     pops = torch.stack([synth.population(A, N, seed=b, t0=21540, t1=21555) for b in range(B)])
     eng = SimEngine(net.x.cuda().unsqueeze(0).repeat(B, 1, 1).contiguous(), net.edge_index, net.edge_attr, net.Nmax,
-                    pops.cuda(), congestion_constant=net.congestion_constant, seed=3, fused=fused)
+                    pops.cuda(), congestion_constant=net.congestion_constant, seed=3, fused=fused, timestep=timestep)
     torch.manual_seed(0)
     pol = MPNNPolicyNet(net.edge_index, N, None, device="cuda")
     val = MPNNValueNetSimple(net.edge_index, N, device="cuda")
@@ -42,6 +47,11 @@ def test_ppo_update_matches_oracle_autograd(fused, lazy, rollout):
     assert tr.rollout == (rollout or "unfused")
     tr.keep_grad = True
     tr.collect()
+    done_t = tr.done_frames
+    assert done_t.tolist() == [timestep == 300 and t == 12 for t in range(T)]
+    if timestep == 300:     # the frame after the episode end observes the reset state at the reset clock
+        assert float(tr.times[13]) == 21540.0 and float(tr.times[12]) == 21540.0 + 12 * 300
+        assert int(tr.counts[13].sum()) == 0
     # ---- snapshot everything the update reads (CPU copies, reference (frame, env, node) order) ----
     emb0 = pol.nodes_embedding.weight.detach().cpu().clone()
     crit0 = [p.detach().cpu().clone() for p in crit]
@@ -63,8 +73,8 @@ def test_ppo_update_matches_oracle_autograd(fused, lazy, rollout):
     nf_all[..., 6] = torch.arange(N, dtype=torch.float32)
     with torch.no_grad():
         v_all = nets.critic_value(nf_all, times.view(T + 1, 1, 1).expand(T + 1, B, 1), *cw).squeeze(-1)   # (T+1, B)
-        nodone = torch.zeros((T, B), dtype=torch.bool)
-        adv, tgt = ppo.gae(reward, v_all[:T], v_all[1:], nodone, nodone, average_gae=True)
+        dmask = done_t.view(T, 1).expand(T, B)
+        adv, tgt = ppo.gae(reward, v_all[:T], v_all[1:], dmask, dmask, average_gae=True)
     close(adv_g.cpu(), adv, "advantage")
     close(tgt_g.cpu(), tgt, "value_target")
     t_idx, b_idx = idx // B, idx % B
