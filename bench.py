@@ -79,6 +79,16 @@ def parse():
     ap.add_argument("--epochs", type=int, default=1)
     ap.add_argument("--sub-batch", type=int, default=32)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--departure-window", type=int, default=0,
+                    help="seconds after the episode start within which ALL agents depart (0 = the whole 61-minute episode, "
+                         "BASELINE's workload; e.g. 600 = the congested regime: the network fills up inside the rollout)")
+    ap.add_argument("--congested-window", type=int, default=600,
+                    help="also time --congested-steps iterations with every agent departing within this many seconds "
+                         "(0 = skip); reported under congested_regime")
+    ap.add_argument("--congested-steps", type=int, default=2)
+    ap.add_argument("--metrics-envs", type=int, default=1,
+                    help="environments that keep the per-node logs of SimulatorEnv._step (delta_travel_time, pop / withdraw "
+                         "masks); the per-frame leg histogram is kept for all of them")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="do not bracket the Direction kernel with HIP events (lets small batches use the graph replay)")
@@ -94,10 +104,11 @@ def build_trainer(args, rank, device):
     W, H = synth.torus_for_edges(args.edges)
     net = synth.torus_network(W, H)
     N = net.num_roads
-    # every environment of every rank gets its own population (seed + rank, env index)
-    pops = torch.stack([synth.population(args.agents, N, seed=args.seed + 1000 * rank + b) for b in range(args.envs)])
+    # every environment of every rank gets its own population, drawn on the device (seed + rank)
+    pops = synth.population_batch(args.agents, N, args.envs, seed=args.seed + 1000 * rank, device=device,
+                                  t1=args.departure_window + synth.EPISODE_START if args.departure_window else synth.EPISODE_END)
     engine = SimEngine(net.x.to(device).unsqueeze(0).repeat(args.envs, 1, 1).contiguous(), net.edge_index,
-                       net.edge_attr, net.Nmax, pops.to(device), congestion_constant=net.congestion_constant,
+                       net.edge_attr, net.Nmax, pops, congestion_constant=net.congestion_constant,
                        device=device, seed=args.seed + rank)
     torch.manual_seed(args.seed)       # identical initial weights on every rank (also broadcast by the trainer)
     ff = net.x[:, 3 * net.Nmax + 2][net.edge_index[1]]
@@ -108,7 +119,7 @@ def build_trainer(args, rank, device):
     trainer = VecPPOTrainer(engine, pol.nodes_embedding.weight,
                             [l[0].weight, l[0].bias, l[2].weight, l[2].bias, l[4].weight, l[4].bias],
                             rollout_steps=args.rollout_steps, num_epochs=args.epochs, sub_batch_size=args.sub_batch,
-                            extra_params=dormant, seed=args.seed)
+                            extra_params=dormant, seed=args.seed, metrics_envs=args.metrics_envs)
     return net, engine, trainer
 
 
@@ -189,6 +200,36 @@ def main():
     late0 = LATE_FRAME if T > LATE_FRAME else 0
     lib.check(L.tarl_prof_collect(late0, ms_all, ms_late, nfr))
     L.tarl_prof_enable(0)
+    trainer.check_flags()
+
+    # ---- second line of evidence: the congested regime -------------------------------------------------------------------
+    # The headline workload spreads the departures over the 61-minute episode (BASELINE config), so the 256 timed frames see
+    # a filling network. Here every agent departs within --congested-window seconds: the FIFOs fill up, most rows pop /
+    # withdraw / enqueue in every frame. Same engine, same kernels, populations re-drawn and re-packed.
+    congested = None
+    if args.congested_window > 0 and not args.departure_window:
+        from tarl_hip import synth
+        engine.agents.copy_(synth.population_batch(args.agents, engine.N, B, seed=args.seed + 1000 * rank + 17,
+                                                   device=device, t1=synth.EPISODE_START + args.congested_window))
+        engine.fs.order_valid = False
+        engine._packed_stale = True
+        trainer.train_iteration()                       # warm-up (re-pack, re-sort)
+        dist_utils.barrier()
+        torch.cuda.synchronize()
+        t1_ = time.perf_counter()
+        cf = 0
+        for _ in range(args.congested_steps):
+            cf += trainer.train_iteration()
+        torch.cuda.synchronize()
+        dist_utils.barrier()
+        cel = dist_utils.allreduce_max_float(time.perf_counter() - t1_, device)
+        trainer.check_flags()
+        on_way = float(engine.agents[:, :, 7].sum()) / B
+        arrived = float(engine.agents[:, :, 8].sum()) / B
+        congested = {"value": cf * world / cel, "unit": "env-steps/s", "steps": args.congested_steps,
+                     "ms_per_step": cel / args.congested_steps * 1e3, "departure_window_s": args.congested_window,
+                     "agents_on_the_way_at_the_end_per_env": on_way, "agents_arrived_per_env": arrived,
+                     "note": "all agents depart within the window: the network is loaded for most of the rollout"}
 
     if rank == 0:
         total_frames = frames * world
@@ -244,6 +285,7 @@ def main():
             "msgpass_pair_edges_per_sec": (B * E) / (dir_s + rows_s) if (dir_s + rows_s) > 0 else None,
             "roofline": rf_rows, "roofline_direction": rf_dir, "roofline_insert_choice": rf_ic,
             "setup_seconds": setup_s, "timed_seconds": elapsed,
+            "congested_regime": congested,
         }
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args, net)

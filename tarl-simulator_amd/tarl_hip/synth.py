@@ -97,6 +97,22 @@ def population(num_agents: int, num_roads: int, *, seed: int = 0, t0: int = EPIS
     return a
 
 
+def population_batch(num_agents: int, num_roads: int, num_envs: int, *, seed: int = 0, device="cuda",
+                     t0: int = EPISODE_START, t1: int = EPISODE_END, dummy_departure: float = 48 * 3600.0) -> torch.Tensor:
+    """``num_envs`` independent populations ``(B, num_agents + 1, 9)`` drawn directly on ``device`` from one seeded device
+    generator (same distributions as :func:`population`): set-up takes milliseconds instead of a host loop over the
+    environments, which matters when 8 ranks share the host cores."""
+    dev = torch.device(device)
+    g = torch.Generator(device=dev).manual_seed(int(seed))
+    a = torch.zeros((num_envs, num_agents + 1, 9), dtype=torch.float32, device=dev)
+    shape = (num_envs, num_agents)
+    a[:, 1:, 0] = torch.randint(0, num_roads, shape, generator=g, device=dev).float()
+    a[:, 1:, 1] = torch.randint(0, num_roads, shape, generator=g, device=dev).float()
+    a[:, 1:, 2] = torch.randint(t0, t1 + 1, shape, generator=g, device=dev).float()
+    a[:, 0, 2] = dummy_departure
+    return a
+
+
 def random_state(net: SynthNetwork, *, seed: int = 0, t: float = 100.0, fill: float = 0.5,
                  num_agents: int | None = None) -> torch.Tensor:
     """A random but *consistent* mid-simulation state for kernel parity tests: FIFO prefixes hold distinct agent ids,

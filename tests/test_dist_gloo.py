@@ -43,6 +43,31 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def test_eight_rank_exchange():
+    """The 8-GPU job's exchange pattern (one rank per GPU), rehearsed on the CPU: gradient all-reduce of pre-scaled seeds =
+    the mean over 8 ranks, identical on every rank; global advantage statistics; rank 0's weights everywhere; max-reduce."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    ref = torch.stack([torch.randn(1000, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]).mean(0)
+    allv = torch.cat([r[3] for r in res]).double()
+    for _, g, s_, _, w, m in res:
+        assert torch.equal(g, res[0][1]) and torch.allclose(g, ref, atol=1e-6)
+        assert torch.equal(s_, res[0][2]) and torch.equal(w, torch.zeros(5)) and m == float(world)
+    s0 = res[0][2]
+    cnt, mean = s0[2], s0[0] / s0[2]
+    std = torch.sqrt((s0[1] - cnt * mean * mean) / (cnt - 1))
+    assert int(cnt) == 257 * world and abs(mean - allv.mean()) < 1e-9 and abs(std - allv.std()) < 1e-9
+
+
 def test_two_rank_exchange_matches_single_process():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

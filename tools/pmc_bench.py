@@ -6,9 +6,9 @@ MI355X_MICROARCH.md's HBM / rocprofv3 section prescribes):
 
   cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_f -o run -- \
-      python3 bench.py --steps 1 --warmup 1 --cpu-seconds 0 --no-kernel-timing
+      python3 bench.py --steps 1 --warmup 1 --cpu-seconds 0 --congested-window 0 --no-kernel-timing
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_w -o run -- \
-      python3 bench.py --steps 1 --warmup 1 --cpu-seconds 0 --no-kernel-timing
+      python3 bench.py --steps 1 --warmup 1 --cpu-seconds 0 --congested-window 0 --no-kernel-timing
   python3 tools/pmc_bench.py gpurun_out/pmc_f gpurun_out/pmc_w --out profiles/r02_pmc_traffic.json
 
 Reduction: for every rollout kernel the launches of the LAST iteration's frames >= --first-frame (default 200: the
@@ -75,7 +75,7 @@ def main():
     w = per_kernel(a.write_dir, "WRITE_SIZE")
     T = a.rollout_steps
     out = {"note": ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) of "
-                    "`python3 bench.py --steps 1 --warmup 1 --cpu-seconds 0 --no-kernel-timing`; counters are KiB; "
+                    "`python3 bench.py --steps 1 --warmup 1 --cpu-seconds 0 --congested-window 0 --no-kernel-timing`; counters are KiB; "
                     "hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B); "
                     f"mean over the last iteration's frames >= {a.first_frame}. " + a.note).strip(),
            "config": {"edges": a.edges, "agents": a.agents, "envs": a.envs, "rollout_steps": T},
