@@ -155,6 +155,30 @@ int tarl_policy_edge_logits_bwd(const tarl_plan* plan, const float* road_index, 
                                 int64_t ri_nstride, int64_t B, const float* grad_logits, float* grad_emb,
                                 int64_t num_embeddings, tarl_stream stream);
 
+/* ---- the per-edge MLP head of MPNNPolicyNet (src/agents/mpnn_agent.py:35-41; evaluation spelled out at :227-231) -----
+ * logits[m][e] = W3 relu(W2 relu(W1 cat(x[m][src(e)], x[m][dst(e)], edge_attr[e]) + b1) + b2) + b3, 33 -> 64 -> 32 -> 1,
+ * weights in the reference's state-dict layout (edge_mlp.{0,2,4}.{weight,bias}: w1 [64][33], w2 [32][64], w3 [32]).
+ * obs16 [M][N][16] = x = cat(node_features (7), agent_features[agent_index] (9)) per node (:166-178), built by
+ *   tarl_policy_obs16 (from the reference's observation tensors: node_features [M][N][>=7] with row stride nf_ld,
+ *   agent_index int64 [M][N], agent_features [A][9] shared (a_mstride = 0) or per sample) or by tarl_fused_obs16 (from the
+ *   packed state of the fused engine, environment b = sample m; x supplies the static LENGTH / MAX_FLOW columns).
+ * precision 0: fp32 MFMA (v_mfma_f32_32x32x2_f32; exact fp32 products); 1: bf16 MFMA (v_mfma_f32_32x32x16_bf16; inputs,
+ *   weights and the first hidden activation rounded to bf16, fp32 accumulation) — BASELINE config 5's bf16 features.
+ * tarl_policy_edge_mlp_bwd ACCUMULATES (+=) the gradients of sum(grad_logits * logits) into gw1 [64][33], gb1 [64],
+ *   gw2 [32][64], gb2 [32], gw3 [32], gb3 [1] (fp32, fixed reduction order); scratch: fp32
+ *   [tarl_policy_edge_mlp_bwd_scratch_floats(plan, M)]. Observations receive no gradient. */
+int tarl_policy_obs16(const float* node_features, int64_t nf_ld, const int64_t* agent_index,
+                      const float* agent_features, int64_t num_agents, int64_t a_mstride, int64_t M, int64_t num_nodes,
+                      float* obs16, tarl_stream stream);
+int tarl_policy_edge_mlp_fwd(const tarl_plan* plan, const float* obs16, int64_t M, const float* edge_attr,
+                             const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                             const float* b3, int precision, float* logits, tarl_stream stream);
+int64_t tarl_policy_edge_mlp_bwd_scratch_floats(const tarl_plan* plan, int64_t M);
+int tarl_policy_edge_mlp_bwd(const tarl_plan* plan, const float* obs16, int64_t M, const float* edge_attr,
+                             const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                             const float* b3, const float* grad_logits, float* scratch, float* gw1, float* gb1,
+                             float* gw2, float* gb2, float* gw3, float* gb3, tarl_stream stream);
+
 /* tarl_critic_mlp_fwd == MPNNValueNetSimple.forward (:428-450): value = W3 relu(W2 relu(W1 [counts, time] + b1) + b2) + b3
  *   with the reference's state-dict layout: w1 [64][N+1] (last input column = time), w2 [64][64], w3 [64] (= [1][64]).
  *   counts [M][ldc] = the NUMBER_OF_AGENT observation column per node (row stride ldc >= N); time_rows[m / rows_per_time]
@@ -363,6 +387,11 @@ int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, int64_t B, in
                        uint8_t* sel_scratch, int64_t* acc_scratch, uint8_t* choice, float* log_prob, float* entropy,
                        float* reward, uint8_t* counts, int32_t metrics_envs, float* dtt_node, uint8_t* events,
                        int32_t* leg, tarl_stream stream);
+
+/* x = cat(node_features, agent_features[head of the FIFO]) [B][N][16] of the packed state (see tarl_policy_obs16) */
+int tarl_fused_obs16(const tarl_plan* plan, const tarl_fused* f, const float* x, int64_t B, int64_t x_bstride,
+                     int64_t ldx, int32_t Nmax, const float* agent_features, int64_t num_agents, int64_t a_bstride,
+                     float* obs16, tarl_stream stream);
 
 /* tarl_rollout_env == tarl_fused_rollout with the other mapping: ONE workgroup per environment keeps that environment's
  *   hot records and static columns in LDS (56 B per road + 16 KB; tarl_rollout_env_supported(plan) tells whether the

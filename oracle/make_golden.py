@@ -337,6 +337,51 @@ def gen_nets():
          **{k.replace(".", "__"): v for k, v in sd.items()})
 
 
+def gen_edge_mlp():
+    """The per-edge MLP head MPNNPolicyNet carries as parameters (src/agents/mpnn_agent.py:35-41), evaluated the way the
+    commented lines of its update_edges specify (:227-231) on x = cat(node_features, agent_features[agent_index])
+    (:166-178): the reference's own module (its own U(-0.1, 0.1) weights and zero biases), a second copy of it with
+    non-zero biases, unbatched and batched inputs, and the parameter gradients of sum(coef * logits) by autograd."""
+    from src.agents.mpnn_agent import MPNNPolicyNet
+    net = synth.torus_network(3, 3, heterogeneous=True, seed=6)
+    R, E = net.num_roads, net.edge_index.size(1)
+    ff = net.x[:, 3 * net.Nmax + 2][net.edge_index[1]]
+    torch.manual_seed(21)
+    pol = MPNNPolicyNet(net.edge_index, R, ff, device="cpu")
+    pol.agent_features = synth.population(60, R, seed=3)
+    pol.agent_features[1:, 3] = torch.rand(60, generator=torch.Generator().manual_seed(4)) * 50.0   # arrival times
+    pol.agent_features[1:, 7] = (torch.rand(60, generator=torch.Generator().manual_seed(5)) < 0.5).float()
+    rec = dict(edge_index=net.edge_index, edge_attr=net.edge_attr, agent_features=pol.agent_features.clone())
+    g = torch.Generator().manual_seed(8)
+    nfs, ais = [], []
+    for b in range(3):
+        x = synth.random_state(net, seed=30 + b, t=30.0, num_agents=60)
+        nfs.append(x[:, 3 * net.Nmax:].clone())
+        ais.append(x[:, 0].long().clamp(max=60))
+    nf, ai = torch.stack(nfs), torch.stack(ais)                                  # (3, R, 7), (3, R)
+    coef = torch.randn((3, E), generator=g)
+    for tag, biased in (("ref", False), ("biased", True)):
+        mlp = pol.edge_mlp
+        if biased:
+            with torch.no_grad():
+                for lin in (mlp[0], mlp[2], mlp[4]):
+                    lin.bias.copy_(torch.randn(lin.bias.shape, generator=g) * 0.1)
+        for p_ in mlp.parameters():
+            p_.grad = None
+        x16 = torch.cat((nf, pol.agent_features[ai]), dim=-1)                    # (:177-178), batched
+        ei = net.edge_index
+        e_ij = torch.cat([x16[:, ei[0]], x16[:, ei[1]], net.edge_attr.expand(3, -1, -1)], dim=-1)   # (:228-230)
+        logits = mlp(e_ij).squeeze(-1)                                           # (:231) -> (3, E)
+        (logits * coef).sum().backward()
+        rec.update({f"{tag}__logits": logits.detach().clone()})
+        for k, v in mlp.state_dict().items():
+            rec[f"{tag}__{k.replace('.', '__')}"] = v.clone()
+        for k, p_ in mlp.named_parameters():
+            rec[f"{tag}__grad__{k.replace('.', '__')}"] = p_.grad.clone()
+    rec.update(node_features=nf, agent_index=ai, coef=coef)
+    save("edge_mlp", **rec)
+
+
 def gen_value_mpnn():
     """MPNNValueNet (src/agents/mpnn_agent.py:265-402), the message-passing critic the reference defines but never
     instantiates, in eval mode (Dropout = identity): unbatched and batched forward with its own random weights."""
@@ -503,6 +548,7 @@ if __name__ == "__main__":
     gen_graphdist()
     gen_env_rollout()
     gen_nets()
+    gen_edge_mlp()
     gen_value_mpnn()
     gen_builders()
     gen_routing()

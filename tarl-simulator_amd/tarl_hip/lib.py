@@ -41,6 +41,11 @@ SIGNATURES = {
     "tarl_graphdist_logprob_entropy_bwd": (C.c_int, [_p, _p, _i64, _f32, _p, _p, _p, _p, _p, _p, _p]),
     "tarl_policy_edge_logits_fwd": (C.c_int, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _p]),
     "tarl_policy_edge_logits_bwd": (C.c_int, [_p, _p, _i64, _i64, _i64, _p, _p, _i64, _p]),
+    "tarl_policy_obs16": (C.c_int, [_p, _i64, _p, _p, _i64, _i64, _i64, _i64, _p, _p]),
+    "tarl_fused_obs16": (C.c_int, [_p, _p] + _STATE + [_p, _i64, _i64, _p, _p]),
+    "tarl_policy_edge_mlp_fwd": (C.c_int, [_p, _p, _i64, _p] + [_p] * 6 + [C.c_int, _p, _p]),
+    "tarl_policy_edge_mlp_bwd_scratch_floats": (_i64, [_p, _i64]),
+    "tarl_policy_edge_mlp_bwd": (C.c_int, [_p, _p, _i64, _p] + [_p] * 6 + [_p, _p] + [_p] * 6 + [_p]),
     "tarl_critic_mlp_fwd": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64] + [_p] * 6 + [_p, _p, _p, _p]),
     "tarl_critic_mlp_bwd": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64] + [_p] * 3 + [_p, _p, _p, _p] + [_p] * 6 + [_p]),
     "tarl_value_mpnn_fwd": (C.c_int, [_p, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),

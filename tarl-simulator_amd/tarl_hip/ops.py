@@ -376,6 +376,80 @@ def policy_edge_logits_bwd(plan: Plan, node_features, grad_logits, num_embedding
     return grad_emb
 
 
+# ---- per-edge MLP policy head ----------------------------------------------------------------------------------------------
+class EdgeMlpWeights:
+    """Flat views of the reference's ``edge_mlp.{0,2,4}.{weight,bias}`` tensors (device, fp32, contiguous)."""
+
+    def __init__(self, w1, b1, w2, b2, w3, b3):
+        self.w1, self.b1, self.w2, self.b2, self.w3, self.b3 = (_contig(t.detach(), torch.float32, n) for t, n in
+                                                               ((w1, "w1"), (b1, "b1"), (w2, "w2"), (b2, "b2"),
+                                                                (w3.reshape(-1), "w3"), (b3, "b3")))
+        if self.w1.shape != (64, 33) or self.w2.shape != (32, 64) or self.w3.numel() != 32:
+            raise ValueError("edge_mlp must be 33 -> 64 -> 32 -> 1")
+
+    def ptrs(self):
+        return [t.data_ptr() for t in (self.w1, self.b1, self.w2, self.b2, self.w3, self.b3)]
+
+
+def policy_obs16(node_features, agent_index, agent_features):
+    """x = cat(node_features[..., :7], agent_features[agent_index]) -> (M, N, 16) (src/agents/mpnn_agent.py:166-178).
+    ``node_features`` (N, >=7) or (M, N, >=7) (last dim contiguous), ``agent_index`` int64 matching, ``agent_features``
+    (A, 9) shared or (M, A, 9)."""
+    L = _lib.load()
+    _check_dev(node_features, torch.float32, "node_features")
+    nf = node_features.unsqueeze(0) if node_features.dim() == 2 else node_features
+    M, N = nf.shape[:2]
+    if nf.stride(-1) != 1 or nf.stride(0) != N * nf.stride(1):     # rows may be strided (a view of x), samples may not
+        nf = nf.contiguous()
+    ai = _contig(agent_index.reshape(M, N).to(torch.int64), torch.int64, "agent_index")
+    ag = _contig(agent_features, torch.float32, "agent_features")
+    A = ag.size(-2)
+    obs = torch.empty((M, N, 16), dtype=torch.float32, device=nf.device)
+    _lib.check(L.tarl_policy_obs16(nf.data_ptr(), nf.stride(1), ai.data_ptr(), ag.data_ptr(), A,
+                                   A * 9 if ag.dim() == 3 else 0, M, N, obs.data_ptr(), _lib.current_stream()))
+    return obs
+
+
+def fused_obs16(plan: Plan, fs, x, Nmax, agent_features, out=None):
+    """The same observation from the packed state of the fused engine: (B, N, 16)."""
+    L = _lib.load()
+    B, N, bs, ldx = _state(x, Nmax)
+    A, abs_ = _agents(agent_features, B)
+    obs = out if out is not None else torch.empty((B, N, 16), dtype=torch.float32, device=x.device)
+    _lib.check(L.tarl_fused_obs16(plan.handle, fs.ref, x.data_ptr(), B, bs, ldx, Nmax, agent_features.data_ptr(), A, abs_,
+                                  obs.data_ptr(), _lib.current_stream()))
+    return obs
+
+
+def policy_edge_mlp(plan: Plan, obs16, ec: EdgeConst, w: EdgeMlpWeights, *, bf16=False, out=None):
+    """obs16 (M, N, 16) -> logits (M, E) of the per-edge MLP head (fp32 MFMA, or bf16 MFMA with ``bf16=True``)."""
+    L = _lib.load()
+    _contig(obs16, torch.float32, "obs16")
+    M = obs16.size(0)
+    if obs16.shape[1:] != (plan.num_nodes, 16):
+        raise ValueError("obs16 must be (M, num_nodes, 16)")
+    logits = out if out is not None else torch.empty((M, plan.num_edges), dtype=torch.float32, device=obs16.device)
+    _lib.check(L.tarl_policy_edge_mlp_fwd(plan.handle, obs16.data_ptr(), M, ec.edge_attr.data_ptr(), *w.ptrs(),
+                                          1 if bf16 else 0, logits.data_ptr(), _lib.current_stream()))
+    return logits
+
+
+def policy_edge_mlp_bwd(plan: Plan, obs16, ec: EdgeConst, w: EdgeMlpWeights, grad_logits, grads):
+    """Accumulates into ``grads`` = (gw1, gb1, gw2, gb2, gw3, gb3), tensors shaped like the weights (fp32, contiguous)."""
+    L = _lib.load()
+    _contig(obs16, torch.float32, "obs16")
+    gl = _contig(grad_logits, torch.float32, "grad_logits")
+    M = obs16.size(0)
+    if gl.numel() != M * plan.num_edges:
+        raise ValueError("grad_logits must be (M, E)")
+    scratch = torch.empty(int(L.tarl_policy_edge_mlp_bwd_scratch_floats(plan.handle, M)), dtype=torch.float32,
+                          device=obs16.device)
+    gs = [_contig(g, torch.float32, "grad") for g in grads]
+    _lib.check(L.tarl_policy_edge_mlp_bwd(plan.handle, obs16.data_ptr(), M, ec.edge_attr.data_ptr(), *w.ptrs(),
+                                          gl.data_ptr(), scratch.data_ptr(), *(g.data_ptr() for g in gs),
+                                          _lib.current_stream()))
+
+
 # ---- critic -----------------------------------------------------------------------------------------------------------
 class CriticWeights:
     """Flat views of the reference's ``final_mlp.{0,2,4}.{weight,bias}`` tensors (device, fp32, contiguous)."""

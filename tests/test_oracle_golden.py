@@ -271,3 +271,20 @@ def test_value_mpnn_oracle_vs_reference():
     vb = nets.value_mpnn(sd, g["edge_index"], g["agent_features"], g["node_features_b"], g["edge_attr_b"].squeeze(-1),
                          g["agent_index_b"], g["time_b"].view(-1))
     assert torch.allclose(vb, g["value_b"].view(-1), rtol=1e-6, atol=1e-7)
+
+
+def test_edge_mlp_oracle_matches_reference_module():
+    """oracle.nets.edge_mlp_logits == the reference's own edge_mlp module applied as src/agents/mpnn_agent.py:227-231
+    specifies (fixture generated by oracle/make_golden.py:gen_edge_mlp), and autograd through it gives the recorded
+    parameter gradients."""
+    from oracle import nets
+    g = load_golden("edge_mlp")
+    x16 = torch.cat((g["node_features"], g["agent_features"][g["agent_index"]]), dim=-1)
+    for tag in ("ref", "biased"):
+        ws = [g[f"{tag}__{k}"].clone().requires_grad_(True) for k in ("0__weight", "0__bias", "2__weight", "2__bias",
+                                                                        "4__weight", "4__bias")]
+        logits = nets.edge_mlp_logits(x16, g["edge_index"], g["edge_attr"].expand(3, -1, -1), *ws)
+        assert torch.equal(logits, g[f"{tag}__logits"])
+        (logits * g["coef"]).sum().backward()
+        for w_, k in zip(ws, ("0__weight", "0__bias", "2__weight", "2__bias", "4__weight", "4__bias")):
+            assert torch.allclose(w_.grad, g[f"{tag}__grad__{k}"], rtol=1e-6, atol=1e-3)
