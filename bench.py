@@ -86,6 +86,13 @@ def parse():
                     help="also time --congested-steps iterations with every agent departing within this many seconds "
                          "(0 = skip); reported under congested_regime")
     ap.add_argument("--congested-steps", type=int, default=2)
+    ap.add_argument("--policy-envs", type=int, default=256,
+                    help="environments per GPU of the state-dependent-policy line (policy_head=edge_mlp; 0 = skip)")
+    ap.add_argument("--policy-steps", type=int, default=2)
+    ap.add_argument("--policy-temperature", type=float, default=2000.0,
+                    help="GraphDistribution temperature of the state-dependent-policy line: the head reads raw features "
+                         "(clock times ~2e4), so an untrained head at temperature 1 is near-deterministic, drives every "
+                         "agent down the same turn and gridlocks the network out of the reference's domain")
     ap.add_argument("--metrics-envs", type=int, default=1,
                     help="environments that keep the per-node logs of SimulatorEnv._step (delta_travel_time, pop / withdraw "
                          "masks); the per-frame leg histogram is kept for all of them")
@@ -231,15 +238,68 @@ def main():
                      "agents_on_the_way_at_the_end_per_env": on_way, "agents_arrived_per_env": arrived,
                      "note": "all agents depart within the window: the network is loaded for most of the rollout"}
 
+    # ---- third line of evidence: the state-dependent policy ---------------------------------------------------------------
+    # The per-edge MLP head (33 -> 64 -> 32 -> 1 on cat(x[src], x[dst], edge_attr); the reference keeps it as parameters,
+    # src/agents/mpnn_agent.py:35-41,227-231) reads the dynamic state, so NOTHING is hoisted: every frame builds the
+    # observation from the packed state, runs the MLP on the matrix cores (fp32 and bf16 variants), the segment softmax,
+    # the sample and the log-prob, then the four-launch simulation frame; the update runs the MLP forward / backward.
+    policy_lines = None
+    layout_tag, rollout_mode, n_roads = trainer.layout_tag, trainer.rollout, engine.N
+    if args.policy_envs > 0:
+        from tarl_hip import synth
+        from tarl_hip.engine import SimEngine
+        from tarl_hip.trainer import VecPPOTrainer
+        from src.agents.mpnn_agent import MPNNPolicyNet, MPNNValueNetSimple
+        Bp = args.policy_envs
+        del trainer, engine
+        torch.cuda.empty_cache()
+        pops = synth.population_batch(args.agents, net.num_roads, Bp, seed=args.seed + 1000 * rank + 31, device=device)
+        eng_p = SimEngine(net.x.to(device).unsqueeze(0).repeat(Bp, 1, 1).contiguous(), net.edge_index, net.edge_attr,
+                          net.Nmax, pops, congestion_constant=net.congestion_constant, device=device,
+                          seed=args.seed + rank)
+        policy_lines = {}
+        for tag, bf in (("fp32", False), ("bf16", True)):
+            torch.manual_seed(args.seed)
+            pol = MPNNPolicyNet(net.edge_index, net.num_roads, None, device=str(device))
+            val = MPNNValueNetSimple(net.edge_index, net.num_roads, device=str(device))
+            l, mm = val.final_mlp, pol.edge_mlp
+            tr_p = VecPPOTrainer(eng_p, pol.nodes_embedding.weight,
+                                 [l[0].weight, l[0].bias, l[2].weight, l[2].bias, l[4].weight, l[4].bias],
+                                 rollout_steps=T, num_epochs=args.epochs, sub_batch_size=args.sub_batch,
+                                 extra_params=[p for n, p in pol.named_parameters() if not n.startswith("nodes_embedding")],
+                                 seed=args.seed, policy="edge_mlp", policy_bf16=bf, temperature=args.policy_temperature,
+                                 edge_mlp_params=[mm[0].weight, mm[0].bias, mm[2].weight, mm[2].bias, mm[4].weight,
+                                                  mm[4].bias])
+            tr_p.train_iteration()
+            dist_utils.barrier()
+            torch.cuda.synchronize()
+            t2_ = time.perf_counter()
+            pf = 0
+            for _ in range(args.policy_steps):
+                pf += tr_p.train_iteration()
+            torch.cuda.synchronize()
+            dist_utils.barrier()
+            pel = dist_utils.allreduce_max_float(time.perf_counter() - t2_, device)
+            tr_p.check_flags()
+            policy_lines[tag] = {"value": pf * world / pel, "unit": "env-steps/s", "envs_per_gpu": Bp,
+                                 "steps": args.policy_steps, "ms_per_step": pel / args.policy_steps * 1e3,
+                                 "edge_mlp_edges_per_sec": pf * world / pel * E,
+                                 "rollout_logits": "bf16 MFMA (v_mfma_f32_32x32x16_bf16)" if bf else
+                                                   "fp32 MFMA (v_mfma_f32_32x32x2_f32)"}
+            del tr_p
+        policy_lines["note"] = ("policy_head=edge_mlp: per-frame observation + 33->64->32->1 MLP per edge + GraphDistribution "
+                                "softmax / sample / log_prob (no table hoist), then the simulation frame; "
+                                f"GraphDistribution temperature {args.policy_temperature:g}")
+
     if rank == 0:
         total_frames = frames * world
         value = total_frames / elapsed
-        NB = B * engine.N
+        NB = B * n_roads
         pmc = None
         try:
             rec = json.load(open(os.path.join(ROOT, PMC_RECORD)))
             if rec["config"] == {"edges": E, "agents": args.agents, "envs": B, "rollout_steps": T} and \
-                    rec.get("layout") == trainer.layout_tag:
+                    rec.get("layout") == layout_tag:
                 pmc = rec
         except (OSError, KeyError, ValueError):
             pass
@@ -274,18 +334,19 @@ def main():
             "metric": "ppo_env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"mpnn+ppo train, {E}-edge synthetic torus dual graph ({engine.N} roads), "
+            "config": {"workload": f"mpnn+ppo train, {E}-edge synthetic torus dual graph ({n_roads} roads), "
                                    f"{args.agents} agents per environment, rollout-steps {T}, epochs {args.epochs}, "
                                    f"sub-batch {args.sub_batch}" +
                                    (" (BASELINE config 4)" if (E, args.agents) == (10000, 16384) else ""),
                        "envs_per_gpu": B, "env_steps_per_step": B * T, "parallelism": f"dp{world} (rollouts sharded, "
-                       "one gradient all-reduce per optimiser step)", "rollout_kernels": trainer.rollout},
+                       "one gradient all-reduce per optimiser step)", "rollout_kernels": rollout_mode},
             "msgpass_edges_per_sec": value * E,
             # Direction + Response pair alone (SURVEY 8d's second metric): B*E edges per frame / the two kernels' live time
             "msgpass_pair_edges_per_sec": (B * E) / (dir_s + rows_s) if (dir_s + rows_s) > 0 else None,
             "roofline": rf_rows, "roofline_direction": rf_dir, "roofline_insert_choice": rf_ic,
             "setup_seconds": setup_s, "timed_seconds": elapsed,
             "congested_regime": congested,
+            "state_dependent_policy": policy_lines,
         }
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args, net)

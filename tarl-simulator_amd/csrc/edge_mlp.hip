@@ -90,104 +90,106 @@ __global__ __launch_bounds__(FB) void k_obs16_cat(const float* __restrict__ nf, 
 }
 
 // ---- forward ------------------------------------------------------------------------------------------------------------
-// LDS plan (fp32): A = Xs [34][129] (later H2s [32][129]) | B = W1s [34][65] (later W2s [64][33]) | C = Hs [64][129]
+// LDS plan (fp32, dynamic, 67.7 KB): Xs [34][129] (later H2s [32][129]) | Hs [64][129] | W1s [34][65] | W2s [64][33].
+// A workgroup stages the weights ONCE and walks EM_TPW consecutive 128-edge tiles of its sample.
+#define EM_TPW 8
 #define EMF_A (34 * (EM_TILE + 1))
-#define EMF_B (34 * (EM_H1 + 1))
 #define EMF_C (EM_H1 * (EM_TILE + 1))
+#define EMF_W1 (34 * (EM_H1 + 1))
+#define EMF_W2 (EM_H1 * (EM_H2 + 1))
+#define EMF_LDS_BYTES ((EMF_A + EMF_C + EMF_W1 + EMF_W2) * sizeof(float))
 __global__ __launch_bounds__(EM_THREADS) void k_edge_mlp_fwd_f32(const int32_t* __restrict__ src,
                                                                  const int32_t* __restrict__ dst, int64_t E, int64_t N,
                                                                  const float* __restrict__ obs,
                                                                  const float* __restrict__ edge_attr, EdgeMlpW W,
                                                                  float* __restrict__ logits) {
-  __shared__ float lds[EMF_A + EMF_B + EMF_C];
-  float* Xs = lds;                 // [k][edge]
-  float* W1s = lds + EMF_A;        // [k][j]
-  float* Hs = lds + EMF_A + EMF_B; // [j][edge]
+  extern __shared__ float lds[];
+  float* Xs = lds;                   // [k][edge]
+  float* Hs = lds + EMF_A;           // [j][edge]
+  float* W1s = Hs + EMF_C;           // [k][j]
+  float* W2s = W1s + EMF_W1;         // [k][j], stride 33
+  float* H2s = Xs;                   // [j][edge] (aliases Xs: dead after the first layer)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t m = blockIdx.y, e0 = (int64_t)blockIdx.x * EM_TILE;
+  const int64_t m = blockIdx.y;
   const float* om = obs + m * N * 16;
-  // gather: 128 edges x 8 float4 (x_i: 4, x_j: 4), transposed into Xs[k][edge]
-#pragma unroll
-  for (int it = 0; it < (EM_TILE * 8) / EM_THREADS; ++it) {
-    const int idx = it * EM_THREADS + tid;
-    const int el = idx >> 3, q = idx & 7;     // q < 4: x[src] quarter q ; else x[dst] quarter q - 4
-    const int64_t e = e0 + el;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e < E) {
-      const int32_t node = q < 4 ? src[e] : dst[e];
-      v = reinterpret_cast<const float4*>(om + (int64_t)node * 16)[q & 3];
-    }
-    const int k = 4 * q;
-    Xs[(k + 0) * (EM_TILE + 1) + el] = v.x;
-    Xs[(k + 1) * (EM_TILE + 1) + el] = v.y;
-    Xs[(k + 2) * (EM_TILE + 1) + el] = v.z;
-    Xs[(k + 3) * (EM_TILE + 1) + el] = v.w;
-  }
-  if (tid < EM_TILE) {
-    const int64_t e = e0 + tid;
-    Xs[32 * (EM_TILE + 1) + tid] = e < E ? edge_attr[e] : 0.0f;
-    Xs[33 * (EM_TILE + 1) + tid] = 0.0f;      // K padded to an even number of MFMA k-steps
-  }
   for (int idx = tid; idx < 34 * EM_H1; idx += EM_THREADS) {
     const int j = idx / 34, k = idx - j * 34;
     W1s[k * (EM_H1 + 1) + j] = k < EM_IN ? W.w1[j * EM_IN + k] : 0.0f;
-  }
-  __syncthreads();
-  f32x16 acc0 = {0}, acc1 = {0};
-#pragma unroll
-  for (int kk = 0; kk < 34; kk += 2) {
-    const int k = kk + (lane >> 5);
-    const float a = Xs[k * (EM_TILE + 1) + wave * 32 + (lane & 31)];
-    const float b0 = W1s[k * (EM_H1 + 1) + (lane & 31)];
-    const float b1 = W1s[k * (EM_H1 + 1) + 32 + (lane & 31)];
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
-  }
-  __syncthreads();   // everyone is done with Xs / W1s: their space becomes H2s / W2s
-  float* W2s = W1s;  // [k][j], stride 33
-  float* H2s = Xs;   // [j][edge]
-  {
-    const int j0 = lane & 31;
-    const float bb0 = W.b1[j0], bb1 = W.b1[j0 + 32];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int lr = wave * 32 + em_row(r, lane);
-      const float v0 = acc0[r] + bb0, v1 = acc1[r] + bb1;
-      Hs[j0 * (EM_TILE + 1) + lr] = v0 > 0.0f ? v0 : 0.0f;
-      Hs[(j0 + 32) * (EM_TILE + 1) + lr] = v1 > 0.0f ? v1 : 0.0f;
-    }
   }
   for (int idx = tid; idx < EM_H2 * EM_H1; idx += EM_THREADS) {
     const int j = idx >> 6, k = idx & 63;
     W2s[k * (EM_H2 + 1) + j] = W.w2[j * EM_H1 + k];
   }
-  __syncthreads();
-  f32x16 c0 = {0};
+  const int j0 = lane & 31;
+  const float bb0 = W.b1[j0], bb1 = W.b1[j0 + 32], bb2 = W.b2[j0];
+  for (int tile = 0; tile < EM_TPW; ++tile) {
+    const int64_t e0 = ((int64_t)blockIdx.x * EM_TPW + tile) * EM_TILE;
+    if (e0 >= E) break;        // uniform
+    __syncthreads();           // the previous tile's readers of H2s (= Xs) are done; the weights are staged
+    // gather: 128 edges x 8 float4 (x_i: 4, x_j: 4), transposed into Xs[k][edge]
 #pragma unroll
-  for (int kk = 0; kk < EM_H1; kk += 2) {
-    const int k = kk + (lane >> 5);
-    const float a = Hs[k * (EM_TILE + 1) + wave * 32 + (lane & 31)];
-    const float b = W2s[k * (EM_H2 + 1) + (lane & 31)];
-    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c0, 0, 0, 0);
-  }
-  {
-    const int j0 = lane & 31;
-    const float bb = W.b2[j0];
+    for (int it = 0; it < (EM_TILE * 8) / EM_THREADS; ++it) {
+      const int idx = it * EM_THREADS + tid;
+      const int el = idx >> 3, q = idx & 7;     // q < 4: x[src] quarter q ; else x[dst] quarter q - 4
+      const int64_t e = e0 + el;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < E) {
+        const int32_t node = q < 4 ? src[e] : dst[e];
+        v = reinterpret_cast<const float4*>(om + (int64_t)node * 16)[q & 3];
+      }
+      const int k = 4 * q;
+      Xs[(k + 0) * (EM_TILE + 1) + el] = v.x;
+      Xs[(k + 1) * (EM_TILE + 1) + el] = v.y;
+      Xs[(k + 2) * (EM_TILE + 1) + el] = v.z;
+      Xs[(k + 3) * (EM_TILE + 1) + el] = v.w;
+    }
+    if (tid < EM_TILE) {
+      const int64_t e = e0 + tid;
+      Xs[32 * (EM_TILE + 1) + tid] = e < E ? edge_attr[e] : 0.0f;
+      Xs[33 * (EM_TILE + 1) + tid] = 0.0f;      // K padded to an even number of MFMA k-steps
+    }
+    __syncthreads();
+    f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+    for (int kk = 0; kk < 34; kk += 2) {
+      const int k = kk + (lane >> 5);
+      const float a = Xs[k * (EM_TILE + 1) + wave * 32 + (lane & 31)];
+      const float b0 = W1s[k * (EM_H1 + 1) + (lane & 31)];
+      const float b1 = W1s[k * (EM_H1 + 1) + 32 + (lane & 31)];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {   // each wave writes / reads only its own 32 edge columns of Hs
+      const int lr = wave * 32 + em_row(r, lane);
+      const float v0 = acc0[r] + bb0, v1 = acc1[r] + bb1;
+      Hs[j0 * (EM_TILE + 1) + lr] = v0 > 0.0f ? v0 : 0.0f;
+      Hs[(j0 + 32) * (EM_TILE + 1) + lr] = v1 > 0.0f ? v1 : 0.0f;
+    }
+    __syncthreads();   // Hs complete; everyone is done with Xs: its space becomes H2s
+    f32x16 c0 = {0};
+#pragma unroll
+    for (int kk = 0; kk < EM_H1; kk += 2) {
+      const int k = kk + (lane >> 5);
+      const float a = Hs[k * (EM_TILE + 1) + wave * 32 + (lane & 31)];
+      const float b = W2s[k * (EM_H2 + 1) + (lane & 31)];
+      c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c0, 0, 0, 0);
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int lr = wave * 32 + em_row(r, lane);
-      const float v = c0[r] + bb;
+      const float v = c0[r] + bb2;
       H2s[j0 * (EM_TILE + 1) + lr] = v > 0.0f ? v : 0.0f;
     }
-  }
-  __syncthreads();
-  if (tid < EM_TILE) {
-    const int64_t e = e0 + tid;
-    if (e < E) {
-      float s = 0.0f;
+    __syncthreads();
+    if (tid < EM_TILE) {
+      const int64_t e = e0 + tid;
+      if (e < E) {
+        float sacc = 0.0f;
 #pragma unroll 8
-      for (int j = 0; j < EM_H2; ++j) s += H2s[j * (EM_TILE + 1) + tid] * W.w3[j];
-      logits[m * E + e] = s + W.b3[0];
+        for (int j = 0; j < EM_H2; ++j) sacc += H2s[j * (EM_TILE + 1) + tid] * W.w3[j];
+        logits[m * E + e] = sacc + W.b3[0];
+      }
     }
   }
 }
@@ -206,30 +208,8 @@ __global__ __launch_bounds__(EM_THREADS) void k_edge_mlp_fwd_bf16(const int32_t*
   __shared__ __attribute__((aligned(16))) uint16_t W2b[EM_H2 * EMB_KH];
   __shared__ float H2s[EM_H2 * (EM_TILE + 1)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t m = blockIdx.y, e0 = (int64_t)blockIdx.x * EM_TILE;
+  const int64_t m = blockIdx.y;
   const float* om = obs + m * N * 16;
-#pragma unroll
-  for (int it = 0; it < (EM_TILE * 8) / EM_THREADS; ++it) {
-    const int idx = it * EM_THREADS + tid;
-    const int el = idx >> 3, q = idx & 7;
-    const int64_t e = e0 + el;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e < E) {
-      const int32_t node = q < 4 ? src[e] : dst[e];
-      v = reinterpret_cast<const float4*>(om + (int64_t)node * 16)[q & 3];
-    }
-    uint16_t* d = Xb + el * EMB_KX + 4 * q;
-    d[0] = f32_to_bf16_rne(v.x);
-    d[1] = f32_to_bf16_rne(v.y);
-    d[2] = f32_to_bf16_rne(v.z);
-    d[3] = f32_to_bf16_rne(v.w);
-  }
-  if (tid < EM_TILE) {
-    const int64_t e = e0 + tid;
-    uint16_t* d = Xb + tid * EMB_KX;
-    d[32] = f32_to_bf16_rne(e < E ? edge_attr[e] : 0.0f);
-    for (int k = 33; k < 48; ++k) d[k] = 0;
-  }
   for (int idx = tid; idx < EM_H1 * 48; idx += EM_THREADS) {
     const int j = idx / 48, k = idx - j * 48;
     W1b[j * EMB_KX + k] = k < EM_IN ? f32_to_bf16_rne(W.w1[j * EM_IN + k]) : (uint16_t)0;
@@ -238,53 +218,75 @@ __global__ __launch_bounds__(EM_THREADS) void k_edge_mlp_fwd_bf16(const int32_t*
     const int j = idx >> 6, k = idx & 63;
     W2b[j * EMB_KH + k] = f32_to_bf16_rne(W.w2[j * EM_H1 + k]);
   }
-  __syncthreads();
   // lane l (r = l & 31, h = l >> 5) holds A[row r][k = 16 s + 8 h + 0..7] and B[k = 16 s + 8 h + 0..7][col r]
   const int r32 = lane & 31, h8 = (lane >> 5) * 8;
-  f32x16 acc0 = {0}, acc1 = {0};
+  const float bb0 = W.b1[r32], bb1 = W.b1[r32 + 32], bb2 = W.b2[r32];
+  for (int tile = 0; tile < EM_TPW; ++tile) {
+    const int64_t e0 = ((int64_t)blockIdx.x * EM_TPW + tile) * EM_TILE;
+    if (e0 >= E) break;        // uniform
+    __syncthreads();           // the previous tile's readers are done; the weights are staged
 #pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    const bf16x8 a = *reinterpret_cast<const bf16x8*>(Xb + (wave * 32 + r32) * EMB_KX + 16 * s + h8);
-    const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(W1b + r32 * EMB_KX + 16 * s + h8);
-    const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(W1b + (32 + r32) * EMB_KX + 16 * s + h8);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc1, 0, 0, 0);
-  }
-  {
-    const float bb0 = W.b1[r32], bb1 = W.b1[r32 + 32];
+    for (int it = 0; it < (EM_TILE * 8) / EM_THREADS; ++it) {
+      const int idx = it * EM_THREADS + tid;
+      const int el = idx >> 3, q = idx & 7;
+      const int64_t e = e0 + el;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < E) {
+        const int32_t node = q < 4 ? src[e] : dst[e];
+        v = reinterpret_cast<const float4*>(om + (int64_t)node * 16)[q & 3];
+      }
+      uint16_t* d = Xb + el * EMB_KX + 4 * q;
+      d[0] = f32_to_bf16_rne(v.x);
+      d[1] = f32_to_bf16_rne(v.y);
+      d[2] = f32_to_bf16_rne(v.z);
+      d[3] = f32_to_bf16_rne(v.w);
+    }
+    if (tid < EM_TILE) {
+      const int64_t e = e0 + tid;
+      uint16_t* d = Xb + tid * EMB_KX;
+      d[32] = f32_to_bf16_rne(e < E ? edge_attr[e] : 0.0f);
+      for (int k = 33; k < 48; ++k) d[k] = 0;
+    }
+    __syncthreads();
+    f32x16 acc0 = {0}, acc1 = {0};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int s = 0; s < 3; ++s) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(Xb + (wave * 32 + r32) * EMB_KX + 16 * s + h8);
+      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(W1b + r32 * EMB_KX + 16 * s + h8);
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(W1b + (32 + r32) * EMB_KX + 16 * s + h8);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {   // a wave's rows of Hb are its own 32 edges
       const int lr = wave * 32 + em_row(r, lane);
       const float v0 = acc0[r] + bb0, v1 = acc1[r] + bb1;
       Hb[lr * EMB_KH + r32] = f32_to_bf16_rne(v0 > 0.0f ? v0 : 0.0f);
       Hb[lr * EMB_KH + 32 + r32] = f32_to_bf16_rne(v1 > 0.0f ? v1 : 0.0f);
     }
-  }
-  __syncthreads();
-  f32x16 c0 = {0};
+    __syncthreads();
+    f32x16 c0 = {0};
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const bf16x8 a = *reinterpret_cast<const bf16x8*>(Hb + (wave * 32 + r32) * EMB_KH + 16 * s + h8);
-    const bf16x8 b = *reinterpret_cast<const bf16x8*>(W2b + r32 * EMB_KH + 16 * s + h8);
-    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
-  }
-  {
-    const float bb = W.b2[r32];
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(Hb + (wave * 32 + r32) * EMB_KH + 16 * s + h8);
+      const bf16x8 b = *reinterpret_cast<const bf16x8*>(W2b + r32 * EMB_KH + 16 * s + h8);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int lr = wave * 32 + em_row(r, lane);
-      const float v = c0[r] + bb;
+      const float v = c0[r] + bb2;
       H2s[r32 * (EM_TILE + 1) + lr] = v > 0.0f ? v : 0.0f;
     }
-  }
-  __syncthreads();
-  if (tid < EM_TILE) {
-    const int64_t e = e0 + tid;
-    if (e < E) {
-      float s = 0.0f;
+    __syncthreads();
+    if (tid < EM_TILE) {
+      const int64_t e = e0 + tid;
+      if (e < E) {
+        float sacc = 0.0f;
 #pragma unroll 8
-      for (int j = 0; j < EM_H2; ++j) s += H2s[j * (EM_TILE + 1) + tid] * W.w3[j];
-      logits[m * E + e] = s + W.b3[0];
+        for (int j = 0; j < EM_H2; ++j) sacc += H2s[j * (EM_TILE + 1) + tid] * W.w3[j];
+        logits[m * E + e] = sacc + W.b3[0];
+      }
     }
   }
 }
@@ -433,11 +435,20 @@ extern "C" int tarl_policy_edge_mlp_fwd(const tarl_plan* plan, const float* obs1
   TARL_REQUIRE(((uintptr_t)obs16) % 16 == 0, "obs16 must be 16-byte aligned");
   if (plan->E == 0) return TARL_OK;
   const EdgeMlpW W{w1, b1, w2, b2, w3, b3};
-  const dim3 grid((unsigned)ceil_div(plan->E, EM_TILE), (unsigned)M);
-  if (precision == 0)
-    hipLaunchKernelGGL(k_edge_mlp_fwd_f32, grid, dim3(EM_THREADS), 0, (hipStream_t)stream, plan->src, plan->dst, plan->E,
-                       plan->N, obs16, edge_attr, W, logits);
-  else
+  const dim3 grid((unsigned)ceil_div(ceil_div(plan->E, EM_TILE), EM_TPW), (unsigned)M);
+  if (precision == 0) {
+    // the opt-in to > 64 KB of dynamic LDS is a per-device attribute of the function
+    static bool lds_set[64] = {false};
+    int devid = 0;
+    TARL_CHECK_HIP(hipGetDevice(&devid));
+    if (!lds_set[devid & 63]) {
+      TARL_CHECK_HIP(hipFuncSetAttribute((const void*)k_edge_mlp_fwd_f32, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)EMF_LDS_BYTES));
+      lds_set[devid & 63] = true;
+    }
+    hipLaunchKernelGGL(k_edge_mlp_fwd_f32, grid, dim3(EM_THREADS), EMF_LDS_BYTES, (hipStream_t)stream, plan->src,
+                       plan->dst, plan->E, plan->N, obs16, edge_attr, W, logits);
+  } else
     hipLaunchKernelGGL(k_edge_mlp_fwd_bf16, grid, dim3(EM_THREADS), 0, (hipStream_t)stream, plan->src, plan->dst, plan->E,
                        plan->N, obs16, edge_attr, W, logits);
   TARL_LAUNCH_CHECK();

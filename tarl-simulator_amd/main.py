@@ -1,7 +1,7 @@
 """Command line of the MI355X build. The flag set is the reference CLI's contract (main.py of the reference: --algo,
 --scenario, --mode, --timestep_size, --start-end-time, --epochs, --rollout-steps, --seed, --device, --output-dir,
 --profile, --torch-compile) plus ``--steps`` (used by the reference's README but missing from its parser) and
-``--num-envs`` (vectorised environments per GPU)."""
+``--num-envs`` (vectorised environments per GPU) and ``--policy-head``."""
 import argparse
 import os
 import sys
@@ -29,6 +29,9 @@ OPTIONS = (
     ("--torch-compile", dict(action="store_true", help="accepted and ignored: the kernels are hand-written HIP")),
     ("--steps", dict(type=int, default=None, help="number of eval steps (overrides start/end time)")),
     ("--num-envs", dict(type=int, default=1, help="vectorised environments per GPU for mpnn+ppo training")),
+    ("--policy-head", dict(choices=("embedding", "edge_mlp", "edge_mlp_bf16"), default="embedding",
+                           help="mpnn / mpnn+ppo: the reference's live embedding head, or the per-edge MLP head it keeps "
+                                "as parameters (state-dependent; fp32 or bf16 MFMA)")),
 )
 
 

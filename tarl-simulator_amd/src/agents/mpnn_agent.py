@@ -30,8 +30,31 @@ class _EdgeLogits(torch.autograd.Function):
         return g.view(ctx.shape), None, None
 
 
+class _EdgeMlp(torch.autograd.Function):
+    """The per-edge MLP head on the HIP kernels (tarl_policy_edge_mlp_fwd / _bwd); gradients for its six parameters."""
+
+    @staticmethod
+    def forward(ctx, obs16, plan, ec, bf16, w1, b1, w2, b2, w3, b3):
+        from tarl_hip import ops
+        w = ops.EdgeMlpWeights(w1, b1, w2, b2, w3, b3)
+        ctx.saved = (obs16, plan, ec, w, [t.shape for t in (w1, b1, w2, b2, w3, b3)])
+        return ops.policy_edge_mlp(plan, obs16, ec, w, bf16=bf16)
+
+    @staticmethod
+    def backward(ctx, grad_logits):
+        from tarl_hip import ops
+        obs16, plan, ec, w, shapes = ctx.saved
+        grads = [torch.zeros_like(t) for t in (w.w1, w.b1, w.w2, w.b2, w.w3, w.b3)]
+        ops.policy_edge_mlp_bwd(plan, obs16, ec, w, grad_logits.contiguous(), grads)
+        return (None, None, None, None) + tuple(g.view(sh) for g, sh in zip(grads, shapes))
+
+
 class MPNNPolicyNet(MessagePassingBase, Agents):
     h = ObservationFeatureHelpers()
+    # Which head produces the logits. "embedding": the reference's live forward (logit = nodes_embedding of the target
+    # road, src/agents/mpnn_agent.py:215-217). "edge_mlp" / "edge_mlp_bf16": the per-edge MLP the reference keeps as
+    # parameters and spells out in its commented lines (:227-231), on fp32 / bf16 MFMA — a state-dependent policy.
+    policy_head = "embedding"
 
     def __init__(self, edge_index, num_nodes, free_flow_time_travel, device):
         Agents.__init__(self, device=device)
@@ -84,6 +107,16 @@ class MPNNPolicyNet(MessagePassingBase, Agents):
         """node_features (N,7) or (B,N,7) -> logits (E,) or (B,E)."""
         require_cuda(node_features, "node_features")
         plan = cached_plan(self.edge_index, self.num_nodes)
+        if self.policy_head != "embedding":
+            from tarl_hip import ops
+            from .._compat import cached_edge_const
+            ea = edge_features if edge_features.dim() <= 2 else edge_features[0]     # static: the same for every sample
+            ec = cached_edge_const(ea.reshape(-1, 1), node_features.device)
+            obs16 = ops.policy_obs16(node_features, agent_index, self.agent_features.to(node_features.device))
+            m = self.edge_mlp
+            logits = _EdgeMlp.apply(obs16, plan, ec, self.policy_head == "edge_mlp_bf16", m[0].weight, m[0].bias,
+                                    m[2].weight, m[2].bias, m[4].weight, m[4].bias)
+            return logits if node_features.dim() == 3 else logits.view(-1)
         return _EdgeLogits.apply(self.nodes_embedding.weight, node_features, plan)
 
     def update_edges(self, x, edge_index, edge_attr=None):

@@ -87,10 +87,15 @@ def ppo_train(env, policy_module, value_module, *, total_frames=128, frames_per_
                        device=g.x.device, timestep=sim.timestep, seed=seed + 7919 * rank, fused=sim.Nmax <= 255)
     l = value_net.final_mlp
     dormant = [p for n, p in policy_net.named_parameters() if not n.startswith("nodes_embedding")]
+    head = getattr(policy_net, "policy_head", "embedding")
+    m = policy_net.edge_mlp
     trainer = VecPPOTrainer(engine, policy_net.nodes_embedding.weight,
                             [l[0].weight, l[0].bias, l[2].weight, l[2].bias, l[4].weight, l[4].bias],
                             rollout_steps=frames_per_batch, num_epochs=num_epochs, sub_batch_size=sub_batch_size,
-                            extra_params=dormant, seed=seed)
+                            extra_params=dormant, seed=seed,
+                            policy="embedding" if head == "embedding" else "edge_mlp",
+                            edge_mlp_params=[m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias],
+                            policy_bf16=head == "edge_mlp_bf16")
     log = writer = None
     if log_dir is not None and rank == 0:      # rank 0 alone writes
         os.makedirs(log_dir, exist_ok=True)

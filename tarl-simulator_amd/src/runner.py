@@ -25,6 +25,7 @@ class RunnerArgs:
     torch_compile: bool = False
     steps: int = None          # README / BASELINE use --steps; the reference CLI lacks it
     num_envs: int = 1
+    policy_head: str = "embedding"
 
 
 class Runner:
@@ -70,6 +71,7 @@ class Runner:
             g, h = self.env.simulator.graph, self.env.simulator.h
             free_flow = g.x[:, h.FREE_FLOW_TIME_TRAVEL][g.edge_index[1]]
             self.policy_net = MPNNPolicyNet(g.edge_index, g.x.size(0), free_flow, device=str(self.device))
+            self.policy_net.policy_head = a.policy_head
             self.policy_net.load(a.scenario)
             self.value_net = MPNNValueNetSimple(g.edge_index, g.x.size(0), device=str(self.device))
             self.value_net.load(a.scenario)

@@ -148,7 +148,7 @@ class SimEngine:
         self._x_stale = True
         prev = self._last_step_time
         self._last_step_time = float(self.time)
-        tables = self.tables
+        tables = getattr(self, "tables", None)
         if action is not None:
             ops.fused_apply_choice(self.plan, self.fs, action)
             tables = None

@@ -22,13 +22,31 @@ from .flatparams import FlatParams
 class VecPPOTrainer:
     def __init__(self, engine, emb_param, critic_params, *, rollout_steps, num_epochs=1, sub_batch_size=32, lr=1e-3,
                  gamma=0.99, lmbda=0.95, clip_epsilon=0.2, entropy_coef=0.01, critic_coef=1.0, temperature=1.0,
-                 extra_params=(), seed=0, lazy_log_prob=False, rank_offset=True, rollout=None, metrics_envs=1):
+                 extra_params=(), seed=0, lazy_log_prob=False, rank_offset=True, rollout=None, metrics_envs=1,
+                 policy="embedding", edge_mlp_params=None, policy_bf16=False):
         """``emb_param``: nn.Parameter (num_nodes, 1) — MPNNPolicyNet.nodes_embedding.weight;
         ``critic_params``: [w1 (64,N+1), b1, w2 (64,64), b2, w3 (1,64), b3] — MPNNValueNetSimple.final_mlp.{0,2,4};
         ``extra_params``: further actor/critic parameters that never receive gradient on the live path (the dormant
         edge MLPs) — they sit in the flat buffer so that the optimiser covers ``loss_module.parameters()`` like the
         reference's does."""
         self.eng = engine
+        # policy: "embedding" = the reference's live head (logit = embedding of the target road: state-independent, its
+        # distribution is tabulated once per update); "edge_mlp" = the per-edge MLP head it carries as parameters
+        # (src/agents/mpnn_agent.py:35-41,227-231): state-DEPENDENT, so every frame evaluates observation -> MLP (MFMA) ->
+        # segment softmax -> sample -> log-prob before the simulation step. ``edge_mlp_params`` = [w1, b1, w2, b2, w3, b3]
+        # (edge_mlp.{0,2,4}.{weight,bias}; they must also be in ``extra_params`` so that they live in the flat buffer);
+        # ``policy_bf16``: rollout logits on the bf16 MFMA path (the update always runs in fp32).
+        self.policy = policy
+        self.policy_bf16 = bool(policy_bf16)
+        self.edge_mlp_params = list(edge_mlp_params) if edge_mlp_params is not None else None
+        if policy == "edge_mlp":
+            if engine.fs is None or self.edge_mlp_params is None or len(self.edge_mlp_params) != 6:
+                raise ValueError("policy='edge_mlp' needs the fused engine and the six edge_mlp parameter tensors")
+            ids = {id(p) for p in extra_params}
+            if not all(id(p) in ids for p in self.edge_mlp_params):
+                raise ValueError("edge_mlp_params must be part of extra_params (the optimiser's flat buffer)")
+        elif policy != "embedding":
+            raise ValueError("policy must be 'embedding' or 'edge_mlp'")
         # lazy_log_prob: do not produce sample_log_prob for every collected frame (as the reference's collector does)
         # but only, exactly, for the frames a minibatch actually reads. Same training result; off by default so that a
         # frame does everything the reference's frame does.
@@ -56,6 +74,8 @@ class VecPPOTrainer:
         mode = rollout or os.environ.get("TARL_ROLLOUT", "auto")
         if engine.fs is None:
             mode = "unfused"
+        elif policy == "edge_mlp":
+            mode = "frames+policy"      # per-frame policy evaluation in front of the four-launch frame
         elif mode == "auto":
             mode = "env" if (engine.env_rollout_supported and engine.B * engine.N <= 800_000) else "frames"
         elif mode == "env" and not engine.env_rollout_supported:
@@ -63,12 +83,14 @@ class VecPPOTrainer:
         self.rollout = mode
         self.layout_tag = ops.FUSED_LAYOUT
         # rollout buffers, written directly by the kernels: ENV-MINOR ([frame][node][env]) for "frames"
-        self.env_minor = mode == "frames"
+        self.env_minor = mode in ("frames", "frames+policy")
         shp = (lambda t: (t, N, B)) if self.env_minor else (lambda t: (t, B, N))
         # fused rollouts write one BYTE per (frame, node, env): the count and the rank of the chosen out-edge
         byte = mode in ("frames", "env")
         self.counts = torch.zeros(shp(self.T + 1), dtype=torch.uint8 if byte else torch.float32, device=dev)
-        self.choice = torch.zeros(shp(self.T), dtype=torch.uint8 if byte else torch.int32, device=dev)
+        # "frames+policy": the action comes from the per-frame sampler as edge ids, env-major
+        self.choice = torch.zeros((self.T, B, N) if mode == "frames+policy" else shp(self.T),
+                                  dtype=torch.uint8 if byte else torch.int32, device=dev)
         # per-step logs of SimulatorEnv._step, accumulated on the device by the rollout kernels: the leg histogram's
         # (departed, arrived) per frame for every environment, delta_travel_time / pop + withdraw masks per node for the
         # first ``metrics_envs`` environments (the reference logs them for its single environment)
@@ -93,6 +115,7 @@ class VecPPOTrainer:
         self.last = {}
         self.done_frames = torch.zeros(self.T, dtype=torch.bool)
         self.done_mask = None
+        self.obs_idx = None
 
     # -- views of the live parameters -----------------------------------------------------------------------------------
     def _emb(self):
@@ -102,6 +125,66 @@ class VecPPOTrainer:
         w1, b1, w2, b2, w3, b3 = (p.data for p in self.critic_params)
         return ops.CriticWeights(w1, b1, w2, b2, w3.reshape(-1), b3)
 
+    def _edge_mlp(self):
+        return ops.EdgeMlpWeights(*(p.data for p in self.edge_mlp_params))
+
+    # -- HOT LOOP A, state-dependent policy --------------------------------------------------------------------------------
+    @torch.no_grad()
+    def _collect_edge_mlp(self):
+        """T frames with the per-edge MLP policy: per frame observation (from the packed state) -> edge MLP on MFMA ->
+        GraphDistribution softmax / sample / log_prob -> the four-launch simulation frame with that action. Nothing is
+        hoisted. The update only ever reads the observations of its minibatch frames, and those frames are a random draw
+        that does not depend on the data: the draw is made up front and only their observations are kept."""
+        from .engine import EPISODE_END
+        eng = self.eng
+        T, B, N = self.T, eng.B, eng.N
+        eng.reset()
+        self.counts[0].zero_()
+        M = min(self.M, T * B)
+        if self.obs_idx is not None:                    # test hook: these frames instead of a random draw
+            self._mb_idx = [self.obs_idx.to(eng.device)]
+        else:
+            self._mb_idx = [torch.randperm(T * B, generator=self.gen, device=eng.device)[:M] for _ in range(self.num_epochs)]
+        flat = torch.cat(self._mb_idx)
+        order = torch.argsort(flat, stable=True)
+        t_sorted = torch.div(flat[order], B, rounding_mode="floor").tolist()
+        b_sorted = (flat[order] % B)
+        self.obs_mb = torch.empty((flat.numel(), N, 16), dtype=torch.float32, device=eng.device)
+        w = self._edge_mlp()
+        if getattr(self, "_obs_buf", None) is None:
+            self._obs_buf = torch.empty((B, N, 16), dtype=torch.float32, device=eng.device)
+            self._logits_buf = torch.empty((B, eng.E), dtype=torch.float32, device=eng.device)
+        host_times, done, pos = [], [False] * T, 0
+        for t in range(T):
+            host_times.append(float(eng.time))
+            obs = ops.fused_obs16(eng.plan, eng.fs, eng._x, eng.Nmax, eng.agents, out=self._obs_buf)
+            lo = pos
+            while pos < len(t_sorted) and t_sorted[pos] == t:
+                pos += 1
+            if pos > lo:                                   # frames of a minibatch: keep their observation
+                self.obs_mb.index_copy_(0, order[lo:pos], obs.index_select(0, b_sorted[lo:pos]))
+            logits = ops.policy_edge_mlp(eng.plan, obs, eng.ec, w, bf16=self.policy_bf16, out=self._logits_buf)
+            proba = ops.graphdist_softmax(eng.plan, logits, self.temperature)
+            self.sample_counter += 1
+            _, choice = ops.graphdist_sample(eng.plan, proba, seed=self.seed ^ 0x5DEECE66D, counter=self.sample_counter,
+                                             want_onehot=False, want_choice=True)
+            lp, _ = ops.graphdist_logprob_entropy(eng.plan, proba, choice=choice, want_entropy=False)
+            self.choice[t].copy_(choice)
+            self.logp[t].copy_(lp)
+            is_done = eng.frame_fused(action=choice, reward=self.reward[t], counts=self.counts[t + 1])
+            if is_done:
+                done[t] = True
+                if t + 1 < T:
+                    eng.reset()
+                    self.counts[t + 1].zero_()
+        host_times.append(float(eng.time))
+        self.times.copy_(torch.tensor(host_times, dtype=torch.float32))
+        self.done_frames = torch.tensor(done, dtype=torch.bool)
+        self.done_mask = (self.done_frames.to(eng.device, torch.uint8).view(T, 1).expand(T, B).contiguous()
+                          if any(done) else None)
+        self._epoch = 0
+        return T * B
+
     # -- HOT LOOP A -------------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def collect(self):
@@ -110,6 +193,8 @@ class VecPPOTrainer:
         is followed by a reset, like the collector's auto-reset: the rollout is split at that frame, the reset observation
         becomes the next frame's observation and ``done_frames`` marks the frame for GAE."""
         from .engine import EPISODE_END
+        if self.policy == "edge_mlp":
+            return self._collect_edge_mlp()
         eng = self.eng
         eng.reset()
         emb = self._emb()
@@ -195,8 +280,11 @@ class VecPPOTrainer:
         cw = self._critic()
         if self.env_minor and B % 128 == 0:
             v = ops.critic_forward_slabs(cw, self.counts, self.times)           # reads [frame][node][env] bytes as is
-        elif self.env_minor:    # odd batch sizes: the count bytes as fp32 rows first
+        elif self.env_minor and self.counts.dtype == torch.uint8:    # odd batch sizes: the count bytes as fp32 rows first
             _, rows = ops.rollout_gather(eng.plan, T + 1, B, True, counts=self.counts)
+            v, _, _ = ops.critic_forward(cw, rows, self.times, rows_per_time=B)
+        elif self.env_minor:
+            rows = self.counts.permute(0, 2, 1).contiguous().view((T + 1) * B, N)
             v, _, _ = ops.critic_forward(cw, rows, self.times, rows_per_time=B)
         else:
             v, _, _ = ops.critic_forward(cw, self.counts.view((T + 1) * B, N), self.times, rows_per_time=B)
@@ -214,12 +302,23 @@ class VecPPOTrainer:
         eng = self.eng
         T, B, N, E = self.T, eng.B, eng.N, eng.E
         M = min(self.M, T * B)
-        if idx is None:
+        if self.policy == "edge_mlp":       # the draw was made before the rollout (its observations were kept)
+            k = self._epoch
+            idx = self._mb_idx[k]
+            M = idx.numel()
+            off = sum(i.numel() for i in self._mb_idx[:k])
+            obs_mb = self.obs_mb[off:off + M]
+            self._epoch += 1
+        elif idx is None:
             idx = torch.randperm(T * B, generator=self.gen, device=eng.device)[:M]
         else:
             idx = idx.to(eng.device)
             M = idx.numel()
-        if self.rollout == "unfused":
+        if self.policy == "edge_mlp":
+            t_idx, b_idx = torch.div(idx, B, rounding_mode="floor"), idx % B
+            counts_mb = self.counts[t_idx, :, b_idx].contiguous()               # (M, N) fp32 rows of the sampled frames
+            choice_mb = self.choice.view(T * B, N).index_select(0, idx)
+        elif self.rollout == "unfused":
             counts_mb = self.counts[:T].view(T * B, N).index_select(0, idx)
             choice_mb = self.choice.view(T * B, N).index_select(0, idx)
         else:   # one launch: the sampled frames' action bytes -> edge ids, count bytes -> fp32 rows
@@ -236,7 +335,11 @@ class VecPPOTrainer:
         tgt_mb = target.view(-1).index_select(0, idx)
         time_mb = self.times[:T].index_select(0, torch.div(idx, B, rounding_mode="floor"))
         # actor forward (the live policy reads only the static ROAD_INDEX column: broadcast one observation over M rows)
-        logits = ops.policy_edge_logits(eng.plan, nf, self._emb())
+        if self.policy == "edge_mlp":
+            wmlp = self._edge_mlp()
+            logits = ops.policy_edge_mlp(eng.plan, obs_mb, eng.ec, wmlp)          # fp32 MFMA
+        else:
+            logits = ops.policy_edge_logits(eng.plan, nf, self._emb())
         proba = ops.graphdist_softmax(eng.plan, logits, self.temperature)
         lp_new, ent = ops.graphdist_logprob_entropy(eng.plan, proba, choice=choice_mb)
         cw = self._critic()
@@ -249,8 +352,13 @@ class VecPPOTrainer:
         self.flat.zero_grad()
         g_logits = ops.graphdist_logprob_entropy_bwd(eng.plan, proba, self.temperature, choice=choice_mb,
                                                      grad_log_prob=g_lp, grad_entropy=g_ent, log_prob_fwd=lp_new)
-        g_emb = ops.policy_edge_logits_bwd(eng.plan, nf, g_logits, self.emb_param.numel())
-        self.flat.grad_view(self.emb_param).add_(g_emb.view_as(self.emb_param))
+        if self.policy == "edge_mlp":
+            gm = [self.flat.grad_view(p) for p in self.edge_mlp_params]
+            ops.policy_edge_mlp_bwd(eng.plan, obs_mb, eng.ec, wmlp, g_logits,
+                                    (gm[0], gm[1], gm[2], gm[3], gm[4].view(-1), gm[5]))
+        else:
+            g_emb = ops.policy_edge_logits_bwd(eng.plan, nf, g_logits, self.emb_param.numel())
+            self.flat.grad_view(self.emb_param).add_(g_emb.view_as(self.emb_param))
         gw = [self.flat.grad_view(p) for p in self.critic_params]
         ops.critic_backward(cw, counts_mb, time_mb, 1, h1, h2, g_val,
                             (gw[0], gw[1], gw[2], gw[3], gw[4].view(-1), gw[5]))

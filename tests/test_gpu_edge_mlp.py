@@ -93,3 +93,133 @@ def test_fused_obs16_matches_the_exported_state():
     ref = torch.cat((nf, torch.gather(eng.agents, 1, head.unsqueeze(-1).expand(B, N, 9))), dim=-1)
     assert torch.equal(obs, ref)
     assert float(obs[:, :, 1].sum()) > 0 and float(obs[:, :, 14].sum()) > 0   # counts and ON_WAY flags are live
+
+
+@pytest.mark.parametrize("bf16_rollout", [False, True])
+def test_ppo_update_with_edge_mlp_policy_matches_oracle_autograd(bf16_rollout):
+    """One PPO update with the state-dependent head (per-frame observation -> MLP -> GraphDistribution in the rollout; MLP
+    forward / backward in the minibatch step) against the oracle with torch autograd on the SAME rollout and frames."""
+    from oracle import dist, nets, ppo
+    from src.agents.mpnn_agent import MPNNPolicyNet, MPNNValueNetSimple
+    from tarl_hip import synth
+    from tarl_hip.engine import SimEngine
+    from tarl_hip.trainer import VecPPOTrainer
+    net = synth.torus_network(4, 4, heterogeneous=True, seed=2)
+    N, E = net.num_roads, net.edge_index.size(1)
+    B, A, T, M = 128, 300, 12, 16
+    TEMP = 500.0            # the head sees raw features (clock times ~2e4): a temperature keeps the softmax from saturating
+    pops = torch.stack([synth.population(A, N, seed=b, t0=21540, t1=21550) for b in range(B)])
+    eng = SimEngine(net.x.cuda().unsqueeze(0).repeat(B, 1, 1).contiguous(), net.edge_index, net.edge_attr, net.Nmax,
+                    pops.cuda(), congestion_constant=net.congestion_constant, seed=3)
+    torch.manual_seed(0)
+    pol = MPNNPolicyNet(net.edge_index, N, None, device="cuda")
+    val = MPNNValueNetSimple(net.edge_index, N, device="cuda")
+    l = val.final_mlp
+    crit = [l[0].weight, l[0].bias, l[2].weight, l[2].bias, l[4].weight, l[4].bias]
+    mlp = [pol.edge_mlp[0].weight, pol.edge_mlp[0].bias, pol.edge_mlp[2].weight, pol.edge_mlp[2].bias,
+           pol.edge_mlp[4].weight, pol.edge_mlp[4].bias]
+    extra = [p for n, p in pol.named_parameters() if not n.startswith("nodes_embedding")]
+    tr = VecPPOTrainer(eng, pol.nodes_embedding.weight, crit, rollout_steps=T, num_epochs=1, sub_batch_size=M,
+                       extra_params=extra, policy="edge_mlp", edge_mlp_params=mlp, policy_bf16=bf16_rollout,
+                       temperature=TEMP)
+    assert tr.rollout == "frames+policy"
+    tr.keep_grad = True
+    idx = torch.randperm(T * B, generator=torch.Generator().manual_seed(4))[:M]
+    tr.obs_idx = idx
+    tr.collect()
+    mlp0 = [p.detach().cpu().clone() for p in mlp]
+    crit0 = [p.detach().cpu().clone() for p in crit]
+    counts = tr.counts.permute(0, 2, 1).cpu()            # (T+1, B, N)
+    choice, reward, times = tr.choice.cpu(), tr.reward.cpu(), tr.times.cpu()
+    x16 = tr.obs_mb.cpu()                                 # observations of the minibatch frames (tested on their own above)
+    assert float(reward.abs().sum()) > 0 and float(x16[:, :, 1].sum()) > 0
+    adv_g, tgt_g = tr.advantages()
+    out = tr.minibatch_step(adv_g, tgt_g)
+    # ---- oracle ----
+    wm = [p.clone().requires_grad_(True) for p in mlp0]
+    cw = [p.clone().requires_grad_(True) for p in crit0]
+    nf_all = torch.zeros((T + 1, B, N, 7))
+    nf_all[..., 1] = counts
+    with torch.no_grad():
+        v_all = nets.critic_value(nf_all, times.view(T + 1, 1, 1).expand(T + 1, B, 1), *cw).squeeze(-1)
+        nodone = torch.zeros((T, B), dtype=torch.bool)
+        adv, tgt = ppo.gae(reward, v_all[:T], v_all[1:], nodone, nodone, average_gae=True)
+    close(adv_g.cpu(), adv, "advantage")
+    t_idx, b_idx = idx // B, idx % B
+    onehot = torch.zeros((M, E), dtype=torch.int64)
+    onehot.scatter_(1, choice[t_idx, b_idx].long(), 1)
+    ea = net.edge_attr.expand(M, -1, -1)
+    with torch.no_grad():
+        lp_old = dist.GraphDist(nets.edge_mlp_logits(x16, net.edge_index, ea, *mlp0), net.edge_index, TEMP).log_prob(onehot)
+    if not bf16_rollout:     # the rollout's stored behaviour log-prob == the exact one (fp32 rollout)
+        close(tr.logp.view(-1).cpu()[idx], lp_old, "sample_log_prob")
+    lp_old = tr.logp.view(-1).cpu()[idx]
+    d = dist.GraphDist(nets.edge_mlp_logits(x16, net.edge_index, ea, *wm), net.edge_index, TEMP)
+    lp_new, ent = d.log_prob(onehot), d.entropy()
+    value = nets.critic_value(nf_all[t_idx, b_idx], times[t_idx].view(M, 1), *cw).squeeze(-1)
+    losses = ppo.clip_ppo_loss(lp_new, lp_old, adv.view(-1)[idx], value, tgt.view(-1)[idx], ent)
+    (losses["loss_objective"] + losses["loss_critic"] + losses["loss_entropy"]).backward()
+    o = out.cpu()
+    for i, k in enumerate(["loss_objective", "loss_critic", "loss_entropy"]):
+        assert abs(o[i].item() - losses[k].item()) <= TOL * max(1.0, abs(losses[k].item())), k
+    g = tr.last_grad.cpu()
+    assert float(g[:N].abs().sum()) == 0.0                                  # the embedding is not on this policy's path
+    off = N + sum(c.numel() for c in crit0) + sum(p.numel() for p in extra[:4])       # edge_mlp_test comes first
+    for i, ref in enumerate(wm):
+        n = ref.numel()
+        close(g[off:off + n], ref.grad.reshape(-1), f"grad edge_mlp[{i}]")
+        off += n
+    assert sum(float(r.grad.abs().sum()) for r in wm) > 0
+    for p_gpu, p0, gr, name in [(mlp[i], mlp0[i], wm[i].grad, f"edge_mlp{i}") for i in range(6)]:
+        q = p0.clone()
+        ppo.adam_step(q, gr, torch.zeros_like(q), torch.zeros_like(q), 1)
+        close(p_gpu.detach().cpu(), q, f"param {name}")
+
+
+def test_mirror_policy_net_with_edge_mlp_head_golden_and_cli(tmp_path, monkeypatch, capsys):
+    """MPNNPolicyNet(policy_head="edge_mlp").forward == the reference module's evaluation of its edge_mlp (golden), with
+    autograd through the HIP kernels; and `main.py --algo mpnn+ppo --policy-head edge_mlp` trains that head end to end."""
+    import importlib
+    import sys
+    from conftest import PKG
+    sys.path.insert(0, PKG)
+    from src.agents.mpnn_agent import MPNNPolicyNet
+    g = load_golden("edge_mlp")
+    ei = g["edge_index"]
+    N = g["node_features"].size(1)
+    pol = MPNNPolicyNet(ei, N, None, device="cuda")
+    pol.policy_head = "edge_mlp"
+    pol.agent_features = g["agent_features"].cuda()
+    with torch.no_grad():
+        for k in ("0", "2", "4"):
+            getattr(pol.edge_mlp, k).weight.copy_(g[f"biased__{k}__weight"])
+            getattr(pol.edge_mlp, k).bias.copy_(g[f"biased__{k}__bias"])
+    ea = g["edge_attr"].cuda()
+    logits = pol(g["node_features"].cuda(), ea.expand(3, -1, -1), g["agent_index"].cuda())
+    close(logits.detach().cpu(), g["biased__logits"], "mirror logits")
+    (logits * g["coef"].cuda()).sum().backward()
+    for k in ("0", "2", "4"):
+        close(getattr(pol.edge_mlp, k).weight.grad.cpu().reshape(-1), g[f"biased__grad__{k}__weight"].reshape(-1), f"grad {k}.weight")
+        close(getattr(pol.edge_mlp, k).bias.grad.cpu().reshape(-1), g[f"biased__grad__{k}__bias"].reshape(-1), f"grad {k}.bias")
+    l1 = pol(g["node_features"][0].cuda(), ea, g["agent_index"][0].cuda())          # unbatched, like the env's frames
+    assert l1.shape == (ei.size(1),) and torch.allclose(l1, logits[0].detach(), atol=1e-4)
+    # end to end through the CLI
+    monkeypatch.chdir(tmp_path)
+    main = importlib.import_module("main").main
+    from src.runner import Runner
+    created = []
+    orig_setup = Runner.setup
+
+    def spy_setup(self):
+        orig_setup(self)
+        created.append(self)
+    monkeypatch.setattr(Runner, "setup", spy_setup)
+    main(["--algo", "mpnn+ppo", "--mode", "train", "--scenario", "synthetic-1024-1024", "--rollout-steps", "24",
+          "--epochs", "2", "--steps", "6", "--num-envs", "4", "--policy-head", "edge_mlp", "--output-dir",
+          str(tmp_path / "run"), "--seed", "1"])
+    assert "Simulation Summary" in capsys.readouterr().out
+    r = created[-1]
+    torch.manual_seed(1)
+    fresh = MPNNPolicyNet(r.policy_net.edge_index, r.policy_net.num_nodes, None, device="cuda")
+    assert not torch.equal(fresh.edge_mlp[4].weight, r.policy_net.edge_mlp[4].weight)      # the head trained
+    assert torch.equal(fresh.nodes_embedding.weight, r.policy_net.nodes_embedding.weight)   # the embedding is off the path
