@@ -26,7 +26,7 @@ Also reported on the same JSON line:
                         the counter bytes; ``survey_8d_*``: SURVEY §8d's per-edge figure for the reference's AoS layout,
                         kept for continuity only (it charges every record once per out-edge: not a fraction of peak).
   roofline_direction  — the same for k_fused_direction (DirectionMPNN.message + aggregate, the scatter kernel the
-                        north star names); roofline_insert_choice — the insert(t) + choice(t+1) launch.
+                        north star names); roofline_insert — the insert launch (latency-bound).
   cpu_baseline        — the oracle (CPU restatement of the reference path, torch CPU) timed on this host's cores on a
                         bounded sample of the same workload (rank 0, N=1 only). A reported baseline, not a target.
 """
@@ -58,9 +58,9 @@ COMPULSORY = {
     # post word 4 + head words 8 + tail word 4 in; head words 8 + tail word 4 + count byte 1 out (event word, slot store
     # and agent rows only where something moves)
     "k_fused_rows": {"per_node_env": 16.0 + 13.0},
-    # choice(t+1): the action byte (= SELECTED_ROAD of frame t+1) out; insert(t): departure window, a few words per
-    # admitted agent
-    "k_fused_insert_choice": {"per_node_env": 1.0},
+    # insert(t): departure window, a few words per admitted agent, the accumulator banks (the actions of all frames are
+    # drawn on a side stream: k_fused_choice_all, 1 byte per (frame, road, environment))
+    "k_fused_insert": {"per_node_env": 0.0},
 }
 # SURVEY §8d's per-unit figures for the reference's AoS layout (kept as ``survey_8d_*`` keys only): Direction message +
 # aggregate 52 B/edge + 4 B/node; row pass = Direction update 32 B/node + Response message/aggregate 24 B/edge.
@@ -329,7 +329,7 @@ def main():
 
         rf_rows, rows_s = roofline(1, "k_fused_rows", "DirectionMPNN.update + ResponseMPNN + withdraw; the dominant kernel")
         rf_dir, dir_s = roofline(0, "k_fused_direction", "DirectionMPNN message + aggregate on the packed hot records")
-        rf_ic, _ = roofline(2, "k_fused_insert_choice", "insert(t) + GraphDistribution sample / log_prob of frame t+1")
+        rf_ic, _ = roofline(2, "k_fused_insert", "insert_agent_into_network + reward; a latency chain, one wave per environment")
         out = {
             "metric": "ppo_env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -343,7 +343,7 @@ def main():
             "msgpass_edges_per_sec": value * E,
             # Direction + Response pair alone (SURVEY 8d's second metric): B*E edges per frame / the two kernels' live time
             "msgpass_pair_edges_per_sec": (B * E) / (dir_s + rows_s) if (dir_s + rows_s) > 0 else None,
-            "roofline": rf_rows, "roofline_direction": rf_dir, "roofline_insert_choice": rf_ic,
+            "roofline": rf_rows, "roofline_direction": rf_dir, "roofline_insert": rf_ic,
             "setup_seconds": setup_s, "timed_seconds": elapsed,
             "congested_regime": congested,
             "state_dependent_policy": policy_lines,

@@ -41,6 +41,7 @@ typedef enum {
 #define TARL_FLAG_COUNT_AT_NMAX 1
 #define TARL_FLAG_AMBIGUOUS_EDGES 2
 #define TARL_FLAG_PACK_RANGE 4
+#define TARL_FLAG_CHOICE_OVERFLOW 8
 
 typedef struct tarl_plan tarl_plan; /* opaque static per-graph plan */
 typedef void* tarl_stream;          /* hipStream_t */
@@ -376,17 +377,24 @@ int tarl_fused_apply_choice(const tarl_plan* plan, const tarl_fused* f, int64_t 
  *   per-node series dtt_node fp32 [T][N][metrics_envs] (delta_travel_time of the node's out-edges,
  *   src/direction_mpnn.py:94-96) and events uint8 [T][N][metrics_envs] (bit 0: Response pop, bit 1: withdraw — the masks
  *   of update_history / withdraw_history).
- *   Scratch (device): ins_scratch int32 [B][2A]; sel_scratch uint8 [N][B] (only used without a choice buffer) +
- *   acc_scratch int64 [acc_slots][B]: with acc_scratch and two distinct SELECTED_ROAD slices frame t+1's choice work
- *   shares ONE launch with frame t's insert (a latency chain that leaves the chip idle); TARL_ROLLOUT_MERGE=0 disables it. */
+ *   Scratch (device): ins_scratch int32 [B][2A]; sel_scratch uint8 [N][B] (only used without a choice buffer);
+ *   acc_scratch int64 [acc_slots][B]; choice_scratch int32 [tarl_fused_rollout_scratch_ints(plan, T, B)], 16-byte aligned,
+ *   ZERO before its first use (the library leaves it zeroed again).
+ *   Scheduling of the GraphDistribution sample (state-independent for the live policy, so the T actions are T independent
+ *   draws from one set of tables; same Philox streams and arithmetic in every mode, identical results):
+ *     with a choice buffer and choice_scratch (default, TARL_ROLLOUT_MERGE=2) the whole action buffer is filled in blocks
+ *     of 32 frames on a side stream, in the shadow of the latency-bound frame kernels, and each frame is three launches
+ *     (Direction gather, row pass, insert); with acc_scratch and two distinct SELECTED_ROAD slices (TARL_ROLLOUT_MERGE=1)
+ *     frame t+1's choice shares ONE launch with frame t's insert; otherwise (TARL_ROLLOUT_MERGE=0) a launch per frame. */
+int64_t tarl_fused_rollout_scratch_ints(const tarl_plan* plan, int64_t T, int64_t B);
 int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, int64_t T,
                        const float* times_host, float prev_time, const float* thresholds, const int64_t* log_probs,
                        const float* entropy1, uint64_t policy_seed, uint64_t policy_counter0, float* agent_features,
                        int64_t num_agents, int64_t a_bstride, const float* edge_attr, const float* log_edge_attr,
                        float log_eps, int use_cong, uint64_t seed, uint64_t counter0, int32_t* ins_scratch,
-                       uint8_t* sel_scratch, int64_t* acc_scratch, uint8_t* choice, float* log_prob, float* entropy,
-                       float* reward, uint8_t* counts, int32_t metrics_envs, float* dtt_node, uint8_t* events,
-                       int32_t* leg, tarl_stream stream);
+                       uint8_t* sel_scratch, int64_t* acc_scratch, int32_t* choice_scratch, uint8_t* choice,
+                       float* log_prob, float* entropy, float* reward, uint8_t* counts, int32_t metrics_envs,
+                       float* dtt_node, uint8_t* events, int32_t* leg, tarl_stream stream);
 
 /* x = cat(node_features, agent_features[head of the FIFO]) [B][N][16] of the packed state (see tarl_policy_obs16) */
 int tarl_fused_obs16(const tarl_plan* plan, const tarl_fused* f, const float* x, int64_t B, int64_t x_bstride,

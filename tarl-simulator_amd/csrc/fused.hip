@@ -379,6 +379,126 @@ __global__ __launch_bounds__(TILE) void k_fused_choice(const int32_t* __restrict
                     uniform, pseed, pcounter, sel_out, sel_prev, choice, nchunk, want_lp);
 }
 
+// ---- the whole rollout's actions in one pass (state-independent policy) -----------------------------------------------------
+// The live policy's distribution does not read the state, so the T actions of a rollout are T independent draws from ONE
+// set of tables: instead of a choice launch per frame (instruction-bound: ~16 us of scalar table walks that the frame loop
+// had to wait for), the action buffer [T][N][B] is filled by launches of 32 frames each on a side stream, in the shadow of
+// the latency-bound frame kernels. One workgroup = one (environment tile, frame): it walks ALL nodes, so a frame's
+// log-prob is a register sum (no atomics) — the same Philox indices, thresholds and 2^-32 fixed-point terms as the
+// per-frame kernel, hence the same bits.
+// A node that draws nothing (u at / beyond its last threshold through rounding, ~1e-7 per draw) keeps the PREVIOUS frame's
+// SELECTED_ROAD: frames are concurrent here, so such an entry is marked SEL_UNRESOLVED, listed, and resolved by
+// k_choice_fixup (walk back to the last frame that drew something; before frame 0: the packed state's code).
+#define SEL_UNRESOLVED 0xFEu      // = SEL_CARRIED | 0x7E: no rank (out-degree <= 126) and not SEL_RAW
+#define FIX_CAP 65536
+struct __attribute__((aligned(4))) PRec {   // per out-edge (CSR order, padded by 4): inverse-CDF threshold + log-prob
+  float thr;
+  int32_t lg_lo, lg_hi;                      // log(p + 1e-8) in 2^-32 fixed point
+  int32_t pad;
+};
+
+__global__ __launch_bounds__(FB) void k_pack_ptab(int64_t E, const float* __restrict__ thr,
+                                                  const long long* __restrict__ lgt, PRec* __restrict__ ptab) {
+  const int64_t k = (int64_t)blockIdx.x * FB + threadIdx.x;
+  if (k >= E + 4) return;
+  if (k < E) {
+    const long long lg = lgt[k];
+    ptab[k] = PRec{thr[k], (int32_t)(uint32_t)(lg & 0xffffffffll), (int32_t)(lg >> 32), 0};
+  } else {
+    ptab[k] = PRec{2.0f, 0, 0, 0};
+  }
+}
+
+#define CHOICE_SEG 128    // nodes per workgroup of the all-frames choice (a frame's log-prob = the sum of its segments)
+__global__ __launch_bounds__(TILE) void k_fused_choice_all(const NodeRec* __restrict__ nodes, const PRec* __restrict__ ptab,
+                                                           const int32_t* __restrict__ group_of_node, uint32_t G,
+                                                           uint32_t B, uint32_t N, int64_t t0, uint64_t pseed,
+                                                           uint64_t pcounter0, const uint8_t* __restrict__ sel0,
+                                                           uint8_t* __restrict__ choice, long long* __restrict__ lp_acc,
+                                                           int32_t* __restrict__ fix, int32_t* __restrict__ flags) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int64_t t = t0 + blockIdx.z;
+  const uint32_t i0 = blockIdx.y * CHOICE_SEG;
+  const uint32_t i1 = (i0 + CHOICE_SEG < N) ? i0 + CHOICE_SEG : N;
+  uint8_t* out = choice + t * (int64_t)N * B;
+  long long lp = 0;
+  bool bad = false;
+  PhiloxRun rng;
+  for (uint32_t i = i0; i < i1; ++i) {      // i, and everything indexed by it alone, is wave-uniform
+    const uint32_t row = i * B + b;
+    const int32_t gi = group_of_node[i];
+    uint32_t code;
+    if (gi >= 0) {
+      const float u = rng.uniform(pseed, pcounter0 + (uint64_t)t, (uint64_t)b * G + (uint64_t)gi);
+      const NodeRec nr = nodes[i];
+      const PRec* pr = ptab + nr.out0;
+      bool found = false;
+      long long lpn = 0;
+      code = SEL_UNRESOLVED;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {       // four records from consecutive addresses (padded table)
+        const bool hit = !found && q < nr.out_deg && (u < pr[q].thr);
+        const long long lgk = ((long long)pr[q].lg_hi << 32) | (long long)(uint32_t)pr[q].lg_lo;
+        code = hit ? (uint32_t)q : code;
+        lpn = hit ? lgk : lpn;
+        found = found || hit;
+      }
+      for (int32_t q = 4; q < nr.out_deg; ++q) {
+        const bool hit = !found && (u < pr[q].thr);
+        const long long lgk = ((long long)pr[q].lg_hi << 32) | (long long)(uint32_t)pr[q].lg_lo;
+        code = hit ? (uint32_t)q : code;
+        lpn = hit ? lgk : lpn;
+        found = found || hit;
+      }
+      if (found) {
+        lp += lpn;
+      } else {
+        bad = true;
+        const int32_t pos = atomicAdd(&fix[0], 1);
+        if (pos < FIX_CAP) {
+          fix[2 + 2 * pos] = (int32_t)t;
+          fix[3 + 2 * pos] = (int32_t)row;
+        } else {
+          atomicOr(flags, FLAG_CHOICE_OVERFLOW);
+        }
+      }
+    } else {
+      code = (sel0[row] & 0x7Fu) | SEL_CARRIED;   // no out-edges: SELECTED_ROAD never changes
+    }
+    out[row] = (uint8_t)code;
+  }
+  // order-independent 2^-32 fixed-point sum over the node segments; an action with a node that drew nothing is poisoned
+  // far beyond any legitimate sum (it is infeasible: log_prob = -inf, src/reinforcement_learning.py:88-92)
+  if (lp_acc) atomicAdd((unsigned long long*)&lp_acc[t * B + b], (unsigned long long)(bad ? -(1ll << 50) : lp));
+}
+
+__global__ __launch_bounds__(FB) void k_choice_lp_finish(int64_t n, long long* __restrict__ lp_acc,
+                                                         float* __restrict__ log_prob) {
+  const int64_t i = (int64_t)blockIdx.x * FB + threadIdx.x;
+  if (i >= n) return;
+  const long long v = lp_acc[i];
+  lp_acc[i] = 0;     // re-armed for the next rollout
+  log_prob[i] = (v < -(1ll << 49)) ? -INFINITY : (float)((double)v / LP_FIX);
+}
+
+__global__ __launch_bounds__(ENVB) void k_choice_fixup(uint32_t B, uint32_t N, const uint8_t* __restrict__ sel0,
+                                                       uint8_t* __restrict__ choice, int32_t* __restrict__ fix) {
+  int32_t cnt = fix[0];
+  if (cnt > FIX_CAP) cnt = FIX_CAP;
+  const int64_t NB = (int64_t)N * B;
+  for (int32_t idx = threadIdx.x; idx < cnt; idx += ENVB) {
+    const int64_t t = fix[2 + 2 * idx];
+    const int64_t row = fix[3 + 2 * idx];
+    uint32_t c = SEL_UNRESOLVED;
+    for (int64_t tt = t - 1; tt >= 0 && c == SEL_UNRESOLVED; --tt) c = choice[tt * NB + row];
+    if (c == SEL_UNRESOLVED) c = sel0[row];
+    choice[t * NB + row] = (uint8_t)((c & 0x7Fu) | SEL_CARRIED);   // a concurrent reader sees the marker or this: same walk
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) fix[0] = 0;
+}
+
 // ---- Direction gather on the dense words (env-minor: lane = environment) ---------------------------------------------------
 // Two passes inside the workgroup. Pass 1 (every (node, environment) pair of the chunk): admissibility masks and the
 // summed turn probability P — no random numbers — and the default post word (nobody chosen). A pair needs the Gumbel
@@ -1303,6 +1423,37 @@ extern "C" int tarl_fused_apply_choice(const tarl_plan* plan, const tarl_fused* 
   return TARL_OK;
 }
 
+// side stream + events of the all-frames choice (one set per device, created on first use, kept for the process lifetime)
+#define CHOICE_CHUNK 32          // frames per side-stream block (the first block is CHOICE_FIRST frames: it is waited for)
+#define CHOICE_FIRST 4
+#define CHOICE_MAX_CHUNKS 256
+struct ChoiceSide {
+  hipStream_t stream;
+  hipEvent_t start;
+  hipEvent_t done[CHOICE_MAX_CHUNKS];
+  bool ready;
+};
+static ChoiceSide g_choice_side[64];
+
+static int choice_side(ChoiceSide** out) {
+  int dev = 0;
+  TARL_CHECK_HIP(hipGetDevice(&dev));
+  ChoiceSide* cs = &g_choice_side[dev & 63];
+  if (!cs->ready) {
+    TARL_CHECK_HIP(hipStreamCreateWithFlags(&cs->stream, hipStreamNonBlocking));
+    TARL_CHECK_HIP(hipEventCreateWithFlags(&cs->start, hipEventDisableTiming));
+    for (int i = 0; i < CHOICE_MAX_CHUNKS; ++i) TARL_CHECK_HIP(hipEventCreateWithFlags(&cs->done[i], hipEventDisableTiming));
+    cs->ready = true;
+  }
+  *out = cs;
+  return TARL_OK;
+}
+
+extern "C" int64_t tarl_fused_rollout_scratch_ints(const tarl_plan* plan, int64_t T, int64_t B) {
+  // unresolved-draw list | packed policy records | per-(frame, environment) log-prob accumulators (int64)
+  return plan && T >= 1 && B >= 1 ? (int64_t)(4 + 2 * FIX_CAP) + 4 * (plan->E + 4) + 2 * T * B : -1;
+}
+
 // T consecutive frames with device noise: the collector loop in one foreign call. Each frame is choice -> direction ->
 // rows -> insert on the caller's stream; frame t+1's choice shares the launch of frame t's insert
 // (k_fused_insert_choice). The action of frame t is written into slice t of the action buffer, which is also the
@@ -1316,7 +1467,8 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
                                   uint64_t policy_counter0, float* agent_features, int64_t A, int64_t a_bstride,
                                   const float* edge_attr, const float* log_edge_attr, float log_eps, int use_cong,
                                   uint64_t seed, uint64_t counter0, int32_t* ins_scratch, uint8_t* sel_scratch,
-                                  int64_t* acc_scratch, uint8_t* choice, float* log_prob, float* entropy, float* reward,
+                                  int64_t* acc_scratch, int32_t* choice_scratch, uint8_t* choice, float* log_prob,
+                                  float* entropy, float* reward,
                                   uint8_t* counts, int32_t metrics_envs, float* dtt_node, uint8_t* events, int32_t* leg,
                                   tarl_stream stream) {
   int rc = tarl_check_fused_core(plan, f, B, Nmax);
@@ -1344,15 +1496,56 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
   };
   // steady state: frame t's insert and frame t+1's choice share ONE launch (k_fused_insert_choice); needs two distinct
   // SELECTED_ROAD slices and double-buffered log-prob accumulator banks
+  // TARL_ROLLOUT_MERGE: 2 (default) = all actions precomputed on a side stream (needs the action buffer + choice_scratch),
+  // 1 = frame t+1's choice shares frame t's insert launch, 0 = a choice launch per frame
   const char* knob = getenv("TARL_ROLLOUT_MERGE");
-  const bool merge = (choice || sel_scratch) && acc_scratch && T > 1 && !(knob && atoi(knob) == 0);
+  const int mode = knob ? atoi(knob) : 2;
+  const bool ahead = mode >= 2 && choice && choice_scratch && ceil_div(T, CHOICE_CHUNK) + 1 <= CHOICE_MAX_CHUNKS &&
+                     ceil_div(N, CHOICE_SEG) < 65536;
+  const bool merge = !ahead && mode >= 1 && (choice || sel_scratch) && acc_scratch && T > 1;
   long long* acc_buf[2] = {(long long*)f->acc_lp, merge ? (long long*)acc_scratch : (long long*)f->acc_lp};
   if (merge) TARL_CHECK_HIP(hipMemsetAsync(acc_scratch, 0, (size_t)(f->acc_slots * B) * sizeof(int64_t), s));
-  hipLaunchKernelGGL(k_fused_choice, grid_c, dim3(threads), 0, s, plan->out_ptr, plan->out_eid, plan->group_of_node,
-                     plan->G, B, N, acc_buf[0], fb.acc_slots, thresholds, (const long long*)log_probs,
-                     (const float*)nullptr, policy_seed, policy_counter0, slice(0), (const uint8_t*)f->sel8,
-                     (int32_t*)nullptr, nchunk_choice(), want_lp);
-  TARL_LAUNCH_CHECK();
+  ChoiceSide* side = nullptr;
+  if (ahead) {
+    rc = choice_side(&side);
+    if (rc) return rc;
+    int32_t* fix = choice_scratch;
+    PRec* ptab = (PRec*)(choice_scratch + 4 + 2 * FIX_CAP);
+    TARL_REQUIRE(((uintptr_t)ptab) % 16 == 0, "choice_scratch must be 16-byte aligned");
+    // the side stream starts behind everything already queued on the caller's stream (tables, reset, earlier rollouts)
+    TARL_CHECK_HIP(hipEventRecord(side->start, s));
+    TARL_CHECK_HIP(hipStreamWaitEvent(side->stream, side->start, 0));
+    TARL_CHECK_HIP(hipMemsetAsync(fix, 0, 2 * sizeof(int32_t), side->stream));
+    hipLaunchKernelGGL(k_pack_ptab, dim3((unsigned)ceil_div(plan->E + 4, FB)), dim3(FB), 0, side->stream, plan->E,
+                       thresholds, (const long long*)log_probs, ptab);
+    TARL_LAUNCH_CHECK();
+    long long* lp_acc = (long long*)(ptab + plan->E + 4);     // [T][B], zero between rollouts (k_choice_lp_finish re-arms)
+    for (int64_t c = 0, t0 = 0; t0 < T; ++c) {
+      const int64_t want = c == 0 ? CHOICE_FIRST : CHOICE_CHUNK;
+      const unsigned nf = (unsigned)(T - t0 < want ? T - t0 : want);
+      hipLaunchKernelGGL(k_fused_choice_all, dim3((unsigned)ceil_div(B, threads), (unsigned)ceil_div(N, CHOICE_SEG), nf),
+                         dim3(threads), 0, side->stream, (const NodeRec*)f->node_rec, (const PRec*)ptab,
+                         plan->group_of_node, (uint32_t)plan->G, (uint32_t)B, (uint32_t)N, t0, policy_seed,
+                         policy_counter0, (const uint8_t*)f->sel8, choice, log_prob ? lp_acc : nullptr, fix, f->flags);
+      TARL_LAUNCH_CHECK();
+      hipLaunchKernelGGL(k_choice_fixup, dim3(1), dim3(ENVB), 0, side->stream, (uint32_t)B, (uint32_t)N,
+                         (const uint8_t*)f->sel8, choice, fix);
+      TARL_LAUNCH_CHECK();
+      if (log_prob) {
+        hipLaunchKernelGGL(k_choice_lp_finish, dim3((unsigned)ceil_div((int64_t)nf * B, FB)), dim3(FB), 0, side->stream,
+                           (int64_t)nf * B, lp_acc + t0 * B, log_prob + t0 * B);
+        TARL_LAUNCH_CHECK();
+      }
+      TARL_CHECK_HIP(hipEventRecord(side->done[c], side->stream));
+      t0 += nf;
+    }
+  } else {
+    hipLaunchKernelGGL(k_fused_choice, grid_c, dim3(threads), 0, s, plan->out_ptr, plan->out_eid, plan->group_of_node,
+                       plan->G, B, N, acc_buf[0], fb.acc_slots, thresholds, (const long long*)log_probs,
+                       (const float*)nullptr, policy_seed, policy_counter0, slice(0), (const uint8_t*)f->sel8,
+                       (int32_t*)nullptr, nchunk_choice(), want_lp);
+    TARL_LAUNCH_CHECK();
+  }
   for (int64_t t = 0; t < T; ++t) {
     const int cur = merge ? (int)(t & 1) : 0;
     const float time = times_host[t];
@@ -1368,6 +1561,8 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
                        dtt_node ? dtt_node + t * N * m : nullptr,
                        metrics_envs,
                        leg ? leg + t * 2 * B : nullptr};
+    if (ahead && (t == 0 || (t >= CHOICE_FIRST && (t - CHOICE_FIRST) % CHOICE_CHUNK == 0)))
+      TARL_CHECK_HIP(hipStreamWaitEvent(s, side->done[t == 0 ? 0 : 1 + (t - CHOICE_FIRST) / CHOICE_CHUNK], 0));
     const bool timed = tarl_prof_mark(s, 0) != nullptr;
     rc = launch_direction(grid_d, threads, s, plan, f, edge_attr, log_edge_attr, sel_t, nullptr, nullptr, log_eps, time,
                           t > 0 ? times_host[t - 1] : prev_time, seed, counter0 + (uint64_t)t, B, out);
@@ -1377,9 +1572,13 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
     if (rc) return rc;
     if (timed) (void)tarl_prof_mark(s, 2);
     float* reward_t = reward ? reward + t * B : nullptr;
-    float* lp_t = log_prob ? log_prob + t * B : nullptr;
+    float* lp_t = (log_prob && !ahead) ? log_prob + t * B : nullptr;   // ahead: written by k_fused_choice_all
     float* ent_t = entropy ? entropy + t * B : nullptr;
-    if (merge && t + 1 < T) {
+    if (ahead) {
+      hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(INSB), 0, s, (int)Nmax, B, N, fbt, P, sel_t,
+                         agent_features, A, a_bstride, use_cong, time, ins_scratch, entropy1, reward_t, out, lp_t, ent_t);
+      TARL_LAUNCH_CHECK();
+    } else if (merge && t + 1 < T) {
       const ChoiceArgs C{plan->out_ptr, plan->out_eid, plan->group_of_node, plan->G, thresholds,
                          (const long long*)log_probs, policy_seed, policy_counter0 + (uint64_t)(t + 1), nchunk_choice(),
                          want_lp, slice(t + 1), acc_buf[cur ^ 1], grid_c.x, grid_c.x * grid_c.y};

@@ -41,6 +41,7 @@
 #define FLAG_COUNT_AT_NMAX 1      // a FIFO count reached Nmax: outside the reference's defined domain (it raises IndexError)
 #define FLAG_AMBIGUOUS_EDGES 2    // two out-edges of one node lead to the same ROAD_INDEX: SELECTED_ROAD has no unique rank
 #define FLAG_PACK_RANGE 4         // pack: a count above 255 / an agent id at or above 2^24
+#define FLAG_CHOICE_OVERFLOW 8    // more than 65536 nodes drew nothing in one block of frames (degenerate policy tables)
 
 // Static per-graph records (built by pack; shared by all environments, read through the scalar cache). One node record
 // and ONE base address per row give the hot kernels everything static they need: a row's in-edge records and out-edge

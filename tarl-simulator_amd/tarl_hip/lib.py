@@ -66,7 +66,8 @@ SIGNATURES = {
                                    _f32, _f32, _p, _u64, _u64] + [_p] * 10),
     "tarl_fused_apply_choice": (C.c_int, [_p, _p, _i64, _p, _p]),
     "tarl_fused_rollout": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _f32, _p, _p, _p, _u64, _u64, _p, _i64, _i64, _p, _p,
-                                     _f32, C.c_int, _u64, _u64] + [_p] * 8 + [_i32, _p, _p, _p, _p]),
+                                     _f32, C.c_int, _u64, _u64] + [_p] * 9 + [_i32, _p, _p, _p, _p]),
+    "tarl_fused_rollout_scratch_ints": (_i64, [_p, _i64, _i64]),
     "tarl_rollout_gather": (C.c_int, [_p, _p, _p, _i64, _i64, C.c_int, _p, _i64, _p, _p, _p]),
     "tarl_rollout_env_supported": (C.c_int, [_p]),
     "tarl_rollout_env_scratch_bytes": (_i64, [_p]),
@@ -93,7 +94,7 @@ class FusedStruct(C.Structure):
                 [("acc_slots", C.c_int64), ("flags", C.c_void_p)])
 
 
-FLAG_COUNT_AT_NMAX, FLAG_AMBIGUOUS_EDGES, FLAG_PACK_RANGE = 1, 2, 4
+FLAG_COUNT_AT_NMAX, FLAG_AMBIGUOUS_EDGES, FLAG_PACK_RANGE, FLAG_CHOICE_OVERFLOW = 1, 2, 4, 8
 
 
 _lib = None

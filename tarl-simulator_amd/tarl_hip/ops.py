@@ -651,6 +651,8 @@ def raise_on_flags(v: int):
                              "on this graph; construct SimEngine(..., fused=False)")
     if v & _lib.FLAG_PACK_RANGE:
         raise _lib.TarlError("pack: a FIFO count above 255 or an agent id at / above 2^24 does not fit the packed words")
+    if v & _lib.FLAG_CHOICE_OVERFLOW:
+        raise _lib.TarlError("more than 65536 nodes drew no action in one block of frames: degenerate policy tables")
 
 
 def fused_pack(plan: Plan, fs: FusedState, x, Nmax, agent_features, congestion_constant=None, sort_agents=None, *,
@@ -775,6 +777,10 @@ def fused_rollout(plan: Plan, fs: FusedState, tables: PolicyTables, agent_featur
         fs.acc_scratch = torch.zeros_like(fs.acc_lp)
     if choice is None and getattr(fs, "sel_scratch", None) is None:
         fs.sel_scratch = torch.empty_like(fs.sel8)
+    need = int(L.tarl_fused_rollout_scratch_ints(plan.handle, T, B))
+    if getattr(fs, "choice_scratch", None) is None or fs.choice_scratch.numel() < need:
+        # unresolved-draw list + packed policy records + per-(frame, env) log-prob accumulators of the side stream
+        fs.choice_scratch = torch.zeros(need, dtype=torch.int32, device=fs.sel8.device)
     tarr = (C.c_float * T)(*[float(t) for t in times])
     _lib.check(L.tarl_fused_rollout(plan.handle, fs.ref, B, fs.Nmax, T, tarr,
                                     float(times[0] - 1 if prev_time is None else prev_time), tables.thresholds.data_ptr(),
@@ -783,7 +789,8 @@ def fused_rollout(plan: Plan, fs: FusedState, tables: PolicyTables, agent_featur
                                     ec.log_edge_attr.data_ptr(), ec.log_eps, 1 if use_cong else 0, int(seed),
                                     int(counter0), scratch.data_ptr(),
                                     _lib.ptr(getattr(fs, "sel_scratch", None)) if choice is None else None,
-                                    fs.acc_scratch.data_ptr(), _lib.ptr(choice), _lib.ptr(log_prob), _lib.ptr(entropy),
+                                    fs.acc_scratch.data_ptr(), fs.choice_scratch.data_ptr(), _lib.ptr(choice),
+                                    _lib.ptr(log_prob), _lib.ptr(entropy),
                                     _lib.ptr(reward), _lib.ptr(counts), int(metrics_envs), _lib.ptr(dtt_node),
                                     _lib.ptr(events), _lib.ptr(leg), _lib.current_stream()))
 

@@ -67,7 +67,8 @@ def test_entry_points_reject_bad_arguments_on_the_host():
     assert L.tarl_apsp(null, null, 1, 0, null, 0, null, null, null) == -1
     assert b"null" in L.tarl_last_error()
     assert L.tarl_fused_rollout(null, null, 1, 15, 1, null, 0.0, null, null, null, 0, 0, null, 1, 9, null, null, 0.0, 0, 0,
-                                0, null, null, null, null, null, null, null, null, 0, null, null, null, null) == -1
+                                0, null, null, null, null, null, null, null, null, null, 0, null, null, null, null) == -1
+    assert L.tarl_fused_rollout_scratch_ints(null, 1, 1) == -1
     assert L.tarl_rollout_env(null, null, 1, 15, 1, null, 0.0, null, null, null, 0, 0, null, 1, 9, null, null, 0.0, 0, 0, 0,
                               null, null, null, null, null, null, null, 0, null, null, null, null) == -1
     assert L.tarl_rollout_gather(null, null, null, 1, 1, 1, null, 0, null, null, null) == -1

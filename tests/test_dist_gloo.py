@@ -39,7 +39,8 @@ def _worker(rank, world, port, q):
     dist_utils.broadcast_(wts, src=0)
     mx = dist_utils.allreduce_max_float(1.0 + rank, "cpu")
     dist_utils.barrier()
-    q.put((rank, grad, stats, adv, wts, mx))
+    # numpy arrays pickle by value (torch tensors travel as file descriptors that die with this process)
+    q.put((rank, grad.numpy(), stats.numpy(), adv.numpy(), wts.numpy(), mx))
     dist.destroy_process_group()
 
 
@@ -57,6 +58,7 @@ def test_eight_rank_exchange():
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
+    res = [(r, *(torch.from_numpy(a) for a in arrs), m) for r, *arrs, m in res]
     ref = torch.stack([torch.randn(1000, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]).mean(0)
     allv = torch.cat([r[3] for r in res]).double()
     for _, g, s_, _, w, m in res:
@@ -79,6 +81,7 @@ def test_two_rank_exchange_matches_single_process():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    res = [(r, *(torch.from_numpy(a) for a in arrs), m) for r, *arrs, m in res]
     (_, g0, s0, a0, w0, m0), (_, g1, s1, a1, w1, m1) = res
     # identical on both ranks, equal to the mean of the per-rank gradients
     ref = torch.stack([torch.randn(1000, generator=torch.Generator().manual_seed(100 + r)) for r in range(2)]).mean(0)

@@ -179,9 +179,10 @@ def test_critic_slab_mode_matches_row_major(ops):
 
 
 @pytest.mark.parametrize("B,T,merge", [(5, 30, "1"), (5, 30, "0"), (70, 7, "1"), (3, 1, "1"), (130, 2, "1"),
-                                       (130, 3, "1"), (300, 5, "1")])
+                                       (130, 3, "1"), (300, 5, "1"), (5, 70, "2"), (300, 33, "2"), (3, 1, "2")])
 def test_rollout_launcher_equals_frame_loop(ops, monkeypatch, B, T, merge):
-    """SimEngine.rollout_fused (tarl_fused_rollout: the whole collector loop in one foreign call; with merge = 1 frame
+    """SimEngine.rollout_fused (tarl_fused_rollout: the whole collector loop in one foreign call; with merge = 2 — the
+    default — all actions are drawn in blocks of 32 frames on a side stream; with merge = 1 frame
     t+1's choice shares a launch with frame t's insert, SELECTED_ROAD and the log-prob accumulators double-buffered)
     == T calls of frame_fused; then a second rollout continues from the state the first left (odd and even T end in
     different buffers)."""

@@ -32,7 +32,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tarl-simulator_amd")]
 ROLLOUT_KERNELS = {
     "k_fused_direction": lambda T: T,
     "k_fused_rows": lambda T: T,
-    "k_fused_insert_choice": lambda T: T - 1,
+    "k_fused_insert": lambda T: T,
 }
 
 
