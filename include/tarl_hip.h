@@ -231,15 +231,19 @@ int tarl_critic_mlp_fwd_slabs(const float* counts, int64_t rows_per_slab, int64_
 /* the same two forwards on the rollout buffers' count bytes (uint8 NUMBER_OF_AGENT, widened to fp32 in the LDS staging:
  *   identical values): tarl_critic_mlp_fwd_u8 reads counts uint8 [M][ldc] (the env-major buffer of tarl_rollout_env),
  *   tarl_critic_mlp_fwd_slabs_u8 counts uint8 [M / rows_per_slab][N][rows_per_slab] (the env-minor buffer of
- *   tarl_fused_rollout). */
+ *   tarl_fused_rollout). With split_scratch (tarl_critic_split_scratch_bytes(N) bytes, 16-byte aligned) the first layer runs
+ *   on the bf16 matrix cores at fp32 accuracy: the counts are exact in bf16 and W1 is split into three bf16 pieces with
+ *   hi + mid + lo == W1 exactly, every product exact, fp32 accumulation (the value differs from the fp32 chain only by
+ *   the order of the fp32 additions, ~1e-7 relative); NULL: fp32 MFMA on the widened bytes. */
+int64_t tarl_critic_split_scratch_bytes(int64_t N);
 int tarl_critic_mlp_fwd_u8(const uint8_t* counts, int64_t ldc, int64_t M, int64_t N, const float* time_rows,
                            int64_t rows_per_time, const float* w1, const float* b1, const float* w2, const float* b2,
                            const float* w3, const float* b3, float* value, float* h1_out, float* h2_out,
                            tarl_stream stream);
 int tarl_critic_mlp_fwd_slabs_u8(const uint8_t* counts, int64_t rows_per_slab, int64_t M, int64_t N,
                                  const float* time_rows, int64_t rows_per_time, const float* w1, const float* b1,
-                                 const float* w2, const float* b2, const float* w3, const float* b3, float* value,
-                                 tarl_stream stream);
+                                 const float* w2, const float* b2, const float* w3, const float* b3, void* split_scratch,
+                                 float* value, tarl_stream stream);
 
 /* ---- MPNNValueNet (src/agents/mpnn_agent.py:265-402; the message-passing critic the reference defines but never
  * instantiates) in evaluation mode (Dropout = identity), M samples:

@@ -308,6 +308,170 @@ __global__ __launch_bounds__(CR_THREADS) void k_critic_fwd_slab(const XT* __rest
   }
 }
 
+// ---- slab-input forward on the rollout's count BYTES, first layer on the bf16 matrix cores at fp32 accuracy ----------------
+// The observation is a small integer per node (NUMBER_OF_AGENT <= 255): exact in bf16. W1 is split once per call into three
+// bf16 pieces with hi + mid + lo == W1 exactly (8 + 8 + 8 significand bits), so
+//     h1 = X W1^T = X hi^T + X mid^T + X lo^T
+// with every product exact (8-bit count x 8-bit piece) and fp32 accumulation: the same value as the fp32 chain up to the
+// order of the fp32 additions (~1e-7 relative; contract 1e-4), at 16x the MFMA rate per piece. The pass then runs at HBM
+// speed on 1 byte per (frame, node, environment) instead of at the fp32-MFMA rate on 4.
+// Orientation: D^T = W X^T, so that the count bytes are the B operand straight from their k-major ([node][env]) layout —
+// no transpose in LDS: lane (col = env, half h) reads its 8 bytes Xs[8h + j][env]; A = the weight pieces, k-contiguous.
+typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
+#define CB_XLD 144     // bytes per k-row of the X stage (128 envs + pad, 16-byte aligned)
+#define CB_WLD 40      // bf16 per j-row of a W stage (32 k + pad): 80-byte rows, 16-byte aligned
+
+__device__ __forceinline__ uint16_t cr_bf16_rne(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+// w1 [64][N+1] -> w3 [3][64][Kpad] bf16 (k >= N zero-padded): hi = bf16(w), mid = bf16(w - hi), lo = bf16(w - hi - mid)
+__global__ __launch_bounds__(CR_THREADS) void k_split_w1(const float* __restrict__ w1, int64_t N, int64_t Kpad,
+                                                         uint16_t* __restrict__ w3) {
+  const int64_t idx = (int64_t)blockIdx.x * CR_THREADS + threadIdx.x;
+  if (idx >= CR_H * Kpad) return;
+  const int64_t j = idx / Kpad, k = idx - j * Kpad;
+  const float w = k < N ? w1[j * (N + 1) + k] : 0.0f;
+  const uint16_t hi = cr_bf16_rne(w);
+  const float r1 = w - __uint_as_float((uint32_t)hi << 16);
+  const uint16_t mid = cr_bf16_rne(r1);
+  const float r2 = r1 - __uint_as_float((uint32_t)mid << 16);
+  const uint16_t lo = cr_bf16_rne(r2);
+  w3[idx] = hi;
+  w3[CR_H * Kpad + idx] = mid;
+  w3[2 * CR_H * Kpad + idx] = lo;
+}
+
+__global__ __launch_bounds__(CR_THREADS) void k_critic_fwd_slab_u8x3(const uint8_t* __restrict__ counts, int64_t rps,
+                                                                     int64_t M, int64_t N, int64_t Kpad,
+                                                                     const float* __restrict__ time_rows,
+                                                                     int64_t rows_per_time,
+                                                                     const uint16_t* __restrict__ w3, CriticParams P,
+                                                                     float* __restrict__ value) {
+  // staging: 2 x (Xs [32][144] bytes + Wb [3][64][40] bf16); the epilogue reuses the space as Hs [64][129] + W2s [64][65] f32
+  __shared__ __attribute__((aligned(16))) uint8_t lds_raw[(CR_H * (CR_BM + 1) + CR_H * (CR_H + 1)) * 4];
+  const int XB = CR_BK * CB_XLD, WB = 3 * CR_H * CB_WLD * 2, BUF = XB + WB;   // bytes
+  static_assert(2 * (CR_BK * CB_XLD + 3 * CR_H * CB_WLD * 2) <= (CR_H * (CR_BM + 1) + CR_H * (CR_H + 1)) * 4, "LDS plan");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t row0 = (int64_t)blockIdx.x * CR_BM;
+  const int64_t ldw = N + 1;
+  const uint8_t* xbase = counts + (row0 / rps) * (N * rps) + (row0 % rps);   // element (env r, node k) at xbase[k * rps + r]
+  const int64_t WP = CR_H * Kpad;      // one weight piece
+
+  uint4 xr;            // 16 count bytes: k = tid >> 3, envs 16 * (tid & 7) ..
+  uint4 wr[3];         // 8 bf16 of each piece: j = tid >> 2, k = 8 * (tid & 3) ..
+  auto fetch = [&](int64_t k0) {
+    const int k = tid >> 3, seg = tid & 7;
+    xr = (k0 + k < N) ? *reinterpret_cast<const uint4*>(xbase + (k0 + k) * rps + seg * 16) : make_uint4(0u, 0u, 0u, 0u);
+    const int j = tid >> 2, q = tid & 3;
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) wr[pc] = *reinterpret_cast<const uint4*>(w3 + pc * WP + (int64_t)j * Kpad + k0 + 8 * q);
+  };
+  auto stash = [&](int buf) {
+    uint8_t* Xs = lds_raw + buf * BUF;
+    uint16_t* Wb = reinterpret_cast<uint16_t*>(Xs + XB);
+    const int k = tid >> 3, seg = tid & 7;
+    *reinterpret_cast<uint4*>(Xs + k * CB_XLD + seg * 16) = xr;
+    const int j = tid >> 2, q = tid & 3;
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<uint4*>(Wb + (pc * CR_H + j) * CB_WLD + 8 * q) = wr[pc];
+  };
+
+  f32x16 acc0 = {0}, acc1 = {0};     // D^T: rows j (0..31 / 32..63), cols = this wave's 32 environments
+  const int r32 = lane & 31, h8 = (lane >> 5) * 8;
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  int buf = 0;
+  for (int64_t k0 = 0; k0 < N; k0 += CR_BK) {
+    const bool more = k0 + CR_BK < N;
+    if (more) fetch(k0 + CR_BK);             // global loads in flight during the MFMAs below
+    const uint8_t* Xs = lds_raw + buf * BUF;
+    const uint16_t* Wb = reinterpret_cast<const uint16_t*>(Xs + XB);
+#pragma unroll
+    for (int s = 0; s < CR_BK / 16; ++s) {
+      // B fragment: lane (col r32 = env, half h) holds X^T[k = 16 s + 8 h + j][env], j = 0..7: small integers, exact in bf16
+      cbf16x8 bx;
+      uint16_t* bxp = reinterpret_cast<uint16_t*>(&bx);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float c = (float)Xs[(16 * s + h8 + j) * CB_XLD + wave * 32 + r32];
+        bxp[j] = (uint16_t)(__float_as_uint(c) >> 16);
+      }
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) {
+        const cbf16x8 a0 = *reinterpret_cast<const cbf16x8*>(Wb + (pc * CR_H + r32) * CB_WLD + 16 * s + h8);
+        const cbf16x8 a1 = *reinterpret_cast<const cbf16x8*>(Wb + (pc * CR_H + 32 + r32) * CB_WLD + 16 * s + h8);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bx, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bx, acc1, 0, 0, 0);
+      }
+    }
+    if (more) stash(buf ^ 1);                // the other buffer: nobody reads it in this iteration
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // epilogue: + time * W1[:, N] + b1, ReLU -> Hs [j][env]; then the second and third layer exactly as k_critic_fwd_slab
+  float* Hs = reinterpret_cast<float*>(lds_raw);     // [j][row], stride 129
+  float* W2s = Hs + CR_H * (CR_BM + 1);              // [k][j],  stride 65
+  {
+    const int lr = wave * 32 + r32;                  // this lane's environment (column of D^T)
+    const int64_t gr = row0 + lr;
+    const float tm = (gr < M) ? time_rows[gr / rows_per_time] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = mfma_row(r, lane);               // row of D^T = hidden unit
+      float v0 = acc0[r] + tm * P.w1[(int64_t)j * ldw + N] + P.b1[j];
+      float v1 = acc1[r] + tm * P.w1[(int64_t)(j + 32) * ldw + N] + P.b1[j + 32];
+      Hs[j * (CR_BM + 1) + lr] = v0 > 0.0f ? v0 : 0.0f;
+      Hs[(j + 32) * (CR_BM + 1) + lr] = v1 > 0.0f ? v1 : 0.0f;
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < (CR_H * CR_H) / CR_THREADS; ++it) {
+    const int idx = it * CR_THREADS + tid;
+    const int j = idx >> 6, k = idx & 63;
+    W2s[k * (CR_H + 1) + j] = P.w2[j * CR_H + k];
+  }
+  __syncthreads();
+  f32x16 c0 = {0}, c1 = {0};
+#pragma unroll
+  for (int kk = 0; kk < CR_H; kk += 2) {
+    const int k = kk + (lane >> 5);
+    const float a = Hs[k * (CR_BM + 1) + wave * 32 + (lane & 31)];
+    const float b0 = W2s[k * (CR_H + 1) + (lane & 31)];
+    const float b1 = W2s[k * (CR_H + 1) + 32 + (lane & 31)];
+    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, c1, 0, 0, 0);
+  }
+  __syncthreads();
+  {
+    const int j0 = lane & 31;
+    const float bb0 = P.b2[j0], bb1 = P.b2[j0 + 32];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int lr = wave * 32 + mfma_row(r, lane);
+      float v0 = c0[r] + bb0, v1 = c1[r] + bb1;
+      v0 = v0 > 0.0f ? v0 : 0.0f;
+      v1 = v1 > 0.0f ? v1 : 0.0f;
+      Hs[j0 * (CR_BM + 1) + lr] = v0;
+      Hs[(j0 + 32) * (CR_BM + 1) + lr] = v1;
+    }
+  }
+  __syncthreads();
+  if (tid < CR_BM) {
+    const int64_t gr = row0 + tid;
+    if (gr < M) {
+      float sacc = 0.0f;
+#pragma unroll 8
+      for (int j = 0; j < CR_H; ++j) sacc += Hs[j * (CR_BM + 1) + tid] * P.w3[j];
+      value[gr] = sacc + P.b3[0];
+    }
+  }
+}
+
 // ---- backward (minibatch-sized M) ------------------------------------------------------------------------------------
 // stage 1: one workgroup per row m: dh2, dh1 (masked by the ReLUs) -> scratch; stage 2: weight gradients as plain
 // reductions over m (deterministic order), dW1 over a (j, k) grid with k-coalesced reads of the counts.
@@ -434,11 +598,31 @@ extern "C" int tarl_critic_mlp_fwd_slabs(const float* counts, int64_t rows_per_s
   return critic_fwd_slabs(counts, rows_per_slab, M, N, time_rows, rows_per_time, w1, b1, w2, b2, w3, b3, value, stream);
 }
 
+extern "C" int64_t tarl_critic_split_scratch_bytes(int64_t N) {
+  return N >= 1 ? 3 * CR_H * ceil_div(N, CR_BK) * CR_BK * (int64_t)sizeof(uint16_t) : -1;
+}
+
 extern "C" int tarl_critic_mlp_fwd_slabs_u8(const uint8_t* counts, int64_t rows_per_slab, int64_t M, int64_t N,
                                             const float* time_rows, int64_t rows_per_time, const float* w1,
                                             const float* b1, const float* w2, const float* b2, const float* w3,
-                                            const float* b3, float* value, tarl_stream stream) {
-  return critic_fwd_slabs(counts, rows_per_slab, M, N, time_rows, rows_per_time, w1, b1, w2, b2, w3, b3, value, stream);
+                                            const float* b3, void* split_scratch, float* value, tarl_stream stream) {
+  if (!split_scratch)     // fp32 MFMA on the widened bytes
+    return critic_fwd_slabs(counts, rows_per_slab, M, N, time_rows, rows_per_time, w1, b1, w2, b2, w3, b3, value, stream);
+  TARL_REQUIRE(rows_per_slab >= CR_BM && rows_per_slab % CR_BM == 0, "rows_per_slab must be a multiple of 128");
+  TARL_REQUIRE(M % rows_per_slab == 0, "M must be a whole number of slabs");
+  TARL_REQUIRE(counts && time_rows && w1 && b1 && w2 && b2 && w3 && b3 && value, "null argument");
+  TARL_REQUIRE(M >= 1 && N >= 1 && rows_per_time >= 1, "bad sizes");
+  TARL_REQUIRE(((uintptr_t)counts) % 16 == 0 && ((uintptr_t)split_scratch) % 16 == 0, "counts / scratch must be 16-byte aligned");
+  const int64_t Kpad = ceil_div(N, CR_BK) * CR_BK;
+  const CriticParams P{w1, b1, w2, b2, w3, b3};
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_split_w1, dim3((unsigned)ceil_div(CR_H * Kpad, CR_THREADS)), dim3(CR_THREADS), 0, s, w1, N, Kpad,
+                     (uint16_t*)split_scratch);
+  TARL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_critic_fwd_slab_u8x3, dim3((unsigned)(M / CR_BM)), dim3(CR_THREADS), 0, s, counts, rows_per_slab, M,
+                     N, Kpad, time_rows, rows_per_time, (const uint16_t*)split_scratch, P, value);
+  TARL_LAUNCH_CHECK();
+  return TARL_OK;
 }
 
 extern "C" int tarl_critic_mlp_bwd(const float* counts, int64_t ldc, int64_t M, int64_t N, const float* time_rows,

@@ -57,7 +57,8 @@ SIGNATURES = {
     "tarl_adam_step": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _f64, _f64, _f64, _f64, _f32, _p]),
     "tarl_critic_mlp_fwd_slabs": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64] + [_p] * 6 + [_p, _p]),
     "tarl_critic_mlp_fwd_u8": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64] + [_p] * 6 + [_p, _p, _p, _p]),
-    "tarl_critic_mlp_fwd_slabs_u8": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64] + [_p] * 6 + [_p, _p]),
+    "tarl_critic_mlp_fwd_slabs_u8": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64] + [_p] * 6 + [_p, _p, _p]),
+    "tarl_critic_split_scratch_bytes": (_i64, [_i64]),
     "tarl_fused_pack": (C.c_int, [_p, _p] + _STATE + [_p, _p, _p, _i64, _i64, _p]),
     "tarl_fused_reset": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _i64, _p]),
     "tarl_fused_export": (C.c_int, [_p, _p] + _STATE + [_f32, _p]),

@@ -893,7 +893,10 @@ def rollout_env(plan: Plan, fs: FusedState, tables: PolicyTables, agent_features
     return tdev
 
 
-def critic_forward_slabs(cw: CriticWeights, counts, time_rows):
+_SPLIT_SCRATCH = {}
+
+
+def critic_forward_slabs(cw: CriticWeights, counts, time_rows, *, exact_chain=False):
     """counts (S, N, R) fp32 or uint8 contiguous = [frame][node][env] with R % 128 == 0 -> value (S*R,) in (frame, env)
     order; ``time_rows`` (S,) is each frame's clock."""
     L = _lib.load()
@@ -904,8 +907,19 @@ def critic_forward_slabs(cw: CriticWeights, counts, time_rows):
     if N != cw.N or R % 128 or time_rows.numel() < S:
         raise ValueError("counts must be (S, N, R) with R a multiple of 128 and one time per slab")
     value = torch.empty(S * R, dtype=torch.float32, device=counts.device)
-    fn = L.tarl_critic_mlp_fwd_slabs_u8 if u8 else L.tarl_critic_mlp_fwd_slabs
-    _lib.check(fn(counts.data_ptr(), R, S * R, N, time_rows.data_ptr(), R, cw.w1.data_ptr(), cw.b1.data_ptr(),
-                  cw.w2.data_ptr(), cw.b2.data_ptr(), cw.w3.data_ptr(), cw.b3.data_ptr(), value.data_ptr(),
-                  _lib.current_stream()))
+    args = (counts.data_ptr(), R, S * R, N, time_rows.data_ptr(), R, cw.w1.data_ptr(), cw.b1.data_ptr(), cw.w2.data_ptr(),
+            cw.b2.data_ptr(), cw.w3.data_ptr(), cw.b3.data_ptr())
+    if u8:
+        # count bytes: first layer on the bf16 matrix cores at fp32 accuracy (W1 as three exact bf16 pieces);
+        # exact_chain=True keeps the k-ordered fp32 MFMA chain (bit-identical to the row-major kernel)
+        scratch = None
+        if not exact_chain:
+            key = (str(counts.device), N)
+            scratch = _SPLIT_SCRATCH.get(key)
+            if scratch is None:
+                scratch = torch.empty(int(L.tarl_critic_split_scratch_bytes(N)), dtype=torch.uint8, device=counts.device)
+                _SPLIT_SCRATCH[key] = scratch
+        _lib.check(L.tarl_critic_mlp_fwd_slabs_u8(*args, _lib.ptr(scratch), value.data_ptr(), _lib.current_stream()))
+    else:
+        _lib.check(L.tarl_critic_mlp_fwd_slabs(*args, value.data_ptr(), _lib.current_stream()))
     return value

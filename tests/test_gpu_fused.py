@@ -176,6 +176,24 @@ def test_critic_slab_mode_matches_row_major(ops):
     rows = counts.permute(0, 2, 1).contiguous().view(S * R, N)
     v_rows, _, _ = ops.critic_forward(cw, rows, times, rows_per_time=R)
     assert torch.equal(v_slab, v_rows)        # same tiles, same k order, same MFMA chain
+    # the rollout's count BYTES: the exact-chain variant is bit-identical too; the default runs the first layer on the bf16
+    # matrix cores with W1 split into three exact bf16 pieces — fp32 accuracy, only the order of the fp32 additions differs
+    c8 = counts.to(torch.uint8)
+    assert torch.equal(ops.critic_forward_slabs(cw, c8, times, exact_chain=True), v_rows)
+    v8 = ops.critic_forward_slabs(cw, c8, times)
+    ref64 = torch.nn.Sequential(lin[0], torch.nn.ReLU(), lin[1], torch.nn.ReLU(), lin[2]).double()(
+        torch.cat([rows.cpu().double(), times.cpu().double().repeat_interleave(R).unsqueeze(1)], dim=1)).view(-1)
+    scale = float(ref64.abs().max())
+    err8, err32 = float((v8.cpu().double() - ref64).abs().max()), float((v_rows.cpu().double() - ref64).abs().max())
+    assert err8 <= 1e-5 * scale and err8 <= 4 * err32 + 1e-6 * scale, (err8, err32, scale)
+    # a K that is not a multiple of the 32-node chunk, counts up to 255, one slab of 128 rows
+    N2 = 77
+    c2 = torch.randint(0, 256, (2, N2, 128), generator=gen).to(torch.uint8).cuda()
+    lin2 = torch.nn.Linear(N2 + 1, 64)
+    cw2 = ops.CriticWeights(lin2.weight.detach().cuda().contiguous(), lin2.bias.detach().cuda().contiguous(), cw.w2, cw.b2,
+                            cw.w3, cw.b3)
+    a, b = ops.critic_forward_slabs(cw2, c2, times[:2]), ops.critic_forward_slabs(cw2, c2, times[:2], exact_chain=True)
+    assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
 
 
 @pytest.mark.parametrize("B,T,merge", [(5, 30, "1"), (5, 30, "0"), (70, 7, "1"), (3, 1, "1"), (130, 2, "1"),
