@@ -119,7 +119,7 @@ __global__ __launch_bounds__(FB) void k_pack_static(int64_t N, int64_t E, const 
   if (i >= N) return;
   const float4 sti = st0[i];
   const int32_t a0 = in_ptr[i], a1 = in_ptr[i + 1], o0 = P.out_ptr[i], o1 = P.out_ptr[i + 1];
-  nodes[i] = NodeRec{a0, a1 - a0, o0, o1 - o0, sti.x, sti.y, sti.z, sti.w};
+  nodes[i] = NodeRec{a0, a1 - a0, o0, o1 - o0, sti.x, sti.y, sti.z, sti.w, entry_tt(sti, 0.0f)};
   for (int32_t k = o0; k < o1; ++k) out_pad[k] = P.out_dst[k];
   for (int32_t k = a0; k < a1; ++k) {
     const int32_t j = in_src[k];
@@ -673,60 +673,89 @@ __global__ __launch_bounds__(TILE) void k_fused_direction(
 }
 
 // ---- the row pass: Direction update + Response pop + withdraw on the slot store, then refresh the dense words -----------
-// One row of the pass, its dense words and the first four downstream post words already in registers.
-__device__ __forceinline__ float2 fused_row(uint32_t i, uint32_t b, const NodeRec nr, const int32_t* __restrict__ out_ptr,
-                                            const int32_t* __restrict__ out_dst, const uint32_t* __restrict__ post,
+// The pass has two phases inside the workgroup (the trick of the Direction gather, for the same reason). Phase A: every
+// (row, environment) pair, on registers only — Response test from the prefetched post words, idle / event decision, and
+// for an IDLE row (nothing enqueued, no pop, head not due: ~90 % of the pairs in a filling network) the refreshed dense
+// words. EVENT rows (something moves: slot store, event word, agent rows) are only LISTED in LDS. Phase B walks that
+// list densely, one lane per event row. The event path is hundreds of instructions long; issued per wave it ran for every
+// wave (some lane nearly always has an event) at a few active lanes — the kernel is issue-bound, so that was its cost.
+struct RowHead {      // what phase A derives from a row's dense words and hands to phase B through registers / the list
+  uint32_t n0i, head_id0, tail0, who, arrived;
+  bool pop;
+};
+
+// phase A of one row: returns true when the row is an event row (nothing written), false when it was idle (words written)
+__device__ __forceinline__ bool row_phase_a(uint32_t i, uint32_t b, const NodeRec nr, const uint32_t* __restrict__ post,
                                             uint32_t pa, uint2 hp, uint32_t tlw, const uint32_t (&pj4)[4], int Nmax,
-                                            uint32_t B, uint32_t N, const FusedBufs& fb, float* __restrict__ ag,
-                                            int64_t A, int64_t a_bstride, float t,
-                                            const FrameOut& out) {   // -> {count after the pass, agents withdrawn}
-  const PlanOut P{out_ptr, out_dst};
+                                            uint32_t B, uint32_t N, const FusedBufs& fb, int64_t A, float t,
+                                            const FrameOut& out, bool* pop_out, float* n_out) {
+  const uint32_t row = i * B + b;   // 32-bit row indices: N * B < 2^31 (host check)
+  const uint32_t n0i = hp.x & 255u, head_id0 = hp.x >> 8, tail0 = tlw >> 8;
+  const uint32_t arrived = pa & PF_ARRIVED;
+  const uint32_t who = arrived ? (pa >> 8) : 0u;   // the agent the Direction update enqueues
+  // Response message + max-aggregate from the post words (state after the Direction update of every row)
+  bool pop = false;
   {
-    const uint32_t row = i * B + b;   // 32-bit row indices: N * B < 2^31 (host check)
-    const float4 st = make_float4(nr.maxn, nr.ff, nr.road, nr.cong);
-    const uint32_t n0i = hp.x & 255u, head_id0 = hp.x >> 8, tail0 = tlw >> 8;
-    const uint32_t arrived = pa & PF_ARRIVED;
-    const uint32_t who = arrived ? (pa >> 8) : 0u;   // the agent the Direction update enqueues
-
-    // Response message + max-aggregate from the post words (state after the Direction update of every row)
-    bool pop = false;
-    {
-      const uint32_t head = (n0i == 0u) ? who : head_id0;   // head after the Direction update
-      const bool up = (n0i + arrived) > 0u;
+    const uint32_t head = (n0i == 0u) ? who : head_id0;   // head after the Direction update
+    const bool up = (n0i + arrived) > 0u;
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        pop = pop || (q < nr.out_deg && up && (pj4[q] & PF_NONEMPTY) && (pj4[q] >> 8) == head);
-      for (int32_t q = 4; q < nr.out_deg; ++q) {   // out-degree above four: the rest one by one
-        const uint32_t pj = post[(uint32_t)fb.out_pad[nr.out0 + q] * B + b];
-        pop = pop || (up && (pj & PF_NONEMPTY) && (pj >> 8) == head);
-      }
+    for (int q = 0; q < 4; ++q)
+      pop = pop || (q < nr.out_deg && up && (pj4[q] & PF_NONEMPTY) && (pj4[q] >> 8) == head);
+    for (int32_t q = 4; q < nr.out_deg; ++q) {   // out-degree above four: the rest one by one
+      const uint32_t pj = post[(uint32_t)fb.out_pad[nr.out0 + q] * B + b];
+      pop = pop || (up && (pj & PF_NONEMPTY) && (pj >> 8) == head);
     }
+  }
+  const int q = (int)n0i;
+  const bool lazy = (who == 0u) && (q < Nmax - 1);
+  const uint32_t ni = n0i + arrived;   // count after the Direction update
+  if ((int)ni >= Nmax) atomicOr(fb.flags, FLAG_COUNT_AT_NMAX);
+  const uint32_t head_id = (n0i == 0u) ? who : head_id0;
+  // an empty row's head is this frame's garbage triple (0, t, t + tt): its departure needs the division only there
+  const float head_dep = (n0i == 0u) ? t + nr.tt0 : __uint_as_float(hp.y);
+  // is the (unpopped) head a withdraw candidate? (the first two tests of the withdraw scan, on registers)
+  const bool due = !pop && ni > 0u && (int64_t)head_id < A && (head_dep <= t);
+  *pop_out = pop;
+  if (!(lazy && !pop && !due)) return true;
+  // IDLE ROW: nothing moves. Only the dense words are refreshed.
+  fb.hdp[row] = make_uint2((head_id << 8) | ni, __float_as_uint(head_dep));
+  fb.tl[row] = tail0 << 8;
+  if (out.counts8) __builtin_nontemporal_store((uint8_t)ni, &out.counts8[row]);
+  if (out.countsf) __builtin_nontemporal_store((float)ni, &out.countsf[row]);
+  if (out.popped) out.popped[(int64_t)b * N + i] = 0;
+  if (out.withdrawn) out.withdrawn[(int64_t)b * N + i] = 0;
+  if (out.events && b < out.m_env) out.events[(int64_t)i * out.m_env + b] = 0;
+  *n_out = (float)ni;
+  return false;
+}
 
-    // Direction update (every row, also when nothing was chosen): one 12-byte store — or, for a row that received
-    // nobody, nothing at all (lazy garbage slot, see the file header).
-    const float n0 = (float)n0i;
-    const int q = (int)n0i;
-    const float dep_new = t + entry_tt(st, n0);
-    const bool lazy = (who == 0u) && (q < Nmax - 1);
-    const uint32_t ni = n0i + arrived;   // count after the Direction update
-    if ((int)ni >= Nmax) atomicOr(fb.flags, FLAG_COUNT_AT_NMAX);
-    uint32_t head_id = (n0i == 0u) ? who : head_id0;
-    float head_dep = (n0i == 0u) ? dep_new : __uint_as_float(hp.y);
-    // is the (unpopped) head a withdraw candidate? (the first two tests of the withdraw scan, on registers)
-    const bool due = !pop && ni > 0u && (int64_t)head_id < A && (head_dep <= t);
-    if (lazy && !pop && !due) {
-      // IDLE ROW: nothing moves. Only the dense words are refreshed (an empty row's head is this frame's garbage triple).
-      fb.hdp[row] = make_uint2((head_id << 8) | ni, __float_as_uint(head_dep));
-      fb.tl[row] = tail0 << 8;
-      if (out.counts8) __builtin_nontemporal_store((uint8_t)ni, &out.counts8[row]);
-      if (out.countsf) __builtin_nontemporal_store((float)ni, &out.countsf[row]);
-      if (out.popped) out.popped[(int64_t)b * N + i] = 0;
-      if (out.withdrawn) out.withdrawn[(int64_t)b * N + i] = 0;
-      if (out.events && b < out.m_env) out.events[(int64_t)i * out.m_env + b] = 0;
-      return make_float2((float)ni, 0.0f);
-    }
-
-    // EVENT ROW. The FIFO is a ring buffer: logical slot s lives at physical slot (hoff + s) mod Nmax.
+// phase B of one EVENT row (dense words re-read: they are in this CU's cache): Direction update on the slot store,
+// Response pop, withdraw, refreshed dense words + event word. -> {count after the pass, agents withdrawn}
+__device__ __forceinline__ float2 row_phase_b(uint32_t i, uint32_t b, bool pop, const NodeRec nr,
+                                              const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_dst,
+                                              const uint32_t* __restrict__ post, int Nmax, uint32_t B, uint32_t N,
+                                              const FusedBufs& fb, float* __restrict__ ag, int64_t A, int64_t a_bstride,
+                                              float t, const FrameOut& out) {
+  const PlanOut P{out_ptr, out_dst};
+  const uint32_t row = i * B + b;
+  const uint32_t pa = post[row];
+  const uint2 hp = fb.hdp[row];
+  const uint32_t tlw = fb.tl[row];
+  const float4 st = make_float4(nr.maxn, nr.ff, nr.road, nr.cong);
+  const uint32_t n0i = hp.x & 255u, head_id0 = hp.x >> 8, tail0 = tlw >> 8;
+  const uint32_t arrived = pa & PF_ARRIVED;
+  const uint32_t who = arrived ? (pa >> 8) : 0u;
+  const float n0 = (float)n0i;
+  const int q = (int)n0i;
+  // Direction update (every row, also when nothing was chosen): one 12-byte store — or, for a row that received
+  // nobody, nothing at all (lazy garbage slot, see the file header).
+  const float dep_new = t + entry_tt(st, n0);
+  const bool lazy = (who == 0u) && (q < Nmax - 1);
+  const uint32_t ni = n0i + arrived;   // count after the Direction update
+  uint32_t head_id = (n0i == 0u) ? who : head_id0;
+  float head_dep = (n0i == 0u) ? dep_new : __uint_as_float(hp.y);
+  {
+    // The FIFO is a ring buffer: logical slot s lives at physical slot (hoff + s) mod Nmax.
     float* sl = fb.slots + (int64_t)row * fb.lds;  // slot s = sl[3s .. 3s+2] = {id, arrival, departure}
     const uint2 r1 = fb.rec1[row];
     int hoff = r1_hoff(r1.y);
@@ -816,9 +845,9 @@ __device__ __forceinline__ float2 fused_row(uint32_t i, uint32_t b, const NodeRe
     fb.tl[row] = (tail_id << 8) | TLF_AUTH;
     const uint2 r1n = make_uint2(__float_as_uint(head_arr), r1_code(lazy ? q : -1, hoff));
     if (r1n.x != r1.x || r1n.y != r1.y) fb.rec1[row] = r1n;
-    // per-node count before insertion (the insert kernel adds this frame's arrivals); write-once stream
-    if (out.counts8) __builtin_nontemporal_store((uint8_t)n, &out.counts8[row]);
-    if (out.countsf) __builtin_nontemporal_store((float)n, &out.countsf[row]);
+    // per-node count before insertion (the insert kernel adds this frame's arrivals)
+    if (out.counts8) out.counts8[row] = (uint8_t)n;
+    if (out.countsf) out.countsf[row] = (float)n;
     if (out.popped) out.popped[(int64_t)b * N + i] = pop ? 1 : 0;
     if (out.withdrawn) out.withdrawn[(int64_t)b * N + i] = c > 0 ? 1 : 0;
     if (out.events && b < out.m_env) out.events[(int64_t)i * out.m_env + b] = (uint8_t)((pop ? 1 : 0) | (c > 0 ? 2 : 0));
@@ -827,8 +856,7 @@ __device__ __forceinline__ float2 fused_row(uint32_t i, uint32_t b, const NodeRe
 }
 
 // NCH rows per lane: ALL their loads (dense words, downstream post words) are issued before the first row is processed,
-// so a wave keeps 8 * NCH independent requests in flight instead of one row's dependent phases (the pass is bound by
-// memory latency, not bytes: 66 % of the wave cycles were waits with one row at a time).
+// so a wave keeps 8 * NCH independent requests in flight instead of one row's dependent phases.
 template <int NCH>
 __global__ __launch_bounds__(TILE) void k_fused_rows(const NodeRec* __restrict__ nodes,
                                                      const int32_t* __restrict__ out_pad,
@@ -837,34 +865,59 @@ __global__ __launch_bounds__(TILE) void k_fused_rows(const NodeRec* __restrict__
                                                      const uint32_t* __restrict__ post, int Nmax, uint32_t B, uint32_t N,
                                                      FusedBufs fb, float* __restrict__ ag, int64_t A, int64_t a_bstride,
                                                      float t, FrameOut out) {
+  __shared__ int32_t s_cnt;
+  __shared__ uint16_t s_item[TILE * NCH];   // (row offset in the chunk) << 9 | pop << 8 | lane
+  __shared__ float s_nsum[TILE], s_wsum[TILE];
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  const bool valid = b < B;
   const uint32_t i0 = blockIdx.y * NCH;
-  uint32_t pa[NCH], tlw[NCH], pj[NCH][4];
-  uint2 hp[NCH];
+  if (threadIdx.x == 0) s_cnt = 0;
+  s_nsum[threadIdx.x] = 0.0f;
+  s_wsum[threadIdx.x] = 0.0f;
+  __syncthreads();
+  float nsum = 0.0f;
+  if (valid) {
+    uint32_t pa[NCH], tlw[NCH], pj[NCH][4];
+    uint2 hp[NCH];
 #pragma unroll
-  for (int r = 0; r < NCH; ++r) {
-    const uint32_t i = (i0 + r < N) ? i0 + r : N - 1;   // clamped: the tail rows are loaded twice, used once
-    const uint32_t row = i * B + b;
-    pa[r] = post[row];
-    hp[r] = fb.hdp[row];
-    tlw[r] = fb.tl[row];
-    const int32_t* od = out_pad + nodes[i].out0;   // four targets from consecutive addresses (padded array)
+    for (int r = 0; r < NCH; ++r) {
+      const uint32_t i = (i0 + r < N) ? i0 + r : N - 1;   // clamped: the tail rows are loaded twice, used once
+      const uint32_t row = i * B + b;
+      pa[r] = post[row];
+      hp[r] = fb.hdp[row];
+      tlw[r] = fb.tl[row];
+      const int32_t* od = out_pad + nodes[i].out0;   // four targets from consecutive addresses (padded array)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) pj[r][q] = post[(uint32_t)od[q] * B + b];
-  }
-  float nsum = 0.0f, wsum = 0.0f;
-#pragma unroll
-  for (int r = 0; r < NCH; ++r)
-    if (i0 + r < N) {
-      const float2 nc = fused_row(i0 + r, b, nodes[i0 + r], out_ptr, out_dst, post, pa[r], hp[r], tlw[r], pj[r], Nmax, B,
-                                  N, fb, ag, A, a_bstride, t, out);
-      nsum += nc.x;
-      wsum += nc.y;
+      for (int q = 0; q < 4; ++q) pj[r][q] = post[(uint32_t)od[q] * B + b];
     }
-  const int64_t bank = (int64_t)(blockIdx.y % (unsigned)fb.acc_slots) * B + b;
-  atomicAdd(&fb.acc_n[bank], nsum);
-  if (wsum != 0.0f) atomicAdd(&fb.acc_w[bank], wsum);
+#pragma unroll
+    for (int r = 0; r < NCH; ++r)
+      if (i0 + r < N) {
+        bool pop;
+        float n = 0.0f;
+        if (row_phase_a(i0 + r, b, nodes[i0 + r], post, pa[r], hp[r], tlw[r], pj[r], Nmax, B, N, fb, A, t, out, &pop, &n))
+          s_item[atomicAdd(&s_cnt, 1)] = (uint16_t)((r << 9) | (pop ? 256 : 0) | threadIdx.x);
+        else
+          nsum += n;
+      }
+  }
+  __syncthreads();
+  const int32_t cnt = s_cnt;
+  for (int32_t idx = threadIdx.x; idx < cnt; idx += blockDim.x) {
+    const uint32_t item = s_item[idx];
+    const uint32_t r = item >> 9, lane2 = item & 255u;
+    const float2 nc = row_phase_b(i0 + r, blockIdx.x * blockDim.x + lane2, (item & 256u) != 0u, nodes[i0 + r], out_ptr,
+                                  out_dst, post, Nmax, B, N, fb, ag, A, a_bstride, t, out);
+    atomicAdd(&s_nsum[lane2], nc.x);     // small integers: exact in fp32 in any order
+    if (nc.y != 0.0f) atomicAdd(&s_wsum[lane2], nc.y);
+  }
+  __syncthreads();
+  if (valid) {
+    const int64_t bank = (int64_t)(blockIdx.y % (unsigned)fb.acc_slots) * B + b;
+    atomicAdd(&fb.acc_n[bank], nsum + s_nsum[threadIdx.x]);
+    const float ws = s_wsum[threadIdx.x];
+    if (ws != 0.0f) atomicAdd(&fb.acc_w[bank], ws);
+  }
 }
 
 // ---- insert + reward + log-prob reduction (one wave per environment) -----------------------------------------------------

@@ -51,6 +51,7 @@ struct __attribute__((aligned(4))) NodeRec {
   int32_t in0, in_deg;      // CSC range of the row's in-edges
   int32_t out0, out_deg;    // CSR range of its out-edges
   float maxn, ff, road, cong;   // = st0
+  float tt0;                    // travel time assigned at count 0: an empty row's garbage head departs at t + tt0
 };
 struct __attribute__((aligned(4))) InRec {
   int32_t src;      // upstream row
