@@ -266,10 +266,10 @@ int tarl_value_mpnn_bwd(const tarl_plan* plan, const float* node_features, int64
  * environments of one node: topology / table loads are wave-uniform and record gathers are coalesced.
  * Caller-owned side buffers that mirror x / agent_features (all device memory, 16-byte aligned). Packed words ("v6"):
  *   hdp  uint32 [N][B][2] = {head_id << 8 | NUMBER_OF_AGENT, bits of the head's departure time}
- *   tl   uint32 [N][B]    = tail_id << 8 | flags (bit 0: rec1 is authoritative for the last frame)
+ *   tl   uint32 [N][B]    = tail_id << 8 | ring-buffer head offset << 1 | bit 0: rec1 is authoritative for the last frame
  *   post uint32 [N][B]    = state after the Direction update: tail' << 8 | non-empty' << 1 | arrived
- *   rec1 uint32 [N][B][2] = {bits of the head's arrival time, (pending-garbage count + 1) << 16 | ring-buffer head offset};
- *                           touched only by rows where something moves in a frame
+ *   rec1 uint32 [N][B][2] = {bits of the head's arrival time, pending-garbage count + 1}; only WRITTEN, and only by rows
+ *                           where something moves in a frame
  *   sel8 uint8  [N][B]    = SELECTED_ROAD as the rank of the chosen out-edge in the node's CSR list (bit 7: carried over
  *                           from the previous frame; 0x7F: the fp32 value in sel [N][B] is authoritative)
  *   static records built by pack and shared by all environments (read through the scalar cache): node_rec int32/fp32
@@ -292,7 +292,7 @@ int tarl_value_mpnn_bwd(const tarl_plan* plan, const float* node_features, int64
  *   (the reference raises IndexError there, src/direction_mpnn.py:172-191: the state is outside its defined domain),
  *   TARL_FLAG_AMBIGUOUS_EDGES = two out-edges of a node lead to the same ROAD_INDEX, TARL_FLAG_PACK_RANGE = a packed
  *   count above 255 / agent id at or above 2^24. The caller reads it at its next synchronisation point.
- * Domain of the fused path: Nmax <= 255, out-degree <= 126, agent ids < 2^24 (refused / flagged otherwise).
+ * Domain of the fused path: Nmax <= 127, out-degree <= 126, agent ids < 2^24 (refused / flagged otherwise).
  * tarl_fused_pack imports x / agent_features (call after construction, reset, or any external write to x); between
  * pack and export the packed state is authoritative for the FIFO columns, NUMBER_OF_AGENT and SELECTED_ROAD;
  * tarl_fused_export writes them back into x in the reference's column layout, bit-identical to the unfused path.

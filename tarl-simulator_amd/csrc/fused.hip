@@ -37,7 +37,7 @@
 // bit-identical to what the unfused kernels (and the reference) produce after every frame (tests/test_gpu_fused.py).
 //
 // Domain: the plan is built on the same node set as x (plan nodes == rows of x): pure road graphs and MATSim graphs
-// with SRC/DEST pseudo-nodes alike. Nmax <= 255, out-degree <= 126, agent ids < 2^24 (checked). A count that reaches Nmax
+// with SRC/DEST pseudo-nodes alike. Nmax <= 127, out-degree <= 126, agent ids < 2^24 (checked). A count that reaches Nmax
 // leaves the reference's defined domain (it raises IndexError one or two steps later): the kernels set
 // FLAG_COUNT_AT_NMAX in the device status word and the host raises when it reads it.
 #include "fused_common.h"
@@ -64,8 +64,8 @@ __global__ __launch_bounds__(FB) void k_pack_nodes(const float* __restrict__ x, 
   if (q < 0 || q > 255 || !(head >= 0.0f && head < 16777216.0f) || !(tail >= 0.0f && tail < 16777216.0f))
     atomicOr(fb.flags, FLAG_PACK_RANGE);
   fb.hdp[gid] = make_uint2(((uint32_t)head << 8) | (uint32_t)(q & 255), __float_as_uint(xi[2 * Nmax]));
-  fb.tl[gid] = ((uint32_t)tail << 8) | TLF_AUTH;
-  fb.rec1[gid] = make_uint2(__float_as_uint(xi[Nmax]), r1_code(-1, 0));
+  fb.tl[gid] = tl_word((uint32_t)tail, 0, TLF_AUTH);
+  fb.rec1[gid] = make_uint2(__float_as_uint(xi[Nmax]), r1_code(-1));
   fb.post[gid] = ((uint32_t)tail << 8) | (q > 0 ? PF_NONEMPTY : 0u);
   // SELECTED_ROAD: the rank of the out-edge it names, or the raw value when it names none of them
   const float sv = xi[L.col_sel()];
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(FB) void k_fused_reset_nodes(int64_t B, int64_t N, 
   if (gid >= B * N) return;
   fb.hdp[gid] = make_uint2(0u, 0u);
   fb.tl[gid] = TLF_AUTH;
-  fb.rec1[gid] = make_uint2(0u, r1_code(-1, 0));
+  fb.rec1[gid] = make_uint2(0u, r1_code(-1));
   fb.post[gid] = 0u;
   if (gid < B) {
     for (int64_t sl_ = 0; sl_ < fb.acc_slots; ++sl_) {
@@ -196,8 +196,9 @@ __global__ __launch_bounds__(FB) void k_export_rows(float* __restrict__ x, Layou
   const uint32_t hd = fb.hdp[row].x;
   const uint32_t code = fb.rec1[row].y;
   const int n = (int)(hd & 255u);
-  const int g = pending_g(fb.tl[row], n, code, Nmax);
-  const float* sl = fb.slots + row * fb.lds + 3 * phys(r1_hoff(code), sidx, Nmax);  // un-rotate the ring buffer
+  const uint32_t tlw = fb.tl[row];
+  const int g = pending_g(tlw, n, code, Nmax);
+  const float* sl = fb.slots + row * fb.lds + 3 * phys(tl_hoff(tlw), sidx, Nmax);  // un-rotate the ring buffer
   if (g >= 0 && sidx == n) {  // pending garbage write of the last Direction update -> first dead slot
     const float tt = entry_tt(fb.st0[i], (float)g);
     xi[sidx] = 0.0f;
@@ -719,7 +720,7 @@ __device__ __forceinline__ bool row_phase_a(uint32_t i, uint32_t b, const NodeRe
   if (!(lazy && !pop && !due)) return true;
   // IDLE ROW: nothing moves. Only the dense words are refreshed.
   fb.hdp[row] = make_uint2((head_id << 8) | ni, __float_as_uint(head_dep));
-  fb.tl[row] = tail0 << 8;
+  fb.tl[row] = tlw & ~TLF_AUTH;      // tail and ring offset stay
   if (out.counts8) __builtin_nontemporal_store((uint8_t)ni, &out.counts8[row]);
   if (out.countsf) __builtin_nontemporal_store((float)ni, &out.countsf[row]);
   if (out.popped) out.popped[(int64_t)b * N + i] = 0;
@@ -729,18 +730,15 @@ __device__ __forceinline__ bool row_phase_a(uint32_t i, uint32_t b, const NodeRe
   return false;
 }
 
-// phase B of one EVENT row (dense words re-read: they are in this CU's cache): Direction update on the slot store,
+// phase B of one EVENT row (its dense words travel with the list entry): Direction update on the slot store,
 // Response pop, withdraw, refreshed dense words + event word. -> {count after the pass, agents withdrawn}
-__device__ __forceinline__ float2 row_phase_b(uint32_t i, uint32_t b, bool pop, const NodeRec nr,
-                                              const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_dst,
-                                              const uint32_t* __restrict__ post, int Nmax, uint32_t B, uint32_t N,
+__device__ __forceinline__ float2 row_phase_b(uint32_t i, uint32_t b, bool pop, uint32_t pa, uint2 hp, uint32_t tlw,
+                                              const NodeRec nr, const int32_t* __restrict__ out_ptr,
+                                              const int32_t* __restrict__ out_dst, int Nmax, uint32_t B, uint32_t N,
                                               const FusedBufs& fb, float* __restrict__ ag, int64_t A, int64_t a_bstride,
                                               float t, const FrameOut& out) {
   const PlanOut P{out_ptr, out_dst};
   const uint32_t row = i * B + b;
-  const uint32_t pa = post[row];
-  const uint2 hp = fb.hdp[row];
-  const uint32_t tlw = fb.tl[row];
   const float4 st = make_float4(nr.maxn, nr.ff, nr.road, nr.cong);
   const uint32_t n0i = hp.x & 255u, head_id0 = hp.x >> 8, tail0 = tlw >> 8;
   const uint32_t arrived = pa & PF_ARRIVED;
@@ -757,8 +755,7 @@ __device__ __forceinline__ float2 row_phase_b(uint32_t i, uint32_t b, bool pop, 
   {
     // The FIFO is a ring buffer: logical slot s lives at physical slot (hoff + s) mod Nmax.
     float* sl = fb.slots + (int64_t)row * fb.lds;  // slot s = sl[3s .. 3s+2] = {id, arrival, departure}
-    const uint2 r1 = fb.rec1[row];
-    int hoff = r1_hoff(r1.y);
+    int hoff = tl_hoff(tlw);     // (the event word rec1 is write-only here: no load sits between the row and its slots)
     if (!lazy && q < Nmax) {
       float* w = sl + 3 * phys(hoff, q, Nmax);
       w[0] = (float)who;
@@ -766,7 +763,8 @@ __device__ __forceinline__ float2 row_phase_b(uint32_t i, uint32_t b, bool pop, 
       w[2] = dep_new;
     }
     int n = (int)ni;
-    float head_arr = (n0i == 0u) ? t : __uint_as_float(r1.x);
+    bool arr_new = n0i == 0u;    // the head's arrival changes: a new head, or the garbage triple of an empty row
+    float head_arr = t;
     uint32_t tail_id = arrived ? who : tail0;
 
     // Response pop: logical shift by one where the LAST slot keeps its value. Ring form: the slot that falls off the
@@ -829,6 +827,7 @@ __device__ __forceinline__ float2 row_phase_b(uint32_t i, uint32_t b, bool pop, 
       n = n - c;
     }
     if (shift + c > 0) {
+      arr_new = true;
       if (lazy && n == 0) {  // the row emptied: its head slot is the (unmaterialised) garbage slot
         head_id = 0u;
         head_arr = t;
@@ -842,9 +841,9 @@ __device__ __forceinline__ float2 row_phase_b(uint32_t i, uint32_t b, bool pop, 
       tail_id = (n >= 1 && n <= Nmax) ? (uint32_t)(long long)sl[3 * phys(hoff, n - 1, Nmax)] : 0u;
     }
     fb.hdp[row] = make_uint2((head_id << 8) | (uint32_t)n, __float_as_uint(head_dep));
-    fb.tl[row] = (tail_id << 8) | TLF_AUTH;
-    const uint2 r1n = make_uint2(__float_as_uint(head_arr), r1_code(lazy ? q : -1, hoff));
-    if (r1n.x != r1.x || r1n.y != r1.y) fb.rec1[row] = r1n;
+    fb.tl[row] = tl_word(tail_id, hoff, TLF_AUTH);
+    if (arr_new) fb.rec1[row].x = __float_as_uint(head_arr);   // otherwise the head, and its arrival, are unchanged
+    fb.rec1[row].y = r1_code(lazy ? q : -1);
     // per-node count before insertion (the insert kernel adds this frame's arrivals)
     if (out.counts8) out.counts8[row] = (uint8_t)n;
     if (out.countsf) out.countsf[row] = (float)n;
@@ -867,6 +866,7 @@ __global__ __launch_bounds__(TILE) void k_fused_rows(const NodeRec* __restrict__
                                                      float t, FrameOut out) {
   __shared__ int32_t s_cnt;
   __shared__ uint16_t s_item[TILE * NCH];   // (row offset in the chunk) << 9 | pop << 8 | lane
+  __shared__ uint4 s_words[TILE * NCH];     // the listed row's {post word, hd, head_dep bits, tl}
   __shared__ float s_nsum[TILE], s_wsum[TILE];
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = b < B;
@@ -895,10 +895,13 @@ __global__ __launch_bounds__(TILE) void k_fused_rows(const NodeRec* __restrict__
       if (i0 + r < N) {
         bool pop;
         float n = 0.0f;
-        if (row_phase_a(i0 + r, b, nodes[i0 + r], post, pa[r], hp[r], tlw[r], pj[r], Nmax, B, N, fb, A, t, out, &pop, &n))
-          s_item[atomicAdd(&s_cnt, 1)] = (uint16_t)((r << 9) | (pop ? 256 : 0) | threadIdx.x);
-        else
+        if (row_phase_a(i0 + r, b, nodes[i0 + r], post, pa[r], hp[r], tlw[r], pj[r], Nmax, B, N, fb, A, t, out, &pop, &n)) {
+          const int32_t pos = atomicAdd(&s_cnt, 1);
+          s_item[pos] = (uint16_t)((r << 9) | (pop ? 256 : 0) | threadIdx.x);
+          s_words[pos] = make_uint4(pa[r], hp[r].x, hp[r].y, tlw[r]);
+        } else {
           nsum += n;
+        }
       }
   }
   __syncthreads();
@@ -906,8 +909,10 @@ __global__ __launch_bounds__(TILE) void k_fused_rows(const NodeRec* __restrict__
   for (int32_t idx = threadIdx.x; idx < cnt; idx += blockDim.x) {
     const uint32_t item = s_item[idx];
     const uint32_t r = item >> 9, lane2 = item & 255u;
-    const float2 nc = row_phase_b(i0 + r, blockIdx.x * blockDim.x + lane2, (item & 256u) != 0u, nodes[i0 + r], out_ptr,
-                                  out_dst, post, Nmax, B, N, fb, ag, A, a_bstride, t, out);
+    const uint4 wd = s_words[idx];
+    const float2 nc = row_phase_b(i0 + r, blockIdx.x * blockDim.x + lane2, (item & 256u) != 0u, wd.x,
+                                  make_uint2(wd.y, wd.z), wd.w, nodes[i0 + r], out_ptr, out_dst, Nmax, B, N, fb, ag, A,
+                                  a_bstride, t, out);
     atomicAdd(&s_nsum[lane2], nc.x);     // small integers: exact in fp32 in any order
     if (nc.y != 0.0f) atomicAdd(&s_wsum[lane2], nc.y);
   }
@@ -1086,9 +1091,9 @@ __device__ __forceinline__ void fused_insert_body(int64_t b, int Nmax, int64_t B
       const long long slot = (long long)n0i + rank;
       const float t_cong = use_cong ? str.w / (str.x + 10.0f - n0) : 0.0f;
       const float tt = (t_cong != t_cong) ? t_cong : fmaxf(str.y, t_cong);
-      const uint32_t code = fb.rec1[rrow].y;   // nobody writes rec1.y before the barrier below
+      const int hoff = tl_hoff(fb.tl[rrow]);   // the tail word's owner below rewrites it with the same offset
       if (slot >= 0 && slot < Nmax) {
-        float* sr = fb.slots + rrow * fb.lds + 3 * phys(r1_hoff(code), (int)slot, Nmax);
+        float* sr = fb.slots + rrow * fb.lds + 3 * phys(hoff, (int)slot, Nmax);
         sr[0] = (float)a;
         sr[1] = t;
         sr[2] = t + tt;
@@ -1099,7 +1104,7 @@ __device__ __forceinline__ void fused_insert_body(int64_t b, int Nmax, int64_t B
         fb.hdp[rrow] = make_uint2(((uint32_t)a << 8) | n0i, __float_as_uint(t + tt));
         fb.rec1[rrow].x = __float_as_uint(t);
       }
-      if (rank == m - 1) fb.tl[rrow] = ((uint32_t)a << 8) | TLF_AUTH;  // new tail; rec1 is authoritative from here on
+      if (rank == m - 1) fb.tl[rrow] = tl_word((uint32_t)a, hoff, TLF_AUTH);  // new tail; rec1 authoritative from here on
       if (rank == 0) commit = (int32_t)m;
     }
     cand_agent[idx] = commit;
@@ -1111,7 +1116,7 @@ __device__ __forceinline__ void fused_insert_body(int64_t b, int Nmax, int64_t B
     const int32_t cmt = cand_agent[idx];
     if (cmt > 0) {
       const int64_t rrow = (int64_t)cand_road[idx] * B + b;
-      fb.rec1[rrow].y = r1_code(-1, r1_hoff(fb.rec1[rrow].y));
+      fb.rec1[rrow].y = r1_code(-1);
       const uint32_t hd = fb.hdp[rrow].x + (uint32_t)cmt;   // count byte: n0 + cmt <= MAX - 3 < 255
       fb.hdp[rrow].x = hd;
       if (out.counts8) out.counts8[rrow] = (uint8_t)(hd & 255u);
@@ -1251,8 +1256,8 @@ int tarl_check_fused_core(const tarl_plan* plan, const tarl_fused* f, int64_t B,
                "fused node buffers missing");
   TARL_REQUIRE(B >= 1 && B < ((int64_t)1 << 31) && Nmax >= 2, "bad sizes");
   TARL_REQUIRE(plan->N * B < ((int64_t)1 << 31), "N * B must stay below 2^31 (32-bit row indices in the frame kernels)");
-  TARL_REQUIRE(Nmax <= 255, "the fused path packs NUMBER_OF_AGENT into one byte: Nmax must be <= 255 (use the unfused "
-                            "entry points for longer FIFOs)");
+  TARL_REQUIRE(Nmax <= 127, "the fused path packs NUMBER_OF_AGENT into one byte and the ring offset into seven bits: "
+                            "Nmax must be <= 127 (use the unfused entry points for longer FIFOs)");
   TARL_REQUIRE(plan->max_out <= 126, "the fused path packs the chosen out-edge's rank into 7 bits: out-degree must be <= 126");
   TARL_REQUIRE(f->acc_slots >= 1 && f->acc_slots <= 4096, "acc_slots out of range");
   TARL_REQUIRE(f->ld_slots >= 3 * (int64_t)Nmax, "slot row stride smaller than 3*Nmax");

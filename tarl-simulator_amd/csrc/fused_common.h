@@ -19,18 +19,21 @@
 // Dense words, read and rewritten by every row every frame (12 + 4 + 1 bytes):
 //   hdp  uint2  {hd = head_id << 8 | n, bits of head_dep}   n = NUMBER_OF_AGENT (<= 255: the fused path requires Nmax <= 255),
 //                                                            ids < 2^24 (the reference keeps them in fp32: exact below 2^24)
-//   tl   u32    tail_id << 8 | flags                         TLF_AUTH: rec1 (head_arr, pending-garbage count) is
-//                                                            authoritative for the last frame; clear = the row was idle in
-//                                                            the last frame: the pending garbage count is n itself and an
-//                                                            empty row's head arrival is the last frame's clock
+//   tl   u32    tail_id << 8 | hoff << 1 | TLF_AUTH          hoff = physical slot of logical slot 0 (ring buffer; < 128: the
+//                                                            fused path requires Nmax <= 127). TLF_AUTH: rec1 (head_arr,
+//                                                            pending-garbage count) is authoritative for the last frame;
+//                                                            clear = the row was idle in the last frame: the pending
+//                                                            garbage count is n itself and an empty row's head arrival is
+//                                                            the last frame's clock
 //   post u32    tail' << 8 | PF_NONEMPTY | PF_ARRIVED        the row's state after the Direction update: tail' = the agent
 //                                                            it enqueues (PF_ARRIVED) or its old tail; written by the
 //                                                            Direction gather, gathered by the upstream rows' Response test
 //   sel8 u8     SELECTED_ROAD as the rank of the chosen out-edge in the node's CSR list (| SEL_CARRIED when the node drew
 //               nothing in this frame and keeps its previous value); SEL_RAW: the fp32 value in `sel` is authoritative
 // Event-only word, read / written by the rows that move something in a frame (a few percent):
-//   rec1 uint2  {bits of head_arr, (g + 1) << 16 | hoff}     g = count at the pending (unmaterialised) garbage write or -1,
-//                                                            hoff = physical slot of logical slot 0 (ring buffer)
+//   rec1 uint2  {bits of head_arr, g + 1}                    g = count at the pending (unmaterialised) garbage write or -1.
+//                                                            WRITE-ONLY in the frame kernels (the event path never waits
+//                                                            for it: the ring offset it needs travels in tl)
 #define TLF_AUTH 1u
 #define PF_ARRIVED 1u
 #define PF_NONEMPTY 2u
@@ -102,9 +105,12 @@ struct FrameOut {
 
 #define LP_FIX 4294967296.0  // 2^32
 
-__device__ __forceinline__ uint32_t r1_code(int g, int hoff) { return ((uint32_t)(g + 1) << 16) | (uint32_t)hoff; }
-__device__ __forceinline__ int r1_hoff(uint32_t code) { return (int)(code & 0xffffu); }
-__device__ __forceinline__ int r1_g(uint32_t code) { return (int)(code >> 16) - 1; }
+__device__ __forceinline__ uint32_t r1_code(int g) { return (uint32_t)(g + 1); }
+__device__ __forceinline__ int r1_g(uint32_t code) { return (int)code - 1; }
+__device__ __forceinline__ int tl_hoff(uint32_t tlw) { return (int)((tlw >> 1) & 127u); }
+__device__ __forceinline__ uint32_t tl_word(uint32_t tail_id, int hoff, uint32_t auth) {
+  return (tail_id << 8) | ((uint32_t)hoff << 1) | auth;
+}
 // pending garbage count of a row from its dense words (+ rec1 when it is authoritative)
 __device__ __forceinline__ int pending_g(uint32_t tlw, int n, uint32_t code, int Nmax) {
   return (tlw & TLF_AUTH) ? r1_g(code) : (n < Nmax - 1 ? n : -1);

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
     r0[i] = make_float4((float)(hp.x >> 8), __uint_as_float(hp.y), (float)n, (float)(tlw >> 8));
     // an idle empty row's head arrival is the previous frame's clock; its pending garbage count is its count
     const float arr = (n == 0 && !(tlw & TLF_AUTH)) ? prev_time : __uint_as_float(q1.x);
-    r1[i] = make_float2(arr, l1_code((float)pending_g(tlw, n, q1.y, Nmax), r1_hoff(q1.y)));
+    r1[i] = make_float2(arr, l1_code((float)pending_g(tlw, n, q1.y, Nmax), tl_hoff(tlw)));
     const bool arrived = (pw & PF_ARRIVED) != 0u;
     pA[i] = make_float2(arrived ? (float)(n + 1) : (float)n, (float)(pw >> 8));
     who_l[i] = arrived ? (float)(pw >> 8) : 0.0f;
@@ -663,8 +663,8 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
     const float4 q0 = r0[i];
     const float2 q1 = r1[i];
     fb.hdp[row] = make_uint2(((uint32_t)q0.x << 8) | (uint32_t)q0.z, __float_as_uint(q0.y));
-    fb.tl[row] = ((uint32_t)q0.w << 8) | TLF_AUTH;
-    fb.rec1[row] = make_uint2(__float_as_uint(q1.x), r1_code((int)l1_g(q1.y), l1_hoff(q1.y)));
+    fb.tl[row] = tl_word((uint32_t)q0.w, l1_hoff(q1.y), TLF_AUTH);
+    fb.rec1[row] = make_uint2(__float_as_uint(q1.x), r1_code((int)l1_g(q1.y)));
     const float who = who_l[i];
     fb.post[row] = ((uint32_t)pA[i].y << 8) | (pA[i].x > 0.0f ? PF_NONEMPTY : 0u) | (who != 0.0f ? PF_ARRIVED : 0u);
     // SELECTED_ROAD back as a rank of this road's out-list (the raw value where it names none of them, as pack does)

@@ -84,7 +84,7 @@ def ppo_train(env, policy_module, value_module, *, total_frames=128, frames_per_
     # seed, so seed + rank gives different trajectories per rank; parameters stay replicated (rank 0's are broadcast)
     engine = SimEngine(g.x, g.edge_index, g.edge_attr, sim.Nmax, agents,
                        congestion_constant=getattr(g, "congestion_constant", None), num_envs=num_envs,
-                       device=g.x.device, timestep=sim.timestep, seed=seed + 7919 * rank, fused=sim.Nmax <= 255)
+                       device=g.x.device, timestep=sim.timestep, seed=seed + 7919 * rank, fused=sim.Nmax <= 127)
     l = value_net.final_mlp
     dormant = [p for n, p in policy_net.named_parameters() if not n.startswith("nodes_embedding")]
     head = getattr(policy_net, "policy_head", "embedding")

@@ -564,8 +564,8 @@ class FusedState:
     def __init__(self, plan: Plan, B: int, A: int, device, Nmax: int = 15):
         L = _lib.load()
         N, E = plan.num_nodes, plan.num_edges
-        if Nmax > 255 or plan.max_out > 126:
-            raise _lib.TarlError(f"the fused path needs Nmax <= 255 and out-degree <= 126 (got Nmax={Nmax}, max out-degree="
+        if Nmax > 127 or plan.max_out > 126:
+            raise _lib.TarlError(f"the fused path needs Nmax <= 127 and out-degree <= 126 (got Nmax={Nmax}, max out-degree="
                                  f"{plan.max_out}); construct SimEngine(..., fused=False) for this graph")
         f32 = dict(dtype=torch.float32, device=device)
         i32 = dict(dtype=torch.int32, device=device)
