@@ -287,7 +287,10 @@ int tarl_value_mpnn_bwd(const tarl_plan* plan, const float* node_features, int64
  *   a_order int32 [B][A] (optional, may be NULL): each environment's agent ids sorted by DEPARTURE_TIME — with it the
  *   insert kernel scans a window of that order from the cursor cur_lo int32 [B] instead of every agent every frame;
  *   a_dep_sorted fp32 [B][A] (required with a_order): DEPARTURE_TIME in that order, so the scan reads departures
- *   sequentially and touches the per-agent arrays only for the few entries that are due.
+ *   sequentially and touches the per-agent arrays only for the few entries that are due. With a_order also a_rank int32
+ *   [B][A] (the inverse permutation: position of agent a in that order), a_win uint32 [B][A][4] and a_ins uint8 [B][A]
+ *   (both filled by pack, in that order): the window record {departure bits, origin, agent id, 0} and the "already
+ *   inserted" flag, so that one scan step is ONE pair of independent loads instead of a chain of four gathers.
  *   flags int32 [1]: sticky device status word (cleared by pack): TARL_FLAG_COUNT_AT_NMAX = a FIFO count reached Nmax
  *   (the reference raises IndexError there, src/direction_mpnn.py:172-191: the state is outside its defined domain),
  *   TARL_FLAG_AMBIGUOUS_EDGES = two out-edges of a node lead to the same ROAD_INDEX, TARL_FLAG_PACK_RANGE = a packed
@@ -320,6 +323,9 @@ typedef struct tarl_fused {
   const int32_t* a_order;
   int32_t* cur_lo;
   const float* a_dep_sorted;
+  void* a_win;
+  uint8_t* a_ins;
+  const int32_t* a_rank;
   int64_t acc_slots;
   int32_t* flags;
 } tarl_fused;

@@ -151,6 +151,16 @@ __global__ __launch_bounds__(FB) void k_pack_agents(const float* __restrict__ ag
   if (a == 0 && fb.cur_lo) fb.cur_lo[b] = 0;
 }
 
+// departure-ordered window records of the insert kernel (after k_pack_agents)
+__global__ __launch_bounds__(FB) void k_pack_window(int64_t B, int64_t A, FusedBufs fb, uint4* __restrict__ a_win) {
+  const int64_t gid = (int64_t)blockIdx.x * FB + threadIdx.x;   // gid = b * A + k (sorted position k)
+  if (gid >= B * A) return;
+  const int64_t b = gid / A;
+  const int32_t a = fb.a_order[gid];
+  a_win[gid] = make_uint4(__float_as_uint(fb.a_dep_sorted[gid]), (uint32_t)fb.a_origin[b * A + a], (uint32_t)a, 0u);
+  fb.a_ins[gid] = fb.a_status[b * A + a] != 0 ? 1 : 0;
+}
+
 // ---- reset: SimulatorEnv._reset on the packed state (zero FIFOs and counters, clear ON_WAY / DONE, re-arm cursors) -------
 __global__ __launch_bounds__(FB) void k_fused_reset_nodes(int64_t B, int64_t N, FusedBufs fb) {
   const int64_t gid = (int64_t)blockIdx.x * FB + threadIdx.x;
@@ -181,6 +191,7 @@ __global__ __launch_bounds__(FB) void k_fused_reset_agents(float* __restrict__ a
   row[AG_ON_WAY] = 0.0f;
   row[AG_DONE] = 0.0f;
   fb.a_status[gid] = 0;
+  if (fb.a_ins) fb.a_ins[b * A + fb.a_rank[gid]] = 0;
 }
 
 // ---- export: rebuild the reference's x layout (three FIFO column blocks + NUMBER_OF_AGENT + SELECTED_ROAD) ----------
@@ -976,21 +987,31 @@ __device__ __forceinline__ void fused_insert_body(int64_t b, int Nmax, int64_t B
       const int64_t k = k0 + tid;
       bool notdue = false;
       if (k < A) {
-        const bool due = dsort[k] <= t;          // sequential read; per-agent arrays only for entries that are due
+        bool due, waiting;
+        int32_t a, origin;
+        if (fb.a_win) {     // one pair of independent loads: {departure, origin, agent} record + "already inserted" byte
+          const uint4 w = fb.a_win[b * A + k];
+          waiting = fb.a_ins[b * A + k] == 0;
+          due = __uint_as_float(w.x) <= t;
+          origin = (int32_t)w.y;
+          a = (int32_t)w.z;
+        } else {            // sequential departures; per-agent arrays only for entries that are due
+          due = dsort[k] <= t;
+          a = due ? ord[k] : 0;
+          waiting = due && fb.a_status[b * A + a] == 0;
+          origin = waiting ? fb.a_origin[b * A + a] : 0;
+        }
         notdue = !due;
         if (!due) {
           atomicMin(&s_lo, (int32_t)k);          // the cursor may not pass this entry
-        } else {
-          const int32_t a = ord[k];
-          if (fb.a_status[b * A + a] == 0) {
-            atomicMin(&s_lo, (int32_t)k);
-            int32_t road = 0, cap = 0;
-            if (fused_target(fb, P, sel8, b, B, N, fb.a_origin[b * A + a], &road, &cap)) {
-              const int32_t pos = atomicAdd(&s_cnt, 1);
-              if (pos < INS_CAP) {
-                s_un_agent[pos] = a;
-                s_un_road[pos] = road;
-              }
+        } else if (waiting) {
+          atomicMin(&s_lo, (int32_t)k);
+          int32_t road = 0, cap = 0;
+          if (fused_target(fb, P, sel8, b, B, N, origin, &road, &cap)) {
+            const int32_t pos = atomicAdd(&s_cnt, 1);
+            if (pos < INS_CAP) {
+              s_un_agent[pos] = a;
+              s_un_road[pos] = road;
             }
           }
         }
@@ -1100,6 +1121,7 @@ __device__ __forceinline__ void fused_insert_body(int64_t b, int Nmax, int64_t B
       }
       agb[(int64_t)a * AG_COLS + AG_ON_WAY] = 1.0f;
       fb.a_status[b * A + a] = 1;
+      if (fb.a_ins) fb.a_ins[b * A + fb.a_rank[b * A + a]] = 1;
       if (rank == 0 && n0i == 0u) {   // new head: id + departure (count byte unchanged), arrival
         fb.hdp[rrow] = make_uint2(((uint32_t)a << 8) | n0i, __float_as_uint(t + tt));
         fb.rec1[rrow].x = __float_as_uint(t);
@@ -1213,6 +1235,7 @@ FusedBufs tarl_to_bufs(const tarl_fused* f) {
                    (const InRec*)f->in_rec, f->out_pad,
                    (long long*)f->acc_lp, f->acc_n,         f->acc_w,        f->a_origin,        f->a_dest,
                    f->a_dep,              f->a_status,      f->a_order,      f->cur_lo,          f->a_dep_sorted,
+                   (const uint4*)f->a_win, f->a_ins,        f->a_rank,
                    f->acc_slots,          f->flags};
 }
 
@@ -1308,6 +1331,11 @@ extern "C" int tarl_fused_pack(const tarl_plan* plan, const tarl_fused* f, const
     hipLaunchKernelGGL(k_pack_agents, dim3((unsigned)ceil_div(B * A, FB)), dim3(FB), 0, s, agent_features, B, A,
                        a_bstride, fb);
     TARL_LAUNCH_CHECK();
+    if (f->a_order && f->a_win) {
+      TARL_REQUIRE(f->a_ins && f->a_rank && f->a_dep_sorted, "a_win needs a_ins, a_rank and a_dep_sorted");
+      hipLaunchKernelGGL(k_pack_window, dim3((unsigned)ceil_div(B * A, FB)), dim3(FB), 0, s, B, A, fb, (uint4*)f->a_win);
+      TARL_LAUNCH_CHECK();
+    }
   }
   return TARL_OK;
 }

@@ -87,6 +87,12 @@ struct FusedBufs {
   const int32_t* a_order;  // [B][A] agent ids sorted by departure time (static), or NULL: scan all agents every frame
   int32_t* cur_lo;      // [B] first position of a_order that may still hold a waiting agent
   const float* a_dep_sorted;  // [B][A] departure times in a_order's order (sequential scan instead of a gather)
+  // departure-ordered window of the insert kernel (built by pack when a_order is given): ONE 16-byte load per entry gives
+  // {departure bits, origin, agent id, 0}; a_ins [B][A] (same order) = 1 once the entry's agent has been inserted (or was
+  // not waiting at pack time); a_rank [B][A] = position of agent a in that order
+  const uint4* a_win;
+  uint8_t* a_ins;
+  const int32_t* a_rank;
   int64_t acc_slots;    // accumulator banks: acc_* are [acc_slots][B]; a workgroup adds into bank (chunk % slots)
   int32_t* flags;       // [1] device status word
 };

@@ -612,6 +612,7 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
           }
           agb[(int64_t)a * AG_COLS + AG_ON_WAY] = 1.0f;
           fb.a_status[b * A + a] = 1;
+          if (fb.a_ins) fb.a_ins[b * A + fb.a_rank[b * A + a]] = 1;
           if (rank == 0 && n0 == 0.0f) {
             r0[r].x = (float)a;
             r0[r].y = t + tt;

@@ -91,7 +91,8 @@ class FusedStruct(C.Structure):
     _fields_ = ([(n, C.c_void_p) for n in ("hdp", "tl", "rec1", "post", "st0", "slots")] +
                 [("ld_slots", C.c_int64)] +
                 [(n, C.c_void_p) for n in ("sel8", "sel", "node_rec", "in_rec", "out_pad", "acc_lp", "acc_n", "acc_w", "a_origin", "a_dest",
-                                           "a_dep", "a_status", "a_order", "cur_lo", "a_dep_sorted")] +
+                                           "a_dep", "a_status", "a_order", "cur_lo", "a_dep_sorted", "a_win", "a_ins",
+                                           "a_rank")] +
                 [("acc_slots", C.c_int64), ("flags", C.c_void_p)])
 
 

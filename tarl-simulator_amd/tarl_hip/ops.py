@@ -592,6 +592,9 @@ class FusedState:
         self.a_order = torch.zeros((B, A), **i32)
         self.a_dep_sorted = torch.zeros((B, A), **f32)
         self.cur_lo = torch.zeros(B, **i32)
+        self.a_win = torch.zeros((B, A, 4), **i32)
+        self.a_ins = torch.zeros((B, A), dtype=torch.uint8, device=device)
+        self.a_rank = torch.zeros((B, A), **i32)
         self.flags = torch.zeros(1, **i32)
         self.order_valid = False
         self.struct = _lib.FusedStruct(self.hdp.data_ptr(), self.tl.data_ptr(), self.rec1.data_ptr(),
@@ -600,8 +603,8 @@ class FusedState:
                                        self.in_rec.data_ptr(), self.out_pad.data_ptr(),
                                        self.acc_lp.data_ptr(), self.acc_n.data_ptr(), self.acc_w.data_ptr(),
                                        self.a_origin.data_ptr(), self.a_dest.data_ptr(), self.a_dep.data_ptr(),
-                                       self.a_status.data_ptr(), None, self.cur_lo.data_ptr(), None, self.acc_slots,
-                                       self.flags.data_ptr())
+                                       self.a_status.data_ptr(), None, self.cur_lo.data_ptr(), None, None, None, None,
+                                       self.acc_slots, self.flags.data_ptr())
         self.B, self.N, self.A, self.Nmax = B, N, A, Nmax
 
     # -- unpacked views of the dense words (tests / debugging; torch plumbing, never on a hot path) ----------------------
@@ -628,8 +631,12 @@ class FusedState:
         order = torch.argsort(dep, dim=1, stable=True)
         self.a_order.copy_(order.to(torch.int32))
         self.a_dep_sorted.copy_(torch.gather(dep, 1, order))
+        self.a_rank.scatter_(1, order, torch.arange(self.A, dtype=torch.int32, device=order.device).expand(self.B, -1))
         self.struct.a_order = self.a_order.data_ptr()
         self.struct.a_dep_sorted = self.a_dep_sorted.data_ptr()
+        self.struct.a_win = self.a_win.data_ptr()       # filled by tarl_fused_pack
+        self.struct.a_ins = self.a_ins.data_ptr()
+        self.struct.a_rank = self.a_rank.data_ptr()
         self.order_valid = True
 
     def check_flags(self):

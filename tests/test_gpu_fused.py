@@ -35,6 +35,9 @@ def check_records(ops, plan, fs, x, Nmax, ag, cc, ec):
     pos = torch.arange(fs.A, device=x.device).unsqueeze(0)
     st_sorted = torch.gather(fs.a_status, 1, fs.a_order.long())
     assert not bool(((pos < fs.cur_lo.unsqueeze(1)) & (st_sorted == 0)).any())
+    # the departure-ordered window: "already inserted" flags mirror the status SoA; records = a fresh pack's
+    assert torch.equal(fs.a_ins, (st_sorted != 0).to(torch.uint8)) and torch.equal(fs.a_win, ref.a_win)
+    assert torch.equal(torch.gather(fs.a_rank, 1, fs.a_order.long()), pos.expand(fs.B, -1).to(torch.int32))
     # some rows carry a pending (lazy, never stored) garbage slot: idle in the last frame, or an event row that received nobody
     assert int((((fs.tl & 1) == 0) | (fs.rec1[..., 1] > 0)).sum()) > 0
 
