@@ -382,6 +382,71 @@ def gen_edge_mlp():
     save("edge_mlp", **rec)
 
 
+def gen_figures():
+    """The series behind the reference's analysis figures (src/transportation_simulator.py:387-517, 672-745), read back
+    from the matplotlib artists its own plot_* methods create: the binned leg histogram at three timestep sizes, the
+    per-road delta-travel-time lines, and the simulated-vs-expected daily counts. Inputs are seeded series of the shape
+    run() / _step record them (lists of [departures, arrivals, on the way, clock], (clock, per-edge tensor), (clock, mask))."""
+    import contextlib
+    import io
+    import types
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    g = torch.Generator().manual_seed(77)
+    rec = {}
+    with contextlib.redirect_stdout(io.StringIO()):
+        for dt in (1, 2, 6):
+            T = 200 // dt + 7
+            dep = torch.randint(0, 9, (T,), generator=g)
+            arr = torch.randint(0, 7, (T,), generator=g)
+            on = torch.cumsum(dep - arr, 0).clamp(min=0)
+            clock = 6 * 3600 - 60 + dt * torch.arange(1, T + 1)
+            vals = torch.stack([dep, arr, on, clock], 1)
+            sim = TransportationSimulator("cpu")
+            sim.timestep = dt
+            # rows as the reference records them: tensors for the counts, a python number for the clock
+            sim.leg_histogram_values = [[vals[i, 0], vals[i, 1], vals[i, 2], int(vals[i, 3])] for i in range(T)]
+            fig = sim.plot_leg_histogram(output_dir=None)
+            lines = fig.axes[0].lines
+            rec[f"leg{dt}__values"] = vals
+            rec[f"leg{dt}__minutes"] = np.asarray(lines[0].get_xdata(), dtype=np.float64)
+            for k, name in enumerate(("on", "dep", "arr")):
+                rec[f"leg{dt}__{name}"] = np.asarray(lines[k].get_ydata(), dtype=np.float64)
+            plt.close(fig)
+        # road optimality: 5 roads, 11 route edges, 9 steps
+        R, E, T = 5, 11, 9
+        src = torch.randint(0, R, (E,), generator=g)
+        dtt = torch.rand((T, E), generator=g) * 40.0 - 5.0
+        clocks = [6 * 3600 + 30 * i for i in range(T)]
+        sim = TransportationSimulator("cpu")
+        sim.graph = types.SimpleNamespace(num_roads=R, edge_index_routes=torch.stack([src, torch.zeros_like(src)]))
+        sim.road_optimality_values = [(clocks[i], dtt[i]) for i in range(T)]
+        fig = sim.plot_road_optimality(output_dir=None)
+        lines = fig.axes[0].lines
+        rec.update(opt__src=src, opt__dtt=dtt, opt__clocks=np.asarray(clocks),
+                   opt__hours=np.asarray(lines[0].get_xdata(), dtype=np.float32),
+                   opt__per_road=np.stack([np.asarray(l.get_ydata(), dtype=np.float32) for l in lines], 1))
+        plt.close(fig)
+        # daily counts: pops then withdrawals over three hours, 6 roads, expected flows for 4 of them
+        R = 6
+        pops = [(3600 * 7 + 600 * i, torch.rand(R, generator=g) < 0.4) for i in range(14)]
+        wds = [(3600 * 7 + 600 * i + 1, torch.rand(R, generator=g) < 0.2) for i in range(14)]
+        expected = {4: 3.5, 0: 2.0, 2: 7.25, 5: 0.0}
+        sim = TransportationSimulator("cpu")
+        sim.model_core = types.SimpleNamespace(response_mpnn=types.SimpleNamespace(update_history=pops))
+        sim.agent.withdraw_history = wds
+        fig = sim.plot_daily_counts(expected, output_dir=None)
+        xy = np.asarray(fig.axes[0].collections[0].get_offsets(), dtype=np.float64)
+        rec.update(daily__clocks=np.asarray([t for t, _ in pops + wds]),
+                   daily__masks=torch.stack([m for _, m in pops + wds]),
+                   daily__expected_keys=np.asarray(list(expected.keys())),
+                   daily__expected_vals=np.asarray(list(expected.values())),
+                   daily__x=xy[:, 0], daily__y=xy[:, 1])
+        plt.close(fig)
+    save("figures", **rec)
+
+
 def gen_value_mpnn():
     """MPNNValueNet (src/agents/mpnn_agent.py:265-402), the message-passing critic the reference defines but never
     instantiates, in eval mode (Dropout = identity): unbatched and batched forward with its own random weights."""
@@ -549,6 +614,7 @@ if __name__ == "__main__":
     gen_env_rollout()
     gen_nets()
     gen_edge_mlp()
+    gen_figures()
     gen_value_mpnn()
     gen_builders()
     gen_routing()

@@ -142,11 +142,14 @@ class Runner:
             print(f"{label:25} {v:10.2f} s   (host enqueue time; kernels run asynchronously)")
         print("-" * 42)
         print(f"{'Total simulation time:':25} {total:10.2f} s")
-        # metric tables of the reference's eval (src/runner.py:160-166) — node metrics and the MSA expected demand; its
-        # matplotlib figures are not reproduced
+        # the reference's eval report (src/runner.py:166-174, 219-226): phase-time pie, node metrics, leg histogram, road
+        # optimality, and the simulated daily counts against the MSA assignment's expected flows
         out_dir = Path(a.output_dir)
         try:
+            sim.plot_computation_time(str(out_dir))
             sim.compute_node_metrics(str(out_dir))
+            sim.plot_leg_histogram(str(out_dir))
+            sim.plot_road_optimality(str(out_dir))
             if sim.graph.x.size(0) <= 4096:          # all-pairs table per MSA iteration: keep it to mid-size graphs
                 from .algorithms.user_equilibrium_msa import run_msa
                 expected = run_msa(sim.graph, agent)
@@ -154,6 +157,9 @@ class Runner:
                 with open(out_dir / "msa_expected_flows.csv", "w") as f:
                     f.write("road,expected_hourly_flow\n")
                     f.writelines(f"{r},{v}\n" for r, v in expected.items())
+                sim.plot_daily_counts(expected, str(out_dir))
+            import matplotlib.pyplot as plt
+            plt.close("all")
         except Exception as exc:  # noqa: BLE001 - analysis output must not fail the run
-            print(f"metric tables skipped: {exc}")
+            print(f"metric tables / figures skipped: {exc}")
         return {"steps": n, "arrived": int(mask.sum()), "avg_travel_time": avg}

@@ -3,7 +3,8 @@ src/transportation_simulator.py). In scope here: the graph layout contract (``gr
 ``edge_index_routes``, ``edge_attr*``, ``num_roads``, ``congestion_constant``), ``config_network`` (MATSim XML ->
 graph, src/matsim_io.py), ``load_network`` for synthetic scenarios, the reference's ``save/<scenario>/network.pt`` cache
 and ``data/<scenario>/network.xml[.gz]``, ``config_parameters / configure_core / set_time / reset / state / run``.
-Plots and CSV metrics are out of scope.
+The metric tables and the analysis figures (``plot_*``, drawn by src/figures.py from the series kept on the device) follow
+the reference's (src/transportation_simulator.py:387-745).
 """
 from __future__ import annotations
 
@@ -111,7 +112,7 @@ class TransportationSimulator:
         self.road_optimality_values.append(
             (self.time, self.model_core.direction_mpnn.road_optimality_data["delta_travel_time"]))
 
-    # -- metrics (tables only; the reference's matplotlib figures are not reproduced) -------------------------------------
+    # -- metrics: tables and figures ----------------------------------------------------------------------------------------
     def compute_node_metrics(self, output_dir: str | None = "data/outputs"):
         """Hourly departures per road (Response pops + withdrawals), their V/C ratio against MAX_FLOW, mean and std over
         the hours; ``node_metrics.csv`` with the reference's columns (src/transportation_simulator.py:563-670). The
@@ -152,6 +153,35 @@ class TransportationSimulator:
             return torch.zeros((0, 4))
         return torch.stack([torch.stack([torch.as_tensor(v, dtype=torch.float32).reshape(()).cpu() for v in row])
                             for row in self.leg_histogram_values])
+
+    def _history(self):
+        return list(getattr(self.model_core.response_mpnn, "update_history", [])) + \
+            list(getattr(self.agent, "withdraw_history", []))
+
+    def plot_leg_histogram(self, output_dir: str | None = "data/outputs"):
+        """Departures / arrivals / agents on the way in bins of ``18 // timestep`` steps
+        (src/transportation_simulator.py:387-451)."""
+        from . import figures
+        return figures.leg_histogram_figure(self.leg_histogram().numpy(), self.timestep, output_dir)
+
+    def plot_road_optimality(self, output_dir: str | None = "data/outputs", road_ids: list = []):
+        """delta_travel_time summed over every road's outgoing route edges, one line per road over the clock
+        (src/transportation_simulator.py:453-517)."""
+        from . import figures
+        return figures.road_optimality_figure(self.road_optimality_values, self.graph.edge_index_routes[0],
+                                              self.graph.num_roads, road_ids, output_dir)
+
+    def plot_computation_time(self, output_dir: str = "data/outputs"):
+        """Pie of the four phase timers (src/transportation_simulator.py:519-561); here they are host enqueue times."""
+        from . import figures
+        return figures.computation_time_figure(self.inserting_time, self.choice_time, self.core_time,
+                                               self.withdraw_time, output_dir)
+
+    def plot_daily_counts(self, expected_counts: dict, output_dir: str | None = "data/outputs"):
+        """Simulated departures per road against the MSA assignment's expected flows, scatter + ``daily_counts.csv``
+        (src/transportation_simulator.py:672-745)."""
+        from . import figures
+        return figures.daily_counts_figure(self._history(), expected_counts, output_dir)
 
     def reset(self):
         from tarl_hip import ops

@@ -314,6 +314,9 @@ def test_all_algorithms_on_a_matsim_scenario(tmp_path, monkeypatch, capsys):
     assert arrived["dijkstra"] >= arrived["random"]          # shortest paths beat a random walk
     assert os.path.exists(tmp_path / "runs" / "policy.pt") and os.path.exists("save/grid/network.pt")
     assert os.path.exists(tmp_path / "runs" / "node_metrics.csv")
+    for name in ("computation_time.png", "leg_histogram.png", "road_optimality.png", "daily_counts.png",
+                 "daily_counts.csv"):                                   # the reference's eval report (src/runner.py:166-174)
+        assert os.path.getsize(tmp_path / "runs" / name) > 0, name
     rows = open(tmp_path / "runs" / "msa_expected_flows.csv").read().splitlines()
     assert rows[0] == "road,expected_hourly_flow" and len(rows) == 1 + 76 and sum(float(r.split(",")[1]) for r in rows[1:]) > 0
 
