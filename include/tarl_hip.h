@@ -221,6 +221,17 @@ int tarl_ppo_loss(const float* log_prob_new, const float* log_prob_old, const fl
 int tarl_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,
                    double lr, double beta1, double beta2, double eps, float grad_scale, tarl_stream stream);
 
+/* tarl_critic_mlp_fwd_splitk: the same network for FEW rows (the optimiser minibatch: 32 rows x N columns would
+ *   otherwise be one MFMA tile walking all columns on one CU). The first layer is split over blocks of 64 input
+ *   columns (partial sums in scratch, tarl_critic_splitk_scratch_floats(M, N) floats), added in block order by a second
+ *   launch that finishes the network: deterministic; differs from tarl_critic_mlp_fwd only by the order of the fp32
+ *   additions. Same arguments otherwise. */
+int64_t tarl_critic_splitk_scratch_floats(int64_t M, int64_t N);
+int tarl_critic_mlp_fwd_splitk(const float* counts, int64_t ldc, int64_t M, int64_t N, const float* time_rows,
+                               int64_t rows_per_time, const float* w1, const float* b1, const float* w2, const float* b2,
+                               const float* w3, const float* b3, float* scratch, float* value, float* h1_out,
+                               float* h2_out, tarl_stream stream);
+
 /* tarl_critic_mlp_fwd_slabs: same network on the env-minor rollout buffer counts [M / rows_per_slab][N][rows_per_slab]
  *   (= [frame][node][env]); rows_per_slab must be a multiple of 128 and M a whole number of slabs. value [M] is in
  *   (frame, env) order. */

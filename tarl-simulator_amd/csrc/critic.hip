@@ -575,6 +575,139 @@ extern "C" int tarl_critic_mlp_fwd_u8(const uint8_t* counts, int64_t ldc, int64_
                     stream);
 }
 
+// ---- few rows (the optimiser minibatch): split-K ----------------------------------------------------------------------------
+// One 128-row MFMA tile walks all N input columns alone (N / 32 dependent stage + MFMA rounds on one CU). For M <= a few
+// hundred rows the first layer is spread over the input columns instead: workgroup (s, rb) multiplies 32 rows by the
+// 64 x 64 block of W1 that belongs to columns [64 s, 64 s + 64) on the vector ALU and parks its partial sums; one
+// workgroup then adds the partials in chunk order (fixed order: deterministic), applies the time column, bias and ReLU and
+// finishes the two small layers. The value differs from k_critic_fwd's only by the order of the fp32 additions.
+#define CK_KC 64
+#define CK_RB 32
+
+__global__ __launch_bounds__(CR_THREADS) void k_critic_splitk_partial(const float* __restrict__ counts, int64_t ldc,
+                                                                      int64_t M, int64_t N,
+                                                                      const float* __restrict__ w1,
+                                                                      float* __restrict__ partial, int64_t Mpad) {
+  __shared__ float Xs[CK_RB * (CK_KC + 1)];     // [row][k]
+  __shared__ float Ws[CK_KC * (CR_H + 1)];      // [k][j]
+  const int tid = threadIdx.x;
+  const int64_t k0 = (int64_t)blockIdx.x * CK_KC, row0 = (int64_t)blockIdx.y * CK_RB, ldw = N + 1;
+#pragma unroll
+  for (int it = 0; it < (CK_RB * CK_KC) / CR_THREADS; ++it) {
+    const int idx = it * CR_THREADS + tid;
+    const int r = idx >> 6, k = idx & 63;
+    const int64_t gr = row0 + r, gk = k0 + k;
+    Xs[r * (CK_KC + 1) + k] = (gr < M && gk < N) ? counts[gr * ldc + gk] : 0.0f;
+  }
+#pragma unroll
+  for (int it = 0; it < (CR_H * CK_KC) / CR_THREADS; ++it) {
+    const int idx = it * CR_THREADS + tid;
+    const int j = idx >> 6, k = idx & 63;
+    const int64_t gk = k0 + k;
+    Ws[k * (CR_H + 1) + j] = (gk < N) ? w1[(int64_t)j * ldw + gk] : 0.0f;
+  }
+  __syncthreads();
+  const int r = tid >> 3, jg = tid & 7;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 8
+  for (int k = 0; k < CK_KC; ++k) {
+    const float x = Xs[r * (CK_KC + 1) + k];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = fmaf(x, Ws[k * (CR_H + 1) + jg + 8 * i], acc[i]);
+  }
+  float* out = partial + ((int64_t)blockIdx.x * Mpad + row0 + r) * CR_H;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[jg + 8 * i] = acc[i];
+}
+
+__global__ __launch_bounds__(CR_THREADS) void k_critic_splitk_finish(const float* __restrict__ partial, int64_t S,
+                                                                     int64_t Mpad, int64_t M, int64_t N,
+                                                                     const float* __restrict__ time_rows,
+                                                                     int64_t rows_per_time, CriticParams P,
+                                                                     float* __restrict__ value,
+                                                                     float* __restrict__ h1_out,
+                                                                     float* __restrict__ h2_out) {
+  __shared__ float H1[CK_RB * (CR_H + 1)];
+  __shared__ float H2[CK_RB * (CR_H + 1)];
+  __shared__ float W2s[CR_H * (CR_H + 1)];      // [k][j] = w2[j][k]
+  const int tid = threadIdx.x;
+  const int64_t row0 = (int64_t)blockIdx.x * CK_RB, ldw = N + 1;
+#pragma unroll
+  for (int it = 0; it < (CR_H * CR_H) / CR_THREADS; ++it) {
+    const int idx = it * CR_THREADS + tid;
+    const int j = idx >> 6, k = idx & 63;
+    W2s[k * (CR_H + 1) + j] = P.w2[j * CR_H + k];
+  }
+  const int r = tid >> 3, jg = tid & 7;
+  const int64_t gr = row0 + r;
+  const float tm = (gr < M) ? time_rows[gr / rows_per_time] : 0.0f;
+  {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t s = 0; s < S; ++s) {
+      const float* in = partial + (s * Mpad + gr) * CR_H;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += in[jg + 8 * i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = jg + 8 * i;
+      float v = acc[i] + tm * P.w1[(int64_t)j * ldw + N] + P.b1[j];
+      v = v > 0.0f ? v : 0.0f;
+      H1[r * (CR_H + 1) + j] = v;
+      if (h1_out && gr < M) h1_out[gr * CR_H + j] = v;
+    }
+  }
+  __syncthreads();
+  {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 8
+    for (int k = 0; k < CR_H; ++k) {
+      const float x = H1[r * (CR_H + 1) + k];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = fmaf(x, W2s[k * (CR_H + 1) + jg + 8 * i], acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = jg + 8 * i;
+      float v = acc[i] + P.b2[j];
+      v = v > 0.0f ? v : 0.0f;
+      H2[r * (CR_H + 1) + j] = v;
+      if (h2_out && gr < M) h2_out[gr * CR_H + j] = v;
+    }
+  }
+  __syncthreads();
+  if (tid < CK_RB && row0 + tid < M) {
+    float s = 0.0f;
+#pragma unroll 8
+    for (int j = 0; j < CR_H; ++j) s += H2[tid * (CR_H + 1) + j] * P.w3[j];
+    value[row0 + tid] = s + P.b3[0];
+  }
+}
+
+extern "C" int64_t tarl_critic_splitk_scratch_floats(int64_t M, int64_t N) {
+  if (M < 1 || N < 1) return -1;
+  return ceil_div(N, CK_KC) * ceil_div(M, CK_RB) * CK_RB * CR_H;
+}
+
+extern "C" int tarl_critic_mlp_fwd_splitk(const float* counts, int64_t ldc, int64_t M, int64_t N,
+                                          const float* time_rows, int64_t rows_per_time, const float* w1,
+                                          const float* b1, const float* w2, const float* b2, const float* w3,
+                                          const float* b3, float* scratch, float* value, float* h1_out, float* h2_out,
+                                          tarl_stream stream) {
+  TARL_REQUIRE(counts && time_rows && w1 && b1 && w2 && b2 && w3 && b3 && value && scratch, "null argument");
+  TARL_REQUIRE(M >= 1 && N >= 1 && rows_per_time >= 1 && ldc >= N, "bad sizes");
+  const int64_t S = ceil_div(N, CK_KC), RB = ceil_div(M, CK_RB);
+  TARL_REQUIRE(S < ((int64_t)1 << 31) && RB < 65536, "split-K critic: too many rows (use tarl_critic_mlp_fwd)");
+  const CriticParams P{w1, b1, w2, b2, w3, b3};
+  hipLaunchKernelGGL(k_critic_splitk_partial, dim3((unsigned)S, (unsigned)RB), dim3(CR_THREADS), 0, (hipStream_t)stream,
+                     counts, ldc, M, N, w1, scratch, RB * CK_RB);
+  TARL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_critic_splitk_finish, dim3((unsigned)RB), dim3(CR_THREADS), 0, (hipStream_t)stream, scratch, S,
+                     RB * CK_RB, M, N, time_rows, rows_per_time, P, value, h1_out, h2_out);
+  TARL_LAUNCH_CHECK();
+  return TARL_OK;
+}
+
 template <typename XT>
 static int critic_fwd_slabs(const XT* counts, int64_t rows_per_slab, int64_t M, int64_t N, const float* time_rows,
                             int64_t rows_per_time, const float* w1, const float* b1, const float* w2, const float* b2,

@@ -90,204 +90,257 @@ __global__ __launch_bounds__(FB) void k_obs16_cat(const float* __restrict__ nf, 
 }
 
 // ---- forward ------------------------------------------------------------------------------------------------------------
-// LDS plan (fp32, dynamic, 67.7 KB): Xs [34][129] (later H2s [32][129]) | Hs [64][129] | W1s [34][65] | W2s [64][33].
-// A workgroup stages the weights ONCE and walks EM_TPW consecutive 128-edge tiles of its sample.
-#define EM_TPW 8
-#define EMF_A (34 * (EM_TILE + 1))
-#define EMF_C (EM_H1 * (EM_TILE + 1))
-#define EMF_W1 (34 * (EM_H1 + 1))
-#define EMF_W2 (EM_H1 * (EM_H2 + 1))
-#define EMF_LDS_BYTES ((EMF_A + EMF_C + EMF_W1 + EMF_W2) * sizeof(float))
-__global__ __launch_bounds__(EM_THREADS) void k_edge_mlp_fwd_f32(const int32_t* __restrict__ src,
-                                                                 const int32_t* __restrict__ dst, int64_t E, int64_t N,
-                                                                 const float* __restrict__ obs,
-                                                                 const float* __restrict__ edge_attr, EdgeMlpW W,
-                                                                 float* __restrict__ logits) {
-  extern __shared__ float lds[];
-  float* Xs = lds;                   // [k][edge]
-  float* Hs = lds + EMF_A;           // [j][edge]
-  float* W1s = Hs + EMF_C;           // [k][j]
-  float* W2s = W1s + EMF_W1;         // [k][j], stride 33
-  float* H2s = Xs;                   // [j][edge] (aliases Xs: dead after the first layer)
+// Register-resident, "transposed" (D^T = W X^T): per 32 edges a wave computes H1^T [64][32] = W1 [64][33+] X^T,
+// H2^T [32][32] = W2 H1^T, logit = w3 . H2^T with the WEIGHTS as the A operands (held in registers for the wave's whole
+// life) and the EDGES as the columns. In the 32x32 accumulator layout lane l then owns, for ITS edge (column l & 31), the
+// hidden units (r & 3) + 8 (r >> 2) + 4 (l >> 5) — sixteen values of one edge per 32-row tile — and the B operand of the
+// next layer wants, per lane, consecutive k of its own column: a dot product does not care in which order k runs, so
+// the second layer simply walks the hidden units in the order the lanes already hold them (W2's columns are permuted
+// to match when its fragments are built). Activations never touch LDS: gather (each half-wave one 32-byte half of the two
+// 64-byte node rows) -> registers -> MFMAs -> 16 fma + one cross-half add -> logit. Waves are persistent: each builds
+// its weight fragments once and walks a contiguous range of 32-edge chunks, prefetching the next chunk's rows.
+#define EMR_WAVES 4
+__device__ __forceinline__ int emr_unit(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+struct EdgeIn {
+  float4 s0, s1, d0, d1;
+  float ea;
+};
+
+__device__ __forceinline__ EdgeIn emr_load(const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                                           const float* __restrict__ edge_attr, const float* __restrict__ obs,
+                                           int32_t E, int64_t N, int32_t m, int32_t c, int lane) {
+  int32_t e = c * 32 + (lane & 31);
+  e = e < E ? e : E - 1;                     // the tail chunk's spare lanes repeat the last edge (never stored)
+  const float* om = obs + (int64_t)m * N * 16 + 8 * (lane >> 5);
+  const float4* ps = reinterpret_cast<const float4*>(om + (int64_t)src[e] * 16);
+  const float4* pd = reinterpret_cast<const float4*>(om + (int64_t)dst[e] * 16);
+  EdgeIn in;
+  in.s0 = ps[0];
+  in.s1 = ps[1];
+  in.d0 = pd[0];
+  in.d1 = pd[1];
+  in.ea = edge_attr[e];
+  return in;
+}
+
+// max(x, 0) as ONE integer instruction: a float is negative exactly when its bit pattern is a negative int32 (fmaxf
+// costs two: the IEEE mode quiets signalling NaNs first). -0 and negative NaNs become +0, positive NaNs pass through.
+__device__ __forceinline__ float emr_relu(float x) {
+  const int32_t i = __float_as_int(x);
+  return __int_as_float(i > 0 ? i : 0);
+}
+
+// chunk g = m * CH + c (host: M * CH < 2^31); a wave walks [g0, g1) keeping (m, c) by increments
+struct ChunkWalk {
+  uint32_t g, g1, CH;
+  int32_t m, c, mn, cn;
+  __device__ __forceinline__ bool init(int64_t E, int64_t M, int wave) {
+    CH = (uint32_t)((E + 31) >> 5);
+    const uint32_t total = (uint32_t)M * CH, nw = gridDim.x * EMR_WAVES, gw = blockIdx.x * EMR_WAVES + wave;
+    const uint32_t per = (total + nw - 1) / nw;
+    g = gw * per;
+    g1 = (g + per < total) ? g + per : total;
+    if (g >= g1) return false;
+    mn = (int32_t)(g / CH);
+    cn = (int32_t)(g - (uint32_t)mn * CH);
+    return true;
+  }
+  __device__ __forceinline__ void step() {      // (m, c) <- the chunk just prefetched; (mn, cn) <- its successor
+    m = mn;
+    c = cn;
+    if (++cn == (int32_t)CH) {
+      cn = 0;
+      ++mn;
+    }
+  }
+};
+
+// fp32: v_mfma_f32_32x32x2_f32, exact fp32 products. k runs [x_src 8h..8h+7] [x_dst 8h..8h+7] for half-wave h (8 + 8
+// k-steps of 2), then one k-step {edge_attr, 1} against {W1[:, 32], b1}: the bias enters the accumulation as an exact
+// product. 34 + 32 MFMAs per 32 edges: the matrix cores are the bound (66 x 16 passes).
+__global__ __launch_bounds__(EMR_WAVES * 64) void k_edge_mlp_fwd_f32(const int32_t* __restrict__ src,
+                                                                     const int32_t* __restrict__ dst, int64_t E,
+                                                                     int64_t N, int64_t M,
+                                                                     const float* __restrict__ obs,
+                                                                     const float* __restrict__ edge_attr, EdgeMlpW W,
+                                                                     float* __restrict__ logits) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t m = blockIdx.y;
-  const float* om = obs + m * N * 16;
-  for (int idx = tid; idx < 34 * EM_H1; idx += EM_THREADS) {
-    const int j = idx / 34, k = idx - j * 34;
-    W1s[k * (EM_H1 + 1) + j] = k < EM_IN ? W.w1[j * EM_IN + k] : 0.0f;
+  const int h = lane >> 5, j = lane & 31;
+  float w1a[2][17], w2a[32];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int u = 32 * a + j;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      w1a[a][t] = W.w1[u * EM_IN + 8 * h + t];
+      w1a[a][8 + t] = W.w1[u * EM_IN + 16 + 8 * h + t];
+    }
+    w1a[a][16] = h == 0 ? W.w1[u * EM_IN + 32] : W.b1[u];
   }
-  for (int idx = tid; idx < EM_H2 * EM_H1; idx += EM_THREADS) {
-    const int j = idx >> 6, k = idx & 63;
-    W2s[k * (EM_H2 + 1) + j] = W.w2[j * EM_H1 + k];
+#pragma unroll
+  for (int t = 0; t < 32; ++t) w2a[t] = W.w2[j * EM_H1 + 32 * (t >> 4) + emr_unit(t & 15, h)];
+  f32x16 b2r;
+  float w3r[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    b2r[r] = W.b2[emr_unit(r, h)];
+    w3r[r] = W.w3[emr_unit(r, h)];
   }
-  const int j0 = lane & 31;
-  const float bb0 = W.b1[j0], bb1 = W.b1[j0 + 32], bb2 = W.b2[j0];
-  for (int tile = 0; tile < EM_TPW; ++tile) {
-    const int64_t e0 = ((int64_t)blockIdx.x * EM_TPW + tile) * EM_TILE;
-    if (e0 >= E) break;        // uniform
-    __syncthreads();           // the previous tile's readers of H2s (= Xs) are done; the weights are staged
-    // gather: 128 edges x 8 float4 (x_i: 4, x_j: 4), transposed into Xs[k][edge]
+  const float b3 = W.b3[0];
+  const f32x16 zero = {0};
+  ChunkWalk cw;
+  if (!cw.init(E, M, wave)) return;
+  EdgeIn nxt = emr_load(src, dst, edge_attr, obs, (int32_t)E, N, cw.mn, cw.cn, lane);
+  for (; cw.g < cw.g1; ++cw.g) {
+    const EdgeIn cur = nxt;
+    cw.step();
+    if (cw.g + 1 < cw.g1) nxt = emr_load(src, dst, edge_attr, obs, (int32_t)E, N, cw.mn, cw.cn, lane);
+    const float xin[17] = {cur.s0.x, cur.s0.y, cur.s0.z, cur.s0.w, cur.s1.x, cur.s1.y, cur.s1.z, cur.s1.w,
+                           cur.d0.x, cur.d0.y, cur.d0.z, cur.d0.w, cur.d1.x, cur.d1.y, cur.d1.z, cur.d1.w,
+                           h == 0 ? cur.ea : 1.0f};
+    f32x16 acc0 = zero, acc1 = zero;
 #pragma unroll
-    for (int it = 0; it < (EM_TILE * 8) / EM_THREADS; ++it) {
-      const int idx = it * EM_THREADS + tid;
-      const int el = idx >> 3, q = idx & 7;     // q < 4: x[src] quarter q ; else x[dst] quarter q - 4
-      const int64_t e = e0 + el;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e < E) {
-        const int32_t node = q < 4 ? src[e] : dst[e];
-        v = reinterpret_cast<const float4*>(om + (int64_t)node * 16)[q & 3];
-      }
-      const int k = 4 * q;
-      Xs[(k + 0) * (EM_TILE + 1) + el] = v.x;
-      Xs[(k + 1) * (EM_TILE + 1) + el] = v.y;
-      Xs[(k + 2) * (EM_TILE + 1) + el] = v.z;
-      Xs[(k + 3) * (EM_TILE + 1) + el] = v.w;
+    for (int t = 0; t < 17; ++t) {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1a[0][t], xin[t], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1a[1][t], xin[t], acc1, 0, 0, 0);
     }
-    if (tid < EM_TILE) {
-      const int64_t e = e0 + tid;
-      Xs[32 * (EM_TILE + 1) + tid] = e < E ? edge_attr[e] : 0.0f;
-      Xs[33 * (EM_TILE + 1) + tid] = 0.0f;      // K padded to an even number of MFMA k-steps
-    }
-    __syncthreads();
-    f32x16 acc0 = {0}, acc1 = {0};
+    f32x16 c0 = b2r;
 #pragma unroll
-    for (int kk = 0; kk < 34; kk += 2) {
-      const int k = kk + (lane >> 5);
-      const float a = Xs[k * (EM_TILE + 1) + wave * 32 + (lane & 31)];
-      const float b0 = W1s[k * (EM_H1 + 1) + (lane & 31)];
-      const float b1 = W1s[k * (EM_H1 + 1) + 32 + (lane & 31)];
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
-    }
+    for (int t = 0; t < 16; ++t) c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2a[t], emr_relu(acc0[t]), c0, 0, 0, 0);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {   // each wave writes / reads only its own 32 edge columns of Hs
-      const int lr = wave * 32 + em_row(r, lane);
-      const float v0 = acc0[r] + bb0, v1 = acc1[r] + bb1;
-      Hs[j0 * (EM_TILE + 1) + lr] = v0 > 0.0f ? v0 : 0.0f;
-      Hs[(j0 + 32) * (EM_TILE + 1) + lr] = v1 > 0.0f ? v1 : 0.0f;
-    }
-    __syncthreads();   // Hs complete; everyone is done with Xs: its space becomes H2s
-    f32x16 c0 = {0};
+    for (int t = 0; t < 16; ++t) c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2a[16 + t], emr_relu(acc1[t]), c0, 0, 0, 0);
+    float part = 0.0f;
 #pragma unroll
-    for (int kk = 0; kk < EM_H1; kk += 2) {
-      const int k = kk + (lane >> 5);
-      const float a = Hs[k * (EM_TILE + 1) + wave * 32 + (lane & 31)];
-      const float b = W2s[k * (EM_H2 + 1) + (lane & 31)];
-      c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c0, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int lr = wave * 32 + em_row(r, lane);
-      const float v = c0[r] + bb2;
-      H2s[j0 * (EM_TILE + 1) + lr] = v > 0.0f ? v : 0.0f;
-    }
-    __syncthreads();
-    if (tid < EM_TILE) {
-      const int64_t e = e0 + tid;
-      if (e < E) {
-        float sacc = 0.0f;
-#pragma unroll 8
-        for (int j = 0; j < EM_H2; ++j) sacc += H2s[j * (EM_TILE + 1) + tid] * W.w3[j];
-        logits[m * E + e] = sacc + W.b3[0];
-      }
-    }
+    for (int r = 0; r < 16; ++r) part = fmaf(emr_relu(c0[r]), w3r[r], part);
+    const float tot = part + __shfl_xor(part, 32);
+    const int32_t e = cw.c * 32 + j;
+    if (h == 0 && e < (int32_t)E) logits[(int64_t)cw.m * E + e] = tot + b3;
   }
 }
 
-// bf16 variant. LDS: Xb [128][56] bf16 | W1b [64][56] bf16 | Hb [128][72] bf16 | W2b [32][72] bf16 | H2s [32][129] f32
-#define EMB_KX 56    // row stride of the 33-wide operands (48 used: 3 k-steps of 16), 16-byte aligned rows
-#define EMB_KH 72    // row stride of the 64-wide operands
-__global__ __launch_bounds__(EM_THREADS) void k_edge_mlp_fwd_bf16(const int32_t* __restrict__ src,
-                                                                  const int32_t* __restrict__ dst, int64_t E, int64_t N,
-                                                                  const float* __restrict__ obs,
-                                                                  const float* __restrict__ edge_attr, EdgeMlpW W,
-                                                                  float* __restrict__ logits) {
-  __shared__ __attribute__((aligned(16))) uint16_t Xb[EM_TILE * EMB_KX];
-  __shared__ __attribute__((aligned(16))) uint16_t W1b[EM_H1 * EMB_KX];
-  __shared__ __attribute__((aligned(16))) uint16_t Hb[EM_TILE * EMB_KH];
-  __shared__ __attribute__((aligned(16))) uint16_t W2b[EM_H2 * EMB_KH];
-  __shared__ float H2s[EM_H2 * (EM_TILE + 1)];
+// ---- bf16: v_mfma_f32_32x32x16_bf16 ----------------------------------------------------------------------------------------
+// layer 1, k-steps of 16: [x_src 0..15] [x_dst 0..15] [edge_attr, 1, 1, 1, 0 ...]: the three ones meet the bias b1 split
+// into three bf16 pieces (hi + mid + lo == b1 exactly), i.e. the fp32 bias enters the fp32 accumulation unrounded.
+// Inputs, weights and the first hidden activation are rounded to bf16 (RNE); fp32 accumulation, fp32 second activation
+// and output: BASELINE config 5's "bf16 MPNN features" (tolerance stated in tests/test_gpu_edge_mlp.py). 6 + 4 MFMAs per
+// 32 edges; the vector ALU (conversions, ReLU, the output dot product) is the bound.
+// relu on eight bf16 at once: rounding keeps the sign, and a bf16 is negative exactly when its bit pattern is a negative
+// int16 — v_pk_max_i16 does two activations per instruction
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 emr_relu8(const bf16x8 v) {
+  s16x8 i = __builtin_bit_cast(s16x8, v);
+  i = __builtin_elementwise_max(i, (s16x8){0, 0, 0, 0, 0, 0, 0, 0});
+  return __builtin_bit_cast(bf16x8, i);
+}
+// two floats -> two bf16 (RNE) in one v_cvt_pk_bf16_f32
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t emr_cvt2(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ bf16x8 emr_pack(const float4 a, const float4 b) {
+  const u32x4 p = {emr_cvt2(a.x, a.y), emr_cvt2(a.z, a.w), emr_cvt2(b.x, b.y), emr_cvt2(b.z, b.w)};
+  return __builtin_bit_cast(bf16x8, p);
+}
+
+__global__ __launch_bounds__(EMR_WAVES * 64) void k_edge_mlp_fwd_bf16(const int32_t* __restrict__ src,
+                                                                      const int32_t* __restrict__ dst, int64_t E,
+                                                                      int64_t N, int64_t M,
+                                                                      const float* __restrict__ obs,
+                                                                      const float* __restrict__ edge_attr, EdgeMlpW W,
+                                                                      float* __restrict__ logits) {
+  // fragment-ordered weights: W1f [2 tiles][3 k-steps][64 lanes][8], W2f [4 k-steps][64 lanes][8]
+  __shared__ __attribute__((aligned(16))) uint16_t W1f[6 * 64 * 8];
+  __shared__ __attribute__((aligned(16))) uint16_t W2f[4 * 64 * 8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t m = blockIdx.y;
-  const float* om = obs + m * N * 16;
-  for (int idx = tid; idx < EM_H1 * 48; idx += EM_THREADS) {
-    const int j = idx / 48, k = idx - j * 48;
-    W1b[j * EMB_KX + k] = k < EM_IN ? f32_to_bf16_rne(W.w1[j * EM_IN + k]) : (uint16_t)0;
-  }
-  for (int idx = tid; idx < EM_H2 * EM_H1; idx += EM_THREADS) {
-    const int j = idx >> 6, k = idx & 63;
-    W2b[j * EMB_KH + k] = f32_to_bf16_rne(W.w2[j * EM_H1 + k]);
-  }
-  // lane l (r = l & 31, h = l >> 5) holds A[row r][k = 16 s + 8 h + 0..7] and B[k = 16 s + 8 h + 0..7][col r]
-  const int r32 = lane & 31, h8 = (lane >> 5) * 8;
-  const float bb0 = W.b1[r32], bb1 = W.b1[r32 + 32], bb2 = W.b2[r32];
-  for (int tile = 0; tile < EM_TPW; ++tile) {
-    const int64_t e0 = ((int64_t)blockIdx.x * EM_TPW + tile) * EM_TILE;
-    if (e0 >= E) break;        // uniform
-    __syncthreads();           // the previous tile's readers are done; the weights are staged
-#pragma unroll
-    for (int it = 0; it < (EM_TILE * 8) / EM_THREADS; ++it) {
-      const int idx = it * EM_THREADS + tid;
-      const int el = idx >> 3, q = idx & 7;
-      const int64_t e = e0 + el;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e < E) {
-        const int32_t node = q < 4 ? src[e] : dst[e];
-        v = reinterpret_cast<const float4*>(om + (int64_t)node * 16)[q & 3];
-      }
-      uint16_t* d = Xb + el * EMB_KX + 4 * q;
-      d[0] = f32_to_bf16_rne(v.x);
-      d[1] = f32_to_bf16_rne(v.y);
-      d[2] = f32_to_bf16_rne(v.z);
-      d[3] = f32_to_bf16_rne(v.w);
-    }
-    if (tid < EM_TILE) {
-      const int64_t e = e0 + tid;
-      uint16_t* d = Xb + tid * EMB_KX;
-      d[32] = f32_to_bf16_rne(e < E ? edge_attr[e] : 0.0f);
-      for (int k = 33; k < 48; ++k) d[k] = 0;
-    }
-    __syncthreads();
-    f32x16 acc0 = {0}, acc1 = {0};
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(Xb + (wave * 32 + r32) * EMB_KX + 16 * s + h8);
-      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(W1b + r32 * EMB_KX + 16 * s + h8);
-      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(W1b + (32 + r32) * EMB_KX + 16 * s + h8);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc1, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {   // a wave's rows of Hb are its own 32 edges
-      const int lr = wave * 32 + em_row(r, lane);
-      const float v0 = acc0[r] + bb0, v1 = acc1[r] + bb1;
-      Hb[lr * EMB_KH + r32] = f32_to_bf16_rne(v0 > 0.0f ? v0 : 0.0f);
-      Hb[lr * EMB_KH + 32 + r32] = f32_to_bf16_rne(v1 > 0.0f ? v1 : 0.0f);
-    }
-    __syncthreads();
-    f32x16 c0 = {0};
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(Hb + (wave * 32 + r32) * EMB_KH + 16 * s + h8);
-      const bf16x8 b = *reinterpret_cast<const bf16x8*>(W2b + r32 * EMB_KH + 16 * s + h8);
-      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int lr = wave * 32 + em_row(r, lane);
-      const float v = c0[r] + bb2;
-      H2s[r32 * (EM_TILE + 1) + lr] = v > 0.0f ? v : 0.0f;
-    }
-    __syncthreads();
-    if (tid < EM_TILE) {
-      const int64_t e = e0 + tid;
-      if (e < E) {
-        float sacc = 0.0f;
-#pragma unroll 8
-        for (int j = 0; j < EM_H2; ++j) sacc += H2s[j * (EM_TILE + 1) + tid] * W.w3[j];
-        logits[m * E + e] = sacc + W.b3[0];
+  for (int idx = tid; idx < 6 * 64 * 8; idx += EMR_WAVES * 64) {
+    const int q = idx & 7, l = (idx >> 3) & 63, f = idx >> 9;
+    const int a = f / 3, ks = f - 3 * a, u = 32 * a + (l & 31), h = l >> 5;
+    uint16_t v = 0;
+    if (ks < 2)
+      v = f32_to_bf16_rne(W.w1[u * EM_IN + 16 * ks + 8 * h + q]);
+    else if (h == 0) {
+      if (q == 0)
+        v = f32_to_bf16_rne(W.w1[u * EM_IN + 32]);
+      else if (q < 4) {      // b1 = hi + mid + lo, each piece a bf16
+        const float b = W.b1[u];
+        const uint16_t hi = f32_to_bf16_rne(b);
+        const float r1 = b - __uint_as_float((uint32_t)hi << 16);
+        const uint16_t mid = f32_to_bf16_rne(r1);
+        const float r2 = r1 - __uint_as_float((uint32_t)mid << 16);
+        v = q == 1 ? hi : q == 2 ? mid : f32_to_bf16_rne(r2);
       }
     }
+    W1f[idx] = v;
+  }
+  for (int idx = tid; idx < 4 * 64 * 8; idx += EMR_WAVES * 64) {
+    const int q = idx & 7, l = (idx >> 3) & 63, ks = idx >> 9;
+    const int u = 32 * (ks >> 1) + emr_unit(8 * (ks & 1) + q, l >> 5);
+    W2f[idx] = f32_to_bf16_rne(W.w2[(l & 31) * EM_H1 + u]);
+  }
+  __syncthreads();
+  bf16x8 w1f[6], w2f[4];
+#pragma unroll
+  for (int f = 0; f < 6; ++f) w1f[f] = *reinterpret_cast<const bf16x8*>(W1f + (f * 64 + lane) * 8);
+#pragma unroll
+  for (int f = 0; f < 4; ++f) w2f[f] = *reinterpret_cast<const bf16x8*>(W2f + (f * 64 + lane) * 8);
+  const int h = lane >> 5;
+  f32x16 b2r;
+  float w3r[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    b2r[r] = W.b2[emr_unit(r, h)];
+    w3r[r] = W.w3[emr_unit(r, h)];
+  }
+  const float b3 = W.b3[0];
+  const f32x16 zero = {0};
+
+  ChunkWalk cw;
+  if (!cw.init(E, M, wave)) return;
+  EdgeIn nxt = emr_load(src, dst, edge_attr, obs, (int32_t)E, N, cw.mn, cw.cn, lane);
+  for (; cw.g < cw.g1; ++cw.g) {
+    const EdgeIn cur = nxt;
+    cw.step();
+    if (cw.g + 1 < cw.g1) nxt = emr_load(src, dst, edge_attr, obs, (int32_t)E, N, cw.mn, cw.cn, lane);
+    const bf16x8 xs = emr_pack(cur.s0, cur.s1), xd = emr_pack(cur.d0, cur.d1);
+    bf16x8 xe = {0};
+    if (h == 0) {
+      xe[0] = (__bf16)cur.ea;
+      xe[1] = (__bf16)1.0f;
+      xe[2] = (__bf16)1.0f;
+      xe[3] = (__bf16)1.0f;
+    }
+    f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[0], xs, zero, 0, 0, 0);
+    f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[3], xs, zero, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[1], xd, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[4], xd, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[2], xe, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[5], xe, acc1, 0, 0, 0);
+    bf16x8 hb[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      u32x4 p0, p1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        p0[q] = emr_cvt2(acc0[8 * s2 + 2 * q], acc0[8 * s2 + 2 * q + 1]);
+        p1[q] = emr_cvt2(acc1[8 * s2 + 2 * q], acc1[8 * s2 + 2 * q + 1]);
+      }
+      hb[s2] = emr_relu8(__builtin_bit_cast(bf16x8, p0));
+      hb[2 + s2] = emr_relu8(__builtin_bit_cast(bf16x8, p1));
+    }
+    f32x16 c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[0], hb[0], b2r, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[1], hb[1], c0, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[2], hb[2], c0, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[3], hb[3], c0, 0, 0, 0);
+    float part = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part = fmaf(emr_relu(c0[r]), w3r[r], part);
+    const float tot = part + __shfl_xor(part, 32);
+    const int32_t e = cw.c * 32 + (lane & 31);
+    if (h == 0 && e < (int32_t)E) logits[(int64_t)cw.m * E + e] = tot + b3;
   }
 }
 
@@ -435,22 +488,17 @@ extern "C" int tarl_policy_edge_mlp_fwd(const tarl_plan* plan, const float* obs1
   TARL_REQUIRE(((uintptr_t)obs16) % 16 == 0, "obs16 must be 16-byte aligned");
   if (plan->E == 0) return TARL_OK;
   const EdgeMlpW W{w1, b1, w2, b2, w3, b3};
-  const dim3 grid((unsigned)ceil_div(ceil_div(plan->E, EM_TILE), EM_TPW), (unsigned)M);
-  if (precision == 0) {
-    // the opt-in to > 64 KB of dynamic LDS is a per-device attribute of the function
-    static bool lds_set[64] = {false};
-    int devid = 0;
-    TARL_CHECK_HIP(hipGetDevice(&devid));
-    if (!lds_set[devid & 63]) {
-      TARL_CHECK_HIP(hipFuncSetAttribute((const void*)k_edge_mlp_fwd_f32, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)EMF_LDS_BYTES));
-      lds_set[devid & 63] = true;
-    }
-    hipLaunchKernelGGL(k_edge_mlp_fwd_f32, grid, dim3(EM_THREADS), EMF_LDS_BYTES, (hipStream_t)stream, plan->src,
-                       plan->dst, plan->E, plan->N, obs16, edge_attr, W, logits);
-  } else
-    hipLaunchKernelGGL(k_edge_mlp_fwd_bf16, grid, dim3(EM_THREADS), 0, (hipStream_t)stream, plan->src, plan->dst, plan->E,
-                       plan->N, obs16, edge_attr, W, logits);
+  // persistent waves: every wave builds its weight fragments once and walks a contiguous range of 32-edge chunks
+  const int64_t chunks = M * ceil_div(plan->E, 32);
+  TARL_REQUIRE(chunks < ((int64_t)1 << 31) && plan->E < ((int64_t)1 << 31) - 32, "edge MLP: batch x edges too large");
+  int64_t blocks = ceil_div(chunks, (int64_t)EMR_WAVES * 16);          // >= 16 chunks per wave
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  if (precision == 0)
+    hipLaunchKernelGGL(k_edge_mlp_fwd_f32, dim3((unsigned)blocks), dim3(EMR_WAVES * 64), 0, (hipStream_t)stream,
+                       plan->src, plan->dst, plan->E, plan->N, M, obs16, edge_attr, W, logits);
+  else
+    hipLaunchKernelGGL(k_edge_mlp_fwd_bf16, dim3((unsigned)blocks), dim3(EMR_WAVES * 64), 0, (hipStream_t)stream,
+                       plan->src, plan->dst, plan->E, plan->N, M, obs16, edge_attr, W, logits);
   TARL_LAUNCH_CHECK();
   return TARL_OK;
 }

@@ -47,6 +47,8 @@ SIGNATURES = {
     "tarl_policy_edge_mlp_bwd_scratch_floats": (_i64, [_p, _i64]),
     "tarl_policy_edge_mlp_bwd": (C.c_int, [_p, _p, _i64, _p] + [_p] * 6 + [_p, _p] + [_p] * 6 + [_p]),
     "tarl_critic_mlp_fwd": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64] + [_p] * 6 + [_p, _p, _p, _p]),
+    "tarl_critic_splitk_scratch_floats": (C.c_int64, [_i64, _i64]),
+    "tarl_critic_mlp_fwd_splitk": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64] + [_p] * 6 + [_p, _p, _p, _p, _p]),
     "tarl_critic_mlp_bwd": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64] + [_p] * 3 + [_p, _p, _p, _p] + [_p] * 6 + [_p]),
     "tarl_value_mpnn_fwd": (C.c_int, [_p, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
     "tarl_value_mpnn_bwd": (C.c_int, [_p, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p]),

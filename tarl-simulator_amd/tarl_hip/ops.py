@@ -463,8 +463,9 @@ class CriticWeights:
         self.N = self.w1.size(1) - 1
 
 
-def critic_forward(cw: CriticWeights, counts, time_rows, rows_per_time=1, *, keep_hidden=False):
-    """counts (M, N) fp32 with contiguous last dim (row stride free); time_rows (ceil(M / rows_per_time),)."""
+def critic_forward(cw: CriticWeights, counts, time_rows, rows_per_time=1, *, keep_hidden=False, split_k=False):
+    """counts (M, N) fp32 with contiguous last dim (row stride free); time_rows (ceil(M / rows_per_time),).
+    split_k (fp32 rows only): spread the first layer of FEW rows over the input columns (tarl_critic_mlp_fwd_splitk)."""
     L = _lib.load()
     u8 = counts.dtype == torch.uint8           # the rollout buffers' count bytes (widened inside the kernel)
     _check_dev(counts, torch.uint8 if u8 else torch.float32, "counts")
@@ -477,6 +478,14 @@ def critic_forward(cw: CriticWeights, counts, time_rows, rows_per_time=1, *, kee
     value = torch.empty(M, dtype=torch.float32, device=counts.device)
     h1 = torch.empty((M, 64), dtype=torch.float32, device=counts.device) if keep_hidden else None
     h2 = torch.empty((M, 64), dtype=torch.float32, device=counts.device) if keep_hidden else None
+    if split_k and not u8:
+        scratch = torch.empty(int(L.tarl_critic_splitk_scratch_floats(M, cw.N)), dtype=torch.float32,
+                              device=counts.device)
+        _lib.check(L.tarl_critic_mlp_fwd_splitk(counts.data_ptr(), counts.stride(0), M, cw.N, time_rows.data_ptr(),
+                                                rows_per_time, cw.w1.data_ptr(), cw.b1.data_ptr(), cw.w2.data_ptr(),
+                                                cw.b2.data_ptr(), cw.w3.data_ptr(), cw.b3.data_ptr(), scratch.data_ptr(),
+                                                value.data_ptr(), _lib.ptr(h1), _lib.ptr(h2), _lib.current_stream()))
+        return value, h1, h2
     fn = L.tarl_critic_mlp_fwd_u8 if u8 else L.tarl_critic_mlp_fwd
     _lib.check(fn(counts.data_ptr(), counts.stride(0), M, cw.N, time_rows.data_ptr(), rows_per_time,
                   cw.w1.data_ptr(), cw.b1.data_ptr(), cw.w2.data_ptr(), cw.b2.data_ptr(),

@@ -343,7 +343,7 @@ class VecPPOTrainer:
         proba = ops.graphdist_softmax(eng.plan, logits, self.temperature)
         lp_new, ent = ops.graphdist_logprob_entropy(eng.plan, proba, choice=choice_mb)
         cw = self._critic()
-        value, h1, h2 = ops.critic_forward(cw, counts_mb, time_mb, 1, keep_hidden=True)
+        value, h1, h2 = ops.critic_forward(cw, counts_mb, time_mb, 1, keep_hidden=True, split_k=M <= 512)
         scale = 1.0 / self.world
         out, g_lp, g_ent, g_val = ops.ppo_loss(lp_new, lp_old, adv_mb, value, tgt_mb, ent,
                                                clip_epsilon=self.clip_epsilon, entropy_coef=self.entropy_coef,

@@ -55,6 +55,13 @@ def test_critic_fwd_bwd_vs_autograd(ops, M, N, rpt):
     v, h1, h2 = ops.critic_forward(cw, cview, dev(times), rpt, keep_hidden=True)
     scale = max(1.0, float(ref.abs().max()))
     assert float((v.cpu() - ref.detach()).abs().max()) <= TOL * scale
+    # the split-K form of the same forward (few rows: the optimiser minibatch): same value and hidden activations up to
+    # the order of the fp32 additions, and deterministic
+    vk, h1k, h2k = ops.critic_forward(cw, cview, dev(times), rpt, keep_hidden=True, split_k=True)
+    assert float((vk.cpu() - ref.detach()).abs().max()) <= TOL * scale
+    assert torch.allclose(h1k, h1, rtol=1e-5, atol=1e-4 * scale) and torch.allclose(h2k, h2, rtol=1e-5, atol=1e-4 * scale)
+    vk2, _, _ = ops.critic_forward(cw, cview, dev(times), rpt, split_k=True)
+    assert torch.equal(vk, vk2)
     grads = [torch.zeros_like(dev(p.detach().reshape(-1) if i == 4 else p.detach())) for i, p in enumerate(params)]
     ops.critic_backward(cw, cview, dev(times), rpt, h1, h2, dev(gv), grads)
     for i, (gp, p) in enumerate(zip(grads, params)):
