@@ -127,6 +127,19 @@ int tarl_graphdist_softmax(const tarl_plan* plan, const float* logits, int64_t B
 int tarl_graphdist_sample(const tarl_plan* plan, const float* proba, int64_t B, const float* uniform, uint64_t seed,
                           uint64_t counter, double* group_sums, int64_t* action_onehot, int32_t* choice,
                           tarl_stream stream);
+/* tarl_graphdist_rollout: the action draw of one rollout frame in ONE launch for a policy whose logits [B][E] change every
+ *   frame: GraphDistribution(logits / temperature).sample() and .log_prob(action) (src/reinforcement_learning.py:16-96),
+ *   i.e. tarl_graphdist_softmax -> tarl_graphdist_sample -> tarl_graphdist_logprob_entropy_fwd with identical arithmetic and
+ *   summation orders (actions and log-probs are bit-identical to that chain), without materialising the probabilities.
+ *   uniform [B][num_groups] or NULL (Philox keyed by seed / counter / b * num_groups + g, as tarl_graphdist_sample).
+ *   scratch: tarl_graphdist_rollout_scratch_bytes(plan, B) bytes, 8-byte aligned. Outputs, each nullable: choice int32
+ *   [B][N] (edge id, -1 = none); choice8 uint8 [B][N] = the rank byte of the rollout buffers (rank of the chosen
+ *   out-edge, or 0x80 | previous rank where nothing was drawn); sel8 uint8 [N][B] = tarl_fused.sel8, updated in place
+ *   (== tarl_fused_apply_choice of the drawn action: the choice phase of SimulatorEnv._step, :228-233); log_prob [B]. */
+int64_t tarl_graphdist_rollout_scratch_bytes(const tarl_plan* plan, int64_t B);
+int tarl_graphdist_rollout(const tarl_plan* plan, const float* logits, int64_t B, float temperature, const float* uniform,
+                           uint64_t seed, uint64_t counter, void* scratch, int32_t* choice, uint8_t* choice8,
+                           uint8_t* sel8, float* log_prob, tarl_stream stream);
 /* tarl_graphdist_mode (:45-55): one-hot (fp32, like zeros_like(proba)) of the per-node argmax, first maximum wins. */
 int tarl_graphdist_mode(const tarl_plan* plan, const float* proba, int64_t B, float* mode_onehot, int32_t* choice,
                         tarl_stream stream);
@@ -442,6 +455,31 @@ int tarl_rollout_env(const tarl_plan* plan, const tarl_fused* f, int64_t B, int3
                      void* static_scratch, uint8_t* choice, float* log_prob, float* entropy, float* reward,
                      uint8_t* counts, int32_t metrics_envs, float* dtt_node, uint8_t* events, int32_t* leg,
                      tarl_stream stream);
+/* tarl_fused_rollout_policy: T consecutive frames of SimulatorEnv._step under a STATE-DEPENDENT policy — the per-edge MLP
+ *   head (MPNNPolicyNet.edge_mlp, src/agents/mpnn_agent.py:35-41, 227-231) — in one foreign call. Nothing of
+ *   GraphDistribution can be hoisted out of the frame; per frame the call queues, on the caller's stream,
+ *     tarl_fused_obs16 -> tarl_policy_edge_mlp_fwd(precision) -> tarl_graphdist_rollout(temperature; policy counter
+ *     policy_counter0 + t; writes the action into tarl_fused.sel8) -> Direction gather -> row pass -> insert (noise counter
+ *     counter0 + t),
+ *   with the same results as those calls made one by one. x / x_bstride / ldx: the reference state tensor (static node
+ *   columns of the observation). Minibatch observations: the (frame, environment) pairs an optimiser step will use are
+ *   drawn BEFORE the rollout; keep_ptr_host (HOST int64 [T + 1], nullable) delimits, per frame, the entries of keep_env /
+ *   keep_slot (device int32): observation row keep_env[j] of that frame is copied to obs_keep [slot][N][16].
+ *   Scratch (device): obs_scratch fp32 [B][N][16] (16-byte aligned), logits_scratch fp32 [B][E], dist_scratch
+ *   (tarl_graphdist_rollout_scratch_bytes), ins_scratch int32 [B][2A].
+ *   Outputs, frame-major, nullable: choice8 uint8 [T][B][N] (ENV-MAJOR rank bytes, bit 7: nothing drawn), log_prob /
+ *   reward fp32 [T][B], counts uint8 [T][N][B] (env-minor, after frame t), and the per-step logs of tarl_fused_rollout. */
+int tarl_fused_rollout_policy(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, int64_t T,
+                              const float* times_host, float prev_time, const float* x, int64_t x_bstride, int64_t ldx,
+                              float* agent_features, int64_t num_agents, int64_t a_bstride, const float* edge_attr,
+                              const float* log_edge_attr, float log_eps, int use_cong, const float* w1, const float* b1,
+                              const float* w2, const float* b2, const float* w3, const float* b3, int precision,
+                              float temperature, uint64_t policy_seed, uint64_t policy_counter0, uint64_t seed,
+                              uint64_t counter0, const int64_t* keep_ptr_host, const int32_t* keep_env,
+                              const int32_t* keep_slot, float* obs_keep, float* obs_scratch, float* logits_scratch,
+                              void* dist_scratch, int32_t* ins_scratch, uint8_t* choice8, float* log_prob, float* reward,
+                              uint8_t* counts, int32_t metrics_envs, float* dtt_node, uint8_t* events, int32_t* leg,
+                              tarl_stream stream);
 /* the action / count bytes of a rollout back in the formats of the unfused entry points: choice_eid int32 [rows][N] =
  *   chosen edge id (-1: none), counts_f fp32 [rows][N], for `rows` (frame, environment) pairs given as flat indices
  *   idx int64 [rows] = t * B + b (NULL: all T * B pairs in order). env_minor != 0: the buffers are [T][N][B], else

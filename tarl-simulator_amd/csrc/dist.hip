@@ -7,6 +7,7 @@
 
 #include "tarl_common.h"
 
+#define SEL_CARRIED 0x80u   // = fused_common.h: rank byte of a node that drew nothing
 #define DIST_BLOCK 256
 #define ENV_BLOCK 1024
 #define LOG_EPS_P 1e-8f  // log(p + 1e-8), src/reinforcement_learning.py:27
@@ -184,6 +185,116 @@ __global__ __launch_bounds__(ENV_BLOCK) void k_logprob_entropy_fwd(const int32_t
   }
 }
 
+// ---- the rollout's action draw in one launch: softmax -> sample -> log_prob ------------------------------------------------
+// A state-dependent policy has new logits for every (environment, edge) every frame; the three launches above would
+// write and re-read the probabilities twice. One workgroup per environment: same arithmetic, same summation orders
+// (per-node sequential max / sum / double running sum, the block scan of k_sample for the group bases, the per-thread
+// node order and reduction tree of k_logprob_entropy_fwd), so actions and log-probs are bit-identical to the chain
+// tarl_graphdist_softmax -> _sample -> _logprob_entropy_fwd; probabilities are recomputed where the chain re-reads them
+// (expf / the division are deterministic). The action is written as the edge id ([B][N], -1 = none), as the rank byte of
+// the rollout buffers ([B][N], SEL_CARRIED | previous rank where nothing was drawn) and straight into the packed
+// state's SELECTED_ROAD byte ([N][B]) — the choice phase of SimulatorEnv._step.
+__device__ __forceinline__ void node_softmax_stats(const float* __restrict__ lb, const int32_t* __restrict__ out_eid,
+                                                   int32_t k0, int32_t k1, float temperature, float* mx_out,
+                                                   float* sum_out) {
+  float mx = -INFINITY;
+  for (int32_t k = k0; k < k1; ++k) mx = fmaxf(mx, lb[out_eid[k]] / temperature);
+  float sum = 0.0f;
+  for (int32_t k = k0; k < k1; ++k) sum = sum + expf(lb[out_eid[k]] / temperature - mx);
+  *mx_out = mx;
+  *sum_out = sum;
+}
+
+__global__ __launch_bounds__(ENV_BLOCK) void k_graphdist_rollout(
+    const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_eid, const int32_t* __restrict__ node_of_group,
+    const float* __restrict__ logits, int64_t B, int64_t N, int64_t E, int64_t G, float temperature,
+    const float* __restrict__ uniform, uint64_t seed, uint64_t counter, double* __restrict__ base_all,
+    float* __restrict__ u_all, int32_t* __restrict__ choice_eid, uint8_t* __restrict__ choice8,
+    uint8_t* __restrict__ sel8, float* __restrict__ log_prob) {
+  __shared__ double s_wave[ENV_BLOCK / 64];
+  __shared__ float s_red[ENV_BLOCK / 64];
+  const int64_t b = blockIdx.x;
+  const float* lb = logits + b * E;
+  double* base = base_all + b * N;       // indexed by NODE (written by the group's thread, read by the node's)
+  float* un = u_all + b * N;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+
+  // phase A (k_sample's): per-group probability sums in double, exclusive scan over the groups
+  double running = 0.0;
+  for (int64_t g0 = 0; g0 < G; g0 += ENV_BLOCK) {
+    const int64_t g = g0 + tid;
+    double s = 0.0;
+    int32_t i = 0;
+    if (g < G) {
+      i = node_of_group[g];
+      const int32_t k0 = out_ptr[i], k1 = out_ptr[i + 1];
+      float mx, sum;
+      node_softmax_stats(lb, out_eid, k0, k1, temperature, &mx, &sum);
+      for (int32_t k = k0; k < k1; ++k) s += (double)(expf(lb[out_eid[k]] / temperature - mx) / sum);
+    }
+    double inc = s;
+    for (int off = 1; off < 64; off <<= 1) {
+      const double v = __shfl_up(inc, off);
+      if (lane >= off) inc += v;
+    }
+    if (lane == 63) s_wave[wid] = inc;
+    __syncthreads();
+    double wbase = 0.0, tot = 0.0;
+    for (int w = 0; w < ENV_BLOCK / 64; ++w) {
+      const double v = s_wave[w];
+      if (w < wid) wbase += v;
+      tot += v;
+    }
+    double exc = __shfl_up(inc, 1);
+    if (lane == 0) exc = 0.0;
+    if (g < G) {
+      base[i] = running + wbase + exc;
+      un[i] = uniform ? uniform[b * G + g] : philox_uniform(seed, counter, (uint64_t)(b * G + g));
+    }
+    running += tot;
+    __syncthreads();
+  }
+  // phase B: pick (k_sample's second loop) and log-prob (k_logprob_entropy_fwd's thread -> node order)
+  float lp = 0.0f, bad = 0.0f;
+  for (int64_t i = tid; i < N; i += ENV_BLOCK) {
+    const int32_t k0 = out_ptr[i], k1 = out_ptr[i + 1];
+    int32_t pick = -1, rank = 0;
+    if (k0 != k1) {
+      float mx, sum;
+      node_softmax_stats(lb, out_eid, k0, k1, temperature, &mx, &sum);
+      const double bg = base[i];
+      const float bg32 = (float)bg, u = un[i];
+      double run = bg;
+      float lg_pick = 0.0f;
+      for (int32_t k = k0; k < k1; ++k) {
+        const int32_t e = out_eid[k];
+        const float p = expf(lb[e] / temperature - mx) / sum;
+        run += (double)p;
+        const float cum = (float)run - bg32;
+        if (pick < 0 && u < cum) {
+          pick = e;
+          rank = k - k0;
+          lg_pick = logf(p + LOG_EPS_P);
+        }
+      }
+      if (pick >= 0)
+        lp += lg_pick;
+      else
+        bad = 1.0f;
+    }
+    if (choice_eid) choice_eid[b * N + i] = pick;
+    if (choice8 || sel8) {
+      uint32_t code = (uint32_t)rank;
+      if (pick < 0) code = ((sel8 ? sel8[i * B + b] : 0u) & 0x7Fu) | SEL_CARRIED;
+      if (sel8) sel8[i * B + b] = (uint8_t)code;
+      if (choice8) choice8[b * N + i] = (uint8_t)code;
+    }
+  }
+  const float lp_t = block_sum(lp, s_red);
+  const float bad_t = block_sum(bad, s_red);
+  if (tid == 0 && log_prob) log_prob[b] = bad_t > 0.0f ? -INFINITY : lp_t;
+}
+
 // ---- backward through the segment softmax ----------------------------------------------------------------------------
 // L = gl*LP + ge*H with LP = sum a log(p+eps), H = -sum p log(p+eps), p = softmax(l/T) per group:
 //   q_k = gl * a_k/(p_k+eps) + ge * (-log(p_k+eps) - p_k/(p_k+eps)),  dL/dl_j = p_j (q_j - sum_k p_k q_k) / T.
@@ -253,6 +364,28 @@ extern "C" int tarl_graphdist_sample(const tarl_plan* plan, const float* proba, 
   hipLaunchKernelGGL(k_sample, dim3((unsigned)B), dim3(ENV_BLOCK), 0, s, plan->out_ptr, plan->out_eid,
                      plan->node_of_group, proba, plan->N, plan->E, plan->G, uniform, seed, counter, group_sums, onehot,
                      choice);
+  TARL_LAUNCH_CHECK();
+  return TARL_OK;
+}
+
+extern "C" int64_t tarl_graphdist_rollout_scratch_bytes(const tarl_plan* plan, int64_t B) {
+  return plan && B >= 1 ? B * plan->N * (int64_t)(sizeof(double) + sizeof(float)) : -1;
+}
+
+extern "C" int tarl_graphdist_rollout(const tarl_plan* plan, const float* logits, int64_t B, float temperature,
+                                      const float* uniform, uint64_t seed, uint64_t counter, void* scratch,
+                                      int32_t* choice, uint8_t* choice8, uint8_t* sel8, float* log_prob,
+                                      tarl_stream stream) {
+  TARL_REQUIRE(plan && logits && scratch, "null argument");
+  TARL_REQUIRE(B >= 1 && B < ((int64_t)1 << 31), "bad B");
+  TARL_REQUIRE(temperature > 0.0f, "temperature must be positive");
+  TARL_REQUIRE(((uintptr_t)scratch) % 8 == 0, "scratch must be 8-byte aligned");
+  if (plan->N == 0) return TARL_OK;
+  double* base = (double*)scratch;
+  float* un = (float*)(base + B * plan->N);
+  hipLaunchKernelGGL(k_graphdist_rollout, dim3((unsigned)B), dim3(ENV_BLOCK), 0, (hipStream_t)stream, plan->out_ptr,
+                     plan->out_eid, plan->node_of_group, logits, B, plan->N, plan->E, plan->G, temperature, uniform, seed,
+                     counter, base, un, choice, choice8, sel8, log_prob);
   TARL_LAUNCH_CHECK();
   return TARL_OK;
 }

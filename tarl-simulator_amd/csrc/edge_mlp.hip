@@ -50,27 +50,46 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
 // ---- obs16: x = cat(node_features, agent_features[agent_index]) from the packed state of the fused engine ----------------
 // node_features = x[:, 3*Nmax:] = {MAX, NUMBER_OF_AGENT, FREE_FLOW, LENGTH, MAX_FLOW, SELECTED_ROAD, ROAD_INDEX}
 // (TransportationSimulator.state, src/transportation_simulator.py:360-366); agent_index = the head-of-FIFO id.
-__global__ __launch_bounds__(FB) void k_obs16_packed(const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_dst,
-                                                     const float* __restrict__ x0, Layout L, int64_t B, int64_t N,
-                                                     FusedBufs fb, const float* __restrict__ ag, int64_t A,
-                                                     int64_t a_bstride, float* __restrict__ obs) {
-  const int64_t gid = (int64_t)blockIdx.x * FB + threadIdx.x;   // gid = i * B + b (env-minor reads)
-  if (gid >= B * N) return;
-  const int64_t i = gid / B, b = gid - i * B;
-  const uint32_t hd = fb.hdp[gid].x;
-  const float4 st = fb.st0[i];
-  const float* xs = x0 + i * L.ldx;     // static columns: environment 0 speaks for all
-  float* o = obs + (b * N + i) * 16;
-  const long long head = (long long)(hd >> 8);
-  const float* arow = ag + b * a_bstride + ((head >= 0 && head < A) ? head : 0) * AG_COLS;
-  float4 v0 = make_float4(st.x, (float)(hd & 255u), st.y, xs[L.col_maxn() + 3]);
-  float4 v1 = make_float4(xs[L.col_maxflow()], sel_value(fb, out_ptr, out_dst, i, gid), st.z, arow[0]);
-  float4 v2 = make_float4(arow[1], arow[2], arow[3], arow[4]);
-  float4 v3 = make_float4(arow[5], arow[6], arow[7], arow[8]);
-  reinterpret_cast<float4*>(o)[0] = v0;
-  reinterpret_cast<float4*>(o)[1] = v1;
-  reinterpret_cast<float4*>(o)[2] = v2;
-  reinterpret_cast<float4*>(o)[3] = v3;
+// A workgroup owns 8 nodes x 64 environments: the packed words are read env-minor (lanes along the environment:
+// coalesced), the 64-byte rows are turned through LDS, and every environment's 8 rows leave as one 512-byte run.
+#define OB_TI 8
+#define OB_TB 64
+#define OB_LD (OB_TI * 16 + 4)     // floats per environment in LDS (+4: the float4 stores of 8 lanes cover all banks)
+__global__ __launch_bounds__(256) void k_obs16_packed(const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_dst,
+                                                      const float* __restrict__ x0, Layout L, int64_t B, int64_t N,
+                                                      FusedBufs fb, const float* __restrict__ ag, int64_t A,
+                                                      int64_t a_bstride, float* __restrict__ obs) {
+  __shared__ __attribute__((aligned(16))) float sm[OB_TB * OB_LD];
+  const int tid = threadIdx.x, bl = tid & 63;
+  const int64_t b = (int64_t)blockIdx.x * OB_TB + bl, i0 = (int64_t)blockIdx.y * OB_TI;
+#pragma unroll
+  for (int r = 0; r < OB_TI / 4; ++r) {
+    const int il = (tid >> 6) + 4 * r;
+    const int64_t i = i0 + il;
+    if (b < B && i < N) {
+      const int64_t gid = i * B + b;
+      const uint32_t hd = fb.hdp[gid].x;
+      const float4 st = fb.st0[i];
+      const float* xs = x0 + i * L.ldx;     // static columns: environment 0 speaks for all
+      const long long head = (long long)(hd >> 8);
+      const float* arow = ag + b * a_bstride + ((head >= 0 && head < A) ? head : 0) * AG_COLS;
+      float4* o = reinterpret_cast<float4*>(sm + bl * OB_LD + il * 16);
+      o[0] = make_float4(st.x, (float)(hd & 255u), st.y, xs[L.col_maxn() + 3]);
+      o[1] = make_float4(xs[L.col_maxflow()], sel_value(fb, out_ptr, out_dst, i, gid), st.z, arow[0]);
+      o[2] = make_float4(arow[1], arow[2], arow[3], arow[4]);
+      o[3] = make_float4(arow[5], arow[6], arow[7], arow[8]);
+    }
+  }
+  __syncthreads();
+  const int part = tid & 31;                 // float4 number inside the environment's 8 rows
+  const int64_t i = i0 + (part >> 2);
+#pragma unroll
+  for (int r = 0; r < OB_TB / 8; ++r) {
+    const int be = (tid >> 5) + 8 * r;
+    const int64_t bb = (int64_t)blockIdx.x * OB_TB + be;
+    if (bb < B && i < N)
+      reinterpret_cast<float4*>(obs + (bb * N + i0) * 16)[part] = reinterpret_cast<const float4*>(sm + be * OB_LD)[part];
+  }
 }
 
 // the same from the reference's tensors: node_features (M, N, >=7 cols, row stride nf_ld) + agent rows gathered by
@@ -471,9 +490,11 @@ extern "C" int tarl_fused_obs16(const tarl_plan* plan, const tarl_fused* f, cons
   TARL_REQUIRE(x && agent_features && obs16 && A >= 1, "null argument");
   if (plan->N == 0) return TARL_OK;
   const Layout L{Nmax, ldx, x_bstride};
-  hipLaunchKernelGGL(k_obs16_packed, dim3((unsigned)ceil_div(B * plan->N, FB)), dim3(FB), 0, (hipStream_t)stream,
-                     plan->out_ptr, plan->out_dst, x, L, B, plan->N, tarl_to_bufs(f), agent_features, A, a_bstride,
-                     obs16);
+  TARL_REQUIRE(((uintptr_t)obs16) % 16 == 0, "obs16 must be 16-byte aligned");
+  TARL_REQUIRE(ceil_div(plan->N, OB_TI) < 65536, "too many node tiles for one grid dimension");
+  hipLaunchKernelGGL(k_obs16_packed, dim3((unsigned)ceil_div(B, OB_TB), (unsigned)ceil_div(plan->N, OB_TI)), dim3(256), 0,
+                     (hipStream_t)stream, plan->out_ptr, plan->out_dst, x, L, B, plan->N, tarl_to_bufs(f), agent_features, A,
+                     a_bstride, obs16);
   TARL_LAUNCH_CHECK();
   return TARL_OK;
 }

@@ -1692,6 +1692,90 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
   return TARL_OK;
 }
 
+// ---- T frames with a STATE-DEPENDENT policy (the per-edge MLP head) in one foreign call --------------------------------------
+// Nothing of GraphDistribution can be hoisted: per frame observation (tarl_fused_obs16) -> logits (tarl_policy_edge_mlp_fwd)
+// -> action + log-prob + SELECTED_ROAD (tarl_graphdist_rollout) -> Direction -> rows -> insert, eight launches queued
+// back to back by one host loop in C (the same entry points a caller could queue himself, minus a foreign-call round
+// trip per launch). The observations of the frames an optimiser minibatch will use are drawn beforehand (the draw does
+// not depend on the data): keep_ptr_host[t] .. keep_ptr_host[t + 1] index the (environment, slot) pairs of frame t.
+__global__ __launch_bounds__(FB) void k_obs_keep(const float4* __restrict__ obs, int64_t row4,
+                                                 const int32_t* __restrict__ env, const int32_t* __restrict__ slot,
+                                                 float4* __restrict__ keep) {
+  const int64_t j = (int64_t)blockIdx.x * FB + threadIdx.x;
+  if (j >= row4) return;
+  keep[(int64_t)slot[blockIdx.y] * row4 + j] = obs[(int64_t)env[blockIdx.y] * row4 + j];
+}
+
+extern "C" int tarl_fused_rollout_policy(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, int64_t T,
+                                         const float* times_host, float prev_time, const float* x, int64_t x_bstride,
+                                         int64_t ldx, float* agent_features, int64_t A, int64_t a_bstride,
+                                         const float* edge_attr, const float* log_edge_attr, float log_eps, int use_cong,
+                                         const float* w1, const float* b1, const float* w2, const float* b2,
+                                         const float* w3, const float* b3, int precision, float temperature,
+                                         uint64_t policy_seed, uint64_t policy_counter0, uint64_t seed,
+                                         uint64_t counter0, const int64_t* keep_ptr_host, const int32_t* keep_env,
+                                         const int32_t* keep_slot, float* obs_keep, float* obs_scratch,
+                                         float* logits_scratch, void* dist_scratch, int32_t* ins_scratch,
+                                         uint8_t* choice8, float* log_prob, float* reward, uint8_t* counts,
+                                         int32_t metrics_envs, float* dtt_node, uint8_t* events, int32_t* leg,
+                                         tarl_stream stream) {
+  int rc = tarl_check_fused_core(plan, f, B, Nmax);
+  if (rc) return rc;
+  TARL_REQUIRE(T >= 1 && times_host, "bad frame count / times");
+  TARL_REQUIRE(x && obs_scratch && logits_scratch && dist_scratch, "observation / logits / sampler scratch missing");
+  TARL_REQUIRE(!keep_ptr_host || (keep_env && keep_slot && obs_keep), "keep list without its arrays");
+  rc = check_frame_args(plan, f, B, agent_features, A, a_bstride, ins_scratch, edge_attr, log_edge_attr);
+  if (rc) return rc;
+  TARL_REQUIRE(metrics_envs >= 0 && metrics_envs <= B, "metrics_envs out of range");
+  TARL_REQUIRE(metrics_envs > 0 || (!dtt_node && !events), "per-node series need metrics_envs > 0");
+  if (plan->N == 0) return TARL_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t N = plan->N, NB = N * B;
+  const unsigned threads = tile_threads(B);
+  const dim3 grid((unsigned)ceil_div(B, threads), (unsigned)num_chunks(plan));
+  const dim3 grid_d((unsigned)ceil_div(B, threads), (unsigned)ceil_div(N, nchunk_dir()));
+  const FusedBufs fb = tarl_to_bufs(f);
+  const PlanOut P{plan->out_ptr, plan->out_dst};
+  for (int64_t t = 0; t < T; ++t) {
+    rc = tarl_fused_obs16(plan, f, x, B, x_bstride, ldx, Nmax, agent_features, A, a_bstride, obs_scratch, stream);
+    if (rc) return rc;
+    if (keep_ptr_host && keep_ptr_host[t + 1] > keep_ptr_host[t]) {
+      const int64_t lo = keep_ptr_host[t], n = keep_ptr_host[t + 1] - lo;
+      TARL_REQUIRE(n < 65536, "more than 65535 kept observations in one frame");
+      hipLaunchKernelGGL(k_obs_keep, dim3((unsigned)ceil_div(N * 4, FB), (unsigned)n), dim3(FB), 0, s,
+                         (const float4*)obs_scratch, N * 4, keep_env + lo, keep_slot + lo, (float4*)obs_keep);
+      TARL_LAUNCH_CHECK();
+    }
+    rc = tarl_policy_edge_mlp_fwd(plan, obs_scratch, B, edge_attr, w1, b1, w2, b2, w3, b3, precision, logits_scratch,
+                                  stream);
+    if (rc) return rc;
+    rc = tarl_graphdist_rollout(plan, logits_scratch, B, temperature, nullptr, policy_seed, policy_counter0 + (uint64_t)t,
+                                dist_scratch, nullptr, choice8 ? choice8 + t * NB : nullptr, f->sel8,
+                                log_prob ? log_prob + t * B : nullptr, stream);
+    if (rc) return rc;
+    const float time = times_host[t];
+    const int64_t m = metrics_envs;
+    const FrameOut out{counts ? counts + t * NB : nullptr,
+                       nullptr,
+                       nullptr,
+                       nullptr,
+                       events ? events + t * N * m : nullptr,
+                       dtt_node ? dtt_node + t * N * m : nullptr,
+                       metrics_envs,
+                       leg ? leg + t * 2 * B : nullptr};
+    rc = launch_direction(grid_d, threads, s, plan, f, edge_attr, log_edge_attr, (const uint8_t*)f->sel8, nullptr, nullptr,
+                          log_eps, time, t > 0 ? times_host[t - 1] : prev_time, seed, counter0 + (uint64_t)t, B, out);
+    if (rc) return rc;
+    rc = launch_rows(grid, threads, s, plan, f, fb, (int)Nmax, B, agent_features, A, a_bstride, time, out);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(INSB), 0, s, (int)Nmax, B, N, fb, P,
+                       (const uint8_t*)f->sel8, agent_features, A, a_bstride, use_cong, time, ins_scratch,
+                       (const float*)nullptr, reward ? reward + t * B : nullptr, out, (float*)nullptr, (float*)nullptr);
+    TARL_LAUNCH_CHECK();
+  }
+  return TARL_OK;
+}
+
 // ---- rollout bytes -> the formats of the unfused entry points (minibatch gather of the PPO update) ------------------------
 __global__ __launch_bounds__(FB) void k_rollout_gather(const uint8_t* __restrict__ choice, const uint8_t* __restrict__ counts,
                                                        int64_t B, int64_t N, int env_minor,

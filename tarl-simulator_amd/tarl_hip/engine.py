@@ -137,10 +137,11 @@ class SimEngine:
             self.fs.check_flags()
 
     def frame_fused(self, *, choice=None, log_prob=None, entropy=None, reward=None, counts=None, uniform=None,
-                    gumbel=None, dtt=None, popped=None, withdrawn=None, action=None):
+                    gumbel=None, dtt=None, popped=None, withdrawn=None, action=None, skip_choice=False):
         """One collector frame (sample + log_prob + choice phase + env step) for all B environments in 4 launches.
         ``choice`` (N, B) int32 and ``counts`` (N, B) fp32 are env-minor. ``action``: an externally sampled action (B, N)
-        int32 edge ids (-1: none) instead of the live policy's own sample (state-dependent policies). Returns done."""
+        int32 edge ids (-1: none) instead of the live policy's own sample (state-dependent policies); ``skip_choice``: the
+        action is already in the packed state's SELECTED_ROAD bytes (ops.graphdist_rollout(sel8=...)). Returns done."""
         if self._packed_stale:
             self.resync()
         self.sample_counter += 1
@@ -151,6 +152,8 @@ class SimEngine:
         tables = getattr(self, "tables", None)
         if action is not None:
             ops.fused_apply_choice(self.plan, self.fs, action)
+            tables = None
+        if skip_choice:
             tables = None
         ops.fused_frame(self.plan, self.fs, tables, self.agents, self.ec, float(self.time), prev_time=prev,
                         use_cong=self.cc is not None, uniform=uniform, policy_seed=self.seed ^ 0x5DEECE66D,
@@ -183,6 +186,38 @@ class SimEngine:
                              policy_counter0=self.sample_counter + 1, seed=self.seed, counter0=self.noise_counter + 1,
                              scratch=self.ins_scratch, choice=choice, log_prob=log_prob, reward=reward,
                              counts=counts[1:], metrics_envs=metrics_envs, dtt_node=dtt_node, events=events, leg=leg)
+        self.sample_counter += T
+        self.noise_counter += T
+        self._last_step_time = times[-1]
+        self.time = t_clock
+        times.append(float(self.time))
+        if check:
+            self.check_flags()
+        return times
+
+    def rollout_policy(self, T, weights, *, bf16, temperature, policy_seed, policy_counter0, choice8, log_prob, reward,
+                       counts, keep=None, obs_keep=None, metrics_envs=0, dtt_node=None, events=None, leg=None,
+                       check=True):
+        """``T`` frames under the per-edge MLP head (``weights``: ops.EdgeMlpWeights) in one foreign call: per frame
+        observation -> logits -> GraphDistribution sample + log-prob -> the simulation frame. ``choice8`` (T,B,N) uint8
+        (ENV-MAJOR rank bytes), ``counts`` (T+1,N,B) uint8 (counts[t + 1] = after frame t), ``log_prob`` / ``reward`` (T,B).
+        Frame t draws its action with Philox counter ``policy_counter0 + t``. Returns the list of clock values."""
+        if self._packed_stale:
+            self.resync()
+        if counts.dtype != torch.uint8 or tuple(counts.shape) != (T + 1, self.N, self.B) or not counts.is_contiguous():
+            raise ValueError(f"counts must be a contiguous uint8 {(T + 1, self.N, self.B)} tensor")
+        times = []
+        t_clock = self.time
+        for _ in range(T):
+            times.append(float(t_clock))
+            t_clock += self.timestep
+        self._x_stale = True
+        ops.fused_rollout_policy(self.plan, self.fs, self._x, self.agents, self.ec, weights, times,
+                                 use_cong=self.cc is not None, bf16=bf16, temperature=temperature, policy_seed=policy_seed,
+                                 policy_counter0=policy_counter0, seed=self.seed, counter0=self.noise_counter + 1,
+                                 scratch=self.ins_scratch, prev_time=self._last_step_time, keep=keep, obs_keep=obs_keep,
+                                 choice8=choice8, log_prob=log_prob, reward=reward, counts=counts[1:],
+                                 metrics_envs=metrics_envs, dtt_node=dtt_node, events=events, leg=leg)
         self.sample_counter += T
         self.noise_counter += T
         self._last_step_time = times[-1]

@@ -36,6 +36,8 @@ SIGNATURES = {
     "tarl_reset_state": (C.c_int, _STATE + [_i64, _p, _i64, _i64, _p]),
     "tarl_graphdist_softmax": (C.c_int, [_p, _p, _i64, _f32, _p, _p]),
     "tarl_graphdist_sample": (C.c_int, [_p, _p, _i64, _p, _u64, _u64, _p, _p, _p, _p]),
+    "tarl_graphdist_rollout_scratch_bytes": (C.c_int64, [_p, _i64]),
+    "tarl_graphdist_rollout": (C.c_int, [_p, _p, _i64, _f32, _p, _u64, _u64, _p, _p, _p, _p, _p, _p]),
     "tarl_graphdist_mode": (C.c_int, [_p, _p, _i64, _p, _p, _p]),
     "tarl_graphdist_logprob_entropy_fwd": (C.c_int, [_p, _p, _i64, _p, _p, _p, _p, _p]),
     "tarl_graphdist_logprob_entropy_bwd": (C.c_int, [_p, _p, _i64, _f32, _p, _p, _p, _p, _p, _p, _p]),
@@ -71,6 +73,9 @@ SIGNATURES = {
     "tarl_fused_rollout": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _f32, _p, _p, _p, _u64, _u64, _p, _i64, _i64, _p, _p,
                                      _f32, C.c_int, _u64, _u64] + [_p] * 9 + [_i32, _p, _p, _p, _p]),
     "tarl_fused_rollout_scratch_ints": (_i64, [_p, _i64, _i64]),
+    "tarl_fused_rollout_policy": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _f32, _p, _i64, _i64, _p, _i64, _i64, _p, _p,
+                                            _f32, C.c_int] + [_p] * 6 + [C.c_int, _f32, _u64, _u64, _u64, _u64] +
+                                  [_p] * 12 + [_i32, _p, _p, _p, _p]),
     "tarl_rollout_gather": (C.c_int, [_p, _p, _p, _i64, _i64, C.c_int, _p, _i64, _p, _p, _p]),
     "tarl_rollout_env_supported": (C.c_int, [_p]),
     "tarl_rollout_env_scratch_bytes": (_i64, [_p]),

@@ -295,6 +295,38 @@ def graphdist_sample(plan: Plan, proba, *, uniform=None, seed=0, counter=0, want
     return onehot, choice
 
 
+def graphdist_rollout(plan: Plan, logits, temperature=1.0, *, uniform=None, seed=0, counter=0, choice=None, choice8=None,
+                      sel8=None, log_prob=None, scratch=None):
+    """sample() + log_prob() of GraphDistribution(logits / temperature) in one launch (bit-identical to softmax -> sample
+    -> logprob). logits (B, E); outputs written in place where given: choice int32 (B, N), choice8 uint8 (B, N) rank
+    bytes, sel8 uint8 (N, B) = the packed state's SELECTED_ROAD bytes; returns log_prob (B,)."""
+    L = _lib.load()
+    _contig(logits, torch.float32, "logits")
+    E, G, N = plan.num_edges, plan.num_groups, plan.num_nodes
+    B = _rows(logits, E, "logits")
+    if uniform is not None:
+        _contig(uniform, torch.float32, "uniform")
+        if uniform.numel() != B * G:
+            raise ValueError("uniform must hold B*num_groups values")
+    for name, t, dt, n in (("choice", choice, torch.int32, B * N), ("choice8", choice8, torch.uint8, B * N),
+                           ("sel8", sel8, torch.uint8, B * N)):
+        if t is not None:
+            _contig(t, dt, name)
+            if t.numel() != n:
+                raise ValueError(f"{name} must hold B * num_nodes values")
+    need = int(L.tarl_graphdist_rollout_scratch_bytes(plan.handle, B))
+    if scratch is None or scratch.numel() * scratch.element_size() < need:
+        scratch = torch.empty((need + 7) // 8, dtype=torch.float64, device=logits.device)
+    if log_prob is None:
+        log_prob = torch.empty(B, dtype=torch.float32, device=logits.device)
+    else:
+        _contig(log_prob, torch.float32, "log_prob")
+    _lib.check(L.tarl_graphdist_rollout(plan.handle, logits.data_ptr(), B, float(temperature), _lib.ptr(uniform), int(seed),
+                                        int(counter), scratch.data_ptr(), _lib.ptr(choice), _lib.ptr(choice8),
+                                        _lib.ptr(sel8), log_prob.data_ptr(), _lib.current_stream()))
+    return log_prob
+
+
 def graphdist_mode(plan: Plan, proba, *, want_choice=False):
     L = _lib.load()
     _contig(proba, torch.float32, "proba")
@@ -809,6 +841,50 @@ def fused_rollout(plan: Plan, fs: FusedState, tables: PolicyTables, agent_featur
                                     _lib.ptr(log_prob), _lib.ptr(entropy),
                                     _lib.ptr(reward), _lib.ptr(counts), int(metrics_envs), _lib.ptr(dtt_node),
                                     _lib.ptr(events), _lib.ptr(leg), _lib.current_stream()))
+
+
+def fused_rollout_policy(plan: Plan, fs: FusedState, x, agent_features, ec: EdgeConst, w: EdgeMlpWeights, times, *,
+                         use_cong, bf16, temperature, policy_seed, policy_counter0, seed, counter0, scratch, prev_time=None,
+                         keep=None, obs_keep=None, choice8=None, log_prob=None, reward=None, counts=None, metrics_envs=0,
+                         dtt_node=None, events=None, leg=None):
+    """``T = len(times)`` frames under the per-edge MLP policy in one foreign call (tarl_fused_rollout_policy).
+    ``keep`` = (ptr, env, slot): ``ptr`` a Python list of T + 1 offsets, ``env`` / ``slot`` int32 device tensors — the
+    observations (frame t, environment env[j]) for ptr[t] <= j < ptr[t + 1] are copied to ``obs_keep[slot[j]]``
+    ((K, N, 16) fp32). ``choice8`` (T, B, N) uint8 ENV-MAJOR rank bytes; ``counts`` (T, N, B) uint8 env-minor; the
+    other outputs as :func:`fused_rollout`."""
+    L = _lib.load()
+    T, B, N = len(times), fs.B, fs.N
+    A, abs_ = _agents(agent_features, B)
+    _, _, bs, ldx = _state(x, fs.Nmax)
+    _contig(scratch, torch.int32, "scratch")
+    _check_rollout_outputs(T, B, N, True, metrics_envs, None, counts, log_prob, None, reward, dtt_node, events, leg)
+    _check_rollout_outputs(T, B, N, False, metrics_envs, choice8, None, None, None, None, None, None, None)
+    dev = fs.sel8.device
+    if getattr(fs, "obs_scratch", None) is None:
+        fs.obs_scratch = torch.empty((B, N, 16), dtype=torch.float32, device=dev)
+        fs.logits_scratch = torch.empty((B, plan.num_edges), dtype=torch.float32, device=dev)
+        fs.dist_scratch = torch.empty((int(L.tarl_graphdist_rollout_scratch_bytes(plan.handle, B)) + 7) // 8,
+                                      dtype=torch.float64, device=dev)
+    kptr = kenv = kslot = None
+    if keep is not None:
+        ptr, kenv, kslot = keep
+        if len(ptr) != T + 1 or ptr[0] != 0 or any(b < a for a, b in zip(ptr, ptr[1:])):
+            raise ValueError("keep pointer list must be T + 1 non-decreasing offsets starting at 0")
+        _contig(kenv, torch.int32, "keep env")
+        _contig(kslot, torch.int32, "keep slot")
+        _contig(obs_keep, torch.float32, "obs_keep")
+        if kenv.numel() < ptr[-1] or kslot.numel() < ptr[-1] or obs_keep.shape[1:] != (N, 16):
+            raise ValueError("keep arrays shorter than the pointer list, or obs_keep not (K, N, 16)")
+        kptr = (C.c_int64 * (T + 1))(*[int(v) for v in ptr])
+    tarr = (C.c_float * T)(*[float(t) for t in times])
+    _lib.check(L.tarl_fused_rollout_policy(
+        plan.handle, fs.ref, B, fs.Nmax, T, tarr, float(times[0] - 1 if prev_time is None else prev_time), x.data_ptr(),
+        bs, ldx, agent_features.data_ptr(), A, abs_, ec.edge_attr.data_ptr(), ec.log_edge_attr.data_ptr(), ec.log_eps,
+        1 if use_cong else 0, *w.ptrs(), 1 if bf16 else 0, float(temperature), int(policy_seed), int(policy_counter0),
+        int(seed), int(counter0), kptr, _lib.ptr(kenv), _lib.ptr(kslot), _lib.ptr(obs_keep), fs.obs_scratch.data_ptr(),
+        fs.logits_scratch.data_ptr(), fs.dist_scratch.data_ptr(), scratch.data_ptr(), _lib.ptr(choice8),
+        _lib.ptr(log_prob), _lib.ptr(reward), _lib.ptr(counts), int(metrics_envs), _lib.ptr(dtt_node), _lib.ptr(events),
+        _lib.ptr(leg), _lib.current_stream()))
 
 
 def rollout_gather(plan: Plan, T, B, env_minor, idx=None, *, choice=None, counts=None):

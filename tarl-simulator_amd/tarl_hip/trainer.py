@@ -86,9 +86,9 @@ class VecPPOTrainer:
         self.env_minor = mode in ("frames", "frames+policy")
         shp = (lambda t: (t, N, B)) if self.env_minor else (lambda t: (t, B, N))
         # fused rollouts write one BYTE per (frame, node, env): the count and the rank of the chosen out-edge
-        byte = mode in ("frames", "env")
+        byte = mode in ("frames", "env", "frames+policy")
         self.counts = torch.zeros(shp(self.T + 1), dtype=torch.uint8 if byte else torch.float32, device=dev)
-        # "frames+policy": the action comes from the per-frame sampler as edge ids, env-major
+        # "frames+policy": the per-frame sampler (one workgroup per environment) writes its rank bytes env-major
         self.choice = torch.zeros((self.T, B, N) if mode == "frames+policy" else shp(self.T),
                                   dtype=torch.uint8 if byte else torch.int32, device=dev)
         # per-step logs of SimulatorEnv._step, accumulated on the device by the rollout kernels: the leg histogram's
@@ -132,9 +132,10 @@ class VecPPOTrainer:
     @torch.no_grad()
     def _collect_edge_mlp(self):
         """T frames with the per-edge MLP policy: per frame observation (from the packed state) -> edge MLP on MFMA ->
-        GraphDistribution softmax / sample / log_prob -> the four-launch simulation frame with that action. Nothing is
-        hoisted. The update only ever reads the observations of its minibatch frames, and those frames are a random draw
-        that does not depend on the data: the draw is made up front and only their observations are kept."""
+        GraphDistribution sample + log_prob (one launch) -> the three-launch simulation frame with that action, all
+        queued by one foreign call per episode segment (tarl_fused_rollout_policy). Nothing is hoisted. The update only
+        ever reads the observations of its minibatch frames, and those frames are a random draw that does not depend on
+        the data: the draw is made up front and only their observations are kept."""
         from .engine import EPISODE_END
         eng = self.eng
         T, B, N = self.T, eng.B, eng.N
@@ -148,40 +149,51 @@ class VecPPOTrainer:
         flat = torch.cat(self._mb_idx)
         order = torch.argsort(flat, stable=True)
         t_sorted = torch.div(flat[order], B, rounding_mode="floor").tolist()
-        b_sorted = (flat[order] % B)
+        keep_env = (flat[order] % B).to(torch.int32).contiguous()
+        keep_slot = order.to(torch.int32).contiguous()
         self.obs_mb = torch.empty((flat.numel(), N, 16), dtype=torch.float32, device=eng.device)
         w = self._edge_mlp()
-        if getattr(self, "_obs_buf", None) is None:
-            self._obs_buf = torch.empty((B, N, 16), dtype=torch.float32, device=eng.device)
-            self._logits_buf = torch.empty((B, eng.E), dtype=torch.float32, device=eng.device)
-        host_times, done, pos = [], [False] * T, 0
-        for t in range(T):
-            host_times.append(float(eng.time))
-            obs = ops.fused_obs16(eng.plan, eng.fs, eng._x, eng.Nmax, eng.agents, out=self._obs_buf)
-            lo = pos
-            while pos < len(t_sorted) and t_sorted[pos] == t:
-                pos += 1
-            if pos > lo:                                   # frames of a minibatch: keep their observation
-                self.obs_mb.index_copy_(0, order[lo:pos], obs.index_select(0, b_sorted[lo:pos]))
-            logits = ops.policy_edge_mlp(eng.plan, obs, eng.ec, w, bf16=self.policy_bf16, out=self._logits_buf)
-            proba = ops.graphdist_softmax(eng.plan, logits, self.temperature)
-            self.sample_counter += 1
-            _, choice = ops.graphdist_sample(eng.plan, proba, seed=self.seed ^ 0x5DEECE66D, counter=self.sample_counter,
-                                             want_onehot=False, want_choice=True)
-            lp, _ = ops.graphdist_logprob_entropy(eng.plan, proba, choice=choice, want_entropy=False)
-            self.choice[t].copy_(choice)
-            self.logp[t].copy_(lp)
-            is_done = eng.frame_fused(action=choice, reward=self.reward[t], counts=self.counts[t + 1])
-            if is_done:
-                done[t] = True
-                if t + 1 < T:
+        pseed = self.seed ^ 0x5DEECE66D
+        m = self.metrics_envs
+        host_times, done, pos, t0 = [], [False] * T, 0, 0
+        while t0 < T:
+            # frames until the episode ends (clock past 7 h) or the batch is full: one foreign call
+            seg, clock = 0, float(eng.time)
+            while t0 + seg < T:
+                seg += 1
+                clock += eng.timestep
+                if clock > EPISODE_END:
+                    break
+            seg_lo = pos                     # the kept (frame, environment) pairs are sorted by frame
+            rel = [0]
+            for t in range(t0, t0 + seg):
+                while pos < len(t_sorted) and t_sorted[pos] == t:
+                    pos += 1
+                rel.append(pos - seg_lo)
+            keep = (rel, keep_env[seg_lo:pos], keep_slot[seg_lo:pos]) if pos > seg_lo else None
+            sl = slice(t0, t0 + seg)
+            times = eng.rollout_policy(seg, w, bf16=self.policy_bf16, temperature=self.temperature, policy_seed=pseed,
+                                       policy_counter0=self.sample_counter + 1, choice8=self.choice[sl],
+                                       log_prob=self.logp[sl], reward=self.reward[sl],
+                                       counts=self.counts[t0:t0 + seg + 1], keep=keep, obs_keep=self.obs_mb,
+                                       metrics_envs=m, dtt_node=self.dtt_node[sl] if m else None,
+                                       events=self.events[sl] if m else None, leg=self.leg[sl], check=False)
+            host_times += times[:-1]
+            self.sample_counter += seg
+            t0 += seg
+            if eng.time > EPISODE_END:
+                done[t0 - 1] = True
+                if t0 < T:
                     eng.reset()
-                    self.counts[t + 1].zero_()
+                    self.counts[t0].zero_()
         host_times.append(float(eng.time))
         self.times.copy_(torch.tensor(host_times, dtype=torch.float32))
         self.done_frames = torch.tensor(done, dtype=torch.bool)
         self.done_mask = (self.done_frames.to(eng.device, torch.uint8).view(T, 1).expand(T, B).contiguous()
                           if any(done) else None)
+        self._flag_host.copy_(eng.fs.flags, non_blocking=True)      # polled at the next collect / checked at the end
+        self._flag_event = torch.cuda.Event()
+        self._flag_event.record()
         self._epoch = 0
         return T * B
 
@@ -315,9 +327,8 @@ class VecPPOTrainer:
             idx = idx.to(eng.device)
             M = idx.numel()
         if self.policy == "edge_mlp":
-            t_idx, b_idx = torch.div(idx, B, rounding_mode="floor"), idx % B
-            counts_mb = self.counts[t_idx, :, b_idx].contiguous()               # (M, N) fp32 rows of the sampled frames
-            choice_mb = self.choice.view(T * B, N).index_select(0, idx)
+            _, counts_mb = ops.rollout_gather(eng.plan, T, B, True, idx, counts=self.counts[:T])     # env-minor bytes
+            choice_mb, _ = ops.rollout_gather(eng.plan, T, B, False, idx, choice=self.choice)        # env-major bytes
         elif self.rollout == "unfused":
             counts_mb = self.counts[:T].view(T * B, N).index_select(0, idx)
             choice_mb = self.choice.view(T * B, N).index_select(0, idx)

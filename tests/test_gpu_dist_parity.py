@@ -151,3 +151,57 @@ def test_rollout_with_gpu_sampling_matches_golden(ops):
         ops.insert_step(x, Nmax, ag, t, congestion_constant=cc)
         t += 1
         assert torch.equal(x.cpu(), g["x"][s]) and torch.equal(ag.cpu(), g["agents"][s])
+
+
+@pytest.mark.parametrize("case", ["golden_mid", "torus_philox", "torus_hot"])
+def test_graphdist_rollout_one_launch_equals_the_chain(ops, case):
+    """tarl_graphdist_rollout (softmax -> sample -> log_prob in one launch, probabilities never materialised) against the
+    three-launch chain: identical actions, rank bytes, SELECTED_ROAD bytes and bit-identical log-probs — on the golden
+    graph (unsorted edges, nodes without out-edges), on the 10k-edge torus with device noise, and with logits hot enough
+    that some nodes draw nothing (cumulative sum below u: the action is then not one edge per node, log_prob = -inf)."""
+    from tarl_hip import synth
+    gen = torch.Generator().manual_seed(11)
+    if case == "golden_mid":
+        g = load_golden("dist_mid")
+        ei = g["edge_index"]
+        N = int(ei.max()) + 1
+        B, T = 5, 0.8
+        logits = torch.randn((B, ei.size(1)), generator=gen) * 3
+    else:
+        net = synth.torus_network(25, 25)
+        ei, N = net.edge_index, net.num_roads
+        B, T = (7, 1.3) if case == "torus_philox" else (4, 1.0)
+        logits = torch.randn((B, ei.size(1)), generator=gen) * (2 if case == "torus_philox" else 30)
+    plan = ops.Plan(ei, N)
+    E, G = ei.size(1), plan.num_groups
+    logits = dev(logits)
+    uniform = None
+    if case != "torus_philox":
+        uniform = torch.rand((B, G), generator=gen)
+        if case == "torus_hot":
+            uniform[:, ::7] = 0.99999994            # the largest fp32 below 1: beyond a rounded-down cumulative sum
+        uniform = dev(uniform)
+    p = ops.graphdist_softmax(plan, logits, T)
+    _, ch = ops.graphdist_sample(plan, p, uniform=uniform, seed=5, counter=17, want_onehot=False, want_choice=True)
+    lp, _ = ops.graphdist_logprob_entropy(plan, p, choice=ch, want_entropy=False)
+    prev = torch.randint(0, 3, (N, B), generator=gen).to(torch.uint8)
+    sel_ref = dev(prev.clone())
+    import ctypes
+    from tarl_hip import lib as _lib
+    f = _lib.FusedStruct()             # tarl_fused_apply_choice only touches sel8: drive it through its C entry
+    f.sel8 = sel_ref.data_ptr()
+    _lib.check(_lib.load().tarl_fused_apply_choice(plan.handle, ctypes.byref(f), B, ch.data_ptr(), _lib.current_stream()))
+    ch2 = torch.full((B, N), -7, dtype=torch.int32, device="cuda")
+    c8 = torch.zeros((B, N), dtype=torch.uint8, device="cuda")
+    sel = dev(prev.clone())
+    lp2 = ops.graphdist_rollout(plan, logits, T, uniform=uniform, seed=5, counter=17, choice=ch2, choice8=c8, sel8=sel)
+    assert torch.equal(ch2, ch)
+    assert torch.equal(lp2, lp), (lp2 - lp).abs().max()
+    assert torch.equal(sel, sel_ref) and torch.equal(c8, sel_ref.t())
+    if case == "torus_hot":
+        assert bool((ch < 0).any()) and bool(torch.isinf(lp).any())
+        assert bool(((c8 & 0x80) != 0).any())
+    else:
+        assert bool(torch.isfinite(lp).all())
+    # only the log-prob (the trainer's use when the state is updated elsewhere)
+    assert torch.equal(ops.graphdist_rollout(plan, logits, T, uniform=uniform, seed=5, counter=17), lp)

@@ -129,8 +129,10 @@ def test_ppo_update_with_edge_mlp_policy_matches_oracle_autograd(bf16_rollout):
     tr.collect()
     mlp0 = [p.detach().cpu().clone() for p in mlp]
     crit0 = [p.detach().cpu().clone() for p in crit]
-    counts = tr.counts.permute(0, 2, 1).cpu()            # (T+1, B, N)
-    choice, reward, times = tr.choice.cpu(), tr.reward.cpu(), tr.times.cpu()
+    assert tr.counts.dtype == torch.uint8 and tr.choice.dtype == torch.uint8     # byte rollout buffers
+    counts = tr.counts.permute(0, 2, 1).float().cpu()    # (T+1, B, N)
+    choice = eng.decode_rollout(False, choice=tr.choice)[0].cpu()               # rank bytes -> (T, B, N) edge ids
+    reward, times = tr.reward.cpu(), tr.times.cpu()
     x16 = tr.obs_mb.cpu()                                 # observations of the minibatch frames (tested on their own above)
     assert float(reward.abs().sum()) > 0 and float(x16[:, :, 1].sum()) > 0
     adv_g, tgt_g = tr.advantages()
@@ -174,6 +176,63 @@ def test_ppo_update_with_edge_mlp_policy_matches_oracle_autograd(bf16_rollout):
         q = p0.clone()
         ppo.adam_step(q, gr, torch.zeros_like(q), torch.zeros_like(q), 1)
         close(p_gpu.detach().cpu(), q, f"param {name}")
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_rollout_policy_call_equals_its_launches_one_by_one(bf16):
+    """tarl_fused_rollout_policy (T frames of observation -> MLP -> sample + log-prob -> simulation frame queued by one
+    foreign call) against the same entry points called one by one from Python on a twin engine: identical action bytes,
+    log-probs, rewards, counts, kept observations and final state; the per-step logs add up."""
+    from src.agents.mpnn_agent import MPNNPolicyNet
+    from tarl_hip import ops, synth
+    from tarl_hip.engine import SimEngine
+    net = synth.torus_network(5, 4, heterogeneous=True, seed=3)
+    N, E = net.num_roads, net.edge_index.size(1)
+    B, A, T, TEMP = 96, 200, 14, 400.0
+    pops = torch.stack([synth.population(A, N, seed=40 + b, t0=21540, t1=21552) for b in range(B)])
+
+    def engine():
+        e = SimEngine(net.x.cuda().unsqueeze(0).repeat(B, 1, 1).contiguous(), net.edge_index, net.edge_attr, net.Nmax,
+                      pops.cuda(), congestion_constant=net.congestion_constant, seed=9)
+        e.reset()
+        return e
+    torch.manual_seed(1)
+    pol = MPNNPolicyNet(net.edge_index, N, None, device="cuda")
+    w = ops.EdgeMlpWeights(*(p.data for p in (pol.edge_mlp[0].weight, pol.edge_mlp[0].bias, pol.edge_mlp[2].weight,
+                                              pol.edge_mlp[2].bias, pol.edge_mlp[4].weight, pol.edge_mlp[4].bias)))
+    e1, e2 = engine(), engine()
+    gen = torch.Generator().manual_seed(6)
+    flat = torch.randperm(T * B, generator=gen)[:20]
+    order = torch.argsort(flat, stable=True)
+    t_sorted = (flat[order] // B).tolist()
+    kenv, kslot = (flat[order] % B).to(torch.int32).cuda(), order.to(torch.int32).cuda()
+    ptr = [sum(1 for v in t_sorted if v < t) for t in range(T + 1)]
+    z8 = lambda *shp: torch.zeros(shp, dtype=torch.uint8, device="cuda")
+    zf = lambda *shp: torch.zeros(shp, dtype=torch.float32, device="cuda")
+    m = 2
+    ch1, ct1, lp1, rw1, keep1 = z8(T, B, N), z8(T + 1, N, B), zf(T, B), zf(T, B), zf(20, N, 16)
+    leg1, dtt1, ev1 = torch.zeros((T, B, 2), dtype=torch.int32, device="cuda"), zf(T, N, m), z8(T, N, m)
+    e1.rollout_policy(T, w, bf16=bf16, temperature=TEMP, policy_seed=77, policy_counter0=5, choice8=ch1, log_prob=lp1,
+                      reward=rw1, counts=ct1, keep=(ptr, kenv, kslot), obs_keep=keep1, metrics_envs=m, dtt_node=dtt1,
+                      events=ev1, leg=leg1)
+    # twin: one entry point at a time
+    ch2, lp2, rw2, keep2 = z8(T, B, N), zf(T, B), zf(T, B), zf(20, N, 16)
+    cf = zf(N, B)
+    for t in range(T):
+        obs = ops.fused_obs16(e2.plan, e2.fs, e2._x, e2.Nmax, e2.agents)
+        if ptr[t + 1] > ptr[t]:
+            j = slice(ptr[t], ptr[t + 1])
+            keep2.index_copy_(0, kslot[j].long(), obs.index_select(0, kenv[j].long()))
+        logits = ops.policy_edge_mlp(e2.plan, obs, e2.ec, w, bf16=bf16)
+        ops.graphdist_rollout(e2.plan, logits, TEMP, seed=77, counter=5 + t, choice8=ch2[t], sel8=e2.fs.sel8,
+                              log_prob=lp2[t])
+        e2.frame_fused(skip_choice=True, reward=rw2[t], counts=cf)
+        assert torch.equal(ct1[t + 1].float(), cf), f"counts frame {t}"
+    assert torch.equal(ch1, ch2) and torch.equal(lp1, lp2) and torch.equal(rw1, rw2) and torch.equal(keep1, keep2)
+    assert e1.time == e2.time and torch.equal(e1.x, e2.x) and torch.equal(e1.agents, e2.agents)
+    assert float(rw1.abs().sum()) > 0 and int(leg1[..., 0].sum()) > 0 and bool(torch.isfinite(lp1).all())
+    assert int(leg1[..., 0].sum()) == int((e1.agents[:, :, 7] + e1.agents[:, :, 8] > 0).sum())     # departed == on way + done
+    assert bool(((ch1 & 0x7F) < 4).all())                     # rank bytes of a torus: four out-edges per road
 
 
 def test_mirror_policy_net_with_edge_mlp_head_golden_and_cli(tmp_path, monkeypatch, capsys):
