@@ -86,7 +86,7 @@ def parse():
                     help="also time --congested-steps iterations with every agent departing within this many seconds "
                          "(0 = skip); reported under congested_regime")
     ap.add_argument("--congested-steps", type=int, default=2)
-    ap.add_argument("--policy-envs", type=int, default=256,
+    ap.add_argument("--policy-envs", type=int, default=2048,
                     help="environments per GPU of the state-dependent-policy line (policy_head=edge_mlp; 0 = skip)")
     ap.add_argument("--policy-steps", type=int, default=2)
     ap.add_argument("--policy-temperature", type=float, default=2000.0,

@@ -177,7 +177,9 @@ int tarl_policy_edge_logits_bwd(const tarl_plan* plan, const float* road_index, 
  *   agent_index int64 [M][N], agent_features [A][9] shared (a_mstride = 0) or per sample) or by tarl_fused_obs16 (from the
  *   packed state of the fused engine, environment b = sample m; x supplies the static LENGTH / MAX_FLOW columns).
  * precision 0: fp32 MFMA (v_mfma_f32_32x32x2_f32; exact fp32 products); 1: bf16 MFMA (v_mfma_f32_32x32x16_bf16; inputs,
- *   weights and the first hidden activation rounded to bf16, fp32 accumulation) — BASELINE config 5's bf16 features.
+ *   weights and the first hidden activation rounded to bf16, fp32 accumulation) — BASELINE config 5's bf16 features;
+ *   2: as 1 with obs16 pointing at bf16 observations, uint16 [M][N][16] (tarl_fused_obs16_bf16): same values, half the
+ *   bytes gathered, deeper prefetch.
  * tarl_policy_edge_mlp_bwd ACCUMULATES (+=) the gradients of sum(grad_logits * logits) into gw1 [64][33], gb1 [64],
  *   gw2 [32][64], gb2 [32], gw3 [32], gb3 [1] (fp32, fixed reduction order); scratch: fp32
  *   [tarl_policy_edge_mlp_bwd_scratch_floats(plan, M)]. Observations receive no gradient. */
@@ -435,6 +437,16 @@ int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, int64_t B, in
 int tarl_fused_obs16(const tarl_plan* plan, const tarl_fused* f, const float* x, int64_t B, int64_t x_bstride,
                      int64_t ldx, int32_t Nmax, const float* agent_features, int64_t num_agents, int64_t a_bstride,
                      float* obs16, tarl_stream stream);
+/* tarl_fused_obs16_bf16: the same observation rounded to bf16 (RNE), uint16 [B][N][16] — the input of
+ *   tarl_policy_edge_mlp_fwd(precision = 2) ("bf16 MPNN features": half the bytes written and gathered).
+ * tarl_fused_obs16_rows: the fp32 observation of a FEW environments: row (env[j], i) -> obs_rows[slot[j]][i][16],
+ *   j < rows (< 65536); env / slot int32 device arrays. */
+int tarl_fused_obs16_bf16(const tarl_plan* plan, const tarl_fused* f, const float* x, int64_t B, int64_t x_bstride,
+                          int64_t ldx, int32_t Nmax, const float* agent_features, int64_t num_agents, int64_t a_bstride,
+                          uint16_t* obs16, tarl_stream stream);
+int tarl_fused_obs16_rows(const tarl_plan* plan, const tarl_fused* f, const float* x, int64_t B, int64_t x_bstride,
+                          int64_t ldx, int32_t Nmax, const float* agent_features, int64_t num_agents, int64_t a_bstride,
+                          const int32_t* env, const int32_t* slot, int64_t rows, float* obs_rows, tarl_stream stream);
 
 /* tarl_rollout_env == tarl_fused_rollout with the other mapping: ONE workgroup per environment keeps that environment's
  *   hot records and static columns in LDS (56 B per road + 16 KB; tarl_rollout_env_supported(plan) tells whether the

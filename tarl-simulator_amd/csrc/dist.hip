@@ -4,6 +4,7 @@
 // scatter_max, torch CPU cumsum). The per-step sort/argsort/unique/cumsum/boundary masks of the reference are all
 // static topology and live in the plan; what remains per call is segment arithmetic.
 #include <math.h>
+#include <stdlib.h>
 
 #include "tarl_common.h"
 
@@ -295,6 +296,133 @@ __global__ __launch_bounds__(ENV_BLOCK) void k_graphdist_rollout(
   if (tid == 0 && log_prob) log_prob[b] = bad_t > 0.0f ? -INFINITY : lp_t;
 }
 
+// The same draw with every node's logits held in registers: when every node has out-edges (groups == nodes, so a thread
+// meets the same nodes in the scan and in the pick), at most 4 (8) of them, and N <= 4096 (2048) nodes — at most J = 4 (2)
+// nodes per thread —,
+// the three dependent rounds of loads (CSR range -> edge id -> logit) are issued once for all of a thread's nodes and
+// everything after them — max, sum, probabilities, the double running sums, the block scans, pick and log-prob — runs
+// out of registers. Same operations in the same order as k_graphdist_rollout (the generic path above).
+// (J nodes x GDR_DEG edges of registers per thread: instantiated for J * GDR_DEG <= 16)
+template <int J, int GDR_DEG, bool SORTED>
+__global__ __launch_bounds__(ENV_BLOCK) void k_graphdist_rollout_reg(
+    const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_eid, const float* __restrict__ logits, int64_t B,
+    int64_t N, int64_t E, float temperature, const float* __restrict__ uniform, uint64_t seed, uint64_t counter,
+    int32_t* __restrict__ choice_eid, uint8_t* __restrict__ choice8, uint8_t* __restrict__ sel8,
+    float* __restrict__ log_prob) {
+  __shared__ float s_red[ENV_BLOCK / 64];
+  const int64_t b = blockIdx.x;
+  const float* lb = logits + b * E;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  int32_t k0[J], deg[J], eid[J][GDR_DEG];
+  float p[J][GDR_DEG];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int64_t i = tid + (int64_t)ENV_BLOCK * j;
+    k0[j] = i < N ? out_ptr[i] : 0;
+    deg[j] = i < N ? out_ptr[i + 1] - k0[j] : 0;
+  }
+#pragma unroll
+  for (int j = 0; j < J; ++j)
+#pragma unroll
+    for (int q = 0; q < GDR_DEG; ++q) eid[j][q] = SORTED ? k0[j] + q : (q < deg[j] ? out_eid[k0[j] + q] : 0);
+#pragma unroll
+  for (int j = 0; j < J; ++j)
+#pragma unroll
+    for (int q = 0; q < GDR_DEG; ++q) p[j][q] = q < deg[j] ? lb[eid[j][q]] / temperature : 0.0f;
+  double base[J], inc[J];
+  float un[J];
+  __shared__ double s_wave_j[J][ENV_BLOCK / 64];
+  // per-node softmax (exp evaluated once per edge: the value the chain recomputes is the same function of the same
+  // argument), per-group double sums, wave-level inclusive scans of all J chunks of 1 024 groups ...
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int64_t g = tid + (int64_t)ENV_BLOCK * j;
+    double s = 0.0;
+    if (g < N) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int q = 0; q < GDR_DEG; ++q)
+        if (q < deg[j]) mx = fmaxf(mx, p[j][q]);
+      float sum = 0.0f;
+#pragma unroll
+      for (int q = 0; q < GDR_DEG; ++q)
+        if (q < deg[j]) {
+          p[j][q] = expf(p[j][q] - mx);
+          sum = sum + p[j][q];
+        }
+#pragma unroll
+      for (int q = 0; q < GDR_DEG; ++q)
+        if (q < deg[j]) {
+          p[j][q] = p[j][q] / sum;
+          s += (double)p[j][q];
+        }
+    }
+    double v_inc = s;
+    for (int off = 1; off < 64; off <<= 1) {
+      const double v = __shfl_up(v_inc, off);
+      if (lane >= off) v_inc += v;
+    }
+    if (lane == 63) s_wave_j[j][wid] = v_inc;
+    inc[j] = v_inc;
+    un[j] = g < N ? (uniform ? uniform[b * N + g] : philox_uniform(seed, counter, (uint64_t)(b * N + g))) : 0.0f;
+  }
+  __syncthreads();
+  // ... then the cross-wave part of k_sample's scan, chunk after chunk (same additions in the same order)
+  double running = 0.0;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    double wbase = 0.0, tot = 0.0;
+    for (int w = 0; w < ENV_BLOCK / 64; ++w) {
+      const double v = s_wave_j[j][w];
+      if (w < wid) wbase += v;
+      tot += v;
+    }
+    double exc = __shfl_up(inc[j], 1);
+    if (lane == 0) exc = 0.0;
+    base[j] = running + wbase + exc;
+    running += tot;
+  }
+  float lp = 0.0f, bad = 0.0f;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int64_t i = tid + (int64_t)ENV_BLOCK * j;
+    if (i >= N) continue;
+    int32_t pick = -1, rank = 0;
+    if (deg[j] != 0) {
+      const double bg = base[j];
+      const float bg32 = (float)bg, u = un[j];
+      double run = bg;
+      float lg_pick = 0.0f;
+#pragma unroll
+      for (int q = 0; q < GDR_DEG; ++q)
+        if (q < deg[j]) {
+          run += (double)p[j][q];
+          const float cum = (float)run - bg32;
+          if (pick < 0 && u < cum) {
+            pick = eid[j][q];
+            rank = q;
+            lg_pick = logf(p[j][q] + LOG_EPS_P);
+          }
+        }
+      if (pick >= 0)
+        lp += lg_pick;
+      else
+        bad = 1.0f;
+    }
+    if (choice_eid) choice_eid[b * N + i] = pick;
+    if (choice8 || sel8) {
+      uint32_t code = (uint32_t)rank;
+      if (pick < 0) code = ((sel8 ? sel8[i * B + b] : 0u) & 0x7Fu) | SEL_CARRIED;
+      if (sel8) sel8[i * B + b] = (uint8_t)code;
+      if (choice8) choice8[b * N + i] = (uint8_t)code;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const float lp_t = block_sum(lp, s_red);
+  const float bad_t = block_sum(bad, s_red);
+  if (tid == 0 && log_prob) log_prob[b] = bad_t > 0.0f ? -INFINITY : lp_t;
+}
+
 // ---- backward through the segment softmax ----------------------------------------------------------------------------
 // L = gl*LP + ge*H with LP = sum a log(p+eps), H = -sum p log(p+eps), p = softmax(l/T) per group:
 //   q_k = gl * a_k/(p_k+eps) + ge * (-log(p_k+eps) - p_k/(p_k+eps)),  dL/dl_j = p_j (q_j - sum_k p_k q_k) / T.
@@ -383,9 +511,40 @@ extern "C" int tarl_graphdist_rollout(const tarl_plan* plan, const float* logits
   if (plan->N == 0) return TARL_OK;
   double* base = (double*)scratch;
   float* un = (float*)(base + B * plan->N);
-  hipLaunchKernelGGL(k_graphdist_rollout, dim3((unsigned)B), dim3(ENV_BLOCK), 0, (hipStream_t)stream, plan->out_ptr,
-                     plan->out_eid, plan->node_of_group, logits, B, plan->N, plan->E, plan->G, temperature, uniform, seed,
-                     counter, base, un, choice, choice8, sel8, log_prob);
+  const char* knob = getenv("TARL_GRAPHDIST_REG");
+  const int J = (int)ceil_div(plan->N, (int64_t)ENV_BLOCK);
+  const int D = plan->max_out <= 4 ? 4 : 8;
+  const bool reg = (!knob || atoi(knob) != 0) && plan->G == plan->N && plan->max_out <= 8 && J * D <= 16;
+#define GDR_LAUNCH(J_, D_, S_)                                                                                          \
+  hipLaunchKernelGGL((k_graphdist_rollout_reg<J_, D_, S_>), dim3((unsigned)B), dim3(ENV_BLOCK), 0, (hipStream_t)stream,   \
+                     plan->out_ptr, plan->out_eid, logits, B, plan->N, plan->E, temperature, uniform, seed, counter, choice,  \
+                     choice8, sel8, log_prob)
+#define GDR_BY_SORT(J_, D_)         \
+  if (plan->src_sorted)             \
+    GDR_LAUNCH(J_, D_, true);       \
+  else                              \
+    GDR_LAUNCH(J_, D_, false)
+  if (reg) {
+    if (D == 4) {
+      switch (J) {
+        case 1: GDR_BY_SORT(1, 4); break;
+        case 2: GDR_BY_SORT(2, 4); break;
+        case 3: GDR_BY_SORT(3, 4); break;
+        default: GDR_BY_SORT(4, 4); break;
+      }
+    } else {
+      if (J == 1) {
+        GDR_BY_SORT(1, 8);
+      } else {
+        GDR_BY_SORT(2, 8);
+      }
+    }
+  } else
+    hipLaunchKernelGGL(k_graphdist_rollout, dim3((unsigned)B), dim3(ENV_BLOCK), 0, (hipStream_t)stream, plan->out_ptr,
+                       plan->out_eid, plan->node_of_group, logits, B, plan->N, plan->E, plan->G, temperature, uniform, seed,
+                       counter, base, un, choice, choice8, sel8, log_prob);
+#undef GDR_BY_SORT
+#undef GDR_LAUNCH
   TARL_LAUNCH_CHECK();
   return TARL_OK;
 }

@@ -92,6 +92,74 @@ __global__ __launch_bounds__(256) void k_obs16_packed(const int32_t* __restrict_
   }
 }
 
+// the same observation rounded to bf16 (RNE) — what the bf16 MLP reads ("bf16 MPNN features"): 32-byte rows, half the
+// bytes written here and gathered there. Same tile plan (8 nodes x 64 environments, 256-byte runs per environment).
+#define OBB_LD (OB_TI * 8 + 4)     // uint32 per environment in LDS
+__global__ __launch_bounds__(256) void k_obs16_packed_bf16(const int32_t* __restrict__ out_ptr,
+                                                           const int32_t* __restrict__ out_dst,
+                                                           const float* __restrict__ x0, Layout L, int64_t B, int64_t N,
+                                                           FusedBufs fb, const float* __restrict__ ag, int64_t A,
+                                                           int64_t a_bstride, uint16_t* __restrict__ obs) {
+  __shared__ __attribute__((aligned(16))) uint32_t sm[OB_TB * OBB_LD];
+  const int tid = threadIdx.x, bl = tid & 63;
+  const int64_t b = (int64_t)blockIdx.x * OB_TB + bl, i0 = (int64_t)blockIdx.y * OB_TI;
+#pragma unroll
+  for (int r = 0; r < OB_TI / 4; ++r) {
+    const int il = (tid >> 6) + 4 * r;
+    const int64_t i = i0 + il;
+    if (b < B && i < N) {
+      const int64_t gid = i * B + b;
+      const uint32_t hd = fb.hdp[gid].x;
+      const float4 st = fb.st0[i];
+      const float* xs = x0 + i * L.ldx;
+      const long long head = (long long)(hd >> 8);
+      const float* arow = ag + b * a_bstride + ((head >= 0 && head < A) ? head : 0) * AG_COLS;
+      const float v[16] = {st.x, (float)(hd & 255u), st.y, xs[L.col_maxn() + 3], xs[L.col_maxflow()],
+                           sel_value(fb, out_ptr, out_dst, i, gid), st.z, arow[0], arow[1], arow[2], arow[3], arow[4],
+                           arow[5], arow[6], arow[7], arow[8]};
+      uint4* o = reinterpret_cast<uint4*>(sm + bl * OBB_LD + il * 8);
+      uint32_t w[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        w[q] = (uint32_t)f32_to_bf16_rne(v[2 * q]) | ((uint32_t)f32_to_bf16_rne(v[2 * q + 1]) << 16);
+      o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+      o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+  }
+  __syncthreads();
+  const int part = tid & 15;                 // uint4 number inside the environment's 8 rows (2 per row)
+  const int64_t i = i0 + (part >> 1);
+#pragma unroll
+  for (int r = 0; r < OB_TB / 16; ++r) {
+    const int be = (tid >> 4) + 16 * r;
+    const int64_t bb = (int64_t)blockIdx.x * OB_TB + be;
+    if (bb < B && i < N)
+      reinterpret_cast<uint4*>(obs + (bb * N + i0) * 16)[part] = reinterpret_cast<const uint4*>(sm + be * OBB_LD)[part];
+  }
+}
+
+// fp32 observation rows of a FEW environments (the frames an optimiser minibatch keeps): row (env[j], i) -> keep[slot[j]][i]
+__global__ __launch_bounds__(FB) void k_obs16_rows(const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_dst,
+                                                   const float* __restrict__ x0, Layout L, int64_t B, int64_t N,
+                                                   FusedBufs fb, const float* __restrict__ ag, int64_t A,
+                                                   int64_t a_bstride, const int32_t* __restrict__ env,
+                                                   const int32_t* __restrict__ slot, float* __restrict__ keep) {
+  const int64_t i = (int64_t)blockIdx.x * FB + threadIdx.x;
+  if (i >= N) return;
+  const int64_t b = env[blockIdx.y];
+  const int64_t gid = i * B + b;
+  const uint32_t hd = fb.hdp[gid].x;
+  const float4 st = fb.st0[i];
+  const float* xs = x0 + i * L.ldx;
+  const long long head = (long long)(hd >> 8);
+  const float* arow = ag + b * a_bstride + ((head >= 0 && head < A) ? head : 0) * AG_COLS;
+  float4* o = reinterpret_cast<float4*>(keep + ((int64_t)slot[blockIdx.y] * N + i) * 16);
+  o[0] = make_float4(st.x, (float)(hd & 255u), st.y, xs[L.col_maxn() + 3]);
+  o[1] = make_float4(xs[L.col_maxflow()], sel_value(fb, out_ptr, out_dst, i, gid), st.z, arow[0]);
+  o[2] = make_float4(arow[1], arow[2], arow[3], arow[4]);
+  o[3] = make_float4(arow[5], arow[6], arow[7], arow[8]);
+}
+
 // the same from the reference's tensors: node_features (M, N, >=7 cols, row stride nf_ld) + agent rows gathered by
 // agent_index (int64 (M, N)) from agent_features (A, 9) (one population) or (M, A, 9)
 __global__ __launch_bounds__(FB) void k_obs16_cat(const float* __restrict__ nf, int64_t nf_ld, const int64_t* __restrict__ aidx,
@@ -265,15 +333,90 @@ __device__ __forceinline__ bf16x8 emr_pack(const float4 a, const float4 b) {
   return __builtin_bit_cast(bf16x8, p);
 }
 
+// Software pipeline of the bf16 kernel: the gathers are two dependent rounds (edge -> node ids -> node rows) of ~1-2 us
+// each against ~0.2 us of arithmetic per chunk. A wave therefore keeps P chunks of rows and P chunks of node ids in
+// flight: step g consumes the rows of chunk g and the ids of chunk g + P (both requested P steps ago), then requests the
+// ids of chunk g + 2P and — with the ids it just consumed — the rows of chunk g + P into the registers it has just
+// freed. The buffers are indexed by g mod P with the loop unrolled P times (a shifting queue would have to MOVE registers
+// whose loads are still in flight, i.e. wait for them), and the ids go out before the rows because the memory counter
+// retires in order. P = 3 with bf16 observations (9 registers per chunk in flight), 1 with fp32 observations (17).
+// Past the end of its range a wave re-requests its last chunk (no divergent control flow inside the loop, which would make
+// the compiler's wait-count tracking give up and wait for everything).
+struct MC {
+  int32_t m, c;
+  uint32_t g;
+  __device__ __forceinline__ void adv(int32_t CH, uint32_t g1) {      // saturates at the last chunk of the range
+    if (g + 1 < g1) {
+      ++g;
+      if (++c == CH) {
+        c = 0;
+        ++m;
+      }
+    }
+  }
+};
+struct EIdx {
+  int32_t s, d;
+  float ea;
+};
+__device__ __forceinline__ EIdx emr_ldidx(const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                                          const float* __restrict__ edge_attr, int32_t E, int32_t c, int lane) {
+  int32_t e = c * 32 + (lane & 31);
+  e = e < E ? e : E - 1;                     // the tail chunk's spare lanes repeat the last edge (never stored)
+  EIdx i;
+  i.s = src[e];
+  i.d = dst[e];
+  i.ea = edge_attr[e];
+  return i;
+}
+template <bool OBS_BF16>
+struct ERows;
+template <>
+struct ERows<false> {      // fp32 observations [M][N][16]: this half-wave's 8 floats of both rows
+  float4 s0, s1, d0, d1;
+  float ea;
+  __device__ __forceinline__ void load(const void* __restrict__ obs, int64_t N, int32_t m, const EIdx& i, int lane) {
+    const float* om = (const float*)obs + (int64_t)m * N * 16 + 8 * (lane >> 5);
+    const float4* ps = reinterpret_cast<const float4*>(om + (int64_t)i.s * 16);
+    const float4* pd = reinterpret_cast<const float4*>(om + (int64_t)i.d * 16);
+    s0 = ps[0];
+    s1 = ps[1];
+    d0 = pd[0];
+    d1 = pd[1];
+    ea = i.ea;
+  }
+  __device__ __forceinline__ bf16x8 xs() const { return emr_pack(s0, s1); }
+  __device__ __forceinline__ bf16x8 xd() const { return emr_pack(d0, d1); }
+};
+template <>
+struct ERows<true> {       // bf16 observations [M][N][16] (tarl_fused_obs16_bf16): 16 bytes of both rows
+  uint4 s, d;
+  float ea;
+  __device__ __forceinline__ void load(const void* __restrict__ obs, int64_t N, int32_t m, const EIdx& i, int lane) {
+    const uint16_t* om = (const uint16_t*)obs + (int64_t)m * N * 16 + 8 * (lane >> 5);
+    s = *reinterpret_cast<const uint4*>(om + (int64_t)i.s * 16);
+    d = *reinterpret_cast<const uint4*>(om + (int64_t)i.d * 16);
+    ea = i.ea;
+  }
+  __device__ __forceinline__ bf16x8 xs() const { return __builtin_bit_cast(bf16x8, s); }
+  __device__ __forceinline__ bf16x8 xd() const { return __builtin_bit_cast(bf16x8, d); }
+};
+
+template <bool OBS_BF16>
 __global__ __launch_bounds__(EMR_WAVES * 64) void k_edge_mlp_fwd_bf16(const int32_t* __restrict__ src,
                                                                       const int32_t* __restrict__ dst, int64_t E,
                                                                       int64_t N, int64_t M,
-                                                                      const float* __restrict__ obs,
+                                                                      const void* __restrict__ obs,
                                                                       const float* __restrict__ edge_attr, EdgeMlpW W,
                                                                       float* __restrict__ logits) {
+  constexpr int P = OBS_BF16 ? 3 : 1;
   // fragment-ordered weights: W1f [2 tiles][3 k-steps][64 lanes][8], W2f [4 k-steps][64 lanes][8]
   __shared__ __attribute__((aligned(16))) uint16_t W1f[6 * 64 * 8];
   __shared__ __attribute__((aligned(16))) uint16_t W2f[4 * 64 * 8];
+  // b2 / w3 in accumulator-row order per half-wave: re-read from LDS every chunk (two addresses per wave: broadcast) so
+  // that 32 registers go to loads in flight instead
+  __shared__ __attribute__((aligned(16))) float B2L[2 * 16];
+  __shared__ __attribute__((aligned(16))) float W3L[2 * 16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int idx = tid; idx < 6 * 64 * 8; idx += EMR_WAVES * 64) {
     const int q = idx & 7, l = (idx >> 3) & 63, f = idx >> 9;
@@ -300,6 +443,10 @@ __global__ __launch_bounds__(EMR_WAVES * 64) void k_edge_mlp_fwd_bf16(const int3
     const int u = 32 * (ks >> 1) + emr_unit(8 * (ks & 1) + q, l >> 5);
     W2f[idx] = f32_to_bf16_rne(W.w2[(l & 31) * EM_H1 + u]);
   }
+  if (tid < 32) {
+    B2L[tid] = W.b2[emr_unit(tid & 15, tid >> 4)];
+    W3L[tid] = W.w3[emr_unit(tid & 15, tid >> 4)];
+  }
   __syncthreads();
   bf16x8 w1f[6], w2f[4];
 #pragma unroll
@@ -307,24 +454,42 @@ __global__ __launch_bounds__(EMR_WAVES * 64) void k_edge_mlp_fwd_bf16(const int3
 #pragma unroll
   for (int f = 0; f < 4; ++f) w2f[f] = *reinterpret_cast<const bf16x8*>(W2f + (f * 64 + lane) * 8);
   const int h = lane >> 5;
-  f32x16 b2r;
-  float w3r[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    b2r[r] = W.b2[emr_unit(r, h)];
-    w3r[r] = W.w3[emr_unit(r, h)];
-  }
+  const float4* b2l = reinterpret_cast<const float4*>(B2L + 16 * h);
+  const float4* w3l = reinterpret_cast<const float4*>(W3L + 16 * h);
   const float b3 = W.b3[0];
   const f32x16 zero = {0};
 
   ChunkWalk cw;
   if (!cw.init(E, M, wave)) return;
-  EdgeIn nxt = emr_load(src, dst, edge_attr, obs, (int32_t)E, N, cw.mn, cw.cn, lane);
-  for (; cw.g < cw.g1; ++cw.g) {
-    const EdgeIn cur = nxt;
-    cw.step();
-    if (cw.g + 1 < cw.g1) nxt = emr_load(src, dst, edge_attr, obs, (int32_t)E, N, cw.mn, cw.cn, lane);
-    const bf16x8 xs = emr_pack(cur.s0, cur.s1), xd = emr_pack(cur.d0, cur.d1);
+  const int32_t CH = (int32_t)cw.CH, Ei = (int32_t)E;
+  const uint32_t g1 = cw.g1;
+  MC cur_mc{cw.mn, cw.cn, cw.g}, row_mc = cur_mc, idx_mc = cur_mc;
+  ERows<OBS_BF16> R[P];
+  EIdx I[P];
+#pragma unroll
+  for (int K = 0; K < P; ++K) {                  // prologue: rows of chunks g0 .. g0+P-1, ids of chunks g0+P .. g0+2P-1
+    R[K].load(obs, N, row_mc.m, emr_ldidx(src, dst, edge_attr, Ei, row_mc.c, lane), lane);
+    row_mc.adv(CH, g1);
+  }
+  idx_mc = row_mc;
+#pragma unroll
+  for (int K = 0; K < P; ++K) {
+    I[K] = emr_ldidx(src, dst, edge_attr, Ei, idx_mc.c, lane);
+    idx_mc.adv(CH, g1);
+  }
+  for (uint32_t g = cw.g; g < g1; g += P) {
+#pragma unroll
+    for (int K = 0; K < P; ++K) {
+    const bool valid = g + K < g1;
+    const ERows<OBS_BF16> cur = R[K];
+    const EIdx use = I[K];
+    const MC mc = cur_mc;
+    I[K] = emr_ldidx(src, dst, edge_attr, Ei, idx_mc.c, lane);
+    R[K].load(obs, N, row_mc.m, use, lane);
+    cur_mc.adv(CH, g1);
+    row_mc.adv(CH, g1);
+    idx_mc.adv(CH, g1);
+    const bf16x8 xs = cur.xs(), xd = cur.xd();
     bf16x8 xe = {0};
     if (h == 0) {
       xe[0] = (__bf16)cur.ea;
@@ -350,16 +515,33 @@ __global__ __launch_bounds__(EMR_WAVES * 64) void k_edge_mlp_fwd_bf16(const int3
       hb[s2] = emr_relu8(__builtin_bit_cast(bf16x8, p0));
       hb[2 + s2] = emr_relu8(__builtin_bit_cast(bf16x8, p1));
     }
-    f32x16 c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[0], hb[0], b2r, 0, 0, 0);
+    f32x16 c0;
+    asm volatile("" ::: "memory");      // keeps the two LDS tables out of loop-invariant registers
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = b2l[q];
+      c0[4 * q] = v.x;
+      c0[4 * q + 1] = v.y;
+      c0[4 * q + 2] = v.z;
+      c0[4 * q + 3] = v.w;
+    }
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[0], hb[0], c0, 0, 0, 0);
     c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[1], hb[1], c0, 0, 0, 0);
     c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[2], hb[2], c0, 0, 0, 0);
     c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[3], hb[3], c0, 0, 0, 0);
     float part = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) part = fmaf(emr_relu(c0[r]), w3r[r], part);
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = w3l[q];
+      part = fmaf(emr_relu(c0[4 * q]), v.x, part);
+      part = fmaf(emr_relu(c0[4 * q + 1]), v.y, part);
+      part = fmaf(emr_relu(c0[4 * q + 2]), v.z, part);
+      part = fmaf(emr_relu(c0[4 * q + 3]), v.w, part);
+    }
     const float tot = part + __shfl_xor(part, 32);
-    const int32_t e = cw.c * 32 + (lane & 31);
-    if (h == 0 && e < (int32_t)E) logits[(int64_t)cw.m * E + e] = tot + b3;
+    const int32_t e = mc.c * 32 + (lane & 31);
+    if (valid && h == 0 && e < Ei) logits[(int64_t)mc.m * E + e] = tot + b3;
+    }
   }
 }
 
@@ -499,13 +681,48 @@ extern "C" int tarl_fused_obs16(const tarl_plan* plan, const tarl_fused* f, cons
   return TARL_OK;
 }
 
+extern "C" int tarl_fused_obs16_bf16(const tarl_plan* plan, const tarl_fused* f, const float* x, int64_t B,
+                                     int64_t x_bstride, int64_t ldx, int32_t Nmax, const float* agent_features, int64_t A,
+                                     int64_t a_bstride, uint16_t* obs16, tarl_stream stream) {
+  int rc = tarl_check_fused_core(plan, f, B, Nmax);
+  if (rc) return rc;
+  TARL_REQUIRE(x && agent_features && obs16 && A >= 1, "null argument");
+  if (plan->N == 0) return TARL_OK;
+  TARL_REQUIRE(((uintptr_t)obs16) % 16 == 0, "obs16 must be 16-byte aligned");
+  TARL_REQUIRE(ceil_div(plan->N, OB_TI) < 65536, "too many node tiles for one grid dimension");
+  const Layout L{Nmax, ldx, x_bstride};
+  hipLaunchKernelGGL(k_obs16_packed_bf16, dim3((unsigned)ceil_div(B, OB_TB), (unsigned)ceil_div(plan->N, OB_TI)), dim3(256),
+                     0, (hipStream_t)stream, plan->out_ptr, plan->out_dst, x, L, B, plan->N, tarl_to_bufs(f), agent_features,
+                     A, a_bstride, obs16);
+  TARL_LAUNCH_CHECK();
+  return TARL_OK;
+}
+
+extern "C" int tarl_fused_obs16_rows(const tarl_plan* plan, const tarl_fused* f, const float* x, int64_t B,
+                                     int64_t x_bstride, int64_t ldx, int32_t Nmax, const float* agent_features, int64_t A,
+                                     int64_t a_bstride, const int32_t* env, const int32_t* slot, int64_t rows,
+                                     float* obs_rows, tarl_stream stream) {
+  int rc = tarl_check_fused_core(plan, f, B, Nmax);
+  if (rc) return rc;
+  TARL_REQUIRE(x && agent_features && A >= 1 && rows >= 0 && rows < 65536, "bad arguments");
+  if (plan->N == 0 || rows == 0) return TARL_OK;
+  TARL_REQUIRE(env && slot && obs_rows && ((uintptr_t)obs_rows) % 16 == 0, "row lists / 16-byte aligned output missing");
+  const Layout L{Nmax, ldx, x_bstride};
+  hipLaunchKernelGGL(k_obs16_rows, dim3((unsigned)ceil_div(plan->N, FB), (unsigned)rows), dim3(FB), 0, (hipStream_t)stream,
+                     plan->out_ptr, plan->out_dst, x, L, B, plan->N, tarl_to_bufs(f), agent_features, A, a_bstride, env, slot,
+                     obs_rows);
+  TARL_LAUNCH_CHECK();
+  return TARL_OK;
+}
+
 extern "C" int tarl_policy_edge_mlp_fwd(const tarl_plan* plan, const float* obs16, int64_t M, const float* edge_attr,
                                         const float* w1, const float* b1, const float* w2, const float* b2,
                                         const float* w3, const float* b3, int precision, float* logits,
                                         tarl_stream stream) {
   TARL_REQUIRE(plan && obs16 && edge_attr && w1 && b1 && w2 && b2 && w3 && b3 && logits, "null argument");
   TARL_REQUIRE(M >= 1 && M < 65536, "bad batch size");
-  TARL_REQUIRE(precision == 0 || precision == 1, "precision: 0 = fp32 MFMA, 1 = bf16 MFMA");
+  TARL_REQUIRE(precision >= 0 && precision <= 2,
+               "precision: 0 = fp32 MFMA, 1 = bf16 MFMA, 2 = bf16 MFMA on bf16 observations");
   TARL_REQUIRE(((uintptr_t)obs16) % 16 == 0, "obs16 must be 16-byte aligned");
   if (plan->E == 0) return TARL_OK;
   const EdgeMlpW W{w1, b1, w2, b2, w3, b3};
@@ -513,13 +730,17 @@ extern "C" int tarl_policy_edge_mlp_fwd(const tarl_plan* plan, const float* obs1
   const int64_t chunks = M * ceil_div(plan->E, 32);
   TARL_REQUIRE(chunks < ((int64_t)1 << 31) && plan->E < ((int64_t)1 << 31) - 32, "edge MLP: batch x edges too large");
   int64_t blocks = ceil_div(chunks, (int64_t)EMR_WAVES * 16);          // >= 16 chunks per wave
-  if (blocks > 256 * 8) blocks = 256 * 8;
+  const int64_t resident = 256 * (precision == 0 ? 2 : 3);              // workgroups the chip holds at once (VGPR-bound)
+  if (blocks > resident) blocks = resident;                             // one round: no tail
   if (precision == 0)
     hipLaunchKernelGGL(k_edge_mlp_fwd_f32, dim3((unsigned)blocks), dim3(EMR_WAVES * 64), 0, (hipStream_t)stream,
                        plan->src, plan->dst, plan->E, plan->N, M, obs16, edge_attr, W, logits);
+  else if (precision == 1)
+    hipLaunchKernelGGL(k_edge_mlp_fwd_bf16<false>, dim3((unsigned)blocks), dim3(EMR_WAVES * 64), 0, (hipStream_t)stream,
+                       plan->src, plan->dst, plan->E, plan->N, M, (const void*)obs16, edge_attr, W, logits);
   else
-    hipLaunchKernelGGL(k_edge_mlp_fwd_bf16, dim3((unsigned)blocks), dim3(EMR_WAVES * 64), 0, (hipStream_t)stream,
-                       plan->src, plan->dst, plan->E, plan->N, M, obs16, edge_attr, W, logits);
+    hipLaunchKernelGGL(k_edge_mlp_fwd_bf16<true>, dim3((unsigned)blocks), dim3(EMR_WAVES * 64), 0, (hipStream_t)stream,
+                       plan->src, plan->dst, plan->E, plan->N, M, (const void*)obs16, edge_attr, W, logits);
   TARL_LAUNCH_CHECK();
   return TARL_OK;
 }

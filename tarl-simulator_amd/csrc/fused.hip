@@ -1724,6 +1724,7 @@ extern "C" int tarl_fused_rollout_policy(const tarl_plan* plan, const tarl_fused
   TARL_REQUIRE(T >= 1 && times_host, "bad frame count / times");
   TARL_REQUIRE(x && obs_scratch && logits_scratch && dist_scratch, "observation / logits / sampler scratch missing");
   TARL_REQUIRE(!keep_ptr_host || (keep_env && keep_slot && obs_keep), "keep list without its arrays");
+  TARL_REQUIRE(precision == 0 || precision == 1, "precision: 0 = fp32 logits, 1 = bf16 logits on bf16 observations");
   rc = check_frame_args(plan, f, B, agent_features, A, a_bstride, ins_scratch, edge_attr, log_edge_attr);
   if (rc) return rc;
   TARL_REQUIRE(metrics_envs >= 0 && metrics_envs <= B, "metrics_envs out of range");
@@ -1737,17 +1738,31 @@ extern "C" int tarl_fused_rollout_policy(const tarl_plan* plan, const tarl_fused
   const FusedBufs fb = tarl_to_bufs(f);
   const PlanOut P{plan->out_ptr, plan->out_dst};
   for (int64_t t = 0; t < T; ++t) {
-    rc = tarl_fused_obs16(plan, f, x, B, x_bstride, ldx, Nmax, agent_features, A, a_bstride, obs_scratch, stream);
-    if (rc) return rc;
-    if (keep_ptr_host && keep_ptr_host[t + 1] > keep_ptr_host[t]) {
-      const int64_t lo = keep_ptr_host[t], n = keep_ptr_host[t + 1] - lo;
-      TARL_REQUIRE(n < 65536, "more than 65535 kept observations in one frame");
-      hipLaunchKernelGGL(k_obs_keep, dim3((unsigned)ceil_div(N * 4, FB), (unsigned)n), dim3(FB), 0, s,
-                         (const float4*)obs_scratch, N * 4, keep_env + lo, keep_slot + lo, (float4*)obs_keep);
-      TARL_LAUNCH_CHECK();
+    const bool keep_t = keep_ptr_host && keep_ptr_host[t + 1] > keep_ptr_host[t];
+    const int64_t lo = keep_t ? keep_ptr_host[t] : 0, n = keep_t ? keep_ptr_host[t + 1] - lo : 0;
+    TARL_REQUIRE(n < 65536, "more than 65535 kept observations in one frame");
+    if (precision == 1) {
+      // bf16 logits read bf16 observations (half the bytes written here and gathered by the MLP); the fp32 rows an
+      // optimiser step keeps are evaluated for their few environments only
+      rc = tarl_fused_obs16_bf16(plan, f, x, B, x_bstride, ldx, Nmax, agent_features, A, a_bstride,
+                                 (uint16_t*)obs_scratch, stream);
+      if (rc) return rc;
+      if (keep_t) {
+        rc = tarl_fused_obs16_rows(plan, f, x, B, x_bstride, ldx, Nmax, agent_features, A, a_bstride, keep_env + lo,
+                                   keep_slot + lo, n, obs_keep, stream);
+        if (rc) return rc;
+      }
+    } else {
+      rc = tarl_fused_obs16(plan, f, x, B, x_bstride, ldx, Nmax, agent_features, A, a_bstride, obs_scratch, stream);
+      if (rc) return rc;
+      if (keep_t) {
+        hipLaunchKernelGGL(k_obs_keep, dim3((unsigned)ceil_div(N * 4, FB), (unsigned)n), dim3(FB), 0, s,
+                           (const float4*)obs_scratch, N * 4, keep_env + lo, keep_slot + lo, (float4*)obs_keep);
+        TARL_LAUNCH_CHECK();
+      }
     }
-    rc = tarl_policy_edge_mlp_fwd(plan, obs_scratch, B, edge_attr, w1, b1, w2, b2, w3, b3, precision, logits_scratch,
-                                  stream);
+    rc = tarl_policy_edge_mlp_fwd(plan, obs_scratch, B, edge_attr, w1, b1, w2, b2, w3, b3, precision == 1 ? 2 : 0,
+                                  logits_scratch, stream);
     if (rc) return rc;
     rc = tarl_graphdist_rollout(plan, logits_scratch, B, temperature, nullptr, policy_seed, policy_counter0 + (uint64_t)t,
                                 dist_scratch, nullptr, choice8 ? choice8 + t * NB : nullptr, f->sel8,

@@ -45,6 +45,8 @@ SIGNATURES = {
     "tarl_policy_edge_logits_bwd": (C.c_int, [_p, _p, _i64, _i64, _i64, _p, _p, _i64, _p]),
     "tarl_policy_obs16": (C.c_int, [_p, _i64, _p, _p, _i64, _i64, _i64, _i64, _p, _p]),
     "tarl_fused_obs16": (C.c_int, [_p, _p] + _STATE + [_p, _i64, _i64, _p, _p]),
+    "tarl_fused_obs16_bf16": (C.c_int, [_p, _p] + _STATE + [_p, _i64, _i64, _p, _p]),
+    "tarl_fused_obs16_rows": (C.c_int, [_p, _p] + _STATE + [_p, _i64, _i64, _p, _p, _i64, _p, _p]),
     "tarl_policy_edge_mlp_fwd": (C.c_int, [_p, _p, _i64, _p] + [_p] * 6 + [C.c_int, _p, _p]),
     "tarl_policy_edge_mlp_bwd_scratch_floats": (_i64, [_p, _i64]),
     "tarl_policy_edge_mlp_bwd": (C.c_int, [_p, _p, _i64, _p] + [_p] * 6 + [_p, _p] + [_p] * 6 + [_p]),

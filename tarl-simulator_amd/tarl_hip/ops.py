@@ -453,9 +453,44 @@ def fused_obs16(plan: Plan, fs, x, Nmax, agent_features, out=None):
     return obs
 
 
-def policy_edge_mlp(plan: Plan, obs16, ec: EdgeConst, w: EdgeMlpWeights, *, bf16=False, out=None):
-    """obs16 (M, N, 16) -> logits (M, E) of the per-edge MLP head (fp32 MFMA, or bf16 MFMA with ``bf16=True``)."""
+def fused_obs16_bf16(plan: Plan, fs, x, Nmax, agent_features, out=None):
+    """The packed state's observation rounded to bf16 (RNE): (B, N, 16) torch.bfloat16."""
     L = _lib.load()
+    B, N, bs, ldx = _state(x, Nmax)
+    A, abs_ = _agents(agent_features, B)
+    obs = out if out is not None else torch.empty((B, N, 16), dtype=torch.bfloat16, device=x.device)
+    _lib.check(L.tarl_fused_obs16_bf16(plan.handle, fs.ref, x.data_ptr(), B, bs, ldx, Nmax, agent_features.data_ptr(), A,
+                                       abs_, obs.data_ptr(), _lib.current_stream()))
+    return obs
+
+
+def fused_obs16_rows(plan: Plan, fs, x, Nmax, agent_features, env, slot, out):
+    """fp32 observation rows of a few environments: ``out[slot[j]] = obs[env[j]]`` (``out`` (K, N, 16), int32 lists)."""
+    L = _lib.load()
+    B, N, bs, ldx = _state(x, Nmax)
+    A, abs_ = _agents(agent_features, B)
+    _contig(env, torch.int32, "env")
+    _contig(slot, torch.int32, "slot")
+    _contig(out, torch.float32, "out")
+    _lib.check(L.tarl_fused_obs16_rows(plan.handle, fs.ref, x.data_ptr(), B, bs, ldx, Nmax, agent_features.data_ptr(), A,
+                                       abs_, env.data_ptr(), slot.data_ptr(), env.numel(), out.data_ptr(),
+                                       _lib.current_stream()))
+    return out
+
+
+def policy_edge_mlp(plan: Plan, obs16, ec: EdgeConst, w: EdgeMlpWeights, *, bf16=False, out=None):
+    """obs16 (M, N, 16) -> logits (M, E) of the per-edge MLP head (fp32 MFMA, or bf16 MFMA with ``bf16=True``);
+    ``obs16`` in torch.bfloat16 (fused_obs16_bf16) selects the bf16 MFMA kernel that reads bf16 observations."""
+    L = _lib.load()
+    if obs16.dtype == torch.bfloat16:
+        _contig(obs16, torch.bfloat16, "obs16")
+        if obs16.shape[1:] != (plan.num_nodes, 16):
+            raise ValueError("obs16 must be (M, num_nodes, 16)")
+        M = obs16.size(0)
+        logits = out if out is not None else torch.empty((M, plan.num_edges), dtype=torch.float32, device=obs16.device)
+        _lib.check(L.tarl_policy_edge_mlp_fwd(plan.handle, obs16.data_ptr(), M, ec.edge_attr.data_ptr(), *w.ptrs(), 2,
+                                              logits.data_ptr(), _lib.current_stream()))
+        return logits
     _contig(obs16, torch.float32, "obs16")
     M = obs16.size(0)
     if obs16.shape[1:] != (plan.num_nodes, 16):

@@ -93,6 +93,21 @@ def test_fused_obs16_matches_the_exported_state():
     ref = torch.cat((nf, torch.gather(eng.agents, 1, head.unsqueeze(-1).expand(B, N, 9))), dim=-1)
     assert torch.equal(obs, ref)
     assert float(obs[:, :, 1].sum()) > 0 and float(obs[:, :, 14].sum()) > 0   # counts and ON_WAY flags are live
+    # the bf16 observation (round to nearest even) and the fp32 rows of a few environments
+    ob = ops.fused_obs16_bf16(eng.plan, eng.fs, eng._x, eng.Nmax, eng.agents)
+    assert ob.dtype == torch.bfloat16 and torch.equal(ob, ref.to(torch.bfloat16))
+    env = torch.tensor([3, 0, 3], dtype=torch.int32, device="cuda")
+    slot = torch.tensor([1, 2, 0], dtype=torch.int32, device="cuda")
+    rows = ops.fused_obs16_rows(eng.plan, eng.fs, eng._x, eng.Nmax, eng.agents, env, slot,
+                                torch.zeros((3, N, 16), device="cuda"))
+    assert torch.equal(rows[1], ref[3]) and torch.equal(rows[2], ref[0]) and torch.equal(rows[0], ref[3])
+    # the bf16 MLP gives the same logits from either observation
+    from src.agents.mpnn_agent import MPNNPolicyNet
+    torch.manual_seed(2)
+    pol = MPNNPolicyNet(net.edge_index, N, None, device="cuda")
+    w = ops.EdgeMlpWeights(*(p.data for p in (pol.edge_mlp[0].weight, pol.edge_mlp[0].bias, pol.edge_mlp[2].weight,
+                                              pol.edge_mlp[2].bias, pol.edge_mlp[4].weight, pol.edge_mlp[4].bias)))
+    assert torch.equal(ops.policy_edge_mlp(eng.plan, obs, eng.ec, w, bf16=True), ops.policy_edge_mlp(eng.plan, ob, eng.ec, w))
 
 
 @pytest.mark.parametrize("bf16_rollout", [False, True])
