@@ -113,13 +113,17 @@ __global__ __launch_bounds__(FB) void k_pack_static(int64_t N, int64_t E, const 
                                                     int32_t* out_pad, int32_t* flags) {
   const int64_t i = (int64_t)blockIdx.x * FB + threadIdx.x;
   if (i < 4) {   // padding entries: any valid row, never used
-    in_rec[E + i] = InRec{0, (int32_t)INRANK_NONE, 0.0f, 0.0f};
+    in_rec[E + i] = InRec{0, (int32_t)INRANK_NONE, 0.0f, 0.0f, 0};
     out_pad[E + i] = 0;
   }
   if (i >= N) return;
   const float4 sti = st0[i];
   const int32_t a0 = in_ptr[i], a1 = in_ptr[i + 1], o0 = P.out_ptr[i], o1 = P.out_ptr[i + 1];
-  nodes[i] = NodeRec{a0, a1 - a0, o0, o1 - o0, sti.x, sti.y, sti.z, sti.w, entry_tt(sti, 0.0f)};
+  NodeRec nr{a0, a1 - a0, o0, o1 - o0, sti.x, sti.y, sti.z, sti.w, entry_tt(sti, 0.0f), {0, 0, 0}, {0, 0, 0, 0}, {}};
+  for (int q = 0; q < 4; ++q) {
+    nr.out4[q] = q < o1 - o0 ? P.out_dst[o0 + q] : (int32_t)i;
+    nr.in4[q] = InRec{0, (int32_t)INRANK_NONE, 0.0f, 0.0f, 0};
+  }
   for (int32_t k = o0; k < o1; ++k) out_pad[k] = P.out_dst[k];
   for (int32_t k = a0; k < a1; ++k) {
     const int32_t j = in_src[k];
@@ -134,8 +138,10 @@ __global__ __launch_bounds__(FB) void k_pack_static(int64_t N, int64_t E, const 
       atomicOr(flags, FLAG_AMBIGUOUS_EDGES);
       r = (int)INRANK_NONE;
     }
-    in_rec[k] = InRec{j, r, edge_attr ? edge_attr[in_eid[k]] : 0.0f, st0[j].x};
+    in_rec[k] = InRec{j, r, edge_attr ? edge_attr[in_eid[k]] : 0.0f, st0[j].x, in_eid[k]};
+    if (k - a0 < 4) nr.in4[k - a0] = in_rec[k];
   }
+  nodes[i] = nr;
 }
 
 __global__ __launch_bounds__(FB) void k_pack_agents(const float* __restrict__ ag, int64_t B, int64_t A,
@@ -443,7 +449,7 @@ __global__ __launch_bounds__(TILE) void k_fused_choice_all(const NodeRec* __rest
     uint32_t code;
     if (gi >= 0) {
       const float u = rng.uniform(pseed, pcounter0 + (uint64_t)t, (uint64_t)b * G + (uint64_t)gi);
-      const NodeRec nr = nodes[i];
+      const NodeRec& nr = nodes[i];
       const PRec* pr = ptab + nr.out0;
       bool found = false;
       long long lpn = 0;
@@ -537,7 +543,7 @@ __device__ __forceinline__ bool edge_admissible(uint32_t cj, int32_t rk, const f
 // wave-uniform and must compile to SCALAR loads (through a struct member the compiler has to assume they alias the post
 // stores and falls back to dependent vector loads — measured: 48 -> 85 us per launch).
 template <int NCH>
-__global__ __launch_bounds__(TILE) void k_fused_direction(
+__global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fused_direction(
     const NodeRec* __restrict__ nodes, const InRec* __restrict__ in_rec, const int32_t* __restrict__ in_eid,
     const float* __restrict__ log_edge_attr, const uint2* __restrict__ hdp, const uint32_t* __restrict__ tl,
     const uint2* __restrict__ rec1, const uint8_t* __restrict__ sel8, const float* __restrict__ sel_raw,
@@ -565,7 +571,7 @@ __global__ __launch_bounds__(TILE) void k_fused_direction(
       const uint32_t row = i * B + b;
       me[r] = hdp[row];
       tlw[r] = tl[row];
-      const InRec* ir = in_rec + nodes[i].in0;   // four records from consecutive addresses (padded array)
+      const InRec* ir = nodes[i].in4;   // the first four in-edge records travel in the node record
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const uint32_t jrow = (uint32_t)ir[q].src * B + b;
@@ -578,7 +584,8 @@ __global__ __launch_bounds__(TILE) void k_fused_direction(
       const uint32_t i = i0 + r;   // i, and everything indexed by it alone, is wave-uniform
       if (i < N) {
         const uint32_t row = i * B + b;
-        const NodeRec nr = nodes[i];
+        const NodeRec& nr = nodes[i];
+        const InRec* ir4 = nr.in4;
         const InRec* ir = in_rec + nr.in0;
         const float max_i = nr.maxn, n_i = (float)(me[r].x & 255u), road_i = nr.road;
         float P = 0.0f;
@@ -586,9 +593,9 @@ __global__ __launch_bounds__(TILE) void k_fused_direction(
         for (int q = 0; q < 4; ++q) {
           if (q < nr.in_deg) {   // wave-uniform
             raw_seen = raw_seen || (cj[r][q] == SEL_RAW);
-            const bool m = edge_admissible<false>(cj[r][q], ir[q].rank, sel_raw, 0, hj[r][q], ir[q].max_src, road_i, n_i,
+            const bool m = edge_admissible<false>(cj[r][q], ir4[q].rank, sel_raw, 0, hj[r][q], ir4[q].max_src, road_i, n_i,
                                                   max_i, t);
-            P = P + ir[q].ea * (m ? 1.0f : 0.0f);
+            P = P + ir4[q].ea * (m ? 1.0f : 0.0f);
           }
         }
         for (int32_t q = 4; q < nr.in_deg; ++q) {   // in-degree above four: the rest one by one
@@ -621,7 +628,7 @@ __global__ __launch_bounds__(TILE) void k_fused_direction(
       for (uint32_t i = i0; i < i0 + NCH && i < N; ++i) {
         const uint32_t row = i * B + b;
         const uint2 mw = hdp[row];
-        const NodeRec nr = nodes[i];
+        const NodeRec& nr = nodes[i];
         const InRec* ir = in_rec + nr.in0;
         const float max_i = nr.maxn, n_i = (float)(mw.x & 255u), road_i = nr.road;
         float P = 0.0f;
@@ -652,32 +659,52 @@ __global__ __launch_bounds__(TILE) void k_fused_direction(
     const uint32_t bb = blockIdx.x * blockDim.x + (item % TILE);
     const uint32_t row = i * B + bb;
     const uint2 mw = hdp[row];
-    const NodeRec nr = nodes[i];
-    const InRec* ir = in_rec + nr.in0;
+    const NodeRec& nr = nodes[i];
+    const int32_t in0 = nr.in0, in_deg = nr.in_deg;
     const float max_i = nr.maxn, n_i = (float)(mw.x & 255u), road_i = nr.road;
     float P = 0.0f, best = -FLT_MAX;
     uint32_t best_id = 0u;
     PhiloxRun rng;
-    for (int32_t q = 0; q < nr.in_deg; ++q) {
-      const int32_t k = nr.in0 + q;
-      const int32_t e = in_eid[k];
-      const uint32_t jrow = (uint32_t)ir[q].src * B + bb;
-      const uint2 hx = hdp[jrow];
-      const bool m = edge_admissible<true>(sel8[jrow] & 0x7Fu, ir[q].rank, sel_raw, jrow, hx, ir[q].max_src, road_i, n_i,
-                                           max_i, t);
-      P = P + ir[q].ea * (m ? 1.0f : 0.0f);
+    // the first four in-edges: their records travel in the node record, so the gathers (upstream words, edge constant)
+    // are ONE dependent round behind the list entry; all four are requested before the first is used
+    InRec rc4[4];
+    uint2 hx4[4];
+    uint32_t cx4[4];
+    float le4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rc4[q] = nr.in4[q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t jrow = (uint32_t)rc4[q].src * B + bb;     // beyond in_deg: row 0 (valid, ignored)
+      hx4[q] = hdp[jrow];
+      cx4[q] = sel8[jrow] & 0x7Fu;
+      le4[q] = log_edge_attr[rc4[q].eid];
+    }
+    auto race = [&](int32_t q, const InRec& rc, const uint2 hx, const uint32_t cx, const float le) {
+      const int32_t k = in0 + q;
+      const uint32_t jrow = (uint32_t)rc.src * B + bb;
+      const bool m = edge_admissible<true>(cx, rc.rank, sel_raw, jrow, hx, rc.max_src, road_i, n_i, max_i, t);
+      P = P + rc.ea * (m ? 1.0f : 0.0f);
       float g;
       if (gumbel) {
-        g = gumbel[(int64_t)bb * E + e];
+        g = gumbel[(int64_t)bb * E + rc.eid];
       } else {
         const float u = rng.uniform(seed, counter, (uint64_t)bb * E + (uint64_t)k);
         g = gumbel_from_u01(u);
       }
-      const float score = (m ? log_edge_attr[e] : log_eps) + g;
+      const float score = (m ? le : log_eps) + g;
       if (score > best) {
         best = score;
         best_id = hx.x >> 8;
       }
+    };
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (q < in_deg) race(q, rc4[q], hx4[q], cx4[q], le4[q]);
+    for (int32_t q = 4; q < in_deg; ++q) {
+      const InRec rc = in_rec[in0 + q];
+      const uint32_t jrow = (uint32_t)rc.src * B + bb;
+      race(q, rc, hdp[jrow], sel8[jrow] & 0x7Fu, log_edge_attr[rc.eid]);
     }
     const uint32_t who = (P > 0.0f) ? best_id : 0u;
     if (who != 0u) post[row] = (who << 8) | PF_NONEMPTY | PF_ARRIVED;
@@ -697,7 +724,7 @@ struct RowHead {      // what phase A derives from a row's dense words and hands
 };
 
 // phase A of one row: returns true when the row is an event row (nothing written), false when it was idle (words written)
-__device__ __forceinline__ bool row_phase_a(uint32_t i, uint32_t b, const NodeRec nr, const uint32_t* __restrict__ post,
+__device__ __forceinline__ bool row_phase_a(uint32_t i, uint32_t b, const NodeRec& nr, const uint32_t* __restrict__ post,
                                             uint32_t pa, uint2 hp, uint32_t tlw, const uint32_t (&pj4)[4], int Nmax,
                                             uint32_t B, uint32_t N, const FusedBufs& fb, int64_t A, float t,
                                             const FrameOut& out, bool* pop_out, float* n_out) {
@@ -744,7 +771,7 @@ __device__ __forceinline__ bool row_phase_a(uint32_t i, uint32_t b, const NodeRe
 // phase B of one EVENT row (its dense words travel with the list entry): Direction update on the slot store,
 // Response pop, withdraw, refreshed dense words + event word. -> {count after the pass, agents withdrawn}
 __device__ __forceinline__ float2 row_phase_b(uint32_t i, uint32_t b, bool pop, uint32_t pa, uint2 hp, uint32_t tlw,
-                                              const NodeRec nr, const int32_t* __restrict__ out_ptr,
+                                              const NodeRec& nr, const int32_t* __restrict__ out_ptr,
                                               const int32_t* __restrict__ out_dst, int Nmax, uint32_t B, uint32_t N,
                                               const FusedBufs& fb, float* __restrict__ ag, int64_t A, int64_t a_bstride,
                                               float t, const FrameOut& out) {
@@ -897,7 +924,7 @@ __global__ __launch_bounds__(TILE) void k_fused_rows(const NodeRec* __restrict__
       pa[r] = post[row];
       hp[r] = fb.hdp[row];
       tlw[r] = fb.tl[row];
-      const int32_t* od = out_pad + nodes[i].out0;   // four targets from consecutive addresses (padded array)
+      const int32_t* od = nodes[i].out4;   // the first four targets travel in the node record
 #pragma unroll
       for (int q = 0; q < 4; ++q) pj[r][q] = post[(uint32_t)od[q] * B + b];
     }

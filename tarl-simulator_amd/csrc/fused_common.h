@@ -51,18 +51,28 @@
 // and ONE base address per row give the hot kernels everything static they need: a row's in-edge records and out-edge
 // targets are contiguous (CSC / CSR), so four of them are fetched from consecutive addresses without per-edge index
 // chains (the arrays are padded by four entries: a row with fewer edges reads its successors' and ignores them).
-struct __attribute__((aligned(4))) NodeRec {
-  int32_t in0, in_deg;      // CSC range of the row's in-edges
-  int32_t out0, out_deg;    // CSR range of its out-edges
-  float maxn, ff, road, cong;   // = st0
-  float tt0;                    // travel time assigned at count 0: an empty row's garbage head departs at t + tt0
-};
 struct __attribute__((aligned(4))) InRec {
   int32_t src;      // upstream row
   int32_t rank;     // sel8 rank of src that heads for this row (INRANK_NONE: none)
   float ea;         // turn probability edge_attr[eid]
   float max_src;    // MAX_NUMBER_OF_AGENT of src
+  int32_t eid;      // the edge's id in the caller's edge order (index of log_edge_attr / gumbel / delta_travel_time)
 };
+// 144 bytes per node. The first four out-edge targets and in-edge records sit IN the node record: one address (a function
+// of the node id alone) reaches them, where out_pad[out0 + q] / in_rec[in0 + q] need the record first — one dependent
+// scalar round trip less at the head of every wave of the row pass and of the Direction gather.
+struct __attribute__((aligned(16))) NodeRec {
+  int32_t in0, in_deg;      // CSC range of the row's in-edges
+  int32_t out0, out_deg;    // CSR range of its out-edges
+  float maxn, ff, road, cong;   // = st0
+  float tt0;                    // travel time assigned at count 0: an empty row's garbage head departs at t + tt0
+  int32_t pad_[3];
+  int32_t out4[4];          // out_pad[out0 .. out0 + 3] (beyond out_deg: the node itself, ignored by the readers)
+  InRec in4[4];             // in_rec[in0 .. in0 + 3]   (beyond in_deg: {0, INRANK_NONE, 0, 0})
+};
+#define NODE_REC_WORDS 36
+#define IN_REC_WORDS 5
+static_assert(sizeof(NodeRec) == NODE_REC_WORDS * 4 && sizeof(InRec) == IN_REC_WORDS * 4, "record sizes are part of the buffer contract (tarl_hip/ops.py: FusedState)");
 
 struct FusedBufs {
   uint2* hdp;           // [N][B]

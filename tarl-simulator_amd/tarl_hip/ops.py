@@ -654,8 +654,8 @@ class FusedState:
         self.st0 = torch.zeros((N, 4), **f32)
         self.sel8 = torch.zeros((N, B), dtype=torch.uint8, device=device)
         self.sel = torch.zeros((N, B), **f32)
-        self.node_rec = torch.zeros((N, 9), **i32)           # static records (fused_common.h: NodeRec / InRec)
-        self.in_rec = torch.zeros((E + 4, 4), **i32)
+        self.node_rec = torch.zeros((N, 36), **i32)          # static records (fused_common.h: NodeRec / InRec)
+        self.in_rec = torch.zeros((E + 4, 5), **i32)
         self.out_pad = torch.zeros(E + 4, **i32)
         self.acc_slots = 32      # accumulator banks (spread the per-environment atomics of the N/chunk workgroups)
         self.acc_lp = torch.zeros((self.acc_slots, B), dtype=torch.int64, device=device)
