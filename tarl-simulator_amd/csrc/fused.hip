@@ -977,6 +977,32 @@ __device__ __forceinline__ bool fused_target(const FusedBufs& fb, PlanOut P, con
   return room > 0;
 }
 
+// The same test with the words the admission phase needs afterwards: the target row's count word and tail word come back
+// with it (they are stashed beside the candidate, so that phase reads nothing dynamic again), and a rank below four
+// resolves through the origin's node record (one round: the record and the SELECTED_ROAD byte travel together)
+// instead of out_ptr -> out_dst (two).
+__device__ __forceinline__ bool fused_target_words(const FusedBufs& fb, PlanOut P, const uint8_t* __restrict__ sel8,
+                                                   int64_t b, int64_t B, int64_t N, int32_t origin, int32_t* road,
+                                                   uint32_t* hd_out, uint32_t* tl_out) {
+  if (origin < 0 || origin >= N) return false;
+  const int64_t orow = (int64_t)origin * B + b;
+  const uint32_t c = sel8[orow] & 0x7Fu;
+  const int32_t* o4 = fb.nodes[origin].out4;
+  const int32_t t0 = o4[0], t1 = o4[1], t2 = o4[2], t3 = o4[3];
+  long long r;
+  if (c < 4u)
+    r = (long long)(float)(c == 0u ? t0 : (c == 1u ? t1 : (c == 2u ? t2 : t3)));
+  else
+    r = (long long)(c == SEL_RAW ? fb.sel[orow] : (float)P.out_dst[P.out_ptr[origin] + (int32_t)c]);
+  if (r < 0 || r >= N) return false;
+  const uint32_t hd = fb.hdp[r * B + b].x;
+  *tl_out = fb.tl[r * B + b];
+  const long long room = (long long)(fb.st0[r].x - TARL_CONGESTION_FILE - (float)(hd & 255u));
+  *road = (int32_t)r;
+  *hd_out = hd;
+  return room > 0;
+}
+
 __device__ __forceinline__ void fused_insert_body(int64_t b, int Nmax, int64_t B, int64_t N, FusedBufs fb, PlanOut P,
                                                   const uint8_t* __restrict__ sel8, float* __restrict__ ag, int64_t A,
                                                   int64_t a_bstride, int use_cong, float t,
@@ -988,6 +1014,9 @@ __device__ __forceinline__ void fused_insert_body(int64_t b, int Nmax, int64_t B
   __shared__ int32_t s_adm;
   __shared__ int32_t s_lo;
   __shared__ int32_t s_un_agent[INS_CAP], s_un_road[INS_CAP];
+  // window path: the candidate's position in the departure order and its target row's count / tail words
+  __shared__ int32_t s_un_k[INS_CAP];
+  __shared__ uint32_t s_un_hd[INS_CAP], s_un_tl[INS_CAP];
   float* agb = ag + b * a_bstride;
   int32_t* cand_agent = scratch + b * 2 * A;
   int32_t* cand_road = cand_agent + A;
@@ -1000,6 +1029,20 @@ __device__ __forceinline__ void fused_insert_body(int64_t b, int Nmax, int64_t B
   if (tid == 0) {
     s_cnt = 0;
     s_adm = 0;
+  }
+  // the frame's accumulator banks (filled by the choice kernel and the row pass, complete before this launch) depend on
+  // nothing below: they are requested first and reduced last
+  long long lpf = 0;
+  float nf = 0.0f, wf = 0.0f;
+  if (wid == 0) {
+    for (int64_t sl_ = lane; sl_ < fb.acc_slots; sl_ += 64) {
+      lpf += fb.acc_lp[sl_ * B + b];
+      nf += fb.acc_n[sl_ * B + b];
+      wf += fb.acc_w[sl_ * B + b];
+      fb.acc_lp[sl_ * B + b] = 0;
+      fb.acc_n[sl_ * B + b] = 0.0f;
+      fb.acc_w[sl_ * B + b] = 0.0f;
+    }
   }
   __syncthreads();
   if (fb.a_order) {
@@ -1034,7 +1077,19 @@ __device__ __forceinline__ void fused_insert_body(int64_t b, int Nmax, int64_t B
         } else if (waiting) {
           atomicMin(&s_lo, (int32_t)k);
           int32_t road = 0, cap = 0;
-          if (fused_target(fb, P, sel8, b, B, N, origin, &road, &cap)) {
+          if (fb.a_win) {
+            uint32_t hdw = 0u, tlw = 0u;
+            if (fused_target_words(fb, P, sel8, b, B, N, origin, &road, &hdw, &tlw)) {
+              const int32_t pos = atomicAdd(&s_cnt, 1);
+              if (pos < INS_CAP) {
+                s_un_agent[pos] = a;
+                s_un_road[pos] = road;
+                s_un_k[pos] = (int32_t)k;
+                s_un_hd[pos] = hdw;
+                s_un_tl[pos] = tlw;
+              }
+            }
+          } else if (fused_target(fb, P, sel8, b, B, N, origin, &road, &cap)) {
             const int32_t pos = atomicAdd(&s_cnt, 1);
             if (pos < INS_CAP) {
               s_un_agent[pos] = a;
@@ -1075,6 +1130,60 @@ __device__ __forceinline__ void fused_insert_body(int64_t b, int Nmax, int64_t B
   }
   __syncthreads();
   int32_t Lc = s_cnt;
+  const bool stashed = fb.a_order && fb.a_win && Lc <= INS_CAP;
+  if (stashed) {
+    // Admission straight from the LDS list: a candidate's rank on its road is the number of candidates for the same road
+    // with a smaller agent id (the reference admits in stable agent-id order), so the list needs no sorting, and the
+    // target row's words were stashed with it: nothing dynamic is read here. The rank-0 candidate of a road owns its
+    // count word (the head too when the road was empty), event word and count outputs; the last admitted owns the tail.
+    for (int32_t idx = tid; idx < Lc; idx += INSB) {
+      const int32_t r = s_un_road[idx];
+      const int32_t a = s_un_agent[idx];
+      int32_t rank = 0, total = 0;
+      for (int32_t k = 0; k < Lc; ++k) {
+        const bool same = s_un_road[k] == r;
+        total += same ? 1 : 0;
+        rank += (same && s_un_agent[k] < a) ? 1 : 0;
+      }
+      const int64_t rrow = (int64_t)r * B + b;
+      const float4 str = fb.st0[r];
+      const uint32_t hd = s_un_hd[idx];
+      const uint32_t n0i = hd & 255u;
+      const float n0 = (float)n0i;
+      const long long cap = (long long)(str.x - TARL_CONGESTION_FILE - n0);
+      if (rank < cap) {
+        const long long m = total < cap ? total : cap;  // arrivals admitted on this road
+        const long long slot = (long long)n0i + rank;
+        const float t_cong = use_cong ? str.w / (str.x + 10.0f - n0) : 0.0f;
+        const float tt = (t_cong != t_cong) ? t_cong : fmaxf(str.y, t_cong);
+        const int hoff = tl_hoff(s_un_tl[idx]);
+        if (slot >= 0 && slot < Nmax) {
+          float* sr = fb.slots + rrow * fb.lds + 3 * phys(hoff, (int)slot, Nmax);
+          sr[0] = (float)a;
+          sr[1] = t;
+          sr[2] = t + tt;
+        }
+        agb[(int64_t)a * AG_COLS + AG_ON_WAY] = 1.0f;
+        fb.a_status[b * A + a] = 1;
+        fb.a_ins[b * A + s_un_k[idx]] = 1;
+        if (rank == m - 1) fb.tl[rrow] = tl_word((uint32_t)a, hoff, TLF_AUTH);  // new tail; rec1 authoritative from here on
+        if (rank == 0) {
+          const uint32_t cnt = n0i + (uint32_t)m;      // n0 + m <= MAX - 3 < 255
+          if (n0i == 0u) {   // new head: id + departure, arrival
+            fb.hdp[rrow] = make_uint2(((uint32_t)a << 8) | cnt, __float_as_uint(t + tt));
+            fb.rec1[rrow] = make_uint2(__float_as_uint(t), r1_code(-1));
+          } else {
+            fb.hdp[rrow].x = hd + (uint32_t)m;
+            fb.rec1[rrow].y = r1_code(-1);   // the arrivals overwrote a pending garbage slot: none pending now
+          }
+          if (out.counts8) out.counts8[rrow] = (uint8_t)cnt;
+          if (out.countsf) out.countsf[rrow] = (float)cnt;
+          atomicAdd(&s_adm, (int32_t)m);
+        }
+      }
+    }
+    __syncthreads();
+  } else {
   if (Lc <= INS_CAP) {
     for (int32_t idx = tid; idx < Lc; idx += INSB) {
       const int32_t a = s_un_agent[idx];
@@ -1174,18 +1283,9 @@ __device__ __forceinline__ void fused_insert_body(int64_t b, int Nmax, int64_t B
     }
   }
   __syncthreads();
-  // phase 4: the frame's accumulator banks (filled by the choice kernel and the row pass) -> reward, log-prob; re-arm
+  }
+  // phase 4: the frame's accumulator banks (requested at the top) -> reward, log-prob
   if (wid == 0) {
-    long long lpf = 0;
-    float nf = 0.0f, wf = 0.0f;
-    for (int64_t sl_ = lane; sl_ < fb.acc_slots; sl_ += 64) {
-      lpf += fb.acc_lp[sl_ * B + b];
-      nf += fb.acc_n[sl_ * B + b];
-      wf += fb.acc_w[sl_ * B + b];
-      fb.acc_lp[sl_ * B + b] = 0;
-      fb.acc_n[sl_ * B + b] = 0.0f;
-      fb.acc_w[sl_ * B + b] = 0.0f;
-    }
     for (int off = 32; off > 0; off >>= 1) {
       lpf += __shfl_down(lpf, off);
       nf += __shfl_down(nf, off);      // sums of small integers: exact in fp32 in any order
