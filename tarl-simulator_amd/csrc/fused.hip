@@ -903,15 +903,16 @@ __global__ __launch_bounds__(TILE) void k_fused_rows(const NodeRec* __restrict__
                                                      FusedBufs fb, float* __restrict__ ag, int64_t A, int64_t a_bstride,
                                                      float t, FrameOut out) {
   __shared__ int32_t s_cnt;
-  __shared__ uint16_t s_item[TILE * NCH];   // (row offset in the chunk) << 9 | pop << 8 | lane
-  __shared__ uint4 s_words[TILE * NCH];     // the listed row's {post word, hd, head_dep bits, tl}
-  __shared__ float s_nsum[TILE], s_wsum[TILE];
+  // the event list holds EV_CAP of the TILE * NCH pairs (a filling network lists ~10 %); a pair that finds it full runs its
+  // event path in place. 7 KB instead of 18: the workgroups a CU holds are bounded by its wave slots, not by LDS, and
+  // the waves that have no list entry leave early
+  constexpr int EV_CAP = 384;
+  __shared__ uint16_t s_item[EV_CAP];       // (row offset in the chunk) << 9 | pop << 8 | lane
+  __shared__ uint4 s_words[EV_CAP];         // the listed row's {post word, hd, head_dep bits, tl}
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = b < B;
   const uint32_t i0 = blockIdx.y * NCH;
   if (threadIdx.x == 0) s_cnt = 0;
-  s_nsum[threadIdx.x] = 0.0f;
-  s_wsum[threadIdx.x] = 0.0f;
   __syncthreads();
   float nsum = 0.0f;
   if (valid) {
@@ -935,31 +936,35 @@ __global__ __launch_bounds__(TILE) void k_fused_rows(const NodeRec* __restrict__
         float n = 0.0f;
         if (row_phase_a(i0 + r, b, nodes[i0 + r], post, pa[r], hp[r], tlw[r], pj[r], Nmax, B, N, fb, A, t, out, &pop, &n)) {
           const int32_t pos = atomicAdd(&s_cnt, 1);
-          s_item[pos] = (uint16_t)((r << 9) | (pop ? 256 : 0) | threadIdx.x);
-          s_words[pos] = make_uint4(pa[r], hp[r].x, hp[r].y, tlw[r]);
+          if (pos < EV_CAP) {
+            s_item[pos] = (uint16_t)((r << 9) | (pop ? 256 : 0) | threadIdx.x);
+            s_words[pos] = make_uint4(pa[r], hp[r].x, hp[r].y, tlw[r]);
+          } else {
+            const float2 nc = row_phase_b(i0 + r, b, pop, pa[r], hp[r], tlw[r], nodes[i0 + r], out_ptr, out_dst, Nmax, B, N,
+                                          fb, ag, A, a_bstride, t, out);
+            nsum += nc.x;
+            if (nc.y != 0.0f) atomicAdd(&fb.acc_w[(int64_t)(blockIdx.y % (unsigned)fb.acc_slots) * B + b], nc.y);
+          }
         } else {
           nsum += n;
         }
       }
   }
+  // idle rows' share of the environment's count sum goes out now: a wave without a list entry is done after the barrier
+  // (its slots go to the next workgroup while the event path, a chain of dependent loads a few lanes wide, runs on)
+  const int64_t bank0 = (int64_t)(blockIdx.y % (unsigned)fb.acc_slots) * B;
+  if (valid && nsum != 0.0f) atomicAdd(&fb.acc_n[bank0 + b], nsum);
   __syncthreads();
-  const int32_t cnt = s_cnt;
+  const int32_t cnt = s_cnt < EV_CAP ? s_cnt : EV_CAP;
   for (int32_t idx = threadIdx.x; idx < cnt; idx += blockDim.x) {
     const uint32_t item = s_item[idx];
     const uint32_t r = item >> 9, lane2 = item & 255u;
     const uint4 wd = s_words[idx];
-    const float2 nc = row_phase_b(i0 + r, blockIdx.x * blockDim.x + lane2, (item & 256u) != 0u, wd.x,
-                                  make_uint2(wd.y, wd.z), wd.w, nodes[i0 + r], out_ptr, out_dst, Nmax, B, N, fb, ag, A,
-                                  a_bstride, t, out);
-    atomicAdd(&s_nsum[lane2], nc.x);     // small integers: exact in fp32 in any order
-    if (nc.y != 0.0f) atomicAdd(&s_wsum[lane2], nc.y);
-  }
-  __syncthreads();
-  if (valid) {
-    const int64_t bank = (int64_t)(blockIdx.y % (unsigned)fb.acc_slots) * B + b;
-    atomicAdd(&fb.acc_n[bank], nsum + s_nsum[threadIdx.x]);
-    const float ws = s_wsum[threadIdx.x];
-    if (ws != 0.0f) atomicAdd(&fb.acc_w[bank], ws);
+    const uint32_t b2 = blockIdx.x * blockDim.x + lane2;
+    const float2 nc = row_phase_b(i0 + r, b2, (item & 256u) != 0u, wd.x, make_uint2(wd.y, wd.z), wd.w, nodes[i0 + r],
+                                  out_ptr, out_dst, Nmax, B, N, fb, ag, A, a_bstride, t, out);
+    if (nc.x != 0.0f) atomicAdd(&fb.acc_n[bank0 + b2], nc.x);     // small integers: exact in fp32 in any order
+    if (nc.y != 0.0f) atomicAdd(&fb.acc_w[bank0 + b2], nc.y);
   }
 }
 
