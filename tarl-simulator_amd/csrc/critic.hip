@@ -315,10 +315,13 @@ __global__ __launch_bounds__(CR_THREADS) void k_critic_fwd_slab(const XT* __rest
 // with every product exact (8-bit count x 8-bit piece) and fp32 accumulation: the same value as the fp32 chain up to the
 // order of the fp32 additions (~1e-7 relative; contract 1e-4), at 16x the MFMA rate per piece. The pass then runs at HBM
 // speed on 1 byte per (frame, node, environment) instead of at the fp32-MFMA rate on 4.
-// Orientation: D^T = W X^T, so that the count bytes are the B operand straight from their k-major ([node][env]) layout —
-// no transpose in LDS: lane (col = env, half h) reads its 8 bytes Xs[8h + j][env]; A = the weight pieces, k-contiguous.
+// Orientation: D^T = W X^T: the count bytes are the B operand — lane (col = env, half h) wants the 8 bytes
+// X^T[k = 8h .. 8h+7][env], i.e. 8 consecutive k of ONE environment, while memory (and a straight copy of it in LDS) is
+// env-contiguous per k. The staging therefore transposes 4 x 4 byte blocks in registers on the way in (a thread loads 4
+// environments of 4 consecutive k, writes 4 dwords [env][4 k]): the fragment is then two dword reads instead of eight
+// byte reads per k-step. A = the weight pieces, k-contiguous.
 typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
-#define CB_XLD 144     // bytes per k-row of the X stage (128 envs + pad, 16-byte aligned)
+#define CB_XLD 36      // bytes per ENVIRONMENT row of the transposed X stage (32 k + 4 pad: odd dword stride, conflict-free)
 #define CB_WLD 40      // bf16 per j-row of a W stage (32 k + pad): 80-byte rows, 16-byte aligned
 
 __device__ __forceinline__ uint16_t cr_bf16_rne(float f) {
@@ -350,56 +353,72 @@ __global__ __launch_bounds__(CR_THREADS) void k_critic_fwd_slab_u8x3(const uint8
                                                                      int64_t rows_per_time,
                                                                      const uint16_t* __restrict__ w3, CriticParams P,
                                                                      float* __restrict__ value) {
-  // staging: 2 x (Xs [32][144] bytes + Wb [3][64][40] bf16); the epilogue reuses the space as Hs [64][129] + W2s [64][65] f32
+  // staging: 2 x (Xs [128 envs][36] bytes + Wb [3][64][40] bf16); the epilogue reuses the space as Hs [64][129] + W2s [64][65] f32
   __shared__ __attribute__((aligned(16))) uint8_t lds_raw[(CR_H * (CR_BM + 1) + CR_H * (CR_H + 1)) * 4];
-  const int XB = CR_BK * CB_XLD, WB = 3 * CR_H * CB_WLD * 2, BUF = XB + WB;   // bytes
-  static_assert(2 * (CR_BK * CB_XLD + 3 * CR_H * CB_WLD * 2) <= (CR_H * (CR_BM + 1) + CR_H * (CR_H + 1)) * 4, "LDS plan");
+  const int XB = CR_BM * CB_XLD, WB = 3 * CR_H * CB_WLD * 2, BUF = XB + WB;   // bytes
+  static_assert(2 * (CR_BM * CB_XLD + 3 * CR_H * CB_WLD * 2) <= (CR_H * (CR_BM + 1) + CR_H * (CR_H + 1)) * 4, "LDS plan");
+  static_assert(CR_BK == 32 && CR_BM == 128 && CR_THREADS == 256 && (CR_BM * CB_XLD) % 16 == 0, "X staging plan");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t row0 = (int64_t)blockIdx.x * CR_BM;
   const int64_t ldw = N + 1;
   const uint8_t* xbase = counts + (row0 / rps) * (N * rps) + (row0 % rps);   // element (env r, node k) at xbase[k * rps + r]
   const int64_t WP = CR_H * Kpad;      // one weight piece
 
-  uint4 xr;            // 16 count bytes: k = tid >> 3, envs 16 * (tid & 7) ..
-  uint4 wr[3];         // 8 bf16 of each piece: j = tid >> 2, k = 8 * (tid & 3) ..
-  auto fetch = [&](int64_t k0) {
-    const int k = tid >> 3, seg = tid & 7;
-    xr = (k0 + k < N) ? *reinterpret_cast<const uint4*>(xbase + (k0 + k) * rps + seg * 16) : make_uint4(0u, 0u, 0u, 0u);
+  // Two register stages: the tile of iteration i + 2 is requested while tile i is multiplied and tile i + 1 (requested one
+  // iteration earlier) is written to LDS — an iteration is 12 MFMAs (~0.2 us), far less than a load's round trip, so one
+  // tile ahead left the matrix cores waiting. Loads are unconditional (a k past the end re-reads the last row: its weight
+  // pieces are zero padding; a tile past the end re-reads the last tile): no divergent control flow, exact wait counts.
+  struct Stage {
+    uint32_t xr[4];    // 4 environments (4 * (tid & 31) ..) of 4 consecutive k (4 * (tid >> 5) ..)
+    uint4 wr[3];       // 8 bf16 of each piece: j = tid >> 2, k = 8 * (tid & 3) ..
+  };
+  const int64_t NIT = (N + CR_BK - 1) / CR_BK;
+  auto fetch = [&](Stage& st, int64_t it) {
+    const int64_t k0 = (it < NIT ? it : NIT - 1) * CR_BK;
+    const int kg = tid >> 5, eg = tid & 31;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t k = k0 + 4 * kg + i;
+      st.xr[i] = *reinterpret_cast<const uint32_t*>(xbase + (k < N ? k : N - 1) * rps + 4 * eg);
+    }
     const int j = tid >> 2, q = tid & 3;
 #pragma unroll
-    for (int pc = 0; pc < 3; ++pc) wr[pc] = *reinterpret_cast<const uint4*>(w3 + pc * WP + (int64_t)j * Kpad + k0 + 8 * q);
+    for (int pc = 0; pc < 3; ++pc)
+      st.wr[pc] = *reinterpret_cast<const uint4*>(w3 + pc * WP + (int64_t)j * Kpad + k0 + 8 * q);
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](const Stage& st, int buf) {
     uint8_t* Xs = lds_raw + buf * BUF;
     uint16_t* Wb = reinterpret_cast<uint16_t*>(Xs + XB);
-    const int k = tid >> 3, seg = tid & 7;
-    *reinterpret_cast<uint4*>(Xs + k * CB_XLD + seg * 16) = xr;
+    const int kg = tid >> 5, eg = tid & 31;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {      // byte e of the four k-rows -> one dword [env 4 eg + e][k 4 kg .. 4 kg + 3]
+      const uint32_t v = ((st.xr[0] >> (8 * e)) & 0xFFu) | (((st.xr[1] >> (8 * e)) & 0xFFu) << 8) |
+                         (((st.xr[2] >> (8 * e)) & 0xFFu) << 16) | (((st.xr[3] >> (8 * e)) & 0xFFu) << 24);
+      *reinterpret_cast<uint32_t*>(Xs + (4 * eg + e) * CB_XLD + 4 * kg) = v;
+    }
     const int j = tid >> 2, q = tid & 3;
 #pragma unroll
-    for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<uint4*>(Wb + (pc * CR_H + j) * CB_WLD + 8 * q) = wr[pc];
+    for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<uint4*>(Wb + (pc * CR_H + j) * CB_WLD + 8 * q) = st.wr[pc];
   };
 
   f32x16 acc0 = {0}, acc1 = {0};     // D^T: rows j (0..31 / 32..63), cols = this wave's 32 environments
   const int r32 = lane & 31, h8 = (lane >> 5) * 8;
-  fetch(0);
-  stash(0);
-  __syncthreads();
-  int buf = 0;
-  for (int64_t k0 = 0; k0 < N; k0 += CR_BK) {
-    const bool more = k0 + CR_BK < N;
-    if (more) fetch(k0 + CR_BK);             // global loads in flight during the MFMAs below
+  auto multiply = [&](int buf) {
     const uint8_t* Xs = lds_raw + buf * BUF;
     const uint16_t* Wb = reinterpret_cast<const uint16_t*>(Xs + XB);
 #pragma unroll
     for (int s = 0; s < CR_BK / 16; ++s) {
       // B fragment: lane (col r32 = env, half h) holds X^T[k = 16 s + 8 h + j][env], j = 0..7: small integers, exact in bf16
-      cbf16x8 bx;
-      uint16_t* bxp = reinterpret_cast<uint16_t*>(&bx);
+      const uint32_t* xw = reinterpret_cast<const uint32_t*>(Xs + (wave * 32 + r32) * CB_XLD + 16 * s + h8);
+      const uint32_t x0 = xw[0], x1 = xw[1];
+      uint32_t bw[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float c = (float)Xs[(16 * s + h8 + j) * CB_XLD + wave * 32 + r32];
-        bxp[j] = (uint16_t)(__float_as_uint(c) >> 16);
+      for (int j = 0; j < 4; ++j) {      // two counts -> two bf16 (the top halves of their fp32 images: exact below 256)
+        const uint32_t xs = j < 2 ? x0 : x1;
+        const float c0 = (float)((xs >> (16 * (j & 1))) & 0xFFu), c1 = (float)((xs >> (16 * (j & 1) + 8)) & 0xFFu);
+        bw[j] = (__float_as_uint(c0) >> 16) | (__float_as_uint(c1) & 0xFFFF0000u);
       }
+      const cbf16x8 bx = __builtin_bit_cast(cbf16x8, bw);
 #pragma unroll
       for (int pc = 0; pc < 3; ++pc) {
         const cbf16x8 a0 = *reinterpret_cast<const cbf16x8*>(Wb + (pc * CR_H + r32) * CB_WLD + 16 * s + h8);
@@ -408,9 +427,21 @@ __global__ __launch_bounds__(CR_THREADS) void k_critic_fwd_slab_u8x3(const uint8
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bx, acc1, 0, 0, 0);
       }
     }
-    if (more) stash(buf ^ 1);                // the other buffer: nobody reads it in this iteration
+  };
+  Stage sa, sb;
+  fetch(sa, 0);
+  fetch(sb, 1);
+  stash(sa, 0);
+  __syncthreads();
+  for (int64_t it = 0; it < NIT; it += 2) {
+    fetch(sa, it + 2);
+    multiply(0);                     // tile it
+    stash(sb, 1);                    // tile it + 1 (requested a whole iteration ago)
     __syncthreads();
-    buf ^= 1;
+    fetch(sb, it + 3);
+    if (it + 1 < NIT) multiply(1);   // tile it + 1 (uniform condition, no loads inside)
+    stash(sa, 0);                    // tile it + 2
+    __syncthreads();
   }
 
   // epilogue: + time * W1[:, N] + b1, ReLU -> Hs [j][env]; then the second and third layer exactly as k_critic_fwd_slab
