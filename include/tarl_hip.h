@@ -299,10 +299,11 @@ int tarl_value_mpnn_bwd(const tarl_plan* plan, const float* node_features, int64
  *   sel8 uint8  [N][B]    = SELECTED_ROAD as the rank of the chosen out-edge in the node's CSR list (bit 7: carried over
  *                           from the previous frame; 0x7F: the fp32 value in sel [N][B] is authoritative)
  *   static records built by pack and shared by all environments (read through the scalar cache): node_rec int32/fp32
- *   [N][9] = {CSC start, in-degree, CSR start, out-degree, MAX_NUMBER_OF_AGENT, FREE_FLOW, ROAD_INDEX, congestion_constant,
- *   travel time at count 0};
- *   in_rec [E + 4][4] (CSC order) = {upstream row, the sel8 rank of that row which heads for this road (0xFE: none),
- *   edge_attr, MAX_NUMBER_OF_AGENT of the upstream row}; out_pad int32 [E + 4] (CSR order) = target row of each out-edge
+ *   [N][36] = {CSC start, in-degree, CSR start, out-degree, MAX_NUMBER_OF_AGENT, FREE_FLOW, ROAD_INDEX, congestion_constant,
+ *   travel time at count 0, 3 pad words, the target rows of the first four out-edges, the first four in_rec records};
+ *   in_rec [E + 4][5] (CSC order) = {upstream row, the sel8 rank of that row which heads for this road (0xFE: none),
+ *   edge_attr, MAX_NUMBER_OF_AGENT of the upstream row, edge id}; out_pad int32 [E + 4] (CSR order) = target row of each
+ *   out-edge (sizes are checked against csrc/fused_common.h by static_assert; tarl_hip/ops.py:FusedState allocates them)
  *   st0  [N][4]    = {MAX_NUMBER_OF_AGENT, FREE_FLOW_TIME_TRAVEL, ROAD_INDEX, congestion_constant} (static, shared)
  *   slots [N][B][ld_slots]: slot-interleaved FIFO store, slot s at floats 3s..3s+2 = {agent id, arrival, departure};
  *                  ld_slots >= 3*Nmax (pad to a multiple of 16 floats)
