@@ -335,3 +335,46 @@ def test_fused_equals_unfused_on_a_matsim_graph_with_pseudo_nodes(ops, tmp_path)
             assert torch.equal(e1.x, e2.x), f"state frame {s}"
     assert torch.equal(e1.x, e3.x) and torch.equal(e1.agents, e3.agents)
     assert float(e1.agents[:, :, 8].sum()) > 0 and float(e1.agents[:, :, 7].sum()) > 0      # arrivals and travellers
+
+
+def test_fused_overflow_paths_equal_unfused(ops):
+    """The two LDS lists of the fused frame have in-place fallbacks that the other tests' sizes never reach: the row
+    pass's event list (384 of a workgroup's 256 environments x 4 rows) and the insert kernel's candidate list (256 per
+    environment). 256 environments on a small torus with every agent due in the first seconds: nearly every (row,
+    environment) pair is an event in every frame and thousands of agents are insert candidates at once. Fused frames with
+    device Philox noise against the per-op kernels: actions, rewards, counts, state and agents bit-identical."""
+    from tarl_hip import synth
+    from tarl_hip.engine import SimEngine
+    net = synth.torus_network(4, 4, heterogeneous=True, seed=7)
+    N, B, A, frames = net.num_roads, 256, 1500, 70
+    pops = torch.stack([synth.population(A, N, seed=200 + b, t0=21540, t1=21543) for b in range(B)])
+    e1 = SimEngine(dev(net.x.unsqueeze(0).repeat(B, 1, 1)), net.edge_index, net.edge_attr, net.Nmax, dev(pops.clone()),
+                   congestion_constant=net.congestion_constant, seed=4, fused=False)
+    e2 = SimEngine(dev(net.x.unsqueeze(0).repeat(B, 1, 1)), net.edge_index, net.edge_attr, net.Nmax, dev(pops.clone()),
+                   congestion_constant=net.congestion_constant, seed=4, fused=True)
+    e1.reset()
+    e2.reset()
+    emb = torch.randn(N, generator=torch.Generator().manual_seed(8)).cuda()
+    e2.prepare_policy(emb)
+    ch2 = torch.empty((N, B), dtype=torch.int32, device="cuda")
+    rw2, c2 = torch.empty(B, device="cuda"), torch.empty((N, B), device="cuda")
+    pop2, wd2 = (torch.zeros((B, N), dtype=torch.uint8, device="cuda") for _ in range(2))
+    busiest = 0.0
+    for s in range(frames):
+        logits = ops.policy_edge_logits(e1.plan, e1.node_features, emb)
+        p = ops.graphdist_softmax(e1.plan, logits)
+        _, ch1 = ops.graphdist_sample(e1.plan, p, seed=e2.seed ^ 0x5DEECE66D, counter=s + 1, want_onehot=False,
+                                      want_choice=True)
+        e1.step(choice=ch1)
+        e2.frame_fused(choice=ch2, reward=rw2, counts=c2, popped=pop2, withdrawn=wd2)
+        assert torch.equal(ch1, ch2.t()), f"actions frame {s}"
+        assert torch.equal(e1.reward, rw2) and torch.equal(e1.counts, c2.t()), f"reward / counts frame {s}"
+        assert torch.equal(e1.agents, e2.agents), f"agents frame {s}"
+        if s % 6 == 5 or s == frames - 1:
+            x2 = e2.x
+            assert torch.equal(e1.x, x2), f"state frame {s}"
+            # event rows of the NEXT frame at least: non-empty rows whose head's departure time has passed
+            n_col, dep_col = x2[:, :, 3 * net.Nmax + 1], x2[:, :, 2]
+            busiest = max(busiest, float(((n_col > 0) & (dep_col <= e2.time)).float().mean()))
+    assert float(e2.agents[:, :, 7].sum() + e2.agents[:, :, 8].sum()) > 300 * B      # > 256 admitted per environment
+    assert busiest > 0.45, busiest                     # > 384 of a workgroup's 1024 pairs are event rows in some frame
