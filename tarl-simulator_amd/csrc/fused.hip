@@ -729,7 +729,7 @@ __device__ __forceinline__ bool row_phase_a(uint32_t i, uint32_t b, const NodeRe
                                             uint32_t B, uint32_t N, const FusedBufs& fb, int64_t A, float t,
                                             const FrameOut& out, bool* pop_out, float* n_out) {
   const uint32_t row = i * B + b;   // 32-bit row indices: N * B < 2^31 (host check)
-  const uint32_t n0i = hp.x & 255u, head_id0 = hp.x >> 8, tail0 = tlw >> 8;
+  const uint32_t n0i = hp.x & 255u, head_id0 = hp.x >> 8;
   const uint32_t arrived = pa & PF_ARRIVED;
   const uint32_t who = arrived ? (pa >> 8) : 0u;   // the agent the Direction update enqueues
   // Response message + max-aggregate from the post words (state after the Direction update of every row)
