@@ -250,6 +250,74 @@ def test_rollout_policy_call_equals_its_launches_one_by_one(bf16):
     assert bool(((ch1 & 0x7F) < 4).all())                     # rank bytes of a torus: four out-edges per road
 
 
+def test_policy_collect_across_an_episode_end_equals_a_manual_loop():
+    """VecPPOTrainer(policy="edge_mlp").collect() with 300 s frames: the episode ends inside the batch (clock past 7 h), the
+    collector resets and goes on. The trainer queues one foreign call per episode segment; a twin engine driven entry
+    point by entry point, with the reset done by hand, must give the same action bytes, log-probs, rewards, counts, clocks,
+    kept observations and done marks."""
+    from src.agents.mpnn_agent import MPNNPolicyNet, MPNNValueNetSimple
+    from tarl_hip import ops, synth
+    from tarl_hip.engine import EPISODE_END, SimEngine
+    from tarl_hip.trainer import VecPPOTrainer
+    net = synth.torus_network(4, 4, heterogeneous=True, seed=5)
+    N = net.num_roads
+    B, A, T, M, TEMP = 128, 120, 20, 16, 300.0
+    pops = torch.stack([synth.population(A, N, seed=60 + b, t0=21540, t1=23000) for b in range(B)])
+
+    def engine():
+        return SimEngine(net.x.cuda().unsqueeze(0).repeat(B, 1, 1).contiguous(), net.edge_index, net.edge_attr, net.Nmax,
+                         pops.clone().cuda(), congestion_constant=net.congestion_constant, seed=3, timestep=300)
+    torch.manual_seed(0)
+    pol = MPNNPolicyNet(net.edge_index, N, None, device="cuda")
+    val = MPNNValueNetSimple(net.edge_index, N, device="cuda")
+    l = val.final_mlp
+    crit = [l[0].weight, l[0].bias, l[2].weight, l[2].bias, l[4].weight, l[4].bias]
+    mlp = [pol.edge_mlp[0].weight, pol.edge_mlp[0].bias, pol.edge_mlp[2].weight, pol.edge_mlp[2].bias,
+           pol.edge_mlp[4].weight, pol.edge_mlp[4].bias]
+    extra = [p for n, p in pol.named_parameters() if not n.startswith("nodes_embedding")]
+    e1 = engine()
+    tr = VecPPOTrainer(e1, pol.nodes_embedding.weight, crit, rollout_steps=T, num_epochs=1, sub_batch_size=M,
+                       extra_params=extra, policy="edge_mlp", edge_mlp_params=mlp, policy_bf16=True, temperature=TEMP)
+    idx = torch.randperm(T * B, generator=torch.Generator().manual_seed(9))[:M]
+    tr.obs_idx = idx
+    tr.collect()
+    done = tr.done_frames.tolist()
+    assert sum(done) == 1 and done.index(True) == 12          # (25200 - 21540) / 300 = 12.2: frame 12 passes 7 h
+    # twin, by hand
+    e2 = engine()
+    e2.reset()
+    w = ops.EdgeMlpWeights(*(p.data for p in mlp))
+    order = torch.argsort(idx, stable=True)
+    ch2 = torch.zeros((T, B, N), dtype=torch.uint8, device="cuda")
+    ct2 = torch.zeros((T + 1, N, B), device="cuda")
+    lp2, rw2 = torch.zeros((T, B), device="cuda"), torch.zeros((T, B), device="cuda")
+    keep2 = torch.zeros((M, N, 16), device="cuda")
+    clocks = []
+    pseed = tr.seed ^ 0x5DEECE66D
+    for t in range(T):
+        clocks.append(float(e2.time))
+        obs = ops.fused_obs16(e2.plan, e2.fs, e2._x, e2.Nmax, e2.agents)
+        for j in order.tolist():
+            if int(idx[j]) // B == t:
+                keep2[j] = obs[int(idx[j]) % B]
+        logits = ops.policy_edge_mlp(e2.plan, obs, e2.ec, w, bf16=True)
+        ops.graphdist_rollout(e2.plan, logits, TEMP, seed=pseed, counter=1 + t, choice8=ch2[t], sel8=e2.fs.sel8,
+                              log_prob=lp2[t])
+        is_done = e2.frame_fused(skip_choice=True, reward=rw2[t], counts=ct2[t + 1])
+        assert is_done == (e2.time > EPISODE_END) == done[t]
+        if is_done and t + 1 < T:
+            e2.reset()
+            ct2[t + 1].zero_()
+    clocks.append(float(e2.time))
+    assert torch.equal(tr.choice, ch2) and torch.equal(tr.logp, lp2) and torch.equal(tr.reward, rw2)
+    assert torch.equal(tr.counts.float(), ct2) and tr.times.tolist() == clocks
+    assert torch.equal(tr.obs_mb, keep2)
+    assert torch.equal(e1.x, e2.x) and torch.equal(e1.agents, e2.agents)
+    assert float(rw2.abs().sum()) > 0 and float(rw2[13:].abs().sum()) > 0          # agents are on the road again after the reset
+    adv, tgt = tr.advantages()                                  # GAE with the done mask runs on the byte buffers
+    assert bool(torch.isfinite(adv).all()) and bool(torch.isfinite(tgt).all())
+
+
 def test_mirror_policy_net_with_edge_mlp_head_golden_and_cli(tmp_path, monkeypatch, capsys):
     """MPNNPolicyNet(policy_head="edge_mlp").forward == the reference module's evaluation of its edge_mlp (golden), with
     autograd through the HIP kernels; and `main.py --algo mpnn+ppo --policy-head edge_mlp` trains that head end to end."""
