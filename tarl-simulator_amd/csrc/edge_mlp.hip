@@ -615,18 +615,23 @@ __global__ __launch_bounds__(EM_THREADS) void k_edge_mlp_bwd_edges(const int32_t
 }
 
 // stage 2: C[p][q] += sum_l A[p][l] * Bm[q][l] for an 8 x 8 block of outputs per workgroup (Bm == NULL: a row of ones,
-// i.e. row sums). Fixed order: every thread strides over l, then a fixed LDS tree — deterministic.
+// i.e. row sums), split over ND_SPLIT ranges of l (grid z): a handful of output blocks alone would leave the chip idle
+// behind 300 000-long dot products. Fixed order everywhere — every thread strides over its range, a fixed LDS tree, the
+// ranges added in order by k_nt_reduce: deterministic.
 #define ND_T 256
+#define ND_SPLIT 64
 __global__ __launch_bounds__(ND_T) void k_nt_dot(const float* __restrict__ Am, int64_t P, const float* __restrict__ Bm,
-                                                 int64_t Q, int64_t L, float* __restrict__ Cm, int64_t ldc) {
+                                                 int64_t Q, int64_t L, float* __restrict__ part) {
   __shared__ float red[ND_T];
   const int p0 = blockIdx.x * 8, q0 = blockIdx.y * 8;
+  const int64_t span = (L + ND_SPLIT - 1) / ND_SPLIT, l0 = (int64_t)blockIdx.z * span;
+  const int64_t l1 = l0 + span < L ? l0 + span : L;
   float acc[8][8];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = 0.0f;
-  for (int64_t l = threadIdx.x; l < L; l += ND_T) {
+  for (int64_t l = l0 + threadIdx.x; l < l1; l += ND_T) {
     float a[8], b[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) a[i] = (p0 + i < P) ? Am[(int64_t)(p0 + i) * L + l] : 0.0f;
@@ -647,9 +652,18 @@ __global__ __launch_bounds__(ND_T) void k_nt_dot(const float* __restrict__ Am, i
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
       }
-      if (threadIdx.x == 0 && p0 + i < P && q0 + j < Q) Cm[(int64_t)(p0 + i) * ldc + q0 + j] += red[0];
+      if (threadIdx.x == 0 && p0 + i < P && q0 + j < Q) part[((int64_t)blockIdx.z * P + p0 + i) * Q + q0 + j] = red[0];
       __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(ND_T) void k_nt_reduce(const float* __restrict__ part, int64_t P, int64_t Q,
+                                                    float* __restrict__ Cm, int64_t ldc) {
+  const int64_t idx = (int64_t)blockIdx.x * ND_T + threadIdx.x;
+  if (idx >= P * Q) return;
+  float sum = 0.0f;
+  for (int z = 0; z < ND_SPLIT; ++z) sum += part[(int64_t)z * P * Q + idx];
+  Cm[(idx / Q) * ldc + idx % Q] += sum;
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
@@ -746,7 +760,8 @@ extern "C" int tarl_policy_edge_mlp_fwd(const tarl_plan* plan, const float* obs1
 }
 
 extern "C" int64_t tarl_policy_edge_mlp_bwd_scratch_floats(const tarl_plan* plan, int64_t M) {
-  return plan ? (int64_t)(EM_IN + 2 * EM_H1 + 2 * EM_H2) * M * plan->E : -1;
+  // k-major activations and their gradients + the split partial sums of the largest weight gradient
+  return plan ? (int64_t)(EM_IN + 2 * EM_H1 + 2 * EM_H2) * M * plan->E + (int64_t)ND_SPLIT * EM_H1 * EM_H1 : -1;
 }
 
 extern "C" int tarl_policy_edge_mlp_bwd(const tarl_plan* plan, const float* obs16, int64_t M, const float* edge_attr,
@@ -764,14 +779,16 @@ extern "C" int tarl_policy_edge_mlp_bwd(const tarl_plan* plan, const float* obs1
   float* H2T = H1T + EM_H1 * L;
   float* D1T = H2T + EM_H2 * L;
   float* D2T = D1T + EM_H1 * L;
+  float* part = D2T + EM_H2 * L;          // [ND_SPLIT][P][Q], P * Q <= 64 * 64
   const EdgeMlpW W{w1, b1, w2, b2, w3, b3};
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_edge_mlp_bwd_edges, dim3((unsigned)ceil_div(L, EM_THREADS)), dim3(EM_THREADS), 0, s, plan->src,
                      plan->dst, plan->E, plan->N, M, obs16, edge_attr, W, grad_logits, XT, H1T, H2T, D1T, D2T);
   TARL_LAUNCH_CHECK();
   auto dot = [&](const float* Am, int64_t P, const float* Bm, int64_t Q, float* Cm, int64_t ldc) {
-    hipLaunchKernelGGL(k_nt_dot, dim3((unsigned)ceil_div(P, 8), (unsigned)ceil_div(Q, 8)), dim3(ND_T), 0, s, Am, P, Bm, Q,
-                       L, Cm, ldc);
+    hipLaunchKernelGGL(k_nt_dot, dim3((unsigned)ceil_div(P, 8), (unsigned)ceil_div(Q, 8), ND_SPLIT), dim3(ND_T), 0, s, Am,
+                       P, Bm, Q, L, part);
+    hipLaunchKernelGGL(k_nt_reduce, dim3((unsigned)ceil_div(P * Q, ND_T)), dim3(ND_T), 0, s, part, P, Q, Cm, ldc);
   };
   dot(D1T, EM_H1, XT, EM_IN, gw1, EM_IN);          // dW1 = dh1^T x
   dot(D1T, EM_H1, nullptr, 1, gb1, 1);             // db1
