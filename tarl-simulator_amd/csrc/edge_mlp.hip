@@ -546,71 +546,123 @@ __global__ __launch_bounds__(EMR_WAVES * 64) void k_edge_mlp_fwd_bf16(const int3
 }
 
 // ---- backward -------------------------------------------------------------------------------------------------------------
-// stage 1: one thread per (sample, edge): recompute h1, h2; dh2 = g W3 (masked), dh1 = W2^T dh2 (masked); everything is
-// stored k-major ([k][L], L = M * E) for the reductions of stage 2.
-__global__ __launch_bounds__(EM_THREADS) void k_edge_mlp_bwd_edges(const int32_t* __restrict__ src,
-                                                                   const int32_t* __restrict__ dst, int64_t E, int64_t N,
-                                                                   int64_t M, const float* __restrict__ obs,
-                                                                   const float* __restrict__ edge_attr, EdgeMlpW W,
-                                                                   const float* __restrict__ grad_logits,
-                                                                   float* __restrict__ XT, float* __restrict__ H1T,
-                                                                   float* __restrict__ H2T, float* __restrict__ D1T,
-                                                                   float* __restrict__ D2T) {
-  __shared__ float w1s[EM_H1 * EM_IN], w2s[EM_H2 * EM_H1], w3s[EM_H2], b1s[EM_H1], b2s[EM_H2];
-  for (int i = threadIdx.x; i < EM_H1 * EM_IN; i += EM_THREADS) w1s[i] = W.w1[i];
-  for (int i = threadIdx.x; i < EM_H2 * EM_H1; i += EM_THREADS) w2s[i] = W.w2[i];
-  if (threadIdx.x < EM_H2) {
-    w3s[threadIdx.x] = W.w3[threadIdx.x];
-    b2s[threadIdx.x] = W.b2[threadIdx.x];
+// stage 1, on the matrix cores: the forward's register-resident recomputation per 32 edges (exact fp32 products), then
+// dh2 = g w3 (masked by the second pre-activation) on the lane's own sixteen units and dh1^T [64][32] = W2^T dh2^T as
+// 32 more MFMAs whose B operand is, again, what the lane already holds (A = W2 transposed, its k-order permuted to
+// the accumulator layout), masked by h1 > 0. Everything is stored k-major ([k][L], L = M * E: a half-wave writes 32
+// consecutive floats per unit) for the reductions of stage 2. 98 MFMAs per 32 edges.
+__global__ __launch_bounds__(EMR_WAVES * 64) void k_edge_mlp_bwd_edges(const int32_t* __restrict__ src,
+                                                                       const int32_t* __restrict__ dst, int64_t E,
+                                                                       int64_t N, int64_t M,
+                                                                       const float* __restrict__ obs,
+                                                                       const float* __restrict__ edge_attr, EdgeMlpW W,
+                                                                       const float* __restrict__ grad_logits,
+                                                                       float* __restrict__ XT, float* __restrict__ H1T,
+                                                                       float* __restrict__ H2T, float* __restrict__ D1T,
+                                                                       float* __restrict__ D2T) {
+  __shared__ float W2T[2 * 16 * 64];     // [tile a][k-step s][lane]: W2[unit(s, lane >> 5)][32 a + (lane & 31)]
+  __shared__ __attribute__((aligned(16))) float B2L[2 * 16];
+  __shared__ __attribute__((aligned(16))) float W3L[2 * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, j = lane & 31;
+  for (int idx = tid; idx < 2 * 16 * 64; idx += EMR_WAVES * 64) {
+    const int l = idx & 63, ks = (idx >> 6) & 15, a = idx >> 10;
+    W2T[idx] = W.w2[emr_unit(ks, l >> 5) * EM_H1 + 32 * a + (l & 31)];
   }
-  if (threadIdx.x < EM_H1) b1s[threadIdx.x] = W.b1[threadIdx.x];
+  if (tid < 32) {
+    B2L[tid] = W.b2[emr_unit(tid & 15, tid >> 4)];
+    W3L[tid] = W.w3[emr_unit(tid & 15, tid >> 4)];
+  }
   __syncthreads();
+  float w1a[2][17], w2a[32];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int u = 32 * a + j;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      w1a[a][t] = W.w1[u * EM_IN + 8 * h + t];
+      w1a[a][8 + t] = W.w1[u * EM_IN + 16 + 8 * h + t];
+    }
+    w1a[a][16] = h == 0 ? W.w1[u * EM_IN + 32] : W.b1[u];
+  }
+#pragma unroll
+  for (int t = 0; t < 32; ++t) w2a[t] = W.w2[j * EM_H1 + 32 * (t >> 4) + emr_unit(t & 15, h)];
+  const float4* b2l = reinterpret_cast<const float4*>(B2L + 16 * h);
+  const float4* w3l = reinterpret_cast<const float4*>(W3L + 16 * h);
+  const f32x16 zero = {0};
   const int64_t L = M * E;
-  const int64_t ge = (int64_t)blockIdx.x * EM_THREADS + threadIdx.x;
-  if (ge >= L) return;
-  const int64_t m = ge / E, e = ge - m * E;
-  const float* om = obs + m * N * 16;
-  float x[EM_IN];
-  {
-    const float4* xi = reinterpret_cast<const float4*>(om + (int64_t)src[e] * 16);
-    const float4* xj = reinterpret_cast<const float4*>(om + (int64_t)dst[e] * 16);
+  ChunkWalk cw;
+  if (!cw.init(E, M, wave)) return;
+  EdgeIn nxt = emr_load(src, dst, edge_attr, obs, (int32_t)E, N, cw.mn, cw.cn, lane);
+  for (; cw.g < cw.g1; ++cw.g) {
+    const EdgeIn cur = nxt;
+    cw.step();
+    if (cw.g + 1 < cw.g1) nxt = emr_load(src, dst, edge_attr, obs, (int32_t)E, N, cw.mn, cw.cn, lane);
+    const int32_t e = cw.c * 32 + j;
+    const bool live = e < (int32_t)E;
+    const int64_t l = (int64_t)cw.m * E + (live ? e : 0);
+    const float xin[17] = {cur.s0.x, cur.s0.y, cur.s0.z, cur.s0.w, cur.s1.x, cur.s1.y, cur.s1.z, cur.s1.w,
+                           cur.d0.x, cur.d0.y, cur.d0.z, cur.d0.w, cur.d1.x, cur.d1.y, cur.d1.z, cur.d1.w,
+                           h == 0 ? cur.ea : 1.0f};
+    f32x16 acc0 = zero, acc1 = zero;
+#pragma unroll
+    for (int t = 0; t < 17; ++t) {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1a[0][t], xin[t], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1a[1][t], xin[t], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc0[r] = emr_relu(acc0[r]);
+      acc1[r] = emr_relu(acc1[r]);
+    }
+    asm volatile("" ::: "memory");      // keeps the LDS tables out of loop-invariant registers
+    f32x16 c0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const float4 a = xi[q], b = xj[q];
-      x[4 * q + 0] = a.x; x[4 * q + 1] = a.y; x[4 * q + 2] = a.z; x[4 * q + 3] = a.w;
-      x[16 + 4 * q + 0] = b.x; x[16 + 4 * q + 1] = b.y; x[16 + 4 * q + 2] = b.z; x[16 + 4 * q + 3] = b.w;
+      const float4 v = b2l[q];
+      c0[4 * q] = v.x;
+      c0[4 * q + 1] = v.y;
+      c0[4 * q + 2] = v.z;
+      c0[4 * q + 3] = v.w;
     }
-    x[32] = edge_attr[e];
-  }
 #pragma unroll
-  for (int k = 0; k < EM_IN; ++k) XT[k * L + ge] = x[k];
-  float h1[EM_H1];
+    for (int t = 0; t < 16; ++t) c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2a[t], acc0[t], c0, 0, 0, 0);
 #pragma unroll
-  for (int j = 0; j < EM_H1; ++j) {
-    float a = b1s[j];
+    for (int t = 0; t < 16; ++t) c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2a[16 + t], acc1[t], c0, 0, 0, 0);
+    const float g = grad_logits[l];
+    f32x16 dh2;
 #pragma unroll
-    for (int k = 0; k < EM_IN; ++k) a += w1s[j * EM_IN + k] * x[k];
-    h1[j] = a > 0.0f ? a : 0.0f;
-    H1T[j * L + ge] = h1[j];
-  }
-  const float g = grad_logits[ge];
-  float dh2[EM_H2];
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = w3l[q];
+      dh2[4 * q] = c0[4 * q] > 0.0f ? g * v.x : 0.0f;
+      dh2[4 * q + 1] = c0[4 * q + 1] > 0.0f ? g * v.y : 0.0f;
+      dh2[4 * q + 2] = c0[4 * q + 2] > 0.0f ? g * v.z : 0.0f;
+      dh2[4 * q + 3] = c0[4 * q + 3] > 0.0f ? g * v.w : 0.0f;
+    }
+    f32x16 d0 = zero, d1 = zero;
 #pragma unroll
-  for (int j = 0; j < EM_H2; ++j) {
-    float a = b2s[j];
+    for (int t = 0; t < 16; ++t) {
+      d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(W2T[t * 64 + lane], dh2[t], d0, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(W2T[(16 + t) * 64 + lane], dh2[t], d1, 0, 0, 0);
+    }
+    if (live) {
 #pragma unroll
-    for (int k = 0; k < EM_H1; ++k) a += w2s[j * EM_H1 + k] * h1[k];
-    const float h2 = a > 0.0f ? a : 0.0f;
-    H2T[j * L + ge] = h2;
-    dh2[j] = a > 0.0f ? g * w3s[j] : 0.0f;
-    D2T[j * L + ge] = dh2[j];
-  }
+      for (int t = 0; t < 8; ++t) {
+        XT[(int64_t)(8 * h + t) * L + l] = xin[t];
+        XT[(int64_t)(16 + 8 * h + t) * L + l] = xin[8 + t];
+      }
+      if (h == 0) XT[(int64_t)32 * L + l] = cur.ea;
 #pragma unroll
-  for (int k = 0; k < EM_H1; ++k) {
-    float a = 0.0f;
-#pragma unroll
-    for (int j = 0; j < EM_H2; ++j) a += dh2[j] * w2s[j * EM_H1 + k];
-    D1T[k * L + ge] = h1[k] > 0.0f ? a : 0.0f;
+      for (int r = 0; r < 16; ++r) {
+        const int64_t u = emr_unit(r, h);
+        H1T[u * L + l] = acc0[r];
+        H1T[(32 + u) * L + l] = acc1[r];
+        D1T[u * L + l] = acc0[r] > 0.0f ? d0[r] : 0.0f;
+        D1T[(32 + u) * L + l] = acc1[r] > 0.0f ? d1[r] : 0.0f;
+        H2T[u * L + l] = emr_relu(c0[r]);
+        D2T[u * L + l] = dh2[r];
+      }
+    }
   }
 }
 
@@ -782,8 +834,14 @@ extern "C" int tarl_policy_edge_mlp_bwd(const tarl_plan* plan, const float* obs1
   float* part = D2T + EM_H2 * L;          // [ND_SPLIT][P][Q], P * Q <= 64 * 64
   const EdgeMlpW W{w1, b1, w2, b2, w3, b3};
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_edge_mlp_bwd_edges, dim3((unsigned)ceil_div(L, EM_THREADS)), dim3(EM_THREADS), 0, s, plan->src,
-                     plan->dst, plan->E, plan->N, M, obs16, edge_attr, W, grad_logits, XT, H1T, H2T, D1T, D2T);
+  {
+    const int64_t chunks = M * ceil_div(plan->E, 32);
+    TARL_REQUIRE(chunks < ((int64_t)1 << 31) && plan->E < ((int64_t)1 << 31) - 32, "edge MLP: batch x edges too large");
+    int64_t blocks = ceil_div(chunks, (int64_t)EMR_WAVES * 4);
+    if (blocks > 256) blocks = 256;          // one resident workgroup per CU (the kernel is register-heavy)
+    hipLaunchKernelGGL(k_edge_mlp_bwd_edges, dim3((unsigned)blocks), dim3(EMR_WAVES * 64), 0, s, plan->src, plan->dst,
+                       plan->E, plan->N, M, obs16, edge_attr, W, grad_logits, XT, H1T, H2T, D1T, D2T);
+  }
   TARL_LAUNCH_CHECK();
   auto dot = [&](const float* Am, int64_t P, const float* Bm, int64_t Q, float* Cm, int64_t ldc) {
     hipLaunchKernelGGL(k_nt_dot, dim3((unsigned)ceil_div(P, 8), (unsigned)ceil_div(Q, 8), ND_SPLIT), dim3(ND_T), 0, s, Am,
