@@ -252,7 +252,8 @@ __global__ __launch_bounds__(EMR_WAVES * 64) void k_edge_mlp_fwd_f32(const int32
                                                                      const float* __restrict__ obs,
                                                                      const float* __restrict__ edge_attr, EdgeMlpW W,
                                                                      float* __restrict__ logits) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the chunk walker lives in SGPRs
   const int h = lane >> 5, j = lane & 31;
   float w1a[2][17], w2a[32];
 #pragma unroll
@@ -361,6 +362,7 @@ struct EIdx {
 };
 __device__ __forceinline__ EIdx emr_ldidx(const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
                                           const float* __restrict__ edge_attr, int32_t E, int32_t c, int lane) {
+  c = __builtin_amdgcn_readfirstlane(c);     // wave-uniform by construction: scalar base + 32-bit lane offset
   int32_t e = c * 32 + (lane & 31);
   e = e < E ? e : E - 1;                     // the tail chunk's spare lanes repeat the last edge (never stored)
   EIdx i;
@@ -393,9 +395,11 @@ struct ERows<true> {       // bf16 observations [M][N][16] (tarl_fused_obs16_bf1
   uint4 s, d;
   float ea;
   __device__ __forceinline__ void load(const void* __restrict__ obs, int64_t N, int32_t m, const EIdx& i, int lane) {
-    const uint16_t* om = (const uint16_t*)obs + (int64_t)m * N * 16 + 8 * (lane >> 5);
-    s = *reinterpret_cast<const uint4*>(om + (int64_t)i.s * 16);
-    d = *reinterpret_cast<const uint4*>(om + (int64_t)i.d * 16);
+    // the sample is wave-uniform (scalar base); node rows are 32 bytes: a 32-bit byte offset per lane (host: N < 2^26)
+    const char* om = (const char*)obs + (int64_t)__builtin_amdgcn_readfirstlane(m) * N * 32;
+    const uint32_t hb = 16u * (uint32_t)(lane >> 5);
+    s = *reinterpret_cast<const uint4*>(om + ((uint32_t)i.s * 32u + hb));
+    d = *reinterpret_cast<const uint4*>(om + ((uint32_t)i.d * 32u + hb));
     ea = i.ea;
   }
   __device__ __forceinline__ bf16x8 xs() const { return __builtin_bit_cast(bf16x8, s); }
@@ -417,7 +421,8 @@ __global__ __launch_bounds__(EMR_WAVES * 64) void k_edge_mlp_fwd_bf16(const int3
   // that 32 registers go to loads in flight instead
   __shared__ __attribute__((aligned(16))) float B2L[2 * 16];
   __shared__ __attribute__((aligned(16))) float W3L[2 * 16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the chunk walkers below live in SGPRs
   for (int idx = tid; idx < 6 * 64 * 8; idx += EMR_WAVES * 64) {
     const int q = idx & 7, l = (idx >> 3) & 63, f = idx >> 9;
     const int a = f / 3, ks = f - 3 * a, u = 32 * a + (l & 31), h = l >> 5;
@@ -539,8 +544,9 @@ __global__ __launch_bounds__(EMR_WAVES * 64) void k_edge_mlp_fwd_bf16(const int3
       part = fmaf(emr_relu(c0[4 * q + 3]), v.w, part);
     }
     const float tot = part + __shfl_xor(part, 32);
-    const int32_t e = mc.c * 32 + (lane & 31);
-    if (valid && h == 0 && e < Ei) logits[(int64_t)mc.m * E + e] = tot + b3;
+    const int32_t e = __builtin_amdgcn_readfirstlane(mc.c) * 32 + (lane & 31);
+    float* lrow = logits + (int64_t)__builtin_amdgcn_readfirstlane(mc.m) * E;
+    if (valid && h == 0 && e < Ei) lrow[e] = tot + b3;
     }
   }
 }
@@ -563,7 +569,8 @@ __global__ __launch_bounds__(EMR_WAVES * 64) void k_edge_mlp_bwd_edges(const int
   __shared__ float W2T[2 * 16 * 64];     // [tile a][k-step s][lane]: W2[unit(s, lane >> 5)][32 a + (lane & 31)]
   __shared__ __attribute__((aligned(16))) float B2L[2 * 16];
   __shared__ __attribute__((aligned(16))) float W3L[2 * 16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the chunk walker lives in SGPRs
   const int h = lane >> 5, j = lane & 31;
   for (int idx = tid; idx < 2 * 16 * 64; idx += EMR_WAVES * 64) {
     const int l = idx & 63, ks = (idx >> 6) & 15, a = idx >> 10;
@@ -794,7 +801,8 @@ extern "C" int tarl_policy_edge_mlp_fwd(const tarl_plan* plan, const float* obs1
   const EdgeMlpW W{w1, b1, w2, b2, w3, b3};
   // persistent waves: every wave builds its weight fragments once and walks a contiguous range of 32-edge chunks
   const int64_t chunks = M * ceil_div(plan->E, 32);
-  TARL_REQUIRE(chunks < ((int64_t)1 << 31) && plan->E < ((int64_t)1 << 31) - 32, "edge MLP: batch x edges too large");
+  TARL_REQUIRE(chunks < ((int64_t)1 << 31) && plan->E < ((int64_t)1 << 31) - 32 && plan->N < ((int64_t)1 << 26),
+               "edge MLP: batch x edges too large");
   int64_t blocks = ceil_div(chunks, (int64_t)EMR_WAVES * 16);          // >= 16 chunks per wave
   const int64_t resident = 256 * (precision == 0 ? 2 : 3);              // workgroups the chip holds at once (VGPR-bound)
   if (blocks > resident) blocks = resident;                             // one round: no tail
