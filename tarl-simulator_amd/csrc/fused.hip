@@ -443,48 +443,50 @@ __global__ __launch_bounds__(TILE) void k_fused_choice_all(const NodeRec* __rest
   long long lp = 0;
   bool bad = false;
   PhiloxRun rng;
+  // The node loop issues no vector load at all (a conditional load inside it makes the compiler wait for the previous
+  // iteration's store, vmcnt(0), every time round) and one batch of scalar loads per node: its group, its CSR range, and
+  // the four 16-byte policy records of its first out-edges as ONE 64-byte read of the padded table. The inverse CDF is a
+  // count: thresholds are non-decreasing (fp32 roundings of a running double sum), so the first q with u < thr[q] is
+  // the number of thresholds at or below u. Nodes without out-edges (they keep SELECTED_ROAD) get a loop of their own.
   for (uint32_t i = i0; i < i1; ++i) {      // i, and everything indexed by it alone, is wave-uniform
-    const uint32_t row = i * B + b;
     const int32_t gi = group_of_node[i];
-    uint32_t code;
-    if (gi >= 0) {
-      const float u = rng.uniform(pseed, pcounter0 + (uint64_t)t, (uint64_t)b * G + (uint64_t)gi);
-      const NodeRec& nr = nodes[i];
-      const PRec* pr = ptab + nr.out0;
-      bool found = false;
-      long long lpn = 0;
-      code = SEL_UNRESOLVED;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {       // four records from consecutive addresses (padded table)
-        const bool hit = !found && q < nr.out_deg && (u < pr[q].thr);
-        const long long lgk = ((long long)pr[q].lg_hi << 32) | (long long)(uint32_t)pr[q].lg_lo;
-        code = hit ? (uint32_t)q : code;
-        lpn = hit ? lgk : lpn;
-        found = found || hit;
-      }
-      for (int32_t q = 4; q < nr.out_deg; ++q) {
-        const bool hit = !found && (u < pr[q].thr);
-        const long long lgk = ((long long)pr[q].lg_hi << 32) | (long long)(uint32_t)pr[q].lg_lo;
-        code = hit ? (uint32_t)q : code;
-        lpn = hit ? lgk : lpn;
-        found = found || hit;
-      }
-      if (found) {
-        lp += lpn;
-      } else {
-        bad = true;
-        const int32_t pos = atomicAdd(&fix[0], 1);
-        if (pos < FIX_CAP) {
-          fix[2 + 2 * pos] = (int32_t)t;
-          fix[3 + 2 * pos] = (int32_t)row;
-        } else {
-          atomicOr(flags, FLAG_CHOICE_OVERFLOW);
-        }
-      }
-    } else {
-      code = (sel0[row] & 0x7Fu) | SEL_CARRIED;   // no out-edges: SELECTED_ROAD never changes
+    const int32_t out0 = nodes[i].out0, deg = nodes[i].out_deg;
+    if (deg == 0) continue;                 // == (gi < 0)
+    const uint32_t row = i * B + b;
+    const PRec* pr = ptab + out0;
+    const PRec p0 = pr[0], p1 = pr[1], p2 = pr[2], p3 = pr[3];      // padded table: always readable
+    const float u = rng.uniform(pseed, pcounter0 + (uint64_t)t, (uint64_t)b * G + (uint64_t)gi);
+    uint32_t cnt = (u >= (0 < deg ? p0.thr : INFINITY) ? 1u : 0u) + (u >= (1 < deg ? p1.thr : INFINITY) ? 1u : 0u) +
+                   (u >= (2 < deg ? p2.thr : INFINITY) ? 1u : 0u) + (u >= (3 < deg ? p3.thr : INFINITY) ? 1u : 0u);
+    for (int32_t q = 4; q < deg; ++q) cnt += (u >= pr[q].thr) ? 1u : 0u;
+    const bool found = cnt < (uint32_t)deg;
+    const uint32_t lo = cnt == 0u ? (uint32_t)p0.lg_lo : (cnt == 1u ? (uint32_t)p1.lg_lo : (cnt == 2u ? (uint32_t)p2.lg_lo : (uint32_t)p3.lg_lo));
+    const int32_t hi = cnt == 0u ? p0.lg_hi : (cnt == 1u ? p1.lg_hi : (cnt == 2u ? p2.lg_hi : p3.lg_hi));
+    long long lpn = ((long long)hi << 32) | (long long)lo;
+    if (cnt >= 4u && found) {            // out-degree above four: the term sits further down the table
+      const PRec px = pr[cnt];
+      lpn = ((long long)px.lg_hi << 32) | (long long)(uint32_t)px.lg_lo;
     }
-    out[row] = (uint8_t)code;
+    if (found) {
+      lp += lpn;
+    } else {
+      bad = true;
+      const int32_t pos = atomicAdd(&fix[0], 1);
+      if (pos < FIX_CAP) {
+        fix[2 + 2 * pos] = (int32_t)t;
+        fix[3 + 2 * pos] = (int32_t)row;
+      } else {
+        atomicOr(flags, FLAG_CHOICE_OVERFLOW);
+      }
+    }
+    out[row] = (uint8_t)(found ? cnt : SEL_UNRESOLVED);
+  }
+  if (G != N) {
+    for (uint32_t i = i0; i < i1; ++i)
+      if (group_of_node[i] < 0) {
+        const uint32_t row = i * B + b;
+        out[row] = (uint8_t)((sel0[row] & 0x7Fu) | SEL_CARRIED);   // no out-edges: SELECTED_ROAD never changes
+      }
   }
   // order-independent 2^-32 fixed-point sum over the node segments; an action with a node that drew nothing is poisoned
   // far beyond any legitimate sum (it is infeasible: log_prob = -inf, src/reinforcement_learning.py:88-92)
