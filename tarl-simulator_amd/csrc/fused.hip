@@ -427,8 +427,77 @@ __global__ __launch_bounds__(FB) void k_pack_ptab(int64_t E, const float* __rest
   }
 }
 
+// per node: everything the all-frames draw needs about it in ONE aligned 64-byte scalar read whose address depends on the
+// node index alone (through the CSR range it would be two dependent scalar rounds per node, and those rounds — not the
+// Philox blocks — were what the draw waited for)
+struct __attribute__((aligned(64))) PNode {
+  int32_t gi, deg, out0, pad;
+  float thr[4];                              // +inf beyond the out-degree
+  int32_t lg_lo[4], lg_hi[4];
+};
+static_assert(sizeof(PNode) == 64, "PNode is one 64-byte scalar read");
+typedef int32_t i32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(FB) void k_pack_pnode(int64_t N, const NodeRec* __restrict__ nodes,
+                                                   const int32_t* __restrict__ group_of_node,
+                                                   const float* __restrict__ thr, const long long* __restrict__ lgt,
+                                                   PNode* __restrict__ pnode) {
+  const int64_t i = (int64_t)blockIdx.x * FB + threadIdx.x;
+  if (i >= N) return;
+  PNode pn;
+  pn.gi = group_of_node[i];
+  pn.deg = nodes[i].out_deg;
+  pn.out0 = nodes[i].out0;
+  pn.pad = 0;
+  for (int q = 0; q < 4; ++q) {
+    const bool in = q < pn.deg;
+    const long long lg = in ? lgt[pn.out0 + q] : 0ll;
+    pn.thr[q] = in ? thr[pn.out0 + q] : INFINITY;
+    pn.lg_lo[q] = (int32_t)(uint32_t)(lg & 0xffffffffll);
+    pn.lg_hi[q] = (int32_t)(lg >> 32);
+  }
+  pnode[i] = pn;
+}
+
 #define CHOICE_SEG 128    // nodes per workgroup of the all-frames choice (a frame's log-prob = the sum of its segments)
-__global__ __launch_bounds__(TILE) void k_fused_choice_all(const NodeRec* __restrict__ nodes, const PRec* __restrict__ ptab,
+// one node's draw from its record v and its uniform u: the inverse CDF is a count — thresholds are non-decreasing (fp32
+// roundings of a running double sum), so the first q with u < thr[q] is the number of thresholds at or below u
+__device__ __forceinline__ void choice_node(const i32x16 v, const float u, const PRec* __restrict__ ptab, uint32_t row,
+                                            int64_t t, uint8_t* __restrict__ out, long long& lp, bool& bad,
+                                            int32_t* __restrict__ fix, int32_t* __restrict__ flags) {
+  const int32_t deg = v[1];
+  const PRec* pr = ptab + v[2];
+  uint32_t cnt = (u >= __int_as_float(v[4]) ? 1u : 0u) + (u >= __int_as_float(v[5]) ? 1u : 0u) +
+                 (u >= __int_as_float(v[6]) ? 1u : 0u) + (u >= __int_as_float(v[7]) ? 1u : 0u);
+  for (int32_t q = 4; q < deg; ++q) cnt += (u >= pr[q].thr) ? 1u : 0u;
+  const bool found = cnt < (uint32_t)deg;
+  const uint32_t lo = (uint32_t)(cnt == 0u ? v[8] : (cnt == 1u ? v[9] : (cnt == 2u ? v[10] : v[11])));
+  const int32_t hi = cnt == 0u ? v[12] : (cnt == 1u ? v[13] : (cnt == 2u ? v[14] : v[15]));
+  long long lpn = ((long long)hi << 32) | (long long)lo;
+  if (deg > 4 && cnt >= 4u && found) {  // out-degree above four (wave-uniform): the term sits further down the table
+    const PRec px = pr[cnt];
+    lpn = ((long long)px.lg_hi << 32) | (long long)(uint32_t)px.lg_lo;
+  }
+  if (found) {
+    lp += lpn;
+  } else {
+    bad = true;
+    const int32_t pos = atomicAdd(&fix[0], 1);
+    if (pos < FIX_CAP) {
+      fix[2 + 2 * pos] = (int32_t)t;
+      fix[3 + 2 * pos] = (int32_t)row;
+    } else {
+      atomicOr(flags, FLAG_CHOICE_OVERFLOW);
+    }
+  }
+  out[row] = (uint8_t)(found ? cnt : SEL_UNRESOLVED);
+}
+
+// QUAD (every node has out-edges and their number is a multiple of four: draw index = b * N + i, so nodes 4k .. 4k + 3
+// of an environment share one Philox block): four nodes per step on the block's four words, without the block compare
+// and the word select of the general form. Same indices, same words: the same draws.
+template <bool QUAD>
+__global__ __launch_bounds__(TILE) void k_fused_choice_all(const PNode* __restrict__ pnode, const PRec* __restrict__ ptab,
                                                            const int32_t* __restrict__ group_of_node, uint32_t G,
                                                            uint32_t B, uint32_t N, int64_t t0, uint64_t pseed,
                                                            uint64_t pcounter0, const uint8_t* __restrict__ sel0,
@@ -442,44 +511,40 @@ __global__ __launch_bounds__(TILE) void k_fused_choice_all(const NodeRec* __rest
   uint8_t* out = choice + t * (int64_t)N * B;
   long long lp = 0;
   bool bad = false;
-  PhiloxRun rng;
   // The node loop issues no vector load at all (a conditional load inside it makes the compiler wait for the previous
-  // iteration's store, vmcnt(0), every time round) and one batch of scalar loads per node: its group, its CSR range, and
-  // the four 16-byte policy records of its first out-edges as ONE 64-byte read of the padded table. The inverse CDF is a
-  // count: thresholds are non-decreasing (fp32 roundings of a running double sum), so the first q with u < thr[q] is
-  // the number of thresholds at or below u. Nodes without out-edges (they keep SELECTED_ROAD) get a loop of their own.
-  for (uint32_t i = i0; i < i1; ++i) {      // i, and everything indexed by it alone, is wave-uniform
-    const int32_t gi = group_of_node[i];
-    const int32_t out0 = nodes[i].out0, deg = nodes[i].out_deg;
-    if (deg == 0) continue;                 // == (gi < 0)
-    const uint32_t row = i * B + b;
-    const PRec* pr = ptab + out0;
-    const PRec p0 = pr[0], p1 = pr[1], p2 = pr[2], p3 = pr[3];      // padded table: always readable
-    const float u = rng.uniform(pseed, pcounter0 + (uint64_t)t, (uint64_t)b * G + (uint64_t)gi);
-    uint32_t cnt = (u >= (0 < deg ? p0.thr : INFINITY) ? 1u : 0u) + (u >= (1 < deg ? p1.thr : INFINITY) ? 1u : 0u) +
-                   (u >= (2 < deg ? p2.thr : INFINITY) ? 1u : 0u) + (u >= (3 < deg ? p3.thr : INFINITY) ? 1u : 0u);
-    for (int32_t q = 4; q < deg; ++q) cnt += (u >= pr[q].thr) ? 1u : 0u;
-    const bool found = cnt < (uint32_t)deg;
-    const uint32_t lo = cnt == 0u ? (uint32_t)p0.lg_lo : (cnt == 1u ? (uint32_t)p1.lg_lo : (cnt == 2u ? (uint32_t)p2.lg_lo : (uint32_t)p3.lg_lo));
-    const int32_t hi = cnt == 0u ? p0.lg_hi : (cnt == 1u ? p1.lg_hi : (cnt == 2u ? p2.lg_hi : p3.lg_hi));
-    long long lpn = ((long long)hi << 32) | (long long)lo;
-    if (cnt >= 4u && found) {            // out-degree above four: the term sits further down the table
-      const PRec px = pr[cnt];
-      lpn = ((long long)px.lg_hi << 32) | (long long)(uint32_t)px.lg_lo;
-    }
-    if (found) {
-      lp += lpn;
-    } else {
-      bad = true;
-      const int32_t pos = atomicAdd(&fix[0], 1);
-      if (pos < FIX_CAP) {
-        fix[2 + 2 * pos] = (int32_t)t;
-        fix[3 + 2 * pos] = (int32_t)row;
-      } else {
-        atomicOr(flags, FLAG_CHOICE_OVERFLOW);
+  // iteration's store, vmcnt(0), every time round) and ONE scalar read per node, the 64-byte PNode record, read as one
+  // 16-dword vector (member by member the compiler splits it into three dependent reads around the out-degree test).
+  // Nodes without out-edges (they keep SELECTED_ROAD) get a loop of their own.
+  const i32x16* pv = (const i32x16*)pnode;
+  if (QUAD) {
+    const uint64_t blk0 = (uint64_t)b * (G >> 2);
+    const uint64_t counter = pcounter0 + (uint64_t)t;
+    for (uint32_t i = i0; i < i1; i += 4) {   // i0 and i1 are multiples of four
+      const uint64_t blk = blk0 + (i >> 2);
+      uint32_t o[4];
+      philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)counter, (uint32_t)(counter >> 32), (uint32_t)pseed,
+                    (uint32_t)(pseed >> 32), o);
+      const uint32_t row = i * B + b;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {           // two records (32 scalar registers) at a time
+        const i32x16 va = pv[i + 2 * h], vb = pv[i + 2 * h + 1];
+        choice_node(va, u01_open(o[2 * h]), ptab, row + (2 * h) * B, t, out, lp, bad, fix, flags);
+        choice_node(vb, u01_open(o[2 * h + 1]), ptab, row + (2 * h + 1) * B, t, out, lp, bad, fix, flags);
       }
     }
-    out[row] = (uint8_t)(found ? cnt : SEL_UNRESOLVED);
+  } else {
+    PhiloxRun rng;
+    i32x16 nx = pv[i0];
+    // the first record has arrived before the loop is entered: scalar reads return out of order, so a read still pending
+    // at the loop header would make every iteration wait for the read it has just issued
+    asm volatile("" ::"s"(nx[1]));
+    for (uint32_t i = i0; i < i1; ++i) {      // i, and everything indexed by it alone, is wave-uniform
+      const i32x16 v = nx;
+      nx = pv[i + 1];                         // the table has one record of slack behind node N - 1
+      if (v[1] == 0) continue;                // no out-edges (== no group)
+      const float u = rng.uniform(pseed, pcounter0 + (uint64_t)t, (uint64_t)b * G + (uint64_t)v[0]);
+      choice_node(v, u, ptab, i * B + b, t, out, lp, bad, fix, flags);
+    }
   }
   if (G != N) {
     for (uint32_t i = i0; i < i1; ++i)
@@ -1671,7 +1736,8 @@ static int choice_side(ChoiceSide** out) {
 
 extern "C" int64_t tarl_fused_rollout_scratch_ints(const tarl_plan* plan, int64_t T, int64_t B) {
   // unresolved-draw list | packed policy records | per-(frame, environment) log-prob accumulators (int64)
-  return plan && T >= 1 && B >= 1 ? (int64_t)(4 + 2 * FIX_CAP) + 4 * (plan->E + 4) + 2 * T * B : -1;
+  // | per-node draw records (64-byte aligned)
+  return plan && T >= 1 && B >= 1 ? (int64_t)(4 + 2 * FIX_CAP) + 4 * (plan->E + 4) + 2 * T * B + 16 * (plan->N + 1) : -1;
 }
 
 // T consecutive frames with device noise: the collector loop in one foreign call. Each frame is choice -> direction ->
@@ -1740,11 +1806,19 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
                        thresholds, (const long long*)log_probs, ptab);
     TARL_LAUNCH_CHECK();
     long long* lp_acc = (long long*)(ptab + plan->E + 4);     // [T][B], zero between rollouts (k_choice_lp_finish re-arms)
+    PNode* pnode = (PNode*)(((uintptr_t)(lp_acc + T * B) + 63) & ~(uintptr_t)63);
+    hipLaunchKernelGGL(k_pack_pnode, dim3((unsigned)ceil_div(N, FB)), dim3(FB), 0, side->stream, N,
+                       (const NodeRec*)f->node_rec, plan->group_of_node, thresholds, (const long long*)log_probs, pnode);
+    TARL_LAUNCH_CHECK();
     for (int64_t c = 0, t0 = 0; t0 < T; ++c) {
       const int64_t want = c == 0 ? CHOICE_FIRST : CHOICE_CHUNK;
       const unsigned nf = (unsigned)(T - t0 < want ? T - t0 : want);
-      hipLaunchKernelGGL(k_fused_choice_all, dim3((unsigned)ceil_div(B, threads), (unsigned)ceil_div(N, CHOICE_SEG), nf),
-                         dim3(threads), 0, side->stream, (const NodeRec*)f->node_rec, (const PRec*)ptab,
+      // TARL_CHOICE_QUAD=0 keeps the one-node-per-step form (developer knob)
+      static const bool quad_ok = !(getenv("TARL_CHOICE_QUAD") && atoi(getenv("TARL_CHOICE_QUAD")) == 0);
+      const bool quad = quad_ok && plan->G == N && N % 4 == 0;
+      hipLaunchKernelGGL(quad ? k_fused_choice_all<true> : k_fused_choice_all<false>,
+                         dim3((unsigned)ceil_div(B, threads), (unsigned)ceil_div(N, CHOICE_SEG), nf),
+                         dim3(threads), 0, side->stream, (const PNode*)pnode, (const PRec*)ptab,
                          plan->group_of_node, (uint32_t)plan->G, (uint32_t)B, (uint32_t)N, t0, policy_seed,
                          policy_counter0, (const uint8_t*)f->sel8, choice, log_prob ? lp_acc : nullptr, fix, f->flags);
       TARL_LAUNCH_CHECK();
