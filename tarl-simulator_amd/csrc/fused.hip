@@ -609,7 +609,7 @@ __device__ __forceinline__ bool edge_admissible(uint32_t cj, int32_t rk, const f
 // Every read-only array is its own `const __restrict__` kernel argument: topology, statics and edge constants are
 // wave-uniform and must compile to SCALAR loads (through a struct member the compiler has to assume they alias the post
 // stores and falls back to dependent vector loads — measured: 48 -> 85 us per launch).
-template <int NCH>
+template <int NCH, bool SIB>
 __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fused_direction(
     const NodeRec* __restrict__ nodes, const InRec* __restrict__ in_rec, const int32_t* __restrict__ in_eid,
     const float* __restrict__ log_edge_attr, const uint2* __restrict__ hdp, const uint32_t* __restrict__ tl,
@@ -632,6 +632,9 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
   if (valid) {
     uint2 me[NCH], hj[NCH][4];
     uint32_t tlw[NCH], cj[NCH][4];
+    // SIB: sibling rows — the roads that leave one intersection — have the same upstream rows. When every chunk's rows
+    // list the same first four sources (checked once per graph, tarl_plan::siblings4), the upstream words are gathered
+    // once per chunk instead of once per row: 16 requests per lane instead of 40.
 #pragma unroll
     for (int r = 0; r < NCH; ++r) {
       const uint32_t i = (i0 + r < N) ? i0 + r : N - 1;
@@ -641,9 +644,14 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
       const InRec* ir = nodes[i].in4;   // the first four in-edge records travel in the node record
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const uint32_t jrow = (uint32_t)ir[q].src * B + b;
-        hj[r][q] = hdp[jrow];
-        cj[r][q] = sel8[jrow] & 0x7Fu;
+        if (SIB && r > 0) {
+          hj[r][q] = hj[0][q];
+          cj[r][q] = cj[0][q];
+        } else {
+          const uint32_t jrow = (uint32_t)ir[q].src * B + b;
+          hj[r][q] = hdp[jrow];
+          cj[r][q] = sel8[jrow] & 0x7Fu;
+        }
       }
     }
 #pragma unroll
@@ -1588,15 +1596,23 @@ static int launch_direction(dim3 grid, unsigned threads, hipStream_t s, const ta
                             const float* edge_attr, const float* log_edge_attr, const uint8_t* sel8, const float* gumbel,
                             float* dtt, float log_eps, float time, float prev_time, uint64_t seed, uint64_t counter,
                             int64_t B, const FrameOut& out) {
-#define DIR_LAUNCH(NCH)                                                                                                   \
-  hipLaunchKernelGGL(k_fused_direction<NCH>, grid, dim3(threads), 0, s, (const NodeRec*)f->node_rec,                    \
+#define DIR_LAUNCH(NCH, SIB)                                                                                              \
+  hipLaunchKernelGGL((k_fused_direction<NCH, SIB>), grid, dim3(threads), 0, s, (const NodeRec*)f->node_rec,                    \
                      (const InRec*)f->in_rec, plan->in_eid, log_edge_attr, (const uint2*)f->hdp, (const uint32_t*)f->tl,  \
                      (const uint2*)f->rec1, sel8, (const float*)f->sel, gumbel, dtt, (uint32_t*)f->post, log_eps, time,   \
                      prev_time, seed, counter, (uint32_t)plan->E, (uint32_t)B, (uint32_t)plan->N, out)
+  // TARL_DIR_SIBLINGS=0 keeps the per-row gathers on a sibling graph (developer knob)
+  static const bool sib_ok = !(getenv("TARL_DIR_SIBLINGS") && atoi(getenv("TARL_DIR_SIBLINGS")) == 0);
   switch (nchunk_dir()) {
-    case 1: DIR_LAUNCH(1); break;
-    case 2: DIR_LAUNCH(2); break;
-    default: DIR_LAUNCH(4); break;
+    case 1: DIR_LAUNCH(1, false); break;
+    case 2: DIR_LAUNCH(2, false); break;
+    default:
+      if (sib_ok && plan->siblings4) {
+        DIR_LAUNCH(4, true);
+      } else {
+        DIR_LAUNCH(4, false);
+      }
+      break;
   }
 #undef DIR_LAUNCH
   TARL_LAUNCH_CHECK();

@@ -115,6 +115,18 @@ extern "C" int tarl_plan_create(const int64_t* ei, int64_t E, int64_t N, const i
   p->max_out = max_out;
   p->src_sorted = src_sorted ? 1 : 0;
   p->dst_sorted = dst_sorted ? 1 : 0;
+  {
+    bool sib = N >= 4 && N % 4 == 0;
+    for (int64_t c = 0; sib && c < N; c += 4) {
+      const int32_t a0 = in_ptr[c], deg = in_ptr[c + 1] - a0;
+      for (int64_t r = 1; sib && r < 4; ++r) {
+        const int32_t ar = in_ptr[c + r];
+        sib = in_ptr[c + r + 1] - ar == deg;
+        for (int32_t q = 0; sib && q < deg && q < 4; ++q) sib = in_src[ar + q] == in_src[a0 + q];
+      }
+    }
+    p->siblings4 = sib ? 1 : 0;
+  }
   int rc;
 #define UP(field, vec)                       \
   if ((rc = upload(&p->field, vec)) != TARL_OK) { \

@@ -42,6 +42,8 @@ struct tarl_plan {
   int32_t max_in, max_out;
   int32_t src_sorted;      // 1 when edge_index[0] is non-decreasing and the plan order == original order
   int32_t dst_sorted;      // 1 when CSC order == original order
+  int32_t siblings4;       // 1 when nodes 4c .. 4c + 3 have the same first four in-edge sources for every c (N % 4 == 0):
+                           // the roads leaving one intersection; the Direction gather then reads the upstream rows once
   // device arrays (int32)
   int32_t* in_ptr;         // [N+1]  CSC by destination
   int32_t* in_src;         // [E]    source node of the k-th in-edge
