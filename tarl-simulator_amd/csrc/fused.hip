@@ -427,16 +427,19 @@ __global__ __launch_bounds__(FB) void k_pack_ptab(int64_t E, const float* __rest
   }
 }
 
-// per node: everything the all-frames draw needs about it in ONE aligned 64-byte scalar read whose address depends on the
-// node index alone (through the CSR range it would be two dependent scalar rounds per node, and those rounds — not the
-// Philox blocks — were what the draw waited for)
+// per node: everything the all-frames draw needs about it in ONE aligned scalar read whose address depends on the node
+// index alone (through the CSR range it would be two dependent scalar rounds per node). The thresholds are kept as
+// INTEGERS: a draw is u = f(m) = ((float)m + 0.5f) * 2^-24 of the 24-bit m = word >> 8, f is non-decreasing, so
+// u >= thr  <=>  m >= ithr with ithr = min{m : f(m) >= thr} (2^24: never) — found by bisection with f itself, so the
+// comparison is the same for every m and the three conversion instructions per draw are not issued. The log-prob terms
+// (second half of the record) are copied into LDS per workgroup and looked up by the count.
 struct __attribute__((aligned(64))) PNode {
   int32_t gi, deg, out0, pad;
-  float thr[4];                              // +inf beyond the out-degree
+  uint32_t ithr[4];                          // 2^24 beyond the out-degree
   int32_t lg_lo[4], lg_hi[4];
 };
-static_assert(sizeof(PNode) == 64, "PNode is one 64-byte scalar read");
-typedef int32_t i32x16 __attribute__((ext_vector_type(16)));
+static_assert(sizeof(PNode) == 64, "PNode: a 32-byte scalar read + 32 bytes of log-prob terms");
+typedef int32_t i32x8 __attribute__((ext_vector_type(8)));
 
 __global__ __launch_bounds__(FB) void k_pack_pnode(int64_t N, const NodeRec* __restrict__ nodes,
                                                    const int32_t* __restrict__ group_of_node,
@@ -452,7 +455,16 @@ __global__ __launch_bounds__(FB) void k_pack_pnode(int64_t N, const NodeRec* __r
   for (int q = 0; q < 4; ++q) {
     const bool in = q < pn.deg;
     const long long lg = in ? lgt[pn.out0 + q] : 0ll;
-    pn.thr[q] = in ? thr[pn.out0 + q] : INFINITY;
+    const float th = in ? thr[pn.out0 + q] : INFINITY;
+    uint32_t lo = 0u, hi = 1u << 24;         // the first m with f(m) >= th (NaN / +inf: none)
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (u01_open(mid << 8) >= th)
+        hi = mid;
+      else
+        lo = mid + 1u;
+    }
+    pn.ithr[q] = lo;
     pn.lg_lo[q] = (int32_t)(uint32_t)(lg & 0xffffffffll);
     pn.lg_hi[q] = (int32_t)(lg >> 32);
   }
@@ -460,27 +472,29 @@ __global__ __launch_bounds__(FB) void k_pack_pnode(int64_t N, const NodeRec* __r
 }
 
 #define CHOICE_SEG 128    // nodes per workgroup of the all-frames choice (a frame's log-prob = the sum of its segments)
-// one node's draw from its record v and its uniform u: the inverse CDF is a count — thresholds are non-decreasing (fp32
-// roundings of a running double sum), so the first q with u < thr[q] is the number of thresholds at or below u
-__device__ __forceinline__ void choice_node(const i32x16 v, const float u, const PRec* __restrict__ ptab, uint32_t row,
-                                            int64_t t, uint8_t* __restrict__ out, long long& lp, bool& bad,
+// one node's draw from the first half of its record v and the 24 random bits m: the inverse CDF is a count — thresholds
+// are non-decreasing (fp32 roundings of a running double sum), so the first q with u < thr[q] is the number of thresholds
+// at or below u. lgn: the node's four log-prob terms in LDS (one entry of slack behind them).
+__device__ __forceinline__ void choice_node(const i32x8 v, const uint32_t m, const long long* lgn,
+                                            const PRec* __restrict__ ptab, uint32_t row, int64_t t,
+                                            uint8_t* __restrict__ out, long long& lp, bool& bad,
                                             int32_t* __restrict__ fix, int32_t* __restrict__ flags) {
   const int32_t deg = v[1];
   const PRec* pr = ptab + v[2];
-  uint32_t cnt = (u >= __int_as_float(v[4]) ? 1u : 0u) + (u >= __int_as_float(v[5]) ? 1u : 0u) +
-                 (u >= __int_as_float(v[6]) ? 1u : 0u) + (u >= __int_as_float(v[7]) ? 1u : 0u);
-  for (int32_t q = 4; q < deg; ++q) cnt += (u >= pr[q].thr) ? 1u : 0u;
-  const bool found = cnt < (uint32_t)deg;
-  const uint32_t lo = (uint32_t)(cnt == 0u ? v[8] : (cnt == 1u ? v[9] : (cnt == 2u ? v[10] : v[11])));
-  const int32_t hi = cnt == 0u ? v[12] : (cnt == 1u ? v[13] : (cnt == 2u ? v[14] : v[15]));
-  long long lpn = ((long long)hi << 32) | (long long)lo;
-  if (deg > 4 && cnt >= 4u && found) {  // out-degree above four (wave-uniform): the term sits further down the table
-    const PRec px = pr[cnt];
-    lpn = ((long long)px.lg_hi << 32) | (long long)(uint32_t)px.lg_lo;
+  uint32_t cnt = (m >= (uint32_t)v[4] ? 1u : 0u) + (m >= (uint32_t)v[5] ? 1u : 0u) + (m >= (uint32_t)v[6] ? 1u : 0u) +
+                 (m >= (uint32_t)v[7] ? 1u : 0u);
+  long long lpn = lgn[cnt < 4u ? cnt : 4u];
+  if (deg > 4) {                         // wave-uniform: the thresholds further down the table, as floats
+    const float u = u01_open(m << 8);
+    for (int32_t q = 4; q < deg; ++q) cnt += (u >= pr[q].thr) ? 1u : 0u;
+    if (cnt >= 4u && cnt < (uint32_t)deg) {
+      const PRec px = pr[cnt];
+      lpn = ((long long)px.lg_hi << 32) | (long long)(uint32_t)px.lg_lo;
+    }
   }
-  if (found) {
-    lp += lpn;
-  } else {
+  const bool found = cnt < (uint32_t)deg;
+  lp += lpn;                             // a node that drew nothing poisons the whole sum below
+  if (!found) {
     bad = true;
     const int32_t pos = atomicAdd(&fix[0], 1);
     if (pos < FIX_CAP) {
@@ -503,19 +517,24 @@ __global__ __launch_bounds__(TILE) void k_fused_choice_all(const PNode* __restri
                                                            uint64_t pcounter0, const uint8_t* __restrict__ sel0,
                                                            uint8_t* __restrict__ choice, long long* __restrict__ lp_acc,
                                                            int32_t* __restrict__ fix, int32_t* __restrict__ flags) {
+  __shared__ long long s_lg[CHOICE_SEG * 4 + 4];
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
   const int64_t t = t0 + blockIdx.z;
   const uint32_t i0 = blockIdx.y * CHOICE_SEG;
   const uint32_t i1 = (i0 + CHOICE_SEG < N) ? i0 + CHOICE_SEG : N;
+  for (uint32_t e = threadIdx.x; e < (i1 - i0) * 4; e += blockDim.x) {
+    const PNode& pn = pnode[i0 + (e >> 2)];
+    s_lg[e] = ((long long)pn.lg_hi[e & 3] << 32) | (long long)(uint32_t)pn.lg_lo[e & 3];
+  }
+  __syncthreads();
+  if (b >= B) return;
   uint8_t* out = choice + t * (int64_t)N * B;
   long long lp = 0;
   bool bad = false;
   // The node loop issues no vector load at all (a conditional load inside it makes the compiler wait for the previous
-  // iteration's store, vmcnt(0), every time round) and ONE scalar read per node, the 64-byte PNode record, read as one
-  // 16-dword vector (member by member the compiler splits it into three dependent reads around the out-degree test).
+  // iteration's store, vmcnt(0), every time round) and ONE scalar read per node, the first half of its PNode record, read
+  // as one 8-dword vector (member by member the compiler splits it into dependent reads around the out-degree test).
   // Nodes without out-edges (they keep SELECTED_ROAD) get a loop of their own.
-  const i32x16* pv = (const i32x16*)pnode;
   if (QUAD) {
     const uint64_t blk0 = (uint64_t)b * (G >> 2);
     const uint64_t counter = pcounter0 + (uint64_t)t;
@@ -526,24 +545,18 @@ __global__ __launch_bounds__(TILE) void k_fused_choice_all(const PNode* __restri
                     (uint32_t)(pseed >> 32), o);
       const uint32_t row = i * B + b;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {           // two records (32 scalar registers) at a time
-        const i32x16 va = pv[i + 2 * h], vb = pv[i + 2 * h + 1];
-        choice_node(va, u01_open(o[2 * h]), ptab, row + (2 * h) * B, t, out, lp, bad, fix, flags);
-        choice_node(vb, u01_open(o[2 * h + 1]), ptab, row + (2 * h + 1) * B, t, out, lp, bad, fix, flags);
+      for (int r = 0; r < 4; ++r) {
+        const i32x8 v = *(const i32x8*)(pnode + i + r);
+        choice_node(v, o[r] >> 8, s_lg + (i - i0 + r) * 4, ptab, row + r * B, t, out, lp, bad, fix, flags);
       }
     }
   } else {
     PhiloxRun rng;
-    i32x16 nx = pv[i0];
-    // the first record has arrived before the loop is entered: scalar reads return out of order, so a read still pending
-    // at the loop header would make every iteration wait for the read it has just issued
-    asm volatile("" ::"s"(nx[1]));
     for (uint32_t i = i0; i < i1; ++i) {      // i, and everything indexed by it alone, is wave-uniform
-      const i32x16 v = nx;
-      nx = pv[i + 1];                         // the table has one record of slack behind node N - 1
+      const i32x8 v = *(const i32x8*)(pnode + i);
       if (v[1] == 0) continue;                // no out-edges (== no group)
-      const float u = rng.uniform(pseed, pcounter0 + (uint64_t)t, (uint64_t)b * G + (uint64_t)v[0]);
-      choice_node(v, u, ptab, i * B + b, t, out, lp, bad, fix, flags);
+      const uint32_t w = rng.word(pseed, pcounter0 + (uint64_t)t, (uint64_t)b * G + (uint64_t)v[0]);
+      choice_node(v, w >> 8, s_lg + (i - i0) * 4, ptab, i * B + b, t, out, lp, bad, fix, flags);
     }
   }
   if (G != N) {

@@ -115,6 +115,10 @@ struct PhiloxRun {
   uint64_t blk;
   __device__ __forceinline__ PhiloxRun() : o0(0), o1(0), o2(0), o3(0), blk(~0ull) {}
   __device__ __forceinline__ float uniform(uint64_t seed, uint64_t counter, uint64_t index) {
+    return u01_open(word(seed, counter, index));
+  }
+  // the raw 32-bit word behind uniform()
+  __device__ __forceinline__ uint32_t word(uint64_t seed, uint64_t counter, uint64_t index) {
     const uint64_t b = index >> 2;
     if (b != blk) {
       blk = b;
@@ -124,7 +128,7 @@ struct PhiloxRun {
       o0 = o[0]; o1 = o[1]; o2 = o[2]; o3 = o[3];
     }
     const uint32_t w = (uint32_t)(index & 3);
-    return u01_open(w == 0 ? o0 : (w == 1 ? o1 : (w == 2 ? o2 : o3)));
+    return w == 0 ? o0 : (w == 1 ? o1 : (w == 2 ? o2 : o3));
   }
 };
 
