@@ -704,8 +704,10 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     for (uint32_t i = i0; i < i0 + NCH && i < N; ++i) {
       const uint32_t row = i * B + b;
       const uint2 mw = hdp[row];
-      const float arr_i = ((mw.x & 255u) == 0u && !(tl[row] & TLF_AUTH)) ? t_prev : __uint_as_float(rec1[row].x);
-      const float d = (__uint_as_float(mw.y) - arr_i) - nodes[i].ff;
+      const bool lazy_i = (mw.x & 255u) == 0u && !(tl[row] & TLF_AUTH);   // empty and idle in the last frame: its garbage
+      const float arr_i = lazy_i ? t_prev : __uint_as_float(rec1[row].x);  // head arrived at that frame's clock and
+      const float dep_i = lazy_i ? t_prev + nodes[i].tt0 : __uint_as_float(mw.y);   // departs tt0 later (never stored)
+      const float d = (dep_i - arr_i) - nodes[i].ff;
       out.dtt_node[(int64_t)i * out.m_env + b] = d > 0.0f ? d : (d != d ? d : 0.0f);
     }
   }
@@ -730,8 +732,10 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
             P = P + ir[q].ea * (m ? 1.0f : 0.0f);
           }
           if (dtt) {   // per-edge side output of DirectionMPNN.message (src/direction_mpnn.py:94-96): a property of j
-            const float arr_j = ((hx.x & 255u) == 0u && !(tl[jrow] & TLF_AUTH)) ? t_prev : __uint_as_float(rec1[jrow].x);
-            const float d = (__uint_as_float(hx.y) - arr_j) - nodes[j].ff;
+            const bool lazy_j = (hx.x & 255u) == 0u && !(tl[jrow] & TLF_AUTH);
+            const float arr_j = lazy_j ? t_prev : __uint_as_float(rec1[jrow].x);
+            const float dep_j = lazy_j ? t_prev + nodes[j].tt0 : __uint_as_float(hx.y);
+            const float d = (dep_j - arr_j) - nodes[j].ff;
             dtt[(int64_t)b * E + in_eid[nr.in0 + q]] = d > 0.0f ? d : (d != d ? d : 0.0f);
           }
         }
@@ -844,9 +848,14 @@ __device__ __forceinline__ bool row_phase_a(uint32_t i, uint32_t b, const NodeRe
   const bool due = !pop && ni > 0u && (int64_t)head_id < A && (head_dep <= t);
   *pop_out = pop;
   if (!(lazy && !pop && !due)) return true;
-  // IDLE ROW: nothing moves. Only the dense words are refreshed.
-  fb.hdp[row] = make_uint2((head_id << 8) | ni, __float_as_uint(head_dep));
-  fb.tl[row] = tlw & ~TLF_AUTH;      // tail and ring offset stay
+  // IDLE ROW: nothing moves, and (almost) nothing is written. With agents, the row keeps its head and count: its word
+  // is already what a refresh would store. Empty, its garbage head departs at t + tt0, which changes every frame — but
+  // nobody reads the departure of an empty row that was idle (tail word without TLF_AUTH): this pass recomputes it, the
+  // Direction gather's tests need an agent in the row or MAX_NUMBER_OF_AGENT <= 3 (rows that small keep the eager word),
+  // export and delta_travel_time derive it from the clock. The tail word changes only when its flag has to go.
+  if (n0i == 0u && nr.maxn <= TARL_CONGESTION_FILE)
+    fb.hdp[row] = make_uint2((head_id << 8) | ni, __float_as_uint(head_dep));
+  if (tlw & TLF_AUTH) fb.tl[row] = tlw & ~TLF_AUTH;      // tail and ring offset stay
   if (out.counts8) __builtin_nontemporal_store((uint8_t)ni, &out.counts8[row]);
   if (out.countsf) __builtin_nontemporal_store((float)ni, &out.countsf[row]);
   if (out.popped) out.popped[(int64_t)b * N + i] = 0;

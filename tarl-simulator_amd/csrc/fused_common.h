@@ -18,7 +18,10 @@
 #define INSB 64         // insert kernel: one wave per environment (all resident at once, 3/4 of the wave slots left free)
 
 // ---- packed per-(node, environment) words (layout "v6") ------------------------------------------------------------------
-// Dense words, read and rewritten by every row every frame (12 + 4 + 1 bytes):
+// Dense words, read by every row every frame (12 + 4 + 1 bytes) and rewritten by the rows where something moved (an
+// idle row's words already hold what a refresh would store, with one exception: the departure of an EMPTY row's garbage
+// head changes with the clock — it is not stored while the row idles (tl without TLF_AUTH, n == 0): its readers derive it
+// as last clock + tt0; rows with MAX_NUMBER_OF_AGENT <= 3, whose empty state the Direction tests can see, keep it eager):
 //   hdp  uint2  {hd = head_id << 8 | n, bits of head_dep}   n = NUMBER_OF_AGENT (<= 255: the fused path requires Nmax <= 255),
 //                                                            ids < 2^24 (the reference keeps them in fp32: exact below 2^24)
 //   tl   u32    tail_id << 8 | hoff << 1 | TLF_AUTH          hoff = physical slot of logical slot 0 (ring buffer; < 128: the

@@ -184,9 +184,12 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
     const uint2 q1 = fb.rec1[row];
     const uint32_t pw = fb.post[row];
     const int n = (int)(hp.x & 255u);
-    r0[i] = make_float4((float)(hp.x >> 8), __uint_as_float(hp.y), (float)n, (float)(tlw >> 8));
-    // an idle empty row's head arrival is the previous frame's clock; its pending garbage count is its count
-    const float arr = (n == 0 && !(tlw & TLF_AUTH)) ? prev_time : __uint_as_float(q1.x);
+    // an idle empty row's head arrived at the previous frame's clock and departs tt0 later (the frame kernels do not store
+    // that departure); its pending garbage count is its count
+    const bool lazy_row = n == 0 && !(tlw & TLF_AUTH);
+    const float dep0 = lazy_row ? prev_time + entry_tt(fb.st0[i], 0.0f) : __uint_as_float(hp.y);
+    r0[i] = make_float4((float)(hp.x >> 8), dep0, (float)n, (float)(tlw >> 8));
+    const float arr = lazy_row ? prev_time : __uint_as_float(q1.x);
     r1[i] = make_float2(arr, l1_code((float)pending_g(tlw, n, q1.y, Nmax), tl_hoff(tlw)));
     const bool arrived = (pw & PF_ARRIVED) != 0u;
     pA[i] = make_float2(arrived ? (float)(n + 1) : (float)n, (float)(pw >> 8));

@@ -694,6 +694,7 @@ class FusedState:
 
     @property
     def head_dep(self):
+        """Stored head departure; not maintained for an empty row that idled in the last frame (count 0, tl bit 0 clear)."""
         return self.hdp[..., 1].contiguous().view(torch.float32)
 
     @property
