@@ -98,8 +98,8 @@ def test_fused_equals_unfused_frame_by_frame(ops, W, H, het, B, A, frames, with_
         wd1 = ops.withdraw_step(plan, x1, Nmax, a1, t)
         ops.insert_step(x1, Nmax, a1, t, congestion_constant=cc, reward=r1, counts=c1)
         # fused frame
-        ops.fused_frame(plan, fs, tables, a2, ec, t, use_cong=with_cc, uniform=u_s, gumbel=gum, dtt=dtt2, popped=pop2,
-                        withdrawn=wd2, choice=ch2, log_prob=lp2, entropy=en2, reward=r2, counts=c2)
+        ops.fused_frame(plan, fs, tables, a2, ec, t, use_cong=with_cc, prev_time=t - dt, uniform=u_s, gumbel=gum, dtt=dtt2,
+                        popped=pop2, withdrawn=wd2, choice=ch2, log_prob=lp2, entropy=en2, reward=r2, counts=c2)
         ops.fused_export(plan, fs, x2, Nmax, t)       # back to the reference's column layout
         assert torch.equal(ch1, ch2.t()), f"actions frame {s}"
         assert torch.allclose(lp1, lp2, rtol=LP_RTOL, atol=1e-5) and torch.equal(en1, en2), f"policy frame {s}"

@@ -5,7 +5,6 @@ O=gpurun_out/r02final
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 Q="--cpu-seconds 0 --congested-window 0 --policy-envs 0"
-python bench.py > $O/bench_default.json.log 2> $O/bench_default.err
 for cfg in "c3_b1 --edges 1024 --agents 1024 --envs 1" "c3_b256 --edges 1024 --agents 1024 --envs 256" \
            "c3_b2048 --edges 1024 --agents 1024 --envs 2048" "c4_b1 --envs 1" "c4_b256 --envs 256" "c4_b512 --envs 512" \
            "c4_b1024 --envs 1024" "c4_b2048 --envs 2048" "c4_b8192 --envs 8192" \
@@ -29,5 +28,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_policy -o run --
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -o run -- python3 bench.py $Q --steps 1 --warmup 1 --no-kernel-timing > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -o run -- python3 bench.py $Q --steps 1 --warmup 1 --no-kernel-timing > /dev/null 2>&1
 python3 tools/pmc_bench.py $O/pmc_f $O/pmc_w --out $O/pmc_traffic.json > /dev/null
+# the default bench line last, against the traffic record just measured (in this run's copy of the tree)
+cp $O/pmc_traffic.json profiles/r02_pmc_traffic.json
+python bench.py > $O/bench_default.json.log 2> $O/bench_default.err
 rm -f $O/*/run_kernel_trace.csv
 ls $O
