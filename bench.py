@@ -55,9 +55,9 @@ PMC_RECORD = os.path.join("profiles", "r02_pmc_traffic.json")   # written by too
 COMPULSORY = {
     # head words 8 + tail word 4 + SELECTED_ROAD byte 1 in; post word 4 out
     "k_fused_direction": {"per_node_env": 13.0 + 4.0},
-    # post word 4 + head words 8 + tail word 4 in; head words 8 + tail word 4 + count byte 1 out (event word, slot store
-    # and agent rows only where something moves)
-    "k_fused_rows": {"per_node_env": 16.0 + 13.0},
+    # post word 4 + head words 8 + tail word 4 in; count byte 1 out (an idle row's words already hold what a refresh would
+    # store: head / tail words, event word, slot store and agent rows are written only where something moves)
+    "k_fused_rows": {"per_node_env": 16.0 + 1.0},
     # insert(t): departure window, a few words per admitted agent, the accumulator banks (the actions of all frames are
     # drawn on a side stream: k_fused_choice_all, 1 byte per (frame, road, environment))
     "k_fused_insert": {"per_node_env": 0.0},
