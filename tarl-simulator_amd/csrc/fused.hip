@@ -992,7 +992,7 @@ __device__ __forceinline__ float2 row_phase_b(uint32_t i, uint32_t b, bool pop, 
 // NCH rows per lane: ALL their loads (dense words, downstream post words) are issued before the first row is processed,
 // so a wave keeps 8 * NCH independent requests in flight instead of one row's dependent phases.
 template <int NCH>
-__global__ __launch_bounds__(TILE) void k_fused_rows(const NodeRec* __restrict__ nodes,
+__global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fused_rows(const NodeRec* __restrict__ nodes,
                                                      const int32_t* __restrict__ out_pad,
                                                      const int32_t* __restrict__ out_ptr,
                                                      const int32_t* __restrict__ out_dst,
