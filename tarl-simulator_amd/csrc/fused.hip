@@ -694,7 +694,10 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
           const bool m = edge_admissible<false>(cx, ir[q].rank, sel_raw, 0, hx, ir[q].max_src, road_i, n_i, max_i, t);
           P = P + ir[q].ea * (m ? 1.0f : 0.0f);
         }
-        post[row] = (tlw[r] & ~0xFFu) | ((me[r].x & 255u) ? PF_NONEMPTY : 0u);   // nobody chosen; pass 2 overwrites
+        // nobody chosen (pass 2 overwrites). A row that idled in the last frame (tail word without TLF_AUTH) still holds
+        // exactly this word from the frame before: whatever changes a row's tail, empties or fills it, or hands it an
+        // arrival makes it an event row, and event rows and inserts set the flag
+        if (tlw[r] & TLF_AUTH) post[row] = (tlw[r] & ~0xFFu) | ((me[r].x & 255u) ? PF_NONEMPTY : 0u);
         if (P > 0.0f) s_item[atomicAdd(&s_n, 1)] = (uint16_t)(r * TILE + threadIdx.x);
       }
     }
