@@ -1781,13 +1781,14 @@ extern "C" int64_t tarl_fused_rollout_scratch_ints(const tarl_plan* plan, int64_
   return plan && T >= 1 && B >= 1 ? (int64_t)(4 + 2 * FIX_CAP) + 4 * (plan->E + 4) + 2 * T * B + 16 * (plan->N + 1) : -1;
 }
 
-// T consecutive frames with device noise: the collector loop in one foreign call. Each frame is choice -> direction ->
-// rows -> insert on the caller's stream; frame t+1's choice shares the launch of frame t's insert
-// (k_fused_insert_choice). The action of frame t is written into slice t of the action buffer, which is also the
-// SELECTED_ROAD column that frame's Direction gather and insert read. (Two alternatives were measured and rejected,
-// folding frame t+1's choice into the row pass, and running it on a side stream. Both lose the
-// producer -> consumer adjacency that lets the Direction kernel read what the choice kernel just wrote from the
-// Infinity Cache.)
+// T consecutive frames with device noise: the collector loop in one foreign call. Each frame is direction -> rows ->
+// insert on the caller's stream. The action of frame t is slice t of the action buffer, which is also the
+// SELECTED_ROAD column that frame's Direction gather and insert read. With an action buffer and choice_scratch (the
+// default, TARL_ROLLOUT_MERGE=2) the live policy's draws for ALL frames are made on a side stream in blocks of
+// CHOICE_CHUNK frames (the sample does not depend on the state: k_fused_choice_all), the first, short block is waited
+// for; otherwise frame t+1's choice shares the launch of frame t's insert (k_fused_insert_choice, mode 1) or is a
+// launch of its own (mode 0). Per-frame draws on a side stream and folding them into the row pass were measured and
+// rejected.
 extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, int64_t T,
                                   const float* times_host, float prev_time, const float* thresholds,
                                   const int64_t* log_probs, const float* entropy1, uint64_t policy_seed,
