@@ -697,7 +697,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         // nobody chosen (pass 2 overwrites). A row that idled in the last frame (tail word without TLF_AUTH) still holds
         // exactly this word from the frame before: whatever changes a row's tail, empties or fills it, or hands it an
         // arrival makes it an event row, and event rows and inserts set the flag
-        if (tlw[r] & TLF_AUTH) post[row] = (tlw[r] & ~0xFFu) | ((me[r].x & 255u) ? PF_NONEMPTY : 0u);
+        if (tlw[r] & TLF_AUTH) post[row] = (tlw[r] & ~0xFFu) | ((me[r].x & 255u) ? PF_NONEMPTY : 0u) | PF_TLAUTH;
         if (P > 0.0f) s_item[atomicAdd(&s_n, 1)] = (uint16_t)(r * TILE + threadIdx.x);
       }
     }
@@ -858,7 +858,12 @@ __device__ __forceinline__ bool row_phase_a(uint32_t i, uint32_t b, const NodeRe
   // export and delta_travel_time derive it from the clock. The tail word changes only when its flag has to go.
   if (n0i == 0u && nr.maxn <= TARL_CONGESTION_FILE)
     fb.hdp[row] = make_uint2((head_id << 8) | ni, __float_as_uint(head_dep));
-  if (tlw & TLF_AUTH) fb.tl[row] = tlw & ~TLF_AUTH;      // tail and ring offset stay
+  if (tlw & TLF_AUTH) {
+    fb.tl[row] = tlw & ~TLF_AUTH;      // tail and ring offset stay
+    // ... and the post word's mirror of the flag goes with it (other workgroups may be gathering this word for their
+    // Response test right now: they look at PF_NONEMPTY and the tail id, which do not change)
+    fb.post[row] = pa & ~PF_TLAUTH;
+  }
   if (out.counts8) __builtin_nontemporal_store((uint8_t)ni, &out.counts8[row]);
   if (out.countsf) __builtin_nontemporal_store((float)ni, &out.countsf[row]);
   if (out.popped) out.popped[(int64_t)b * N + i] = 0;
@@ -1023,11 +1028,24 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
       const uint32_t i = (i0 + r < N) ? i0 + r : N - 1;   // clamped: the tail rows are loaded twice, used once
       const uint32_t row = i * B + b;
       pa[r] = post[row];
-      hp[r] = fb.hdp[row];
-      tlw[r] = fb.tl[row];
       const int32_t* od = nodes[i].out4;   // the first four targets travel in the node record
 #pragma unroll
       for (int q = 0; q < 4; ++q) pj[r][q] = post[(uint32_t)od[q] * B + b];
+    }
+    // The post word already says whether the row holds anybody (PF_NONEMPTY), receives somebody (PF_ARRIVED) or still
+    // carries the flag of an event in its tail word (PF_TLAUTH). A row with none of the three is empty and idle: its
+    // head words are {0, unused} and its tail word is flag-free whatever its stale tail id — they are not fetched. In a
+    // filling network that is most rows; the second round of loads only touches the sectors of the others.
+#pragma unroll
+    for (int r = 0; r < NCH; ++r) {
+      const uint32_t i = (i0 + r < N) ? i0 + r : N - 1;
+      const uint32_t row = i * B + b;
+      hp[r] = make_uint2(0u, 0u);
+      tlw[r] = 0u;
+      if (Nmax < 2 || (pa[r] & (PF_ARRIVED | PF_NONEMPTY | PF_TLAUTH))) {   // (a one-slot FIFO has no lazy garbage slot)
+        hp[r] = fb.hdp[row];
+        tlw[r] = fb.tl[row];
+      }
     }
 #pragma unroll
     for (int r = 0; r < NCH; ++r)

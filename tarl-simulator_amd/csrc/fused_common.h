@@ -30,7 +30,7 @@
 //                                                            clear = the row was idle in the last frame: the pending
 //                                                            garbage count is n itself and an empty row's head arrival is
 //                                                            the last frame's clock
-//   post u32    tail' << 8 | PF_NONEMPTY | PF_ARRIVED        the row's state after the Direction update: tail' = the agent
+//   post u32    tail' << 8 | PF_TLAUTH | PF_NONEMPTY | PF_ARRIVED       the row's state after the Direction update: tail' = the agent
 //                                                            it enqueues (PF_ARRIVED) or its old tail; written by the
 //                                                            Direction gather, gathered by the upstream rows' Response test
 //   sel8 u8     SELECTED_ROAD as the rank of the chosen out-edge in the node's CSR list (| SEL_CARRIED when the node drew
@@ -42,6 +42,9 @@
 #define TLF_AUTH 1u
 #define PF_ARRIVED 1u
 #define PF_NONEMPTY 2u
+#define PF_TLAUTH 4u      // the row's tail word carried TLF_AUTH when the Direction gather last wrote this post word (the row
+                          // pass clears both together): with PF_NONEMPTY / PF_ARRIVED clear too, the row pass needs none of
+                          // the row's other words
 #define SEL_RAW 0x7Fu
 #define SEL_CARRIED 0x80u
 #define INRANK_NONE 0xFEu

@@ -16,7 +16,7 @@ from . import lib as _lib
 EPS_GUMBEL = 1e-12   # src/direction_mpnn.py:136
 # revision of the fused path's packed HBM layout / kernel set: a PMC traffic record (profiles/*_pmc_traffic.json) only
 # applies to the revision it was measured on
-FUSED_LAYOUT = "v8"
+FUSED_LAYOUT = "v9"
 
 
 def _check_dev(t: torch.Tensor, dtype, name: str):
