@@ -1126,20 +1126,31 @@ __device__ __forceinline__ bool fused_target_words(const FusedBufs& fb, PlanOut 
   return room > 0;
 }
 
-__device__ __forceinline__ void fused_insert_body(int64_t b, int Nmax, int64_t B, int64_t N, FusedBufs fb, PlanOut P,
+// The insert kernels' LDS block (one per workgroup; the one-environment body and the two-environment kernel share it, so
+// that the latter's rare fall-back into the former costs no second block: 3.9 KB, 41 workgroups per CU)
+struct InsLds {
+  int32_t wave[INSB / 64];
+  int32_t cnt, adm, lo;
+  int32_t cnt2[2], adm2[2], lo2[2];   // k_fused_insert2: one set per environment of the pair
+  int32_t un_agent[INS_CAP], un_road[INS_CAP], un_k[INS_CAP];
+  uint32_t un_hd[INS_CAP], un_tl[INS_CAP];
+};
+#define s_wave L.wave
+#define s_cnt L.cnt
+#define s_adm L.adm
+#define s_lo L.lo
+#define s_un_agent L.un_agent
+#define s_un_road L.un_road
+#define s_un_k L.un_k
+#define s_un_hd L.un_hd
+#define s_un_tl L.un_tl
+__device__ __forceinline__ void fused_insert_body(InsLds& L, int64_t b, int Nmax, int64_t B, int64_t N, FusedBufs fb, PlanOut P,
                                                   const uint8_t* __restrict__ sel8, float* __restrict__ ag, int64_t A,
                                                   int64_t a_bstride, int use_cong, float t,
                                                   int32_t* __restrict__ scratch, const float* __restrict__ entropy_in,
                                                   float* __restrict__ reward, FrameOut out,
                                                   float* __restrict__ log_prob, float* __restrict__ entropy) {
-  __shared__ int32_t s_wave[INSB / 64];
-  __shared__ int32_t s_cnt;
-  __shared__ int32_t s_adm;
-  __shared__ int32_t s_lo;
-  __shared__ int32_t s_un_agent[INS_CAP], s_un_road[INS_CAP];
-  // window path: the candidate's position in the departure order and its target row's count / tail words
-  __shared__ int32_t s_un_k[INS_CAP];
-  __shared__ uint32_t s_un_hd[INS_CAP], s_un_tl[INS_CAP];
+  // (window path: un_k = the candidate's position in the departure order, un_hd / un_tl = its target row's count / tail words)
   float* agb = ag + b * a_bstride;
   int32_t* cand_agent = scratch + b * 2 * A;
   int32_t* cand_road = cand_agent + A;
@@ -1426,6 +1437,16 @@ __device__ __forceinline__ void fused_insert_body(int64_t b, int Nmax, int64_t B
   }
 }
 
+#undef s_wave
+#undef s_cnt
+#undef s_adm
+#undef s_lo
+#undef s_un_agent
+#undef s_un_road
+#undef s_un_k
+#undef s_un_hd
+#undef s_un_tl
+
 __global__ __launch_bounds__(INSB) void k_fused_insert(int Nmax, int64_t B, int64_t N, FusedBufs fb, PlanOut P,
                                                        const uint8_t* __restrict__ sel8, float* __restrict__ ag,
                                                        int64_t A, int64_t a_bstride, int use_cong, float t,
@@ -1433,8 +1454,176 @@ __global__ __launch_bounds__(INSB) void k_fused_insert(int Nmax, int64_t B, int6
                                                        const float* __restrict__ entropy_in,
                                                        float* __restrict__ reward, FrameOut out,
                                                        float* __restrict__ log_prob, float* __restrict__ entropy) {
-  fused_insert_body(blockIdx.x, Nmax, B, N, fb, P, sel8, ag, A, a_bstride, use_cong, t, scratch, entropy_in, reward, out,
-                    log_prob, entropy);
+  __shared__ InsLds L;
+  fused_insert_body(L, blockIdx.x, Nmax, B, N, fb, P, sel8, ag, A, a_bstride, use_cong, t, scratch, entropy_in, reward,
+                    out, log_prob, entropy);
+}
+
+// TWO environments per wave (32 lanes each): with one wave per environment a launch of more than 8 192 environments does
+// not fit the chip's wave slots and runs in two rounds of a latency chain; the window chunks are short and the accumulator
+// banks are 32 wide, so half a wave does an environment's work as fast. Same phases, same order, same results as
+// fused_insert_body on its departure-window path (a_order + a_win): scan from the cursor, candidates unordered in LDS
+// (half the block each), admission by rank among the candidates of the same road. A pair in which either environment
+// has more candidates than its half of the list holds is handed, one environment after the other, to the
+// one-environment body (which rescans from the cursor this kernel has already advanced — the same cursor it would have
+// computed — and reduces the accumulator banks itself: nothing else has been written by then).
+#define INS_CAP2 (INS_CAP / 2)
+__global__ __launch_bounds__(INSB) void k_fused_insert2(int Nmax, int64_t B, int64_t N, FusedBufs fb, PlanOut P,
+                                                        const uint8_t* __restrict__ sel8, float* __restrict__ ag,
+                                                        int64_t A, int64_t a_bstride, int use_cong, float t,
+                                                        int32_t* __restrict__ scratch,
+                                                        const float* __restrict__ entropy_in,
+                                                        float* __restrict__ reward, FrameOut out,
+                                                        float* __restrict__ log_prob, float* __restrict__ entropy) {
+  __shared__ InsLds L;
+  const int tid = threadIdx.x, h = tid >> 5, l = tid & 31;
+  const int64_t b0 = 2 * (int64_t)blockIdx.x, b = b0 + h;
+  const bool live = b < B;
+  const int base = h * INS_CAP2;
+  if (l == 0) {
+    L.cnt2[h] = 0;
+    L.adm2[h] = 0;
+    L.lo2[h] = 0x7fffffff;
+  }
+  // the frame's accumulator banks: requested first, consumed (and re-armed) only once the pair is known to stay here
+  long long lpf = 0;
+  float nf = 0.0f, wf = 0.0f;
+  if (live) {
+    for (int64_t sl_ = l; sl_ < fb.acc_slots; sl_ += 32) {
+      lpf += fb.acc_lp[sl_ * B + b];
+      nf += fb.acc_n[sl_ * B + b];
+      wf += fb.acc_w[sl_ * B + b];
+    }
+  }
+  const int32_t lo = live ? fb.cur_lo[b] : 0;
+  __syncthreads();
+  // phase 1: the departure window, 32 entries per environment and step
+  bool done = !live;
+  int64_t k0 = lo;
+  if (live && k0 >= A) done = true;
+  while (true) {
+    bool notdue = false;
+    if (!done) {
+      const int64_t k = k0 + l;
+      if (k < A) {
+        const uint4 w = fb.a_win[b * A + k];
+        const bool waiting = fb.a_ins[b * A + k] == 0;
+        const bool due = __uint_as_float(w.x) <= t;
+        const int32_t origin = (int32_t)w.y, a = (int32_t)w.z;
+        notdue = !due;
+        if (!due) {
+          atomicMin(&L.lo2[h], (int32_t)k);          // the cursor may not pass this entry
+        } else if (waiting) {
+          atomicMin(&L.lo2[h], (int32_t)k);
+          int32_t road = 0;
+          uint32_t hdw = 0u, tlw = 0u;
+          if (fused_target_words(fb, P, sel8, b, B, N, origin, &road, &hdw, &tlw)) {
+            const int32_t pos = atomicAdd(&L.cnt2[h], 1);
+            if (pos < INS_CAP2) {
+              L.un_agent[base + pos] = a;
+              L.un_road[base + pos] = road;
+              L.un_k[base + pos] = (int32_t)k;
+              L.un_hd[base + pos] = hdw;
+              L.un_tl[base + pos] = tlw;
+            }
+          }
+        }
+      }
+    }
+    const unsigned long long nd = __ballot(notdue);
+    if (!done) {
+      if (((nd >> (32 * h)) & 0xffffffffull) != 0ull || k0 + 32 >= A)
+        done = true;       // sorted by departure: nothing beyond this chunk is due
+      else
+        k0 += 32;
+    }
+    if (__ballot(!done) == 0ull) break;
+  }
+  __syncthreads();
+  if ((L.cnt2[0] > INS_CAP2) || (L.cnt2[1] > INS_CAP2)) {   // wave-uniform, rare
+    if (live && l == 0) fb.cur_lo[b] = L.lo2[h] == 0x7fffffff ? (int32_t)A : L.lo2[h];
+    __syncthreads();
+    fused_insert_body(L, b0, Nmax, B, N, fb, P, sel8, ag, A, a_bstride, use_cong, t, scratch, entropy_in, reward, out,
+                      log_prob, entropy);
+    __syncthreads();
+    if (b0 + 1 < B)
+      fused_insert_body(L, b0 + 1, Nmax, B, N, fb, P, sel8, ag, A, a_bstride, use_cong, t, scratch, entropy_in, reward,
+                        out, log_prob, entropy);
+    return;
+  }
+  if (live) {
+    if (l == 0) fb.cur_lo[b] = L.lo2[h] == 0x7fffffff ? (int32_t)A : L.lo2[h];
+    for (int64_t sl_ = l; sl_ < fb.acc_slots; sl_ += 32) {   // the banks are consumed: re-arm them
+      fb.acc_lp[sl_ * B + b] = 0;
+      fb.acc_n[sl_ * B + b] = 0.0f;
+      fb.acc_w[sl_ * B + b] = 0.0f;
+    }
+    // phase 2: admission straight from the list (see fused_insert_body): rank among the candidates of the same road
+    float* agb = ag + b * a_bstride;
+    const int32_t Lc = L.cnt2[h];
+    for (int32_t idx = l; idx < Lc; idx += 32) {
+      const int32_t r = L.un_road[base + idx];
+      const int32_t a = L.un_agent[base + idx];
+      int32_t rank = 0, total = 0;
+      for (int32_t k = 0; k < Lc; ++k) {
+        const bool same = L.un_road[base + k] == r;
+        total += same ? 1 : 0;
+        rank += (same && L.un_agent[base + k] < a) ? 1 : 0;
+      }
+      const int64_t rrow = (int64_t)r * B + b;
+      const float4 str = fb.st0[r];
+      const uint32_t hd = L.un_hd[base + idx];
+      const uint32_t n0i = hd & 255u;
+      const float n0 = (float)n0i;
+      const long long cap = (long long)(str.x - TARL_CONGESTION_FILE - n0);
+      if (rank < cap) {
+        const long long m = total < cap ? total : cap;  // arrivals admitted on this road
+        const long long slot = (long long)n0i + rank;
+        const float t_cong = use_cong ? str.w / (str.x + 10.0f - n0) : 0.0f;
+        const float tt = (t_cong != t_cong) ? t_cong : fmaxf(str.y, t_cong);
+        const int hoff = tl_hoff(L.un_tl[base + idx]);
+        if (slot >= 0 && slot < Nmax) {
+          float* sr = fb.slots + rrow * fb.lds + 3 * phys(hoff, (int)slot, Nmax);
+          sr[0] = (float)a;
+          sr[1] = t;
+          sr[2] = t + tt;
+        }
+        agb[(int64_t)a * AG_COLS + AG_ON_WAY] = 1.0f;
+        fb.a_status[b * A + a] = 1;
+        fb.a_ins[b * A + L.un_k[base + idx]] = 1;
+        if (rank == m - 1) fb.tl[rrow] = tl_word((uint32_t)a, hoff, TLF_AUTH);  // new tail; rec1 authoritative from here on
+        if (rank == 0) {
+          const uint32_t cnt = n0i + (uint32_t)m;      // n0 + m <= MAX - 3 < 255
+          if (n0i == 0u) {   // new head: id + departure, arrival
+            fb.hdp[rrow] = make_uint2(((uint32_t)a << 8) | cnt, __float_as_uint(t + tt));
+            fb.rec1[rrow] = make_uint2(__float_as_uint(t), r1_code(-1));
+          } else {
+            fb.hdp[rrow].x = hd + (uint32_t)m;
+            fb.rec1[rrow].y = r1_code(-1);   // the arrivals overwrote a pending garbage slot: none pending now
+          }
+          if (out.counts8) out.counts8[rrow] = (uint8_t)cnt;
+          if (out.countsf) out.countsf[rrow] = (float)cnt;
+          atomicAdd(&L.adm2[h], (int32_t)m);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // phase 3: the accumulator banks -> reward, log-prob (32-lane reductions)
+  for (int off = 16; off > 0; off >>= 1) {
+    lpf += __shfl_down(lpf, off, 32);
+    nf += __shfl_down(nf, off, 32);      // sums of small integers: exact in fp32 in any order
+    wf += __shfl_down(wf, off, 32);
+  }
+  if (live && l == 0) {
+    if (reward) reward[b] = -(nf + (float)L.adm2[h]);
+    if (log_prob) log_prob[b] = (lpf < -(1ll << 49)) ? -INFINITY : (float)((double)lpf / LP_FIX);
+    if (entropy) entropy[b] = entropy_in[0];
+    if (out.leg) {
+      out.leg[2 * b + 0] = L.adm2[h];
+      out.leg[2 * b + 1] = (int32_t)wf;
+    }
+  }
 }
 
 // One launch, two roles (rollout steady state): the first B workgroups run frame t's insert (one wave each; the other
@@ -1467,9 +1656,10 @@ __global__ __launch_bounds__(TILE) void k_fused_insert_choice(ChoiceArgs C, int 
                                                               float* __restrict__ log_prob,
                                                               float* __restrict__ entropy) {
   // insert workgroups first: their dependent-load chains start at once and the choice workgroups fill the chip around them
+  __shared__ InsLds L;
   if (blockIdx.x < (unsigned)B) {
     if (threadIdx.x >= INSB) return;   // whole waves leave before any barrier
-    fused_insert_body((int64_t)blockIdx.x, Nmax, B, N, fb, P, sel8, ag, A, a_bstride, use_cong, t, scratch, entropy_in,
+    fused_insert_body(L, (int64_t)blockIdx.x, Nmax, B, N, fb, P, sel8, ag, A, a_bstride, use_cong, t, scratch, entropy_in,
                       reward, out, log_prob, entropy);
   } else {
     const unsigned cb = blockIdx.x - (unsigned)B;
@@ -1929,8 +2119,15 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
     float* lp_t = (log_prob && !ahead) ? log_prob + t * B : nullptr;   // ahead: written by k_fused_choice_all
     float* ent_t = entropy ? entropy + t * B : nullptr;
     if (ahead) {
-      hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(INSB), 0, s, (int)Nmax, B, N, fbt, P, sel_t,
-                         agent_features, A, a_bstride, use_cong, time, ins_scratch, entropy1, reward_t, out, lp_t, ent_t);
+      // TARL_INSERT_PAIR=0 keeps one wave per environment (developer knob)
+      static const bool pair_ok = !(getenv("TARL_INSERT_PAIR") && atoi(getenv("TARL_INSERT_PAIR")) == 0);
+      if (pair_ok && f->a_order && f->a_win) {
+        hipLaunchKernelGGL(k_fused_insert2, dim3((unsigned)ceil_div(B, 2)), dim3(INSB), 0, s, (int)Nmax, B, N, fbt, P, sel_t,
+                           agent_features, A, a_bstride, use_cong, time, ins_scratch, entropy1, reward_t, out, lp_t, ent_t);
+      } else {
+        hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(INSB), 0, s, (int)Nmax, B, N, fbt, P, sel_t,
+                           agent_features, A, a_bstride, use_cong, time, ins_scratch, entropy1, reward_t, out, lp_t, ent_t);
+      }
       TARL_LAUNCH_CHECK();
     } else if (merge && t + 1 < T) {
       const ChoiceArgs C{plan->out_ptr, plan->out_eid, plan->group_of_node, plan->G, thresholds,

@@ -12,9 +12,9 @@
 #define ENVB 1024       // one-workgroup-per-environment kernels
 #define TILE 256        // environments per workgroup in the env-minor kernels (one per lane)
 #define LOG_EPS_P 1e-8f
-#define INS_CAP 256     // LDS candidate list of the insert kernel (entries; 5 KB with the stashed target words: every
-                        // environment of a 4 096-environment launch is resident at once; a longer backlog takes the
-                        // ordered global-scratch path)
+#define INS_CAP 192     // LDS candidate list of the insert kernels (entries; 3.9 KB with the stashed target words: every
+                        // workgroup of a 16 384-environment launch — two environments each, half the list each — is resident
+                        // at once; a longer backlog takes the ordered global-scratch path)
 #define INSB 64         // insert kernel: one wave per environment (all resident at once, 3/4 of the wave slots left free)
 
 // ---- packed per-(node, environment) words (layout "v6") ------------------------------------------------------------------
