@@ -1131,7 +1131,7 @@ __device__ __forceinline__ bool fused_target_words(const FusedBufs& fb, PlanOut 
 struct InsLds {
   int32_t wave[INSB / 64];
   int32_t cnt, adm, lo;
-  int32_t cnt2[2], adm2[2], lo2[2];   // k_fused_insert2: one set per environment of the pair
+  int32_t cnt2[8], adm2[8], lo2[8];   // k_fused_insert2: one set per environment of the wave
   int32_t un_agent[INS_CAP], un_road[INS_CAP], un_k[INS_CAP];
   uint32_t un_hd[INS_CAP], un_tl[INS_CAP];
 };
@@ -1467,7 +1467,7 @@ __global__ __launch_bounds__(INSB) void k_fused_insert(int Nmax, int64_t B, int6
 // has more candidates than its half of the list holds is handed, one environment after the other, to the
 // one-environment body (which rescans from the cursor this kernel has already advanced — the same cursor it would have
 // computed — and reduces the accumulator banks itself: nothing else has been written by then).
-#define INS_CAP2 (INS_CAP / 2)
+template <int EPW>   // environments per wave: 2 or 4
 __global__ __launch_bounds__(INSB) void k_fused_insert2(int Nmax, int64_t B, int64_t N, FusedBufs fb, PlanOut P,
                                                         const uint8_t* __restrict__ sel8, float* __restrict__ ag,
                                                         int64_t A, int64_t a_bstride, int use_cong, float t,
@@ -1476,8 +1476,10 @@ __global__ __launch_bounds__(INSB) void k_fused_insert2(int Nmax, int64_t B, int
                                                         float* __restrict__ reward, FrameOut out,
                                                         float* __restrict__ log_prob, float* __restrict__ entropy) {
   __shared__ InsLds L;
-  const int tid = threadIdx.x, h = tid >> 5, l = tid & 31;
-  const int64_t b0 = 2 * (int64_t)blockIdx.x, b = b0 + h;
+  constexpr int LPE = 64 / EPW;            // lanes per environment
+  constexpr int INS_CAP2 = INS_CAP / EPW;  // its share of the candidate list
+  const int tid = threadIdx.x, h = tid / LPE, l = tid % LPE;
+  const int64_t b0 = EPW * (int64_t)blockIdx.x, b = b0 + h;
   const bool live = b < B;
   const int base = h * INS_CAP2;
   if (l == 0) {
@@ -1489,7 +1491,7 @@ __global__ __launch_bounds__(INSB) void k_fused_insert2(int Nmax, int64_t B, int
   long long lpf = 0;
   float nf = 0.0f, wf = 0.0f;
   if (live) {
-    for (int64_t sl_ = l; sl_ < fb.acc_slots; sl_ += 32) {
+    for (int64_t sl_ = l; sl_ < fb.acc_slots; sl_ += LPE) {
       lpf += fb.acc_lp[sl_ * B + b];
       nf += fb.acc_n[sl_ * B + b];
       wf += fb.acc_w[sl_ * B + b];
@@ -1532,28 +1534,31 @@ __global__ __launch_bounds__(INSB) void k_fused_insert2(int Nmax, int64_t B, int
     }
     const unsigned long long nd = __ballot(notdue);
     if (!done) {
-      if (((nd >> (32 * h)) & 0xffffffffull) != 0ull || k0 + 32 >= A)
+      if (((nd >> (LPE * h)) & ((1ull << LPE) - 1ull)) != 0ull || k0 + LPE >= A)
         done = true;       // sorted by departure: nothing beyond this chunk is due
       else
-        k0 += 32;
+        k0 += LPE;
     }
     if (__ballot(!done) == 0ull) break;
   }
   __syncthreads();
-  if ((L.cnt2[0] > INS_CAP2) || (L.cnt2[1] > INS_CAP2)) {   // wave-uniform, rare
+  bool over = false;
+#pragma unroll
+  for (int e = 0; e < EPW; ++e) over = over || (L.cnt2[e] > INS_CAP2);
+  if (over) {   // wave-uniform, rare
     if (live && l == 0) fb.cur_lo[b] = L.lo2[h] == 0x7fffffff ? (int32_t)A : L.lo2[h];
     __syncthreads();
-    fused_insert_body(L, b0, Nmax, B, N, fb, P, sel8, ag, A, a_bstride, use_cong, t, scratch, entropy_in, reward, out,
-                      log_prob, entropy);
-    __syncthreads();
-    if (b0 + 1 < B)
-      fused_insert_body(L, b0 + 1, Nmax, B, N, fb, P, sel8, ag, A, a_bstride, use_cong, t, scratch, entropy_in, reward,
-                        out, log_prob, entropy);
+    for (int e = 0; e < EPW; ++e) {
+      if (b0 + e < B)
+        fused_insert_body(L, b0 + e, Nmax, B, N, fb, P, sel8, ag, A, a_bstride, use_cong, t, scratch, entropy_in, reward,
+                          out, log_prob, entropy);
+      __syncthreads();
+    }
     return;
   }
   if (live) {
     if (l == 0) fb.cur_lo[b] = L.lo2[h] == 0x7fffffff ? (int32_t)A : L.lo2[h];
-    for (int64_t sl_ = l; sl_ < fb.acc_slots; sl_ += 32) {   // the banks are consumed: re-arm them
+    for (int64_t sl_ = l; sl_ < fb.acc_slots; sl_ += LPE) {   // the banks are consumed: re-arm them
       fb.acc_lp[sl_ * B + b] = 0;
       fb.acc_n[sl_ * B + b] = 0.0f;
       fb.acc_w[sl_ * B + b] = 0.0f;
@@ -1561,7 +1566,7 @@ __global__ __launch_bounds__(INSB) void k_fused_insert2(int Nmax, int64_t B, int
     // phase 2: admission straight from the list (see fused_insert_body): rank among the candidates of the same road
     float* agb = ag + b * a_bstride;
     const int32_t Lc = L.cnt2[h];
-    for (int32_t idx = l; idx < Lc; idx += 32) {
+    for (int32_t idx = l; idx < Lc; idx += LPE) {
       const int32_t r = L.un_road[base + idx];
       const int32_t a = L.un_agent[base + idx];
       int32_t rank = 0, total = 0;
@@ -1610,10 +1615,10 @@ __global__ __launch_bounds__(INSB) void k_fused_insert2(int Nmax, int64_t B, int
   }
   __syncthreads();
   // phase 3: the accumulator banks -> reward, log-prob (32-lane reductions)
-  for (int off = 16; off > 0; off >>= 1) {
-    lpf += __shfl_down(lpf, off, 32);
-    nf += __shfl_down(nf, off, 32);      // sums of small integers: exact in fp32 in any order
-    wf += __shfl_down(wf, off, 32);
+  for (int off = LPE / 2; off > 0; off >>= 1) {
+    lpf += __shfl_down(lpf, off, LPE);
+    nf += __shfl_down(nf, off, LPE);      // sums of small integers: exact in fp32 in any order
+    wf += __shfl_down(wf, off, LPE);
   }
   if (live && l == 0) {
     if (reward) reward[b] = -(nf + (float)L.adm2[h]);
@@ -2121,8 +2126,11 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
     if (ahead) {
       // TARL_INSERT_PAIR=0 keeps one wave per environment (developer knob)
       static const bool pair_ok = !(getenv("TARL_INSERT_PAIR") && atoi(getenv("TARL_INSERT_PAIR")) == 0);
+      // environments per wave of the insert kernel (TARL_INSERT_EPW = 2, 4 or 8; default 4)
+      static const int epw_env = getenv("TARL_INSERT_EPW") ? atoi(getenv("TARL_INSERT_EPW")) : 4;
+      static const int epw = epw_env == 2 ? 2 : (epw_env == 8 ? 8 : 4);
       if (pair_ok && f->a_order && f->a_win) {
-        hipLaunchKernelGGL(k_fused_insert2, dim3((unsigned)ceil_div(B, 2)), dim3(INSB), 0, s, (int)Nmax, B, N, fbt, P, sel_t,
+        hipLaunchKernelGGL(epw == 8 ? k_fused_insert2<8> : (epw == 4 ? k_fused_insert2<4> : k_fused_insert2<2>), dim3((unsigned)ceil_div(B, epw)), dim3(INSB), 0, s, (int)Nmax, B, N, fbt, P, sel_t,
                            agent_features, A, a_bstride, use_cong, time, ins_scratch, entropy1, reward_t, out, lp_t, ent_t);
       } else {
         hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(INSB), 0, s, (int)Nmax, B, N, fbt, P, sel_t,
