@@ -1459,15 +1459,18 @@ __global__ __launch_bounds__(INSB) void k_fused_insert(int Nmax, int64_t B, int6
                     out, log_prob, entropy);
 }
 
-// TWO environments per wave (32 lanes each): with one wave per environment a launch of more than 8 192 environments does
-// not fit the chip's wave slots and runs in two rounds of a latency chain; the window chunks are short and the accumulator
-// banks are 32 wide, so half a wave does an environment's work as fast. Same phases, same order, same results as
-// fused_insert_body on its departure-window path (a_order + a_win): scan from the cursor, candidates unordered in LDS
-// (half the block each), admission by rank among the candidates of the same road. A pair in which either environment
-// has more candidates than its half of the list holds is handed, one environment after the other, to the
-// one-environment body (which rescans from the cursor this kernel has already advanced — the same cursor it would have
-// computed — and reduces the accumulator banks itself: nothing else has been written by then).
-template <int EPW>   // environments per wave: 2 or 4
+// SEVERAL environments per wave (EPW = 2, 4 or 8: 32, 16 or 8 lanes each; default 4). With one wave per environment a
+// launch of more than 8 192 environments does not fit the chip's wave slots and runs in two rounds of a latency chain —
+// and below that, fewer waves walk the same chain faster (18 instead of 23 us at 4 096 environments). A frame's window
+// chunk is a handful of entries and the accumulator banks are 32 wide, so a fraction of a wave does an environment's
+// work as fast. Same phases, same order, same results as fused_insert_body on its departure-window path (a_order +
+// a_win): scan from the cursor, candidates unordered in LDS (each environment its share of the block), admission by
+// rank among the candidates of the same road. A wave in which any environment has more candidates than its share of the
+// list holds is handed, one environment after the other, to the one-environment body (which rescans from the cursor this
+// kernel has already advanced — the same cursor it would have computed — and reduces the accumulator banks itself:
+// nothing else has been written by then). More environments per wave shorten the launch further (8: 36 us at 16 384)
+// but send a congested network's long backlogs through the fall-back more often.
+template <int EPW>
 __global__ __launch_bounds__(INSB) void k_fused_insert2(int Nmax, int64_t B, int64_t N, FusedBufs fb, PlanOut P,
                                                         const uint8_t* __restrict__ sel8, float* __restrict__ ag,
                                                         int64_t A, int64_t a_bstride, int use_cong, float t,
@@ -1499,7 +1502,7 @@ __global__ __launch_bounds__(INSB) void k_fused_insert2(int Nmax, int64_t B, int
   }
   const int32_t lo = live ? fb.cur_lo[b] : 0;
   __syncthreads();
-  // phase 1: the departure window, 32 entries per environment and step
+  // phase 1: the departure window, LPE entries per environment and step
   bool done = !live;
   int64_t k0 = lo;
   if (live && k0 >= A) done = true;
@@ -1614,7 +1617,7 @@ __global__ __launch_bounds__(INSB) void k_fused_insert2(int Nmax, int64_t B, int
     }
   }
   __syncthreads();
-  // phase 3: the accumulator banks -> reward, log-prob (32-lane reductions)
+  // phase 3: the accumulator banks -> reward, log-prob (LPE-lane reductions)
   for (int off = LPE / 2; off > 0; off >>= 1) {
     lpf += __shfl_down(lpf, off, LPE);
     nf += __shfl_down(nf, off, LPE);      // sums of small integers: exact in fp32 in any order
