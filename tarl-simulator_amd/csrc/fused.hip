@@ -2129,10 +2129,14 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
     if (ahead) {
       // TARL_INSERT_PAIR=0 keeps one wave per environment (developer knob)
       static const bool pair_ok = !(getenv("TARL_INSERT_PAIR") && atoi(getenv("TARL_INSERT_PAIR")) == 0);
-      // environments per wave of the insert kernel (TARL_INSERT_EPW = 2, 4 or 8; default 4)
-      static const int epw_env = getenv("TARL_INSERT_EPW") ? atoi(getenv("TARL_INSERT_EPW")) : 4;
-      static const int epw = epw_env == 2 ? 2 : (epw_env == 8 ? 8 : 4);
-      if (pair_ok && f->a_order && f->a_win) {
+      // environments per wave of the insert kernel (TARL_INSERT_EPW = 1, 2, 4 or 8). Default: by the size of the
+      // population — a frame's window holds the agents due in it, and an environment's share of the wave (64 / EPW lanes,
+      // INS_CAP / EPW list entries) should take them in one step: 4 up to 32 768 agents (BASELINE config 4: ~5 due per
+      // frame), 2 up to 65 536, one wave per environment beyond (config 5: 262 144 agents, ~70 due per frame)
+      static const int epw_env = getenv("TARL_INSERT_EPW") ? atoi(getenv("TARL_INSERT_EPW")) : 0;
+      const int epw = epw_env == 1 || epw_env == 2 || epw_env == 4 || epw_env == 8 ? epw_env
+                                                                                     : (A <= 32768 ? 4 : (A <= 65536 ? 2 : 1));
+      if (pair_ok && epw > 1 && f->a_order && f->a_win) {
         hipLaunchKernelGGL(epw == 8 ? k_fused_insert2<8> : (epw == 4 ? k_fused_insert2<4> : k_fused_insert2<2>), dim3((unsigned)ceil_div(B, epw)), dim3(INSB), 0, s, (int)Nmax, B, N, fbt, P, sel_t,
                            agent_features, A, a_bstride, use_cong, time, ins_scratch, entropy1, reward_t, out, lp_t, ent_t);
       } else {
