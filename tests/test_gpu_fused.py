@@ -259,6 +259,24 @@ def test_rollout_launcher_equals_frame_loop(ops, monkeypatch, B, T, merge):
     assert float(rw1.abs().sum()) > 0 or T < 5
 
 
+@pytest.mark.parametrize("knob", ["TARL_INSERT_EPW=1", "TARL_INSERT_EPW=2", "TARL_INSERT_EPW=8", "TARL_INSERT_PAIR=0",
+                                  "TARL_CHOICE_QUAD=0", "TARL_DIR_SIBLINGS=0"])
+def test_rollout_launcher_developer_knobs(ops, knob):
+    """The rollout's kernel variants that a developer knob selects once per process (environments per wave of the insert
+    kernel, the one-node-per-step action draw, per-row Direction gathers on a sibling graph): each must pass the
+    rollout-vs-frame-loop comparison in a process of its own."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    k, v = knob.split("=")
+    env[k] = v
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
+                        os.path.abspath(__file__) + "::test_rollout_launcher_equals_frame_loop", "-k", "300-33-2 or 5-70-2"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def relabelled(net, seed):
     """The same network with its roads renumbered by a seeded permutation (ROAD_INDEX follows the rows)."""
     import dataclasses
