@@ -1459,17 +1459,17 @@ __global__ __launch_bounds__(INSB) void k_fused_insert(int Nmax, int64_t B, int6
                     out, log_prob, entropy);
 }
 
-// SEVERAL environments per wave (EPW = 2, 4 or 8: 32, 16 or 8 lanes each; default 4). With one wave per environment a
+// SEVERAL environments per wave (EPW = 2, 4 or 8: 32, 16 or 8 lanes each; chosen by the population size). With one wave per environment a
 // launch of more than 8 192 environments does not fit the chip's wave slots and runs in two rounds of a latency chain —
 // and below that, fewer waves walk the same chain faster (18 instead of 23 us at 4 096 environments). A frame's window
 // chunk is a handful of entries and the accumulator banks are 32 wide, so a fraction of a wave does an environment's
 // work as fast. Same phases, same order, same results as fused_insert_body on its departure-window path (a_order +
 // a_win): scan from the cursor, candidates unordered in LDS (each environment its share of the block), admission by
-// rank among the candidates of the same road. A wave in which any environment has more candidates than its share of the
-// list holds is handed, one environment after the other, to the one-environment body (which rescans from the cursor this
-// kernel has already advanced — the same cursor it would have computed — and reduces the accumulator banks itself:
-// nothing else has been written by then). More environments per wave shorten the launch further (8: 36 us at 16 384)
-// but send a congested network's long backlogs through the fall-back more often.
+// rank among the candidates of the same road. An environment with more candidates than its share of the list holds
+// sits the packed part out and is handed, afterwards, to the one-environment body on the whole wave (which rescans from
+// the cursor this kernel has already advanced — the same cursor it would have computed — and reduces the accumulator
+// banks itself: nothing else of that environment has been written by then). 16 384 environments: 65 us with one wave
+// each, 50 / 40 / 36 us with 2 / 4 / 8 per wave.
 template <int EPW>
 __global__ __launch_bounds__(INSB) void k_fused_insert2(int Nmax, int64_t B, int64_t N, FusedBufs fb, PlanOut P,
                                                         const uint8_t* __restrict__ sel8, float* __restrict__ ag,
@@ -1545,22 +1545,14 @@ __global__ __launch_bounds__(INSB) void k_fused_insert2(int Nmax, int64_t B, int
     if (__ballot(!done) == 0ull) break;
   }
   __syncthreads();
+  // an environment with more candidates than its share of the list holds sits this part out (nothing of it is written
+  // but the cursor) and goes through the one-environment body afterwards
   bool over = false;
 #pragma unroll
   for (int e = 0; e < EPW; ++e) over = over || (L.cnt2[e] > INS_CAP2);
-  if (over) {   // wave-uniform, rare
-    if (live && l == 0) fb.cur_lo[b] = L.lo2[h] == 0x7fffffff ? (int32_t)A : L.lo2[h];
-    __syncthreads();
-    for (int e = 0; e < EPW; ++e) {
-      if (b0 + e < B)
-        fused_insert_body(L, b0 + e, Nmax, B, N, fb, P, sel8, ag, A, a_bstride, use_cong, t, scratch, entropy_in, reward,
-                          out, log_prob, entropy);
-      __syncthreads();
-    }
-    return;
-  }
-  if (live) {
-    if (l == 0) fb.cur_lo[b] = L.lo2[h] == 0x7fffffff ? (int32_t)A : L.lo2[h];
+  if (live && l == 0) fb.cur_lo[b] = L.lo2[h] == 0x7fffffff ? (int32_t)A : L.lo2[h];
+  const bool mine = live && L.cnt2[h] <= INS_CAP2;
+  if (mine) {
     for (int64_t sl_ = l; sl_ < fb.acc_slots; sl_ += LPE) {   // the banks are consumed: re-arm them
       fb.acc_lp[sl_ * B + b] = 0;
       fb.acc_n[sl_ * B + b] = 0.0f;
@@ -1623,13 +1615,22 @@ __global__ __launch_bounds__(INSB) void k_fused_insert2(int Nmax, int64_t B, int
     nf += __shfl_down(nf, off, LPE);      // sums of small integers: exact in fp32 in any order
     wf += __shfl_down(wf, off, LPE);
   }
-  if (live && l == 0) {
+  if (mine && l == 0) {
     if (reward) reward[b] = -(nf + (float)L.adm2[h]);
     if (log_prob) log_prob[b] = (lpf < -(1ll << 49)) ? -INFINITY : (float)((double)lpf / LP_FIX);
     if (entropy) entropy[b] = entropy_in[0];
     if (out.leg) {
       out.leg[2 * b + 0] = L.adm2[h];
       out.leg[2 * b + 1] = (int32_t)wf;
+    }
+  }
+  if (over) {   // wave-uniform, rare: the long backlogs, one environment after the other on the whole wave
+    __syncthreads();
+    for (int e = 0; e < EPW; ++e) {
+      if (b0 + e < B && L.cnt2[e] > INS_CAP2)
+        fused_insert_body(L, b0 + e, Nmax, B, N, fb, P, sel8, ag, A, a_bstride, use_cong, t, scratch, entropy_in, reward,
+                          out, log_prob, entropy);
+      __syncthreads();
     }
   }
 }
@@ -2131,11 +2132,12 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
       static const bool pair_ok = !(getenv("TARL_INSERT_PAIR") && atoi(getenv("TARL_INSERT_PAIR")) == 0);
       // environments per wave of the insert kernel (TARL_INSERT_EPW = 1, 2, 4 or 8). Default: by the size of the
       // population — a frame's window holds the agents due in it, and an environment's share of the wave (64 / EPW lanes,
-      // INS_CAP / EPW list entries) should take them in one step: 4 up to 32 768 agents (BASELINE config 4: ~5 due per
-      // frame), 2 up to 65 536, one wave per environment beyond (config 5: 262 144 agents, ~70 due per frame)
+      // INS_CAP / EPW list entries) should take them in one step: 8 up to 20 000 agents (BASELINE config 4: ~5 due per
+      // frame) when the launch is large (8 at 16 384 environments: 36 us against 40 with 4; at 4 096: 21 against 18),
+      // 4 up to 32 768, 2 up to 65 536, one wave per environment beyond (config 5: 262 144 agents, ~70 per frame)
       static const int epw_env = getenv("TARL_INSERT_EPW") ? atoi(getenv("TARL_INSERT_EPW")) : 0;
       const int epw = epw_env == 1 || epw_env == 2 || epw_env == 4 || epw_env == 8 ? epw_env
-                                                                                     : (A <= 32768 ? 4 : (A <= 65536 ? 2 : 1));
+                                                                                     : (A <= 20000 && B >= 12288 ? 8 : (A <= 32768 ? 4 : (A <= 65536 ? 2 : 1)));
       if (pair_ok && epw > 1 && f->a_order && f->a_win) {
         hipLaunchKernelGGL(epw == 8 ? k_fused_insert2<8> : (epw == 4 ? k_fused_insert2<4> : k_fused_insert2<2>), dim3((unsigned)ceil_div(B, epw)), dim3(INSB), 0, s, (int)Nmax, B, N, fbt, P, sel_t,
                            agent_features, A, a_bstride, use_cong, time, ins_scratch, entropy1, reward_t, out, lp_t, ent_t);
