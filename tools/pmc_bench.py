@@ -66,7 +66,7 @@ def main():
     ap.add_argument("write_dir")
     ap.add_argument("--edges", type=int, default=10000)
     ap.add_argument("--agents", type=int, default=16384)
-    ap.add_argument("--envs", type=int, default=32768)
+    ap.add_argument("--envs", type=int, default=16384)
     ap.add_argument("--rollout-steps", type=int, default=256)
     ap.add_argument("--first-frame", type=int, default=200)
     ap.add_argument("--note", type=str, default="")

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 Q="--cpu-seconds 0 --congested-window 0 --policy-envs 0"
 for cfg in "c3_b1 --edges 1024 --agents 1024 --envs 1" "c3_b256 --edges 1024 --agents 1024 --envs 256" \
            "c3_b2048 --edges 1024 --agents 1024 --envs 2048" "c4_b1 --envs 1" "c4_b256 --envs 256" "c4_b512 --envs 512" \
-           "c4_b1024 --envs 1024" "c4_b2048 --envs 2048" "c4_b4096 --envs 4096" "c4_b8192 --envs 8192" "c4_b16384 --envs 16384" \
+           "c4_b1024 --envs 1024" "c4_b2048 --envs 2048" "c4_b4096 --envs 4096" "c4_b8192 --envs 8192" "c4_b32768 --envs 32768" \
            "c5_b256 --edges 100000 --agents 262144 --envs 256" "c5_b1024 --edges 100000 --agents 262144 --envs 1024"; do
   set -- $cfg; name=$1; shift
   python bench.py $Q --steps 3 --no-kernel-timing "$@" > $O/bench_$name.json.log 2>/dev/null
