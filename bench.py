@@ -48,7 +48,9 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy kernel achieves
 LATE_FRAME = 200          # the roofline window: frames >= 200 of an iteration (traffic and live time alike)
-PMC_RECORD = os.path.join("profiles", "r02_pmc_traffic.json")   # written by tools/pmc_bench.py from --pmc passes of this script
+# written by tools/pmc_bench.py from --pmc passes of this script (one record per workload: the default line and the
+# congested regime), with the per-kernel counter corrections measured by tools/pmc_cal.hip (profiles/r03_pmc_calibration.txt)
+PMC_RECORDS = (os.path.join("profiles", "r03_pmc_traffic.json"), os.path.join("profiles", "r03_pmc_traffic_congested.json"))
 # Compulsory HBM bytes per (road, environment) and launch of the packed env-minor layout: what each kernel
 # must read and write once, neighbour gathers served by the XCD's L2, statics / topology / policy tables through the
 # scalar cache (shared by all environments, not counted).
@@ -153,27 +155,64 @@ def cpu_baseline(args, net):
             if el >= budget_s or steps >= max_steps:
                 return steps, el
 
-    # the oracle's ops are small: more threads can be slower. Probe a few thread counts, keep the fastest.
+    # the oracle's ops are small: more threads can be slower. Probe a few thread counts (always including ALL cores of
+    # this host, the figure BASELINE.md promises), report each, time the long sample with the fastest.
     ncpu = os.cpu_count() or 1
-    best_nt, best_rate = 1, 0.0
-    for nt in sorted({1, min(8, ncpu), min(16, ncpu)}):
+    best_nt, best_rate, by_threads = 1, 0.0, {}
+    for nt in sorted({1, min(8, ncpu), min(16, ncpu), ncpu}):
         torch.set_num_threads(nt)
         rollout(net.x.clone(), synth.population(args.agents, N, seed=args.seed), 21540, 0.3, 2)       # warm up
         st, el = rollout(net.x.clone(), synth.population(args.agents, N, seed=args.seed), 21540, 1.0, 64)
+        by_threads[str(nt)] = st / el
         if st / el > best_rate:
             best_nt, best_rate = nt, st / el
     torch.set_num_threads(best_nt)
     steps, el = rollout(net.x.clone(), synth.population(args.agents, N, seed=args.seed), 21540, args.cpu_seconds, 8192)
     return {"value": steps / el, "unit": "env-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "all_cores": {"cores": ncpu, "value": by_threads[str(ncpu)], "unit": "env-steps/s",
+                          "sample": "1 s probe of the same rollout with torch.set_num_threads(all host cores)"},
+            "by_threads_1s_probe": by_threads,
             "sample": f"{steps} env steps of 1 environment (oracle rollout: policy logits, GraphDistribution sample + "
                       f"log_prob, env step) on the {E}-edge / {args.agents}-agent workload, {el:.1f} s, torch CPU"}
 
 
+def spawn_ranks(args):
+    """``python bench.py --gpus N`` without a launcher: start the N ranks ourselves. This parent never touches the GPU (no
+    HIP call, no torch.cuda query): it starts ``python -m torch.distributed.run --nproc-per-node N bench.py <same flags>``
+    as a CHILD process (no exec of a process that has initialised the GPU anywhere), relays rank 0's JSON line to stdout
+    and everything else to stderr, and exits with the children's return code (non-zero if any rank failed)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this pool
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env)
+    lines = 0
+    for line in proc.stdout:
+        if line.startswith('{"metric"'):
+            lines += 1
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc == 0 and lines != 1:
+        print(f"bench.py: expected one JSON line from rank 0, got {lines}", file=sys.stderr)
+        rc = 1
+    sys.exit(rc)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)              # does not return
     from tarl_hip import dist_utils, lib
     rank, world, local = dist_utils.init_from_env()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run for N>1)"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the product path has no CPU fallback)"
     local = local % torch.cuda.device_count()      # (rehearsal: several ranks may share one GPU under gloo)
     torch.cuda.set_device(local)
@@ -200,8 +239,9 @@ def main():
         frames += trainer.train_iteration()
     torch.cuda.synchronize()
     dist_utils.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = dist_utils.allreduce_max_float(elapsed, device)
+    elapsed_rank = time.perf_counter() - t0
+    elapsed = dist_utils.allreduce_max_float(elapsed_rank, device)
+    per_rank = dist_utils.gather_floats([setup_s, elapsed_rank], device)     # [rank][setup_seconds, timed_seconds]
 
     ms_all, ms_late, nfr = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int64 * 2)()
     late0 = LATE_FRAME if T > LATE_FRAME else 0
@@ -221,6 +261,8 @@ def main():
         engine.fs.order_valid = False
         engine._packed_stale = True
         trainer.train_iteration()                       # warm-up (re-pack, re-sort)
+        if not args.no_kernel_timing:
+            L.tarl_prof_enable(T)
         dist_utils.barrier()
         torch.cuda.synchronize()
         t1_ = time.perf_counter()
@@ -230,6 +272,9 @@ def main():
         torch.cuda.synchronize()
         dist_utils.barrier()
         cel = dist_utils.allreduce_max_float(time.perf_counter() - t1_, device)
+        c_all, c_late, c_nfr = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int64 * 2)()
+        lib.check(L.tarl_prof_collect(late0, c_all, c_late, c_nfr))
+        L.tarl_prof_enable(0)
         trainer.check_flags()
         on_way = float(engine.agents[:, :, 7].sum()) / B
         arrived = float(engine.agents[:, :, 8].sum()) / B
@@ -295,41 +340,66 @@ def main():
         total_frames = frames * world
         value = total_frames / elapsed
         NB = B * n_roads
-        pmc = None
-        try:
-            rec = json.load(open(os.path.join(ROOT, PMC_RECORD)))
-            if rec["config"] == {"edges": E, "agents": args.agents, "envs": B, "rollout_steps": T} and \
-                    rec.get("layout") == layout_tag:
-                pmc = rec
-        except (OSError, KeyError, ValueError):
-            pass
 
-        def roofline(slot, kernel, what):
-            """achieved = HBM bytes per launch (PMC counters of this script's own rollout, frames >= LATE_FRAME) / the live
-            average launch duration over the same frames; without a matching PMC record: the compulsory bytes."""
-            n_late, n_all = max(1, nfr[1]), max(1, nfr[0])
-            late_s, all_s = ms_late[slot] / n_late * 1e-3, ms_all[slot] / n_all * 1e-3
+        def pmc_record(window):
+            """The committed PMC record of this workload (config + layout revision must match), or None."""
+            want = {"edges": E, "agents": args.agents, "envs": B, "rollout_steps": T}
+            if window:
+                want["departure_window"] = window
+            for path in PMC_RECORDS:
+                try:
+                    rec = json.load(open(os.path.join(ROOT, path)))
+                    if rec["config"] == want and rec.get("layout") == layout_tag:
+                        rec["path"] = path
+                        return rec
+                except (OSError, KeyError, ValueError):
+                    pass
+            return None
+
+        def roofline(pmc, ms_late_, ms_all_, nfr_, slot, kernel, what):
+            """achieved = HBM bytes per launch (PMC counters of this script's own rollout, frames >= LATE_FRAME, corrected
+            per kernel with the factors tools/pmc_cal.hip measured for its access shapes) / the live average launch
+            duration over the same frames; without a matching PMC record: the compulsory bytes."""
+            n_late, n_all = max(1, nfr_[1]), max(1, nfr_[0])
+            late_s, all_s = ms_late_[slot] / n_late * 1e-3, ms_all_[slot] / n_all * 1e-3
             comp = COMPULSORY[kernel]["per_node_env"] * NB
-            traffic = pmc["kernels"][kernel]["hbm_bytes_per_launch"] if pmc and kernel in pmc["kernels"] else None
+            k = pmc["kernels"].get(kernel) if pmc else None
+            traffic = k["hbm_bytes_per_launch"] if k else None
             byts = traffic if traffic is not None else comp
             achieved = byts / late_s / 1e9 if late_s > 0 else 0.0
             out = {"bound": "hbm", "kernel": f"{kernel} ({what})", "achieved": achieved, "peak": HBM_PEAK_GBS,
                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                   "traffic_source": (f"{PMC_RECORD}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, "
-                                      f"2*FETCH_SIZE + WRITE_SIZE, mean over frames >= {LATE_FRAME}") if traffic else None,
+                   "traffic_source": (f"{pmc['path']}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, "
+                                      f"mean over frames >= {LATE_FRAME}; bytes = {k.get('formula', '2*FETCH_SIZE + WRITE_SIZE')}"
+                                      ) if k else None,
                    "bytes_basis": "pmc_counters" if traffic is not None else "compulsory",
-                   "avg_launch_us": late_s * 1e6, "frames_timed": int(nfr[1]), "first_frame": late0,
+                   "avg_launch_us": late_s * 1e6, "frames_timed": int(nfr_[1]), "first_frame": late0,
                    "avg_launch_us_all_frames": all_s * 1e6,
                    "compulsory_bytes_per_launch": comp,
-                   "compulsory_frac": (comp / late_s / 1e9 / HBM_PEAK_GBS) if late_s > 0 else 0.0}
+                   "compulsory_frac": (comp / late_s / 1e9 / HBM_PEAK_GBS) if late_s > 0 else 0.0,
+                   "traffic_over_compulsory": (traffic / comp) if (traffic is not None and comp > 0) else None}
+            if k and "raw_frac_bracket" in k:      # the same fraction with no correction / the guide's blanket 2x on FETCH_SIZE
+                out["frac_uncorrected_to_blanket_2x"] = [b_ / late_s / 1e9 / HBM_PEAK_GBS for b_ in k["raw_frac_bracket"]]
             if kernel in SURVEY_8D:
                 pe, pn = SURVEY_8D[kernel]
                 out["survey_8d_bytes_per_launch"] = pe * B * E + pn * NB
             return out, late_s
 
-        rf_rows, rows_s = roofline(1, "k_fused_rows", "DirectionMPNN.update + ResponseMPNN + withdraw; the dominant kernel")
-        rf_dir, dir_s = roofline(0, "k_fused_direction", "DirectionMPNN message + aggregate on the packed hot records")
-        rf_ic, _ = roofline(2, "k_fused_insert", "insert_agent_into_network + reward; a latency chain, one wave per environment")
+        pmc = pmc_record(args.departure_window)
+        rf_rows, rows_s = roofline(pmc, ms_late, ms_all, nfr, 1, "k_fused_rows",
+                                   "DirectionMPNN.update + ResponseMPNN + withdraw; the dominant kernel")
+        rf_dir, dir_s = roofline(pmc, ms_late, ms_all, nfr, 0, "k_fused_direction",
+                                 "DirectionMPNN message + aggregate on the packed hot records")
+        rf_ic, _ = roofline(pmc, ms_late, ms_all, nfr, 2, "k_fused_insert",
+                            "insert_agent_into_network + reward; a latency chain, several environments per wave")
+        if congested is not None and not args.no_kernel_timing:
+            cp = pmc_record(args.congested_window)
+            congested["roofline"], c_rows_s = roofline(cp, c_late, c_all, c_nfr, 1, "k_fused_rows",
+                                                       "the dominant kernel of the loaded network: most rows move something")
+            congested["roofline_direction"], c_dir_s = roofline(cp, c_late, c_all, c_nfr, 0, "k_fused_direction",
+                                                                "DirectionMPNN message + aggregate")
+            congested["roofline_insert"], _ = roofline(cp, c_late, c_all, c_nfr, 2, "k_fused_insert", "insert + reward")
+            congested["msgpass_pair_edges_per_sec"] = (B * E) / (c_dir_s + c_rows_s) if (c_dir_s + c_rows_s) > 0 else None
         out = {
             "metric": "ppo_env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -345,6 +415,8 @@ def main():
             "msgpass_pair_edges_per_sec": (B * E) / (dir_s + rows_s) if (dir_s + rows_s) > 0 else None,
             "roofline": rf_rows, "roofline_direction": rf_dir, "roofline_insert": rf_ic,
             "setup_seconds": setup_s, "timed_seconds": elapsed,
+            "per_rank": {"setup_seconds": [r_[0] for r_ in per_rank], "timed_seconds": [r_[1] for r_ in per_rank]},
+            "world_size_seen_by_backend": dist_utils.world()[1], "dist_backend": dist_utils.backend_name(),
             "congested_regime": congested,
             "state_dependent_policy": policy_lines,
         }

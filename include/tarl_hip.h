@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TARL_ABI_VERSION 2
+#define TARL_ABI_VERSION 3
 
 typedef enum {
   TARL_OK = 0,
@@ -355,6 +355,12 @@ typedef struct tarl_fused {
   const int32_t* a_rank;
   int64_t acc_slots;
   int32_t* flags;
+  /* GLOBAL id of environment 0 of this batch (default 0). The device noise streams — the action draws of the policy and the
+   * Gumbel races of DirectionMPNN.aggregate — are Philox streams indexed by (env_base + b), not by the lane that happens to
+   * serve b: a batch is a window into one global population of environments, so a shard of a larger batch (another
+   * rank's slice in a data-parallel job, or a few environments run alone) reproduces, bit for bit, the trajectories those
+   * environments have inside the larger batch. The reference has a single environment (env_base + b = 0). */
+  int64_t env_base;
 } tarl_fused;
 
 int tarl_fused_pack(const tarl_plan* plan, const tarl_fused* f, const float* x, int64_t B, int64_t x_bstride,
@@ -417,7 +423,9 @@ int tarl_fused_apply_choice(const tarl_plan* plan, const tarl_fused* f, int64_t 
  *   of update_history / withdraw_history).
  *   Scratch (device): ins_scratch int32 [B][2A]; sel_scratch uint8 [N][B] (only used without a choice buffer);
  *   acc_scratch int64 [acc_slots][B]; choice_scratch int32 [tarl_fused_rollout_scratch_ints(plan, T, B)], 16-byte aligned,
- *   ZERO before its first use (the library leaves it zeroed again).
+ *   ZERO before its first use. Layout: draw-fixup list | policy records | per-node draw records | log-prob accumulators
+ *   int64 [T][B] (last: no other offset depends on T, so one buffer sized for the longest rollout serves shorter ones).
+ *   The library re-arms (zeroes) exactly the accumulators a call used; the record tables are rebuilt by every call.
  *   Scheduling of the GraphDistribution sample (state-independent for the live policy, so the T actions are T independent
  *   draws from one set of tables; same Philox streams and arithmetic in every mode, identical results):
  *     with a choice buffer and choice_scratch (default, TARL_ROLLOUT_MERGE=2) the whole action buffer is filled in blocks

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(ENV_BLOCK) void k_graphdist_rollout(
     const float* __restrict__ logits, int64_t B, int64_t N, int64_t E, int64_t G, float temperature,
     const float* __restrict__ uniform, uint64_t seed, uint64_t counter, double* __restrict__ base_all,
     float* __restrict__ u_all, int32_t* __restrict__ choice_eid, uint8_t* __restrict__ choice8,
-    uint8_t* __restrict__ sel8, float* __restrict__ log_prob) {
+    uint8_t* __restrict__ sel8, float* __restrict__ log_prob, uint64_t idx_base) {
   __shared__ double s_wave[ENV_BLOCK / 64];
   __shared__ float s_red[ENV_BLOCK / 64];
   const int64_t b = blockIdx.x;
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(ENV_BLOCK) void k_graphdist_rollout(
     if (lane == 0) exc = 0.0;
     if (g < G) {
       base[i] = running + wbase + exc;
-      un[i] = uniform ? uniform[b * G + g] : philox_uniform(seed, counter, (uint64_t)(b * G + g));
+      un[i] = uniform ? uniform[b * G + g] : philox_uniform(seed, counter, idx_base + (uint64_t)(b * G + g));
     }
     running += tot;
     __syncthreads();
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(ENV_BLOCK) void k_graphdist_rollout_reg(
     const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_eid, const float* __restrict__ logits, int64_t B,
     int64_t N, int64_t E, float temperature, const float* __restrict__ uniform, uint64_t seed, uint64_t counter,
     int32_t* __restrict__ choice_eid, uint8_t* __restrict__ choice8, uint8_t* __restrict__ sel8,
-    float* __restrict__ log_prob) {
+    float* __restrict__ log_prob, uint64_t idx_base) {
   __shared__ float s_red[ENV_BLOCK / 64];
   const int64_t b = blockIdx.x;
   const float* lb = logits + b * E;
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(ENV_BLOCK) void k_graphdist_rollout_reg(
     }
     if (lane == 63) s_wave_j[j][wid] = v_inc;
     inc[j] = v_inc;
-    un[j] = g < N ? (uniform ? uniform[b * N + g] : philox_uniform(seed, counter, (uint64_t)(b * N + g))) : 0.0f;
+    un[j] = g < N ? (uniform ? uniform[b * N + g] : philox_uniform(seed, counter, idx_base + (uint64_t)(b * N + g))) : 0.0f;
   }
   __syncthreads();
   // ... then the cross-wave part of k_sample's scan, chunk after chunk (same additions in the same order)
@@ -500,11 +500,13 @@ extern "C" int64_t tarl_graphdist_rollout_scratch_bytes(const tarl_plan* plan, i
   return plan && B >= 1 ? B * plan->N * (int64_t)(sizeof(double) + sizeof(float)) : -1;
 }
 
-extern "C" int tarl_graphdist_rollout(const tarl_plan* plan, const float* logits, int64_t B, float temperature,
-                                      const float* uniform, uint64_t seed, uint64_t counter, void* scratch,
-                                      int32_t* choice, uint8_t* choice8, uint8_t* sel8, float* log_prob,
-                                      tarl_stream stream) {
+// env_base: global id of the batch's environment 0 (tarl_fused.env_base): the Philox index of (b, group g) is
+// (env_base + b) * G + g
+int tarl_graphdist_rollout_at(const tarl_plan* plan, const float* logits, int64_t B, float temperature,
+                              const float* uniform, uint64_t seed, uint64_t counter, void* scratch, int32_t* choice,
+                              uint8_t* choice8, uint8_t* sel8, float* log_prob, int64_t env_base, tarl_stream stream) {
   TARL_REQUIRE(plan && logits && scratch, "null argument");
+  const uint64_t idx_base = (uint64_t)env_base * (uint64_t)plan->G;
   TARL_REQUIRE(B >= 1 && B < ((int64_t)1 << 31), "bad B");
   TARL_REQUIRE(temperature > 0.0f, "temperature must be positive");
   TARL_REQUIRE(((uintptr_t)scratch) % 8 == 0, "scratch must be 8-byte aligned");
@@ -518,7 +520,7 @@ extern "C" int tarl_graphdist_rollout(const tarl_plan* plan, const float* logits
 #define GDR_LAUNCH(J_, D_, S_)                                                                                          \
   hipLaunchKernelGGL((k_graphdist_rollout_reg<J_, D_, S_>), dim3((unsigned)B), dim3(ENV_BLOCK), 0, (hipStream_t)stream,   \
                      plan->out_ptr, plan->out_eid, logits, B, plan->N, plan->E, temperature, uniform, seed, counter, choice,  \
-                     choice8, sel8, log_prob)
+                     choice8, sel8, log_prob, idx_base)
 #define GDR_BY_SORT(J_, D_)         \
   if (plan->src_sorted)             \
     GDR_LAUNCH(J_, D_, true);       \
@@ -542,11 +544,19 @@ extern "C" int tarl_graphdist_rollout(const tarl_plan* plan, const float* logits
   } else
     hipLaunchKernelGGL(k_graphdist_rollout, dim3((unsigned)B), dim3(ENV_BLOCK), 0, (hipStream_t)stream, plan->out_ptr,
                        plan->out_eid, plan->node_of_group, logits, B, plan->N, plan->E, plan->G, temperature, uniform, seed,
-                       counter, base, un, choice, choice8, sel8, log_prob);
+                       counter, base, un, choice, choice8, sel8, log_prob, idx_base);
 #undef GDR_BY_SORT
 #undef GDR_LAUNCH
   TARL_LAUNCH_CHECK();
   return TARL_OK;
+}
+
+extern "C" int tarl_graphdist_rollout(const tarl_plan* plan, const float* logits, int64_t B, float temperature,
+                                      const float* uniform, uint64_t seed, uint64_t counter, void* scratch,
+                                      int32_t* choice, uint8_t* choice8, uint8_t* sel8, float* log_prob,
+                                      tarl_stream stream) {
+  return tarl_graphdist_rollout_at(plan, logits, B, temperature, uniform, seed, counter, scratch, choice, choice8, sel8,
+                                   log_prob, 0, stream);
 }
 
 extern "C" int tarl_graphdist_mode(const tarl_plan* plan, const float* proba, int64_t B, float* onehot,

@@ -343,7 +343,8 @@ __device__ __forceinline__ void fused_choice_body(unsigned bx, unsigned by, cons
                                                   const float* __restrict__ thr, const long long* __restrict__ lgt,
                                                   const float* __restrict__ uniform, uint64_t pseed, uint64_t pcounter,
                                                   uint8_t* __restrict__ sel_out, const uint8_t* __restrict__ sel_prev,
-                                                  int32_t* __restrict__ choice, int nchunk, int want_lp) {
+                                                  int32_t* __restrict__ choice, int nchunk, int want_lp,
+                                                  int64_t env_base) {
   const int64_t b = (int64_t)bx * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const int32_t i0 = by * nchunk;
@@ -358,7 +359,7 @@ __device__ __forceinline__ void fused_choice_body(unsigned bx, unsigned by, cons
     bool found = false;
     const int32_t gi = group_of_node[i];
     if (gi >= 0) {
-      const float u = uniform ? uniform[b * G + gi] : rng.uniform(pseed, pcounter, (uint64_t)(b * G + gi));
+      const float u = uniform ? uniform[b * G + gi] : rng.uniform(pseed, pcounter, (uint64_t)((env_base + b) * G + gi));
       // first out-edge (plan order) whose threshold exceeds u. Every table operand is wave-uniform (scalar loads), the
       // per-lane part is compare + select: no dependent vector gathers
       long long lpn = 0;
@@ -392,9 +393,10 @@ __global__ __launch_bounds__(TILE) void k_fused_choice(const int32_t* __restrict
                                                        const float* __restrict__ uniform, uint64_t pseed,
                                                        uint64_t pcounter, uint8_t* __restrict__ sel_out,
                                                        const uint8_t* __restrict__ sel_prev,
-                                                       int32_t* __restrict__ choice, int nchunk, int want_lp) {
+                                                       int32_t* __restrict__ choice, int nchunk, int want_lp,
+                                                       int64_t env_base) {
   fused_choice_body(blockIdx.x, blockIdx.y, out_ptr, out_eid, group_of_node, G, B, N, acc_lp, acc_slots, thr, lgt,
-                    uniform, pseed, pcounter, sel_out, sel_prev, choice, nchunk, want_lp);
+                    uniform, pseed, pcounter, sel_out, sel_prev, choice, nchunk, want_lp, env_base);
 }
 
 // ---- the whole rollout's actions in one pass (state-independent policy) -----------------------------------------------------
@@ -516,7 +518,8 @@ __global__ __launch_bounds__(TILE) void k_fused_choice_all(const PNode* __restri
                                                            uint32_t B, uint32_t N, int64_t t0, uint64_t pseed,
                                                            uint64_t pcounter0, const uint8_t* __restrict__ sel0,
                                                            uint8_t* __restrict__ choice, long long* __restrict__ lp_acc,
-                                                           int32_t* __restrict__ fix, int32_t* __restrict__ flags) {
+                                                           int32_t* __restrict__ fix, int32_t* __restrict__ flags,
+                                                           uint64_t env_base) {
   __shared__ long long s_lg[CHOICE_SEG * 4 + 4];
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t t = t0 + blockIdx.z;
@@ -536,7 +539,7 @@ __global__ __launch_bounds__(TILE) void k_fused_choice_all(const PNode* __restri
   // as one 8-dword vector (member by member the compiler splits it into dependent reads around the out-degree test).
   // Nodes without out-edges (they keep SELECTED_ROAD) get a loop of their own.
   if (QUAD) {
-    const uint64_t blk0 = (uint64_t)b * (G >> 2);
+    const uint64_t blk0 = (env_base + (uint64_t)b) * (G >> 2);
     const uint64_t counter = pcounter0 + (uint64_t)t;
     for (uint32_t i = i0; i < i1; i += 4) {   // i0 and i1 are multiples of four
       const uint64_t blk = blk0 + (i >> 2);
@@ -555,7 +558,7 @@ __global__ __launch_bounds__(TILE) void k_fused_choice_all(const PNode* __restri
     for (uint32_t i = i0; i < i1; ++i) {      // i, and everything indexed by it alone, is wave-uniform
       const i32x8 v = *(const i32x8*)(pnode + i);
       if (v[1] == 0) continue;                // no out-edges (== no group)
-      const uint32_t w = rng.word(pseed, pcounter0 + (uint64_t)t, (uint64_t)b * G + (uint64_t)v[0]);
+      const uint32_t w = rng.word(pseed, pcounter0 + (uint64_t)t, (env_base + (uint64_t)b) * G + (uint64_t)v[0]);
       choice_node(v, w >> 8, s_lg + (i - i0) * 4, ptab, i * B + b, t, out, lp, bad, fix, flags);
     }
   }
@@ -628,7 +631,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     const float* __restrict__ log_edge_attr, const uint2* __restrict__ hdp, const uint32_t* __restrict__ tl,
     const uint2* __restrict__ rec1, const uint8_t* __restrict__ sel8, const float* __restrict__ sel_raw,
     const float* __restrict__ gumbel, float* __restrict__ dtt, uint32_t* __restrict__ post, float log_eps, float t,
-    float t_prev, uint64_t seed, uint64_t counter, uint32_t E, uint32_t B, uint32_t N, FrameOut out) {
+    float t_prev, uint64_t seed, uint64_t counter, uint32_t E, uint32_t B, uint32_t N, FrameOut out, uint64_t env_base) {
   __shared__ int32_t s_n;
   __shared__ uint16_t s_item[DIR_LIST];   // (node offset in the chunk) * TILE + lane
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;   // row indices are 32-bit: N * B < 2^31 (host check)
@@ -784,7 +787,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
       if (gumbel) {
         g = gumbel[(int64_t)bb * E + rc.eid];
       } else {
-        const float u = rng.uniform(seed, counter, (uint64_t)bb * E + (uint64_t)k);
+        const float u = rng.uniform(seed, counter, (env_base + (uint64_t)bb) * E + (uint64_t)k);
         g = gumbel_from_u01(u);
       }
       const float score = (m ? le : log_eps) + g;
@@ -1673,7 +1676,7 @@ __global__ __launch_bounds__(TILE) void k_fused_insert_choice(ChoiceArgs C, int 
   } else {
     const unsigned cb = blockIdx.x - (unsigned)B;
     fused_choice_body(cb % C.gx, cb / C.gx, C.out_ptr, C.out_eid, C.group_of_node, C.G, B, N, C.acc_next, fb.acc_slots,
-                      C.thr, C.lgt, nullptr, C.pseed, C.pcounter, C.sel_next, sel8, nullptr, C.nchunk, C.want_lp);
+                      C.thr, C.lgt, nullptr, C.pseed, C.pcounter, C.sel_next, sel8, nullptr, C.nchunk, C.want_lp, fb.env_base);
   }
 }
 
@@ -1685,7 +1688,7 @@ FusedBufs tarl_to_bufs(const tarl_fused* f) {
                    (long long*)f->acc_lp, f->acc_n,         f->acc_w,        f->a_origin,        f->a_dest,
                    f->a_dep,              f->a_status,      f->a_order,      f->cur_lo,          f->a_dep_sorted,
                    (const uint4*)f->a_win, f->a_ins,        f->a_rank,
-                   f->acc_slots,          f->flags};
+                   f->acc_slots,          f->flags,         f->env_base};
 }
 
 // rows per lane of the row pass (tunable: TARL_NCHUNK = 1, 2 or 4; measured 63.7 / 57.8 / 56.0 us per launch)
@@ -1842,7 +1845,7 @@ static int launch_direction(dim3 grid, unsigned threads, hipStream_t s, const ta
   hipLaunchKernelGGL((k_fused_direction<NCH, SIB>), grid, dim3(threads), 0, s, (const NodeRec*)f->node_rec,                    \
                      (const InRec*)f->in_rec, plan->in_eid, log_edge_attr, (const uint2*)f->hdp, (const uint32_t*)f->tl,  \
                      (const uint2*)f->rec1, sel8, (const float*)f->sel, gumbel, dtt, (uint32_t*)f->post, log_eps, time,   \
-                     prev_time, seed, counter, (uint32_t)plan->E, (uint32_t)B, (uint32_t)plan->N, out)
+                     prev_time, seed, counter, (uint32_t)plan->E, (uint32_t)B, (uint32_t)plan->N, out, (uint64_t)f->env_base)
   // TARL_DIR_SIBLINGS=0 keeps the per-row gathers on a sibling graph (developer knob)
   static const bool sib_ok = !(getenv("TARL_DIR_SIBLINGS") && atoi(getenv("TARL_DIR_SIBLINGS")) == 0);
   switch (nchunk_dir()) {
@@ -1917,7 +1920,7 @@ extern "C" int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int6
     hipLaunchKernelGGL(k_fused_choice, grid_c, dim3(threads), 0, s, plan->out_ptr, plan->out_eid, plan->group_of_node,
                        plan->G, B, plan->N, fb.acc_lp, fb.acc_slots, thresholds, (const long long*)log_probs, uniform,
                        policy_seed, policy_counter, f->sel8, (const uint8_t*)f->sel8, choice, nchunk_choice(),
-                       log_prob != nullptr ? 1 : 0);
+                       log_prob != nullptr ? 1 : 0, f->env_base);
     TARL_LAUNCH_CHECK();
   }
   const bool timed = tarl_prof_mark(s, 0) != nullptr;
@@ -1993,8 +1996,8 @@ static int choice_side(ChoiceSide** out) {
 }
 
 extern "C" int64_t tarl_fused_rollout_scratch_ints(const tarl_plan* plan, int64_t T, int64_t B) {
-  // unresolved-draw list | packed policy records | per-(frame, environment) log-prob accumulators (int64)
-  // | per-node draw records (64-byte aligned)
+  // unresolved-draw list | packed policy records | per-node draw records (64-byte aligned) | per-(frame, environment)
+  // log-prob accumulators (int64; last, so that every other offset is independent of T)
   return plan && T >= 1 && B >= 1 ? (int64_t)(4 + 2 * FIX_CAP) + 4 * (plan->E + 4) + 2 * T * B + 16 * (plan->N + 1) : -1;
 }
 
@@ -2064,8 +2067,12 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
     hipLaunchKernelGGL(k_pack_ptab, dim3((unsigned)ceil_div(plan->E + 4, FB)), dim3(FB), 0, side->stream, plan->E,
                        thresholds, (const long long*)log_probs, ptab);
     TARL_LAUNCH_CHECK();
-    long long* lp_acc = (long long*)(ptab + plan->E + 4);     // [T][B], zero between rollouts (k_choice_lp_finish re-arms)
-    PNode* pnode = (PNode*)(((uintptr_t)(lp_acc + T * B) + 63) & ~(uintptr_t)63);
+    // the per-node records come BEFORE the log-prob accumulators, so that no offset depends on T: a caller may reuse one
+    // scratch buffer for rollouts of different lengths (an episode end splits a collector batch), and the accumulators
+    // [T][B] — zero between rollouts, k_choice_lp_finish re-arms what a rollout used — must never be overlaid by a record
+    // table of another call
+    PNode* pnode = (PNode*)(((uintptr_t)(ptab + plan->E + 4) + 63) & ~(uintptr_t)63);
+    long long* lp_acc = (long long*)(pnode + N);
     hipLaunchKernelGGL(k_pack_pnode, dim3((unsigned)ceil_div(N, FB)), dim3(FB), 0, side->stream, N,
                        (const NodeRec*)f->node_rec, plan->group_of_node, thresholds, (const long long*)log_probs, pnode);
     TARL_LAUNCH_CHECK();
@@ -2079,7 +2086,8 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
                          dim3((unsigned)ceil_div(B, threads), (unsigned)ceil_div(N, CHOICE_SEG), nf),
                          dim3(threads), 0, side->stream, (const PNode*)pnode, (const PRec*)ptab,
                          plan->group_of_node, (uint32_t)plan->G, (uint32_t)B, (uint32_t)N, t0, policy_seed,
-                         policy_counter0, (const uint8_t*)f->sel8, choice, log_prob ? lp_acc : nullptr, fix, f->flags);
+                         policy_counter0, (const uint8_t*)f->sel8, choice, log_prob ? lp_acc : nullptr, fix, f->flags,
+                         (uint64_t)f->env_base);
       TARL_LAUNCH_CHECK();
       hipLaunchKernelGGL(k_choice_fixup, dim3(1), dim3(ENVB), 0, side->stream, (uint32_t)B, (uint32_t)N,
                          (const uint8_t*)f->sel8, choice, fix);
@@ -2096,7 +2104,7 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
     hipLaunchKernelGGL(k_fused_choice, grid_c, dim3(threads), 0, s, plan->out_ptr, plan->out_eid, plan->group_of_node,
                        plan->G, B, N, acc_buf[0], fb.acc_slots, thresholds, (const long long*)log_probs,
                        (const float*)nullptr, policy_seed, policy_counter0, slice(0), (const uint8_t*)f->sel8,
-                       (int32_t*)nullptr, nchunk_choice(), want_lp);
+                       (int32_t*)nullptr, nchunk_choice(), want_lp, f->env_base);
     TARL_LAUNCH_CHECK();
   }
   for (int64_t t = 0; t < T; ++t) {
@@ -2163,7 +2171,7 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
                            plan->group_of_node, plan->G, B, N, fbt.acc_lp, fb.acc_slots, thresholds,
                            (const long long*)log_probs, (const float*)nullptr, policy_seed,
                            policy_counter0 + (uint64_t)(t + 1), slice(t + 1), sel_t, (int32_t*)nullptr, nchunk_choice(),
-                           want_lp);
+                           want_lp, f->env_base);
         TARL_LAUNCH_CHECK();
       }
     }
@@ -2246,9 +2254,10 @@ extern "C" int tarl_fused_rollout_policy(const tarl_plan* plan, const tarl_fused
     rc = tarl_policy_edge_mlp_fwd(plan, obs_scratch, B, edge_attr, w1, b1, w2, b2, w3, b3, precision == 1 ? 2 : 0,
                                   logits_scratch, stream);
     if (rc) return rc;
-    rc = tarl_graphdist_rollout(plan, logits_scratch, B, temperature, nullptr, policy_seed, policy_counter0 + (uint64_t)t,
-                                dist_scratch, nullptr, choice8 ? choice8 + t * NB : nullptr, f->sel8,
-                                log_prob ? log_prob + t * B : nullptr, stream);
+    rc = tarl_graphdist_rollout_at(plan, logits_scratch, B, temperature, nullptr, policy_seed,
+                                   policy_counter0 + (uint64_t)t, dist_scratch, nullptr,
+                                   choice8 ? choice8 + t * NB : nullptr, f->sel8, log_prob ? log_prob + t * B : nullptr,
+                                   f->env_base, stream);
     if (rc) return rc;
     const float time = times_host[t];
     const int64_t m = metrics_envs;

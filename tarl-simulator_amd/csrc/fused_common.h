@@ -113,6 +113,7 @@ struct FusedBufs {
   const int32_t* a_rank;
   int64_t acc_slots;    // accumulator banks: acc_* are [acc_slots][B]; a workgroup adds into bank (chunk % slots)
   int32_t* flags;       // [1] device status word
+  int64_t env_base;     // global id of environment 0: the Philox streams are indexed by env_base + b (tarl_hip.h)
 };
 
 // per-frame side outputs (all optional)
@@ -159,4 +160,8 @@ __device__ __forceinline__ float entry_tt(const float4 st, float n) {
 // fused.hip
 FusedBufs tarl_to_bufs(const tarl_fused* f);
 int tarl_check_fused_core(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax);
-hipEvent_t tarl_prof_mark(hipStream_t s, int tag);  // sim.hip: live timing of the frame kernels (tags 0..3)
+hipEvent_t tarl_prof_mark(hipStream_t s, int tag);
+// dist.hip: tarl_graphdist_rollout with the batch's global environment offset
+int tarl_graphdist_rollout_at(const tarl_plan* plan, const float* logits, int64_t B, float temperature,
+                              const float* uniform, uint64_t seed, uint64_t counter, void* scratch, int32_t* choice,
+                              uint8_t* choice8, uint8_t* sel8, float* log_prob, int64_t env_base, tarl_stream stream);  // sim.hip: live timing of the frame kernels (tags 0..3)

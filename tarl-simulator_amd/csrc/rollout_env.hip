@@ -235,7 +235,7 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
           if (k < kb1) {
             const OutEdge r = rr[q];
             if (fresh) {   // first out-edge of a road: draw its uniform
-              u = rng.uniform(pseed, pcounter, (uint64_t)(b * P.G + r.gi));
+              u = rng.uniform(pseed, pcounter, (uint64_t)((fb.env_base + b) * P.G + r.gi));
               found = false;
               fresh = false;
             }
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
           const bool m = m1 || m2;
           const float prob = r.ea * (m ? 1.0f : 0.0f);
           Psum = Psum + prob;
-          const float uu = rng.uniform(seed, counter, (uint64_t)(b * P.E + k));
+          const float uu = rng.uniform(seed, counter, (uint64_t)((fb.env_base + b) * P.E + k));
           const float g = gumbel_from_u01(uu);
           const float score = (m ? r.lea : log_eps) + g;
           if (score > best) {

@@ -53,7 +53,13 @@ def main(argv=None):
         if ns.mode == "train":
             runner.train()
         runner.eval()
-    finally:
+    except BaseException:
+        # a rank that fails must not enter a collective its peers are not in (they may sit in a gradient all-reduce or in
+        # ppo_train's trailing barrier): leave the group WITHOUT a barrier and exit non-zero so the launcher tears the
+        # job down instead of waiting for the communicator's timeout
+        runner.close(failed=True)
+        raise
+    else:
         runner.close()
 
 

@@ -25,9 +25,37 @@ class DirectionMPNN(MessagePassingBase, FeatureHelpers):
         self._noise_counter = 0
         self._uniform = None                 # one-shot injected noise (parity runs)
         self._status = None                  # device status word: a count reached Nmax in an earlier forward
+        self._status_host = None             # pinned mirror of it, filled by a non-blocking copy behind every forward
+        self._status_event = None
 
     def set_time(self, time):
         self.time = time
+        self._poll_status()
+
+    # A count that reaches Nmax leaves the reference's defined domain: its update (src/direction_mpnn.py:172-191) then
+    # writes slot ``Nmax`` of the id block — column 0 of the arrival block —, the arrival into the departure block and
+    # the departure into MAX_NUMBER_OF_AGENT, all inside the row: SILENT corruption of the FIFO, and an IndexError only
+    # several steps later (count >= Nmax + 7). The kernels flag the first such count in a device status word. The word
+    # travels to pinned host memory behind every forward (no host synchronisation on the step path) and is looked at when
+    # it has arrived — at the next forward / set_time — or, blocking, by check().
+    def _poll_status(self, block=False):
+        ev = self._status_event
+        if ev is None:
+            return
+        if block:
+            ev.synchronize()
+        elif not ev.query():
+            return
+        self._status_event = None
+        if int(self._status_host[0]) != 0:
+            self._status.zero_()
+            self._status_host.zero_()
+            raise IndexError("DirectionMPNN: a FIFO count reached Nmax — outside the reference's defined domain (its update "
+                             "silently overwrites the neighbouring FIFO blocks there and raises IndexError a few steps on)")
+
+    def check(self):
+        """Blocking check of the status word (call at the end of a run; one host synchronisation)."""
+        self._poll_status(block=True)
 
     def inject_uniform(self, u: torch.Tensor):
         """Use these ``E`` uniforms for the next forward instead of device noise (the reference draws them with
@@ -41,13 +69,11 @@ class DirectionMPNN(MessagePassingBase, FeatureHelpers):
         require_cuda(x, "x")
         plan = cached_plan(edge_index, x.size(0))
         ec = cached_edge_const(edge_attr, x.device)
-        # A gridlock-relief move into a full FIFO makes the reference's next update index past the row (IndexError,
-        # src/direction_mpnn.py:172-191); the kernel flags it on the device and the next forward raises the same error.
         if self._status is None or self._status.device != x.device:
             self._status = torch.zeros(1, dtype=torch.int32, device=x.device)
-        elif int(self._status.item()) != 0:
-            self._status.zero_()
-            raise IndexError("DirectionMPNN: a FIFO count reached Nmax (index out of range in the reference's update)")
+            self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._status_event = None
+        self._poll_status()
         gumbel = None
         if self._uniform is not None:
             gumbel = ops.gumbel_from_uniform_cpu(self._uniform).to(x.device)
@@ -58,4 +84,7 @@ class DirectionMPNN(MessagePassingBase, FeatureHelpers):
         dtt, _ = ops.direction_step(plan, x, self.Nmax, ec, self.time, congestion_constant=cc, gumbel=gumbel,
                                     seed=seed & 0x7FFFFFFFFFFFFFFF, counter=self._noise_counter, status=self._status)
         self.road_optimality_data = {"delta_travel_time": dtt.view(-1)}
+        self._status_host.copy_(self._status, non_blocking=True)
+        self._status_event = torch.cuda.Event()
+        self._status_event.record()
         return x

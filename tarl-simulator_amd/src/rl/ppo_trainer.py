@@ -70,7 +70,7 @@ def _evaluate(prefix, deterministic, eval_env, policy_module, frames_per_batch):
 def ppo_train(env, policy_module, value_module, *, total_frames=128, frames_per_batch=32, num_epochs=1,
               sub_batch_size=32, device=torch.device("cpu"), checkpoint_path=None, log_dir=None, eval_env=None,
               eval_interval=0, log_interval=1, stochastic_eval=False, num_envs=1, seed=0):
-    from tarl_hip import dist_utils
+    from tarl_hip import dist_utils, ops
     from tarl_hip.engine import SimEngine
     from tarl_hip.trainer import VecPPOTrainer
 
@@ -84,7 +84,8 @@ def ppo_train(env, policy_module, value_module, *, total_frames=128, frames_per_
     # seed, so seed + rank gives different trajectories per rank; parameters stay replicated (rank 0's are broadcast)
     engine = SimEngine(g.x, g.edge_index, g.edge_attr, sim.Nmax, agents,
                        congestion_constant=getattr(g, "congestion_constant", None), num_envs=num_envs,
-                       device=g.x.device, timestep=sim.timestep, seed=seed + 7919 * rank, fused=sim.Nmax <= 127)
+                       device=g.x.device, timestep=sim.timestep, seed=seed + 7919 * rank,
+                       fused=ops.fused_path_supported(g.edge_index, sim.Nmax))   # same decision on every rank
     l = value_net.final_mlp
     dormant = [p for n, p in policy_net.named_parameters() if not n.startswith("nodes_embedding")]
     head = getattr(policy_net, "policy_head", "embedding")

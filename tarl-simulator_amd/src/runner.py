@@ -44,11 +44,19 @@ class Runner:
             self.device = torch.device(args.device)
         torch.manual_seed(args.seed)          # identical initial weights on every rank (also broadcast by the trainer)
 
-    def close(self):
-        """Leave the process group (if this process joined one)."""
+    def close(self, failed=False):
+        """Leave the process group (if this process joined one). ``failed``: this rank is on its way out with an
+        exception — no barrier (the peers are in other collectives), and a communicator that cannot be destroyed cleanly
+        is left to the launcher, which kills the job when this process exits non-zero."""
         import torch.distributed as dist
         from tarl_hip import dist_utils
         if self.world > 1 and dist.is_initialized():
+            if failed:
+                try:
+                    dist.destroy_process_group()
+                except Exception:      # noqa: BLE001 — the original exception is the one to report
+                    pass
+                return
             dist_utils.barrier()
             dist.destroy_process_group()
 

@@ -52,6 +52,20 @@ def allreduce_max_float(v: float, device) -> float:
     return float(t.item())
 
 
+def gather_floats(vals, device):
+    """Every rank's list of floats -> [rank][k] on every rank (all_gather of one small fp64 tensor)."""
+    t = torch.tensor([float(v) for v in vals], dtype=torch.float64, device=device)
+    if world()[1] == 1:
+        return [t.tolist()]
+    out = [torch.empty_like(t) for _ in range(world()[1])]
+    dist.all_gather(out, t)
+    return [o.tolist() for o in out]
+
+
+def backend_name() -> str:
+    return dist.get_backend() if dist.is_available() and dist.is_initialized() else "none"
+
+
 def broadcast_(t: torch.Tensor, src=0):
     if world()[1] > 1:
         dist.broadcast(t, src=src)

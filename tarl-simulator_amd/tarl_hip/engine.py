@@ -18,9 +18,11 @@ EPISODE_END = 7 * 3600          # done = time > 7 * 3600
 
 class SimEngine:
     def __init__(self, x, edge_index, edge_attr, Nmax, agent_features, *, congestion_constant=None, num_envs=None,
-                 device="cuda", timestep=1, seed=0, plan=None, fused=True):
+                 device="cuda", timestep=1, seed=0, plan=None, fused=True, env_base=0):
         """``x`` (N,F) or (B,N,F); ``agent_features`` (A,9) or (B,A,9). 2-D inputs are replicated ``num_envs`` times;
-        3-D inputs are used in place (views are kept, so a caller-owned tensor keeps tracking the state)."""
+        3-D inputs are used in place (views are kept, so a caller-owned tensor keeps tracking the state).
+        ``env_base`` (fused path): global id of this batch's environment 0 — the noise streams of environment b are those
+        of global environment ``env_base + b`` under ``seed``, whichever batch (or rank) it is simulated in."""
         dev = torch.device(device)
         self.Nmax = int(Nmax)
 
@@ -58,7 +60,7 @@ class SimEngine:
         self.dtt = None
         self.status = torch.zeros(1, dtype=torch.int32, device=self.device)    # status word of the unfused kernels
         # fused fast path (csrc/fused.hip): packed hot records + agent SoA mirroring x / agents
-        self.fs = ops.FusedState(self.plan, self.B, self.A, self.device, self.Nmax) if fused else None
+        self.fs = ops.FusedState(self.plan, self.B, self.A, self.device, self.Nmax, env_base=env_base) if fused else None
         self.sample_counter = 0
         if self.fs is not None:
             self.resync()
@@ -75,6 +77,10 @@ class SimEngine:
     def resync(self):
         """Rebuild the fused side buffers from ``x`` / ``agents`` (after construction, reset, or external writes)."""
         if self.fs is not None:
+            # tarl_fused_pack re-arms the sticky device status word: whatever an earlier rollout flagged and nobody has
+            # read yet (only the non-blocking poll in flight) is raised here instead of being lost. Set-up path: the
+            # host synchronisation costs nothing that matters.
+            self.fs.check_flags()
             ops.fused_pack(self.plan, self.fs, self.x, self.Nmax, self.agents, self.cc, ec=self.ec)
             self._packed_stale = False
             self.fs.check_flags()
@@ -101,10 +107,10 @@ class SimEngine:
         if self.fs is not None and not self._packed_stale:
             ops.fused_reset(self.plan, self.fs, self.agents)     # packed state stays authoritative; x exported on demand
             self._x_stale = True
-            self._last_step_time = float(EPISODE_START)
         else:
             ops.reset_state(self.x, self.Nmax, self.agents)
             self.resync()
+        self._last_step_time = float(EPISODE_START)      # both branches: the first frame's prev_time is the reset clock
         self.time = EPISODE_START
         self.counts.zero_()
         self.reward.zero_()

@@ -102,7 +102,7 @@ class FusedStruct(C.Structure):
                 [(n, C.c_void_p) for n in ("sel8", "sel", "node_rec", "in_rec", "out_pad", "acc_lp", "acc_n", "acc_w", "a_origin", "a_dest",
                                            "a_dep", "a_status", "a_order", "cur_lo", "a_dep_sorted", "a_win", "a_ins",
                                            "a_rank")] +
-                [("acc_slots", C.c_int64), ("flags", C.c_void_p)])
+                [("acc_slots", C.c_int64), ("flags", C.c_void_p), ("env_base", C.c_int64)])
 
 
 FLAG_COUNT_AT_NMAX, FLAG_AMBIGUOUS_EDGES, FLAG_PACK_RANGE, FLAG_CHOICE_OVERFLOW = 1, 2, 4, 8

@@ -637,7 +637,10 @@ class FusedState:
     words (hdp, tl, post, sel8), the event-only word rec1, static node records, the slot-interleaved FIFO store and the
     agent SoA. They hold the state between :func:`fused_pack` and :func:`fused_export`."""
 
-    def __init__(self, plan: Plan, B: int, A: int, device, Nmax: int = 15):
+    def __init__(self, plan: Plan, B: int, A: int, device, Nmax: int = 15, env_base: int = 0):
+        """``env_base``: global id of environment 0 of this batch — the device noise streams are indexed by
+        ``env_base + b`` (include/tarl_hip.h: tarl_fused.env_base), so a shard of a larger batch reproduces the larger
+        batch's trajectories."""
         L = _lib.load()
         N, E = plan.num_nodes, plan.num_edges
         if Nmax > 127 or plan.max_out > 126:
@@ -680,8 +683,8 @@ class FusedState:
                                        self.acc_lp.data_ptr(), self.acc_n.data_ptr(), self.acc_w.data_ptr(),
                                        self.a_origin.data_ptr(), self.a_dest.data_ptr(), self.a_dep.data_ptr(),
                                        self.a_status.data_ptr(), None, self.cur_lo.data_ptr(), None, None, None, None,
-                                       self.acc_slots, self.flags.data_ptr())
-        self.B, self.N, self.A, self.Nmax = B, N, A, Nmax
+                                       self.acc_slots, self.flags.data_ptr(), int(env_base))
+        self.B, self.N, self.A, self.Nmax, self.env_base = B, N, A, Nmax, int(env_base)
 
     # -- unpacked views of the dense words (tests / debugging; torch plumbing, never on a hot path) ----------------------
     @property
@@ -725,11 +728,25 @@ class FusedState:
         return C.byref(self.struct)
 
 
+def fused_path_supported(edge_index: torch.Tensor, Nmax: int) -> bool:
+    """Can the packed path (FusedState) represent this graph? Nmax <= 127 (count byte + 7-bit ring offset), out-degree
+    <= 126 (7-bit rank of the chosen out-edge) and no parallel dual edges (two out-edges of one node to the same target
+    have no unique rank: FLAG_AMBIGUOUS_EDGES). Decided on the host from the topology alone, so every rank of a
+    data-parallel job takes the same branch; graphs outside it run on the unfused entry points."""
+    ei = edge_index.detach().to("cpu", torch.int64)
+    if ei.numel() == 0:
+        return Nmax <= 127
+    n = int(ei.max()) + 1
+    key = ei[0] * n + ei[1]
+    return bool(Nmax <= 127 and int(torch.bincount(ei[0]).max()) <= 126 and key.unique().numel() == key.numel())
+
+
 def raise_on_flags(v: int):
     """Turn the bits of a device status word (include/tarl_hip.h: TARL_FLAG_*) into a :class:`TarlError`."""
     if v & _lib.FLAG_COUNT_AT_NMAX:
         raise _lib.TarlError("a FIFO count reached Nmax: the state left the reference's defined domain (its "
-                             "DirectionMPNN.update raises IndexError there, src/direction_mpnn.py:172-191)")
+                             "DirectionMPNN.update silently overwrites the neighbouring FIFO blocks there and raises "
+                             "IndexError only a few steps later, src/direction_mpnn.py:172-191)")
     if v & _lib.FLAG_AMBIGUOUS_EDGES:
         raise _lib.TarlError("two out-edges of one node lead to the same ROAD_INDEX: SELECTED_ROAD has no unique rank "
                              "on this graph; construct SimEngine(..., fused=False)")

@@ -1,0 +1,270 @@
+"""GPU: parity / property tests AT THE GEOMETRY THE BENCH LAUNCHES and on config 5's TRAINING leg (round-2 verdict).
+
+* BASELINE config 4 with **B = 16 384** environments through the default ``tarl_fused_rollout`` path — the grids are 64
+  environment tiles wide, the insert kernel runs eight environments per wave (auto EPW = 8, ``k_fused_insert2<8>``), the
+  action draws are ``k_fused_choice_all<true>`` (four nodes per Philox block), the Direction gather its sibling form.
+  Environments {0, 4 095, 8 191, 16 383} of the batch must be bit-identical (actions, log-probs, rewards, counts, final
+  state, agents) to the SAME environments simulated alone (``env_base`` = their global id: the noise streams are indexed
+  by the environment's global id, not by its lane), and the domain invariants must hold. An index overflow or a
+  tile-mapping slip at this size breaks one of the four.
+  Reference semantics held: src/agents/base.py:244-331 (insert), src/direction_mpnn.py:103-196.
+* two half batches (``env_base`` 0 and B/2) == the whole batch: what a two-rank data-parallel job simulates is exactly
+  what one rank simulates with twice the environments.
+* BASELINE config 5 (100 000 route edges, 25 000 roads, 262 144 agents): one ``VecPPOTrainer`` collect + update against
+  oracle autograd on the same rollout and minibatch frames — the critic with K = 25 001 through
+  ``k_critic_fwd_slab_u8x3`` (GAE pass on count bytes) and the split-K minibatch forward, GAE, advantage normalisation,
+  clipped loss, backward, Adam — and ``k_edge_mlp_fwd_bf16`` on 100 000 edges against ``oracle/nets.edge_mlp_logits``.
+  Reference: src/agents/mpnn_agent.py:35-41,227-231,420-450; src/rl/ppo_trainer.py:129-145."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+BF16_TOL = 2e-2          # tests/test_gpu_edge_mlp.py: bf16 inputs / weights / first hidden activation, fp32 accumulation
+
+
+def close(a, b, what, tol=TOL):
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, f"{what}: max abs err {err:.3e} vs scale {scale:.3e}"
+
+
+def _rollout(eng, T):
+    N, B = eng.N, eng.B
+    ch = torch.zeros((T, N, B), dtype=torch.uint8, device="cuda")
+    ct = torch.zeros((T + 1, N, B), dtype=torch.uint8, device="cuda")
+    lp, rw = torch.zeros((T, B), device="cuda"), torch.zeros((T, B), device="cuda")
+    leg = torch.zeros((T, B, 2), dtype=torch.int32, device="cuda")
+    eng.rollout_fused(T, choice=ch, log_prob=lp, reward=rw, counts=ct, leg=leg)
+    return ch, ct, lp, rw, leg
+
+
+def _invariants(net, x, ag, rw_last, ct_last, t_now):
+    """tests/test_gpu_properties.py::_check_invariants for a handful of environments given as (k, N, F) / (k, A, 9)."""
+    Nmax = net.Nmax
+    n, maxn = x[:, :, 3 * Nmax + 1], x[:, :, 3 * Nmax]
+    assert bool((n >= 0).all()) and bool((n <= maxn).all())
+    assert torch.equal(rw_last, -n.sum(dim=1)) and torch.equal(ct_last.float(), n)
+    slot = torch.arange(Nmax, device=x.device).unsqueeze(0)
+    for b in range(x.size(0)):
+        live = x[b, :, :Nmax][slot < n[b].unsqueeze(1)].long()
+        assert bool((live > 0).all()) and live.numel() == live.unique().numel(), "a queued agent appears twice"
+        assert bool((ag[b, live, 7] == 1).all()) and bool((ag[b, live, 8] == 0).all())
+        assert int(ag[b, :, 7].sum()) >= live.numel()
+        done = ag[b, :, 8] == 1
+        assert bool((ag[b, done, 7] == 0).all())
+        if bool(done.any()):
+            assert bool((ag[b, done, 3] >= ag[b, done, 2]).all()) and float(ag[b, done, 3].max()) < t_now
+
+
+def test_config4_at_the_bench_batch_size_is_batch_independent():
+    from tarl_hip import synth
+    from tarl_hip.engine import EPISODE_START, SimEngine
+    B, A, T = 16384, 16384, 24
+    probe = [0, 4095, 8191, 16383]
+    net = synth.torus_network(25, 25)
+    N = net.num_roads
+    # every agent departs within 800 s: ~20 due per frame and environment — around the packed insert's share of the LDS
+    # list (24 entries per environment at EPW = 8), so both its packed path and its one-environment fall-back run; the
+    # first agents reach the end of their road after 10 s: pops, enqueues and arrivals from frame 10 on
+    pops = synth.population_batch(A, N, B, seed=5, device="cuda", t1=EPISODE_START + 800)
+    emb = torch.randn(N, generator=torch.Generator().manual_seed(1)).cuda()
+    eng = SimEngine(net.x.cuda().unsqueeze(0).repeat(B, 1, 1).contiguous(), net.edge_index, net.edge_attr, net.Nmax,
+                    pops, congestion_constant=net.congestion_constant, seed=11)
+    assert eng.plan.handle is not None and eng.B == B
+    eng.reset()
+    eng.prepare_policy(emb)
+    ch, ct, lp, rw, leg = _rollout(eng, T)
+    eng.check_flags()
+    assert int(leg[..., 0].sum()) > 100 * B and int(leg[..., 1].sum()) > 0        # departures everywhere, some arrivals
+    assert float(rw.abs().sum()) > 0 and bool(torch.isfinite(lp).all())
+    xb = torch.stack([eng.x[b] for b in probe])           # exports the packed state of the whole batch once
+    agb = torch.stack([eng.agents[b] for b in probe])
+    pidx = torch.tensor(probe, device="cuda")
+    _invariants(net, xb, agb, rw[-1, pidx], ct[-1][:, pidx].t(), eng.time)
+    # the same four environments, each simulated ALONE under its global id
+    for k, b in enumerate(probe):
+        solo = SimEngine(net.x.cuda().unsqueeze(0).contiguous(), net.edge_index, net.edge_attr, net.Nmax,
+                         pops[b:b + 1].clone(), congestion_constant=net.congestion_constant, seed=11, env_base=b)
+        solo.reset()
+        solo.prepare_policy(emb)
+        ch1, ct1, lp1, rw1, leg1 = _rollout(solo, T)
+        solo.check_flags()
+        assert torch.equal(ch1[:, :, 0], ch[:, :, b]), f"actions of environment {b}"
+        assert torch.equal(lp1[:, 0], lp[:, b]), f"log-probs of environment {b}"
+        assert torch.equal(rw1[:, 0], rw[:, b]) and torch.equal(leg1[:, 0], leg[:, b]), f"rewards / leg counts of environment {b}"
+        assert torch.equal(ct1[:, :, 0], ct[:, :, b]), f"counts of environment {b}"
+        assert torch.equal(solo.x[0], xb[k]) and torch.equal(solo.agents[0], agb[k]), f"final state of environment {b}"
+    # every environment's frames are self-consistent at this size: reward == -sum of the count bytes, frame by frame
+    assert torch.equal(rw, -ct[1:].sum(dim=1, dtype=torch.float32))
+
+
+def test_two_half_batches_reproduce_the_whole_batch():
+    """What two data-parallel ranks simulate (each its half of the environments, env_base = rank * B / 2, one seed) is
+    bit-identical to one rank simulating all of them."""
+    from tarl_hip import synth
+    from tarl_hip.engine import EPISODE_START, SimEngine
+    B, A, T = 512, 2000, 40
+    net = synth.torus_network(6, 5, heterogeneous=True, seed=4)
+    N = net.num_roads
+    pops = synth.population_batch(A, N, B, seed=8, device="cuda", t1=EPISODE_START + 60)
+    emb = torch.randn(N, generator=torch.Generator().manual_seed(2)).cuda()
+
+    def run(lo, hi, mode):
+        e = SimEngine(net.x.cuda().unsqueeze(0).repeat(hi - lo, 1, 1).contiguous(), net.edge_index, net.edge_attr,
+                      net.Nmax, pops[lo:hi].clone(), congestion_constant=net.congestion_constant, seed=21, env_base=lo)
+        e.reset()
+        e.prepare_policy(emb)
+        if mode == "frames":
+            ch, ct, lp, rw, _ = _rollout(e, T)
+            ch, ct = e.decode_rollout(True, choice=ch, counts=ct)
+        else:
+            ch = torch.zeros((T, e.B, N), dtype=torch.uint8, device="cuda")
+            ct = torch.zeros((T + 1, e.B, N), dtype=torch.uint8, device="cuda")
+            lp, rw = torch.zeros((T, e.B), device="cuda"), torch.zeros((T, e.B), device="cuda")
+            e.rollout_env(T, choice=ch, log_prob=lp, reward=rw, counts=ct)
+            ch, ct = e.decode_rollout(False, choice=ch, counts=ct)
+        return ch, ct, lp, rw, e.x.clone(), e.agents.clone()
+
+    for mode in ("frames", "env"):
+        whole = run(0, B, mode)
+        a, b = run(0, B // 2, mode), run(B // 2, B, mode)
+        for w, u, v, what in zip(whole, a, b, ("actions", "counts", "log-probs", "rewards", "state", "agents")):
+            dim = 0 if what in ("state", "agents") else 1
+            assert torch.equal(w, torch.cat((u, v), dim=dim)), f"{mode}: {what}"
+        assert float(whole[3].abs().sum()) > 0
+
+
+def test_config5_training_leg_matches_oracle_autograd():
+    from oracle import dist, nets, ppo
+    from src.agents.mpnn_agent import MPNNPolicyNet, MPNNValueNetSimple
+    from tarl_hip import synth
+    from tarl_hip.engine import EPISODE_START, SimEngine
+    from tarl_hip.trainer import VecPPOTrainer
+    net = synth.torus_network(25, 250)
+    N, E = net.num_roads, net.edge_index.size(1)
+    assert (N, E) == (25_000, 100_000)
+    B, A, T, M = 128, 262_144, 10, 16
+    # 262 144 agents departing within 40 s: the network is loaded inside the 10 frames (counts matter to the critic)
+    pops = synth.population_batch(A, N, B, seed=3, device="cuda", t1=EPISODE_START + 40)
+    eng = SimEngine(net.x.cuda().unsqueeze(0).repeat(B, 1, 1).contiguous(), net.edge_index, net.edge_attr, net.Nmax,
+                    pops, congestion_constant=net.congestion_constant, seed=3)
+    torch.manual_seed(0)
+    pol = MPNNPolicyNet(net.edge_index, N, None, device="cuda")
+    val = MPNNValueNetSimple(net.edge_index, N, device="cuda")
+    l = val.final_mlp
+    crit = [l[0].weight, l[0].bias, l[2].weight, l[2].bias, l[4].weight, l[4].bias]
+    assert crit[0].shape == (64, N + 1)                                   # K = 25 001
+    tr = VecPPOTrainer(eng, pol.nodes_embedding.weight, crit, rollout_steps=T, num_epochs=1, sub_batch_size=M,
+                       extra_params=[p for n, p in pol.named_parameters() if not n.startswith("nodes_embedding")])
+    assert tr.rollout == "frames" and tr.env_minor and B % 128 == 0       # -> critic_forward_slabs (k_critic_fwd_slab_u8x3)
+    tr.keep_grad = True
+    tr.collect()
+    tr.check_flags()
+    emb0 = pol.nodes_embedding.weight.detach().cpu().clone()
+    crit0 = [p.detach().cpu().clone() for p in crit]
+    choice, counts = (t_.cpu() for t_ in eng.decode_rollout(True, choice=tr.choice, counts=tr.counts))
+    reward, times = tr.reward.cpu(), tr.times.cpu()
+    assert float(counts[-1].sum()) > 1000 * B and float(reward.abs().sum()) > 0
+    idx = torch.randperm(T * B, generator=torch.Generator().manual_seed(4))[:M]
+    adv_g, tgt_g = tr.advantages()
+    out = tr.minibatch_step(adv_g, tgt_g, idx=idx)
+    # ---- oracle (torch autograd on the CPU) ----
+    emb = emb0.clone().requires_grad_(True)
+    cw = [p.clone().requires_grad_(True) for p in crit0]
+    with torch.no_grad():
+        # MPNNValueNetSimple reads the count column and the clock (src/agents/mpnn_agent.py:428-450): evaluated frame by
+        # frame to keep the (T+1, B, N, 7) observation tensor out of host memory
+        v_all = torch.stack([nets.critic_value(_obs(counts[t], N), times[t].view(1, 1).expand(B, 1), *cw).squeeze(-1)
+                             for t in range(T + 1)])
+        nodone = torch.zeros((T, B), dtype=torch.bool)
+        adv, tgt = ppo.gae(reward, v_all[:T], v_all[1:], nodone, nodone, average_gae=True)
+    close(tr.values.cpu(), v_all, "critic values over all frames (GAE pass on count bytes)")
+    close(adv_g.cpu(), adv, "advantage")
+    close(tgt_g.cpu(), tgt, "value_target")
+    t_idx, b_idx = idx // B, idx % B
+    onehot = torch.zeros((M, E), dtype=torch.int64)
+    onehot.scatter_(1, choice[t_idx, b_idx].long(), 1)
+    nf_mb = _obs(counts[t_idx, b_idx], N)
+    with torch.no_grad():
+        lp_old = dist.GraphDist(nets.policy_logits(nf_mb, net.edge_index, emb0), net.edge_index).log_prob(onehot)
+    # An action's log-prob here is a sum of 25 000 terms of ~ -1.39: magnitude 2^15..2^16, where ONE fp32 ulp is
+    # Q = 2^-8 = 3.9e-3. The importance ratio exp(lp_new - lp_old) of the reference itself therefore carries a quantum of
+    # ~0.4 % at this size (its torch.sum is fp32 too), and two correct fp32 evaluations of the same sum differ by a few
+    # ulp. Tolerances on the actor side are stated in that quantum: log-probs within 4 ulp, the surrogate loss within
+    # 8 ulp x max|A| (two log-probs per ratio), the embedding gradient within 8 ulp of its scale. Everything that does
+    # not pass through a 25 000-term fp32 sum (critic values, GAE, advantages, critic loss and gradients, entropy) keeps
+    # the 1e-4 bar.
+    Q = 2.0 ** -8
+    assert 2.0 ** 15 <= float(lp_old.abs().max()) < 2.0 ** 16 and bool(torch.isfinite(lp_old).all())
+    err_lp = float((tr.logp.view(-1).cpu()[idx] - lp_old).abs().max())
+    assert err_lp <= 4 * Q, f"sample_log_prob: {err_lp:.3e} (> 4 ulp of 2^-8)"
+    lp_old = tr.logp.view(-1).cpu()[idx]                    # the update uses the stored one; so does the oracle from here
+    d = dist.GraphDist(nets.policy_logits(nf_mb, net.edge_index, emb), net.edge_index)
+    lp_new, ent = d.log_prob(onehot), d.entropy()
+    value = nets.critic_value(nf_mb, times[t_idx].view(M, 1), *cw).squeeze(-1)
+    adv_mb = adv.view(-1)[idx]
+    losses = ppo.clip_ppo_loss(lp_new, lp_old, adv_mb, value, tgt.view(-1)[idx], ent)
+    (losses["loss_objective"] + losses["loss_critic"] + losses["loss_entropy"]).backward()
+    o = out.cpu()
+    tol_obj = 8 * Q * float(adv_mb.abs().max())
+    assert abs(o[0].item() - losses["loss_objective"].item()) <= tol_obj, \
+        f"loss_objective: {o[0].item()} vs {losses['loss_objective'].item()} (tolerance {tol_obj:.3e})"
+    for i, k in ((1, "loss_critic"), (2, "loss_entropy")):
+        assert abs(o[i].item() - losses[k].item()) <= TOL * max(1.0, abs(losses[k].item())), \
+            f"{k}: {o[i].item()} vs {losses[k].item()}"
+    g = tr.last_grad.cpu()
+    n_emb = emb.grad.numel()
+    close(g[:n_emb], emb.grad.reshape(-1), "grad emb", 8 * Q)
+    assert float(emb.grad.abs().max()) > 0
+    off = n_emb
+    for name, ref in [(f"critic{i}", c.grad) for i, c in enumerate(cw)]:
+        n = ref.numel()
+        close(g[off:off + n], ref.reshape(-1), f"grad {name}")
+        off += n
+    assert float(g[off:].abs().sum()) == 0.0                       # dormant heads receive no gradient
+    # (the Adam kernel is pinned against torch.optim.Adam in tests/test_gpu_ppo_parity.py; here: the step was applied)
+    assert not torch.equal(pol.nodes_embedding.weight.detach().cpu(), emb0)
+    assert not torch.equal(crit[0].detach().cpu(), crit0[0])
+
+
+def _obs(counts, N):
+    """(rows, N) counts -> (rows, N, 7) node features with the columns the nets read (count, ROAD_INDEX)."""
+    nf = torch.zeros(counts.shape + (7,))
+    nf[..., 1] = counts
+    nf[..., 6] = torch.arange(N, dtype=torch.float32)
+    return nf
+
+
+def test_config5_edge_mlp_bf16_on_100k_edges():
+    """k_edge_mlp_fwd_bf16 (and the fp32 MFMA forward) on config 5's 100 000 edges, observations taken from a loaded
+    packed state, against the oracle's restatement of the reference's nn.Sequential (oracle/nets.edge_mlp_logits)."""
+    from oracle import nets
+    from src.agents.mpnn_agent import MPNNPolicyNet
+    from tarl_hip import ops, synth
+    from tarl_hip.engine import EPISODE_START, SimEngine
+    net = synth.torus_network(25, 250)
+    N, E = net.num_roads, net.edge_index.size(1)
+    B, A = 3, 262_144
+    pops = synth.population_batch(A, N, B, seed=6, device="cuda", t1=EPISODE_START + 30)
+    eng = SimEngine(net.x.cuda().unsqueeze(0).repeat(B, 1, 1).contiguous(), net.edge_index, net.edge_attr, net.Nmax,
+                    pops, congestion_constant=net.congestion_constant, seed=2)
+    eng.reset()
+    eng.prepare_policy(torch.randn(N, generator=torch.Generator().manual_seed(3)).cuda())
+    for _ in range(20):
+        eng.frame_fused()
+    eng.check_flags()
+    obs = ops.fused_obs16(eng.plan, eng.fs, eng._x, eng.Nmax, eng.agents)            # (B, N, 16) fp32
+    obs_b = ops.fused_obs16_bf16(eng.plan, eng.fs, eng._x, eng.Nmax, eng.agents)
+    assert float(obs[:, :, 1].sum()) > 1000 and torch.equal(obs_b, obs.to(torch.bfloat16))
+    torch.manual_seed(5)
+    pol = MPNNPolicyNet(net.edge_index, N, None, device="cuda")
+    mm = pol.edge_mlp
+    ws = [mm[0].weight, mm[0].bias, mm[2].weight, mm[2].bias, mm[4].weight, mm[4].bias]
+    w = ops.EdgeMlpWeights(*(p.data for p in ws))
+    ref = nets.edge_mlp_logits(obs.cpu(), net.edge_index, net.edge_attr.expand(B, -1, -1), *[p.detach().cpu() for p in ws])
+    assert ref.shape == (B, E)
+    close(ops.policy_edge_mlp(eng.plan, obs, eng.ec, w).cpu(), ref, "logits (fp32 MFMA, 100k edges)")
+    lb = ops.policy_edge_mlp(eng.plan, obs, eng.ec, w, bf16=True)
+    close(lb.cpu(), ref, "logits (bf16 MFMA, 100k edges)", BF16_TOL)
+    assert torch.equal(ops.policy_edge_mlp(eng.plan, obs_b, eng.ec, w), lb)          # bf16 rows in == fp32 rows rounded inside

@@ -137,3 +137,30 @@ def test_count_reaching_nmax_is_flagged_and_raises(mode):
         return
     with pytest.raises(lib.TarlError, match="reached Nmax"):
         eng.check_flags()
+
+
+def test_drop_in_direction_mpnn_reports_the_domain_exit_without_stalling_the_step_path():
+    """The drop-in DirectionMPNN polls its device status word asynchronously (a pinned copy behind every forward): the
+    forward that drives a count to Nmax returns normally, and check() — or a later forward / set_time once the copy has
+    landed — raises IndexError. Also covers a flag raised by the LAST forward of a run (only check() can see that one)."""
+    from src.direction_mpnn import DirectionMPNN
+    from tarl_hip import synth
+    net = synth.torus_network(2, 2)
+    N, Nmax = net.num_roads, net.Nmax
+    x = net.x.clone()
+    x[:, :Nmax - 1] = torch.arange(1, N * (Nmax - 1) + 1, dtype=torch.float32).view(N, Nmax - 1)
+    x[:, Nmax:2 * Nmax - 1] = 100.0
+    x[:, 2 * Nmax:3 * Nmax - 1] = 200.0
+    x[:, 3 * Nmax + 1] = Nmax - 1
+    first_out = torch.full((N,), -1, dtype=torch.long)
+    for e in range(net.edge_index.size(1) - 1, -1, -1):
+        first_out[net.edge_index[0, e]] = net.edge_index[1, e]
+    x[:, 3 * Nmax + 5] = first_out.to(torch.float32)          # SELECTED_ROAD: every head wants its first out-neighbour
+    xg = x.cuda()
+    mp = DirectionMPNN(Nmax=Nmax, time=21540)
+    mp.noise_seed = 5
+    out = mp(xg, net.edge_index.cuda(), net.edge_attr.cuda(), congestion_constant=net.congestion_constant.cuda())
+    assert out is xg and float(xg[:, 3 * Nmax + 1].max()) == Nmax          # the forward itself returned normally
+    with pytest.raises(IndexError, match="reached Nmax"):
+        mp.check()
+    mp.check()                                                             # reported once, then re-armed

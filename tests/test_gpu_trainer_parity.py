@@ -108,3 +108,47 @@ def test_ppo_update_matches_oracle_autograd(fused, lazy, rollout, timestep):
         ppo.adam_step(q, gr, torch.zeros_like(q), torch.zeros_like(q), 1)
         close(p_gpu.detach().cpu(), q, f"param {name}")
     assert not torch.equal(pol.nodes_embedding.weight.detach().cpu(), emb0)
+
+
+def test_consecutive_collects_with_an_episode_end_keep_every_log_prob_exact():
+    """An episode end splits a collector batch into rollouts of different lengths (here 13 + 11 frames) that share one
+    choice scratch buffer. The log-prob accumulators of the long call must not be overlaid by the record tables of the
+    short one (round-2 advisor finding: offsets inside the scratch depended on T). Two consecutive collect() calls; the
+    stored sample_log_prob of EVERY frame of BOTH batches must equal the exact log-prob of the stored action."""
+    from oracle import dist, nets
+    from src.agents.mpnn_agent import MPNNPolicyNet, MPNNValueNetSimple
+    from tarl_hip import synth
+    from tarl_hip.engine import SimEngine
+    from tarl_hip.trainer import VecPPOTrainer
+
+    net = synth.torus_network(4, 4, heterogeneous=True, seed=2)
+    N, E = net.num_roads, net.edge_index.size(1)
+    B, A, T = 128, 300, 24
+    pops = torch.stack([synth.population(A, N, seed=b, t0=21540, t1=21555) for b in range(B)])
+    eng = SimEngine(net.x.cuda().unsqueeze(0).repeat(B, 1, 1).contiguous(), net.edge_index, net.edge_attr, net.Nmax,
+                    pops.cuda(), congestion_constant=net.congestion_constant, seed=3, fused=True, timestep=300)
+    torch.manual_seed(0)
+    pol = MPNNPolicyNet(net.edge_index, N, None, device="cuda")
+    val = MPNNValueNetSimple(net.edge_index, N, device="cuda")
+    l = val.final_mlp
+    tr = VecPPOTrainer(eng, pol.nodes_embedding.weight, [l[0].weight, l[0].bias, l[2].weight, l[2].bias, l[4].weight, l[4].bias],
+                       rollout_steps=T, num_epochs=1, sub_batch_size=16,
+                       extra_params=[p for n, p in pol.named_parameters() if not n.startswith("nodes_embedding")],
+                       rollout="frames")
+    emb0 = pol.nodes_embedding.weight.detach().cpu().clone()
+    nf = torch.zeros((1, N, 7))
+    nf[..., 6] = torch.arange(N, dtype=torch.float32)
+    d = dist.GraphDist(nets.policy_logits(nf, net.edge_index, emb0), net.edge_index)
+    for it in range(3):
+        tr.collect()
+        torch.cuda.synchronize()
+        assert tr.done_frames.tolist() == [t == 12 for t in range(T)]
+        choice = eng.decode_rollout(True, choice=tr.choice)[0].cpu()          # (T, B, N) edge ids
+        onehot = torch.zeros((T * B, E), dtype=torch.int64)
+        onehot.scatter_(1, choice.view(T * B, N).long(), 1)
+        exact = d.log_prob(onehot).view(T, B)
+        got = tr.logp.cpu()
+        err = (got - exact).abs().max(dim=1).values
+        assert float(err.max()) <= TOL * max(1.0, float(exact.abs().max())), \
+            f"collect {it}: sample_log_prob off by up to {float(err.max()):.3e} (frames {err.nonzero().flatten().tolist()[:8]})"
+    tr.check_flags()
