@@ -77,7 +77,9 @@ def test_config4_at_the_bench_batch_size_is_batch_independent():
     ch, ct, lp, rw, leg = _rollout(eng, T)
     eng.check_flags()
     assert int(leg[..., 0].sum()) > 100 * B and int(leg[..., 1].sum()) > 0        # departures everywhere, some arrivals
-    assert float(rw.abs().sum()) > 0 and bool(torch.isfinite(lp).all())
+    # (a node whose uniform lands beyond its last fp32 threshold draws nothing — ~1e-7 per draw, a hundred of the 1e9 here —
+    # and makes that frame's action infeasible: log_prob = -inf, as in the reference, src/reinforcement_learning.py:88-92)
+    assert float(rw.abs().sum()) > 0 and float(torch.isfinite(lp).float().mean()) > 0.999
     xb = torch.stack([eng.x[b] for b in probe])           # exports the packed state of the whole batch once
     agb = torch.stack([eng.agents[b] for b in probe])
     pidx = torch.tensor(probe, device="cuda")
@@ -188,17 +190,18 @@ def test_config5_training_leg_matches_oracle_autograd():
     nf_mb = _obs(counts[t_idx, b_idx], N)
     with torch.no_grad():
         lp_old = dist.GraphDist(nets.policy_logits(nf_mb, net.edge_index, emb0), net.edge_index).log_prob(onehot)
-    # An action's log-prob here is a sum of 25 000 terms of ~ -1.39: magnitude 2^15..2^16, where ONE fp32 ulp is
-    # Q = 2^-8 = 3.9e-3. The importance ratio exp(lp_new - lp_old) of the reference itself therefore carries a quantum of
-    # ~0.4 % at this size (its torch.sum is fp32 too), and two correct fp32 evaluations of the same sum differ by a few
+    # An action's log-prob here is a sum of 25 000 terms of ~ -1.1: magnitude 2^14..2^15, where ONE fp32 ulp is
+    # Q = 2^-9 = 2e-3. The importance ratio exp(lp_new - lp_old) of the reference itself therefore carries a quantum of
+    # ~0.2 % at this size (its torch.sum is fp32 too), and two correct fp32 evaluations of the same sum differ by a few
     # ulp. Tolerances on the actor side are stated in that quantum: log-probs within 4 ulp, the surrogate loss within
     # 8 ulp x max|A| (two log-probs per ratio), the embedding gradient within 8 ulp of its scale. Everything that does
     # not pass through a 25 000-term fp32 sum (critic values, GAE, advantages, critic loss and gradients, entropy) keeps
     # the 1e-4 bar.
-    Q = 2.0 ** -8
-    assert 2.0 ** 15 <= float(lp_old.abs().max()) < 2.0 ** 16 and bool(torch.isfinite(lp_old).all())
+    import math
+    assert bool(torch.isfinite(lp_old).all()) and float(lp_old.abs().max()) > 2.0 ** 14
+    Q = 2.0 ** (math.floor(math.log2(float(lp_old.abs().max()))) - 23)      # one fp32 ulp at the log-probs' magnitude
     err_lp = float((tr.logp.view(-1).cpu()[idx] - lp_old).abs().max())
-    assert err_lp <= 4 * Q, f"sample_log_prob: {err_lp:.3e} (> 4 ulp of 2^-8)"
+    assert err_lp <= 4 * Q, f"sample_log_prob: {err_lp:.3e} (> 4 ulp = {4 * Q:.3e})"
     lp_old = tr.logp.view(-1).cpu()[idx]                    # the update uses the stored one; so does the oracle from here
     d = dist.GraphDist(nets.policy_logits(nf_mb, net.edge_index, emb), net.edge_index)
     lp_new, ent = d.log_prob(onehot), d.entropy()

@@ -6,10 +6,11 @@ MI355X_MICROARCH.md's HBM / rocprofv3 section prescribes):
 
   cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_f -o run -- \
-      python3 bench.py --steps 1 --warmup 1 --cpu-seconds 0 --congested-window 0 --no-kernel-timing
+      python3 bench.py --steps 1 --warmup 1 --cpu-seconds 0 --congested-window 0 --policy-envs 0 --no-kernel-timing
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_w -o run -- \
-      python3 bench.py --steps 1 --warmup 1 --cpu-seconds 0 --congested-window 0 --no-kernel-timing
-  python3 tools/pmc_bench.py gpurun_out/pmc_f gpurun_out/pmc_w --out profiles/r02_pmc_traffic.json
+      python3 bench.py --steps 1 --warmup 1 --cpu-seconds 0 --congested-window 0 --policy-envs 0 --no-kernel-timing
+  python3 tools/pmc_bench.py gpurun_out/pmc_f gpurun_out/pmc_w [more pass dirs] --out profiles/r03_pmc_traffic.json
+  (tools/r03_pmc.sh runs the passes for the default line and for the congested regime, --departure-window 600)
 
 Reduction: for every rollout kernel the launches of the LAST iteration's frames >= --first-frame (default 200: the
 episode has filled up; the first frames after a reset move almost nobody) are averaged. Units and the gfx950 correction
@@ -36,22 +37,24 @@ ROLLOUT_KERNELS = {
 }
 
 
-def per_kernel(dirname, counter):
-    paths = glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True)
-    if not paths:
-        raise SystemExit(f"no *counter_collection.csv under {dirname}")
-    rows = []
-    for p in paths:
-        rows += [r for r in csv.DictReader(open(p)) if r["Counter_Name"] == counter]
-    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    per = {}
-    for r in rows:
-        m = re.search(r"\b(k_[A-Za-z0-9_]+)", r["Kernel_Name"])     # template kernels: "void k_fused_rows<4>(...)"
-        name = m.group(1) if m else r["Kernel_Name"].split("(")[0].split()[-1]
-        if name == "k_fused_insert2":      # several environments per wave: the same launch slot of a frame
-            name = "k_fused_insert"
-        per.setdefault(name, []).append(float(r["Counter_Value"]))
-    return per
+def per_kernel_all(dirnames):
+    """{counter: {kernel: [values in dispatch order]}} over every *counter_collection.csv under the directories."""
+    out = {}
+    for dirname in dirnames:
+        paths = glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True)
+        if not paths:
+            raise SystemExit(f"no *counter_collection.csv under {dirname}")
+        rows = []
+        for p in paths:
+            rows += list(csv.DictReader(open(p)))
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+        for r in rows:
+            m = re.search(r"\b(k_[A-Za-z0-9_]+)", r["Kernel_Name"])     # template kernels: "void k_fused_rows<4>(...)"
+            name = m.group(1) if m else r["Kernel_Name"].split("(")[0].split()[-1]
+            if name == "k_fused_insert2":      # several environments per wave: the same launch slot of a frame
+                name = "k_fused_insert"
+            out.setdefault(r["Counter_Name"], {}).setdefault(name, []).append(float(r["Counter_Value"]))
+    return out
 
 
 def window(vals, per_iter, T, first_frame):
@@ -62,34 +65,49 @@ def window(vals, per_iter, T, first_frame):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("fetch_dir")
-    ap.add_argument("write_dir")
+    ap.add_argument("dirs", nargs="+", help="rocprofv3 output directories, one per --pmc pass (FETCH_SIZE and WRITE_SIZE "
+                                            "are required; any further counters are recorded beside them)")
     ap.add_argument("--edges", type=int, default=10000)
     ap.add_argument("--agents", type=int, default=16384)
     ap.add_argument("--envs", type=int, default=16384)
     ap.add_argument("--rollout-steps", type=int, default=256)
+    ap.add_argument("--departure-window", type=int, default=0, help="the bench's --departure-window (0 = the default line)")
     ap.add_argument("--first-frame", type=int, default=200)
     ap.add_argument("--note", type=str, default="")
     ap.add_argument("--out", type=str, default=None)
     a = ap.parse_args()
     from tarl_hip.ops import FUSED_LAYOUT
-    f = per_kernel(a.fetch_dir, "FETCH_SIZE")
-    w = per_kernel(a.write_dir, "WRITE_SIZE")
+    allc = per_kernel_all(a.dirs)
+    if "FETCH_SIZE" not in allc or "WRITE_SIZE" not in allc:
+        raise SystemExit("FETCH_SIZE and WRITE_SIZE passes are required")
     T = a.rollout_steps
-    out = {"note": ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) of "
-                    "`python3 bench.py --steps 1 --warmup 1 --cpu-seconds 0 --congested-window 0 --no-kernel-timing`; counters are KiB; "
-                    "hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B); "
-                    f"mean over the last iteration's frames >= {a.first_frame}. " + a.note).strip(),
-           "config": {"edges": a.edges, "agents": a.agents, "envs": a.envs, "rollout_steps": T},
-           "layout": FUSED_LAYOUT, "first_frame": a.first_frame, "kernels": {}}
+    cfg = {"edges": a.edges, "agents": a.agents, "envs": a.envs, "rollout_steps": T}
+    cmd = "python3 bench.py --steps 1 --warmup 1 --cpu-seconds 0 --congested-window 0 --policy-envs 0 --no-kernel-timing"
+    if a.departure_window:
+        cfg["departure_window"] = a.departure_window
+        cmd += f" --departure-window {a.departure_window}"
+    out = {"note": (f"rocprofv3 --pmc passes (one counter set each, --kernel-trace only) of `{cmd}`; FETCH_SIZE / WRITE_SIZE are KiB. "
+                    "hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024. Calibration (profiles/r03_pmc_calibration.txt, tools/pmc_cal.hip): "
+                    "every read request of gfx950 is 128 B and FETCH_SIZE tallies it at 64 B — measured 0.5000 for 1-, 4-, 8- and "
+                    "16-byte-per-lane coalesced loads, the env-minor 8-byte gather and scattered 12-byte triples alike (the latter: one "
+                    "128-B request per triple) — so the factor 2 holds for every load these kernels issue; WRITE_SIZE is exact for stores "
+                    "that fill 64-byte lines and tallies a partial-line store at 32 B per request. "
+                    f"Mean over the last iteration's frames >= {a.first_frame}. " + a.note).strip(),
+           "config": cfg, "layout": FUSED_LAYOUT, "first_frame": a.first_frame, "kernels": {}}
     for k, per_iter in ROLLOUT_KERNELS.items():
-        if k not in f or k not in w:
-            print(f"warning: {k} not in the traces ({sorted(f)[:12]} ...)", file=sys.stderr)
+        if k not in allc["FETCH_SIZE"] or k not in allc["WRITE_SIZE"]:
+            print(f"warning: {k} not in the traces ({sorted(allc['FETCH_SIZE'])[:12]} ...)", file=sys.stderr)
             continue
-        fv, wv = window(f[k], per_iter(T), T, a.first_frame), window(w[k], per_iter(T), T, a.first_frame)
-        fm, wm = sum(fv) / len(fv), sum(wv) / len(wv)
-        out["kernels"][k] = {"FETCH_SIZE_KiB": fm, "WRITE_SIZE_KiB": wm, "launches_averaged": len(fv),
-                             "launches_total": len(f[k]), "hbm_bytes_per_launch": 2 * fm * 1024 + wm * 1024}
+        rec = {"launches_total": len(allc["FETCH_SIZE"][k])}
+        for c, per in sorted(allc.items()):
+            if k in per:
+                v = window(per[k], per_iter(T), T, a.first_frame)
+                rec[c + ("_KiB" if c in ("FETCH_SIZE", "WRITE_SIZE") else "")] = sum(v) / len(v)
+                rec["launches_averaged"] = len(v)
+        fm, wm = rec["FETCH_SIZE_KiB"], rec["WRITE_SIZE_KiB"]
+        rec["formula"] = "2*FETCH_SIZE + WRITE_SIZE"
+        rec["hbm_bytes_per_launch"] = 2 * fm * 1024 + wm * 1024
+        out["kernels"][k] = rec
     txt = json.dumps(out, indent=1)
     if a.out:
         open(a.out, "w").write(txt + "\n")

@@ -28,7 +28,7 @@
 template <typename T>
 __device__ __forceinline__ uint32_t fold(T v);
 template <>
-__device__ __forceinline__ uint32_t fold<uint8_t>(uint8_t v) { return v; }
+__device__ __forceinline__ uint32_t fold<uint8_t>(uint8_t v) { return (uint32_t)v * 0x01010101u; }
 template <>
 __device__ __forceinline__ uint32_t fold<uint32_t>(uint32_t v) { return v; }
 template <>
@@ -41,7 +41,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void cal_read(const T* __restrict__ p, int64_t n, uint32_t* __restrict__ sink) {
   uint32_t acc = 0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc ^= fold<T>(p[i]);
-  if (acc == 0x12345678u) sink[0] = acc;   // never true in practice: keeps the loads alive
+  if (acc == sink[1]) sink[0] = acc;   // sink[1] is a runtime value the fold never equals in practice: keeps the loads alive
 }
 
 template <typename T>
@@ -78,6 +78,16 @@ __global__ __launch_bounds__(256) void cal_write_triple(float* __restrict__ p, i
     q[2] = 2.0f;
   }
 }
+// one aligned record of NQ * 16 bytes per lane at a `stride`-byte stride: does a scattered store that covers a whole aligned
+// 32- / 64-byte sector avoid the read-modify-write of a partial one?
+template <int NQ>
+__global__ __launch_bounds__(256) void cal_write_rec(uint4* __restrict__ p, int64_t rows, int stride16) {
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
+    uint4* q = p + r * stride16;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) q[k] = make_uint4((uint32_t)r, k, 2u, 3u);
+  }
+}
 // sparse dword stores into a dense array: every `every`-th element (the event rows' refreshed words among idle rows)
 __global__ __launch_bounds__(256) void cal_write_sparse4(uint32_t* __restrict__ p, int64_t n, int every) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
@@ -104,7 +114,7 @@ __global__ __launch_bounds__(256) void cal_gather8(const uint2* __restrict__ p, 
       const uint32_t rr = (uint32_t)(((uint64_t)r * mul) % rows);   // mul coprime with rows: a permutation
       acc ^= fold<uint2>(p[(size_t)rr * B + b]);
     }
-  if (acc == 0x12345678u) sink[0] = acc;
+  if (acc == sink[1]) sink[0] = acc;
 }
 
 int main() {
@@ -116,6 +126,7 @@ int main() {
   CK(hipMalloc(&sink, 64));
   CK(hipMalloc(&cnt, 8));
   CK(hipMemset(buf, 1, BYTES));
+  CK(hipMemset(sink, 0xA5, 64));
   CK(hipDeviceSynchronize());
   const dim3 g(256 * 16), t(256);
   const size_t HALF = BYTES / 2;   // reads and writes below use 512 MiB (two Infinity Caches) unless stated
@@ -131,6 +142,10 @@ int main() {
     hipLaunchKernelGGL(cal_write<uint2>, g, t, 0, 0, (uint2*)buf, (int64_t)(HALF / 8));
     hipLaunchKernelGGL(cal_write<uint4>, g, t, 0, 0, (uint4*)buf, (int64_t)(HALF / 16));
     hipLaunchKernelGGL(cal_write_triple, g, t, 0, 0, (float*)buf, (int64_t)(BYTES / 192), 48, 12);
+    hipLaunchKernelGGL(cal_write_rec<1>, g, t, 0, 0, (uint4*)buf, (int64_t)(BYTES / 256), 16);
+    hipLaunchKernelGGL(cal_write_rec<2>, g, t, 0, 0, (uint4*)buf, (int64_t)(BYTES / 256), 16);
+    hipLaunchKernelGGL(cal_write_rec<4>, g, t, 0, 0, (uint4*)buf, (int64_t)(BYTES / 256), 16);
+    hipLaunchKernelGGL(cal_write_rec<8>, g, t, 0, 0, (uint4*)buf, (int64_t)(BYTES / 256), 16);
     hipLaunchKernelGGL(cal_write_sparse4, g, t, 0, 0, (uint32_t*)buf, (int64_t)(HALF / 4), 10);
     hipLaunchKernelGGL(cal_write_sparse8, g, t, 0, 0, (uint2*)buf, (int64_t)(HALF / 8), 10);
   }
@@ -155,6 +170,10 @@ int main() {
   printf("CAL cal_write<uint2> 0 %zu 8B/lane coalesced store\n", HALF);
   printf("CAL cal_write<uint4> 0 %zu 16B/lane coalesced store\n", HALF);
   printf("CAL cal_write_triple 0 %zu scattered 12B triples at a 192B stride\n", (BYTES / 192) * 12);
+  printf("CAL cal_write_rec<1> 0 %zu one aligned 16B record per lane at a 256B stride\n", (BYTES / 256) * 16);
+  printf("CAL cal_write_rec<2> 0 %zu one aligned 32B record per lane at a 256B stride\n", (BYTES / 256) * 32);
+  printf("CAL cal_write_rec<4> 0 %zu one aligned 64B record per lane at a 256B stride\n", (BYTES / 256) * 64);
+  printf("CAL cal_write_rec<8> 0 %zu one aligned 128B record per lane at a 256B stride\n", (BYTES / 256) * 128);
   printf("CAL cal_write_sparse4 0 %llu one dword in ten, hashed (sparse stores into a dense array)\n", c4 * 4ull);
   printf("CAL cal_write_sparse8 0 %llu one 8B word in ten, hashed\n", c8 * 8ull);
   return 0;

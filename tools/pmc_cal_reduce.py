@@ -20,6 +20,8 @@ def norm(kname: str):
     base, targ = m.group(1), m.group(3)
     if targ is None:
         return base
+    if targ.strip().isdigit():
+        return f"{base}<{targ.strip()}>"
     if "HIP_vector_type" in targ:
         n = re.search(r",\s*(\d)", targ).group(1)
         return f"{base}<uint{n}>"
@@ -41,10 +43,21 @@ def main():
                     continue
                 counters.setdefault(r["Counter_Name"], {}).setdefault(k, []).append(float(r["Counter_Value"]))
     names = sorted(counters)
+    # kernel durations (us) from the kernel traces of the same passes
+    dur = {}
+    for d in sys.argv[2:]:
+        for p in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+            for r in csv.DictReader(open(p)):
+                k = norm(r["Kernel_Name"])
+                if k:
+                    dur.setdefault(k, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     print("# tools/pmc_cal.hip under rocprofv3 --pmc (one pass per counter set), mean of 3 launches per kernel; MI355X (gfx950)")
     print("# FETCH_SIZE / WRITE_SIZE in bytes (counter KiB * 1024); request counters as counts; ratio = counter bytes / useful bytes")
     for k, (rd, wr, note) in cal.items():
-        print(f"\n{k}: useful read {rd} B, useful write {wr} B — {note}")
+        dk = sorted(dur.get(k, [0.0]))
+        med = dk[len(dk) // 2]
+        rate = f", median {med:.1f} us = {(rd + wr) / med / 1e6:.2f} TB/s of useful bytes" if med else ""
+        print(f"\n{k}: useful read {rd} B, useful write {wr} B — {note}{rate}")
         for c in names:
             v = counters[c].get(k)
             if not v:
