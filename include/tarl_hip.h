@@ -361,6 +361,11 @@ typedef struct tarl_fused {
    * rank's slice in a data-parallel job, or a few environments run alone) reproduces, bit for bit, the trajectories those
    * environments have inside the larger batch. The reference has a single environment (env_base + b = 0). */
   int64_t env_base;
+  /* hint, 0 = unknown: agents that become due per second and environment at the busiest time of the departure schedule
+   * (DEPARTURE_TIME column, src/agents/base.py:244-262). The rollout launcher sizes the insert kernel's share of a wave
+   * per environment by it (a frame of dt seconds brings ~due_rate * dt candidates). Never changes a result. */
+  float due_rate;
+  int32_t reserved_;
 } tarl_fused;
 
 int tarl_fused_pack(const tarl_plan* plan, const tarl_fused* f, const float* x, int64_t B, int64_t x_bstride,

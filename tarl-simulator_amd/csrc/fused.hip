@@ -1002,24 +1002,58 @@ __device__ __forceinline__ float2 row_phase_b(uint32_t i, uint32_t b, bool pop, 
 
 // NCH rows per lane: ALL their loads (dense words, downstream post words) are issued before the first row is processed,
 // so a wave keeps 8 * NCH independent requests in flight instead of one row's dependent phases.
-template <int NCH>
+// SIB (NCH == 4): the chunk's rows come from the plan's row-chunk table — rows with the same ordered out-edge target list,
+// on a road network the roads that ENTER one intersection — so their four downstream post words are gathered ONCE per
+// chunk instead of once per row (those gathers were a quarter of the pass's reads once a frame's words no longer fit the
+// Infinity Cache: 20 -> 8 post requests per lane and chunk; 923 -> 691 MB read per launch at 16 384 environments, same
+// time: the pass is not bound by its reads). Same rows, same arithmetic, another visiting order.
+// Measured and rejected in round 3: the event path as a launch of its own over lists in global memory
+// (158 + 94 us instead of 236: its stores then hit lines that have left the L2, and a partial-line store to a cold line is a
+// read-modify-write at the memory side, profiles/r03_pmc_calibration.txt); a list for every pair and no in-place fall-back
+// (no spilled register left, 18 KB of LDS: 250 us); the event path's pointers and statics through a block in LDS with
+// further list rounds instead of the in-place fall-back (no spilled SGPR, 7 KB: 275 us); the pop's two slot reads requested
+// before anything is stored (same time).
+struct __attribute__((aligned(32))) RowChunk {
+  int32_t row[4];    // -1: none (a group's remainder)
+  int32_t out4[4];   // the shared first four out-edge targets
+};
+template <int NCH, bool SIB>
 __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fused_rows(const NodeRec* __restrict__ nodes,
                                                      const int32_t* __restrict__ out_pad,
                                                      const int32_t* __restrict__ out_ptr,
                                                      const int32_t* __restrict__ out_dst,
+                                                     const RowChunk* __restrict__ rchunks,
                                                      const uint32_t* __restrict__ post, int Nmax, uint32_t B, uint32_t N,
                                                      FusedBufs fb, float* __restrict__ ag, int64_t A, int64_t a_bstride,
                                                      float t, FrameOut out) {
+  static_assert(!SIB || NCH == 4, "row chunks hold four rows");
   __shared__ int32_t s_cnt;
-  // the event list holds EV_CAP of the TILE * NCH pairs (a filling network lists ~10 %); a pair that finds it full runs its
-  // event path in place. 7 KB instead of 18: the workgroups a CU holds are bounded by its wave slots, not by LDS, and
-  // the waves that have no list entry leave early
+  // the event list holds EV_CAP of the TILE * NCH pairs (a filling network lists ~2 %, a loaded one ~30 %); a pair that
+  // finds it full runs its event path in place. 7 KB instead of 18: the workgroups a CU holds are bounded by its wave
+  // slots, not by LDS, and the waves that have no list entry leave early
   constexpr int EV_CAP = 384;
   __shared__ uint16_t s_item[EV_CAP];       // (row offset in the chunk) << 9 | pop << 8 | lane
   __shared__ uint4 s_words[EV_CAP];         // the listed row's {post word, hd, head_dep bits, tl}
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = b < B;
-  const uint32_t i0 = blockIdx.y * NCH;
+  // the chunk's rows (wave-uniform): consecutive, or the table's
+  int32_t ri[NCH];
+  bool live[NCH];
+  if (SIB) {
+    const RowChunk& rc = rchunks[blockIdx.y];
+#pragma unroll
+    for (int r = 0; r < NCH; ++r) {
+      live[r] = rc.row[r] >= 0;
+      ri[r] = live[r] ? rc.row[r] : rc.row[0];   // a missing row is loaded as the first one and never used
+    }
+  } else {
+    const uint32_t i0 = blockIdx.y * NCH;
+#pragma unroll
+    for (int r = 0; r < NCH; ++r) {
+      live[r] = i0 + r < N;
+      ri[r] = live[r] ? (int32_t)(i0 + r) : (int32_t)(N - 1);   // clamped: the tail rows are loaded twice, used once
+    }
+  }
   if (threadIdx.x == 0) s_cnt = 0;
   __syncthreads();
   float nsum = 0.0f;
@@ -1028,12 +1062,22 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     uint2 hp[NCH];
 #pragma unroll
     for (int r = 0; r < NCH; ++r) {
-      const uint32_t i = (i0 + r < N) ? i0 + r : N - 1;   // clamped: the tail rows are loaded twice, used once
-      const uint32_t row = i * B + b;
+      const uint32_t row = (uint32_t)ri[r] * B + b;
       pa[r] = post[row];
-      const int32_t* od = nodes[i].out4;   // the first four targets travel in the node record
+      if (SIB) {
+        if (r == 0) {
+          const int32_t* od = rchunks[blockIdx.y].out4;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) pj[r][q] = post[(uint32_t)od[q] * B + b];
+          for (int q = 0; q < 4; ++q) pj[0][q] = post[(uint32_t)od[q] * B + b];
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) pj[r][q] = pj[0][q];
+        }
+      } else {
+        const int32_t* od = nodes[ri[r]].out4;   // the first four targets travel in the node record
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pj[r][q] = post[(uint32_t)od[q] * B + b];
+      }
     }
     // The post word already says whether the row holds anybody (PF_NONEMPTY), receives somebody (PF_ARRIVED) or still
     // carries the flag of an event in its tail word (PF_TLAUTH). A row with none of the three is empty and idle: its
@@ -1041,8 +1085,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     // filling network that is most rows; the second round of loads only touches the sectors of the others.
 #pragma unroll
     for (int r = 0; r < NCH; ++r) {
-      const uint32_t i = (i0 + r < N) ? i0 + r : N - 1;
-      const uint32_t row = i * B + b;
+      const uint32_t row = (uint32_t)ri[r] * B + b;
       hp[r] = make_uint2(0u, 0u);
       tlw[r] = 0u;
       if (Nmax < 2 || (pa[r] & (PF_ARRIVED | PF_NONEMPTY | PF_TLAUTH))) {   // (a one-slot FIFO has no lazy garbage slot)
@@ -1052,16 +1095,17 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     }
 #pragma unroll
     for (int r = 0; r < NCH; ++r)
-      if (i0 + r < N) {
+      if (live[r]) {
         bool pop;
         float n = 0.0f;
-        if (row_phase_a(i0 + r, b, nodes[i0 + r], post, pa[r], hp[r], tlw[r], pj[r], Nmax, B, N, fb, A, t, out, &pop, &n)) {
+        const uint32_t i = (uint32_t)ri[r];
+        if (row_phase_a(i, b, nodes[i], post, pa[r], hp[r], tlw[r], pj[r], Nmax, B, N, fb, A, t, out, &pop, &n)) {
           const int32_t pos = atomicAdd(&s_cnt, 1);
           if (pos < EV_CAP) {
             s_item[pos] = (uint16_t)((r << 9) | (pop ? 256 : 0) | threadIdx.x);
             s_words[pos] = make_uint4(pa[r], hp[r].x, hp[r].y, tlw[r]);
           } else {
-            const float2 nc = row_phase_b(i0 + r, b, pop, pa[r], hp[r], tlw[r], nodes[i0 + r], out_ptr, out_dst, Nmax, B, N,
+            const float2 nc = row_phase_b(i, b, pop, pa[r], hp[r], tlw[r], nodes[i], out_ptr, out_dst, Nmax, B, N,
                                           fb, ag, A, a_bstride, t, out);
             nsum += nc.x;
             if (nc.y != 0.0f) atomicAdd(&fb.acc_w[(int64_t)(blockIdx.y % (unsigned)fb.acc_slots) * B + b], nc.y);
@@ -1082,7 +1126,10 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     const uint32_t r = item >> 9, lane2 = item & 255u;
     const uint4 wd = s_words[idx];
     const uint32_t b2 = blockIdx.x * blockDim.x + lane2;
-    const float2 nc = row_phase_b(i0 + r, b2, (item & 256u) != 0u, wd.x, make_uint2(wd.y, wd.z), wd.w, nodes[i0 + r],
+    int32_t i2 = ri[0];
+#pragma unroll
+    for (int q = 1; q < NCH; ++q) i2 = (r == (uint32_t)q) ? ri[q] : i2;
+    const float2 nc = row_phase_b((uint32_t)i2, b2, (item & 256u) != 0u, wd.x, make_uint2(wd.y, wd.z), wd.w, nodes[i2],
                                   out_ptr, out_dst, Nmax, B, N, fb, ag, A, a_bstride, t, out);
     if (nc.x != 0.0f) atomicAdd(&fb.acc_n[bank0 + b2], nc.x);     // small integers: exact in fp32 in any order
     if (nc.y != 0.0f) atomicAdd(&fb.acc_w[bank0 + b2], nc.y);
@@ -1736,7 +1783,7 @@ int tarl_check_fused_core(const tarl_plan* plan, const tarl_fused* f, int64_t B,
   TARL_REQUIRE(plan->max_out <= 126, "the fused path packs the chosen out-edge's rank into 7 bits: out-degree must be <= 126");
   TARL_REQUIRE(f->acc_slots >= 1 && f->acc_slots <= 4096, "acc_slots out of range");
   TARL_REQUIRE(f->ld_slots >= 3 * (int64_t)Nmax, "slot row stride smaller than 3*Nmax");
-  TARL_REQUIRE(num_chunks(plan) < 65536 && ceil_div(plan->N, nchunk_choice()) < 65536 &&
+  TARL_REQUIRE(num_chunks(plan) < 65536 && plan->num_row_chunks < 65536 && ceil_div(plan->N, nchunk_choice()) < 65536 &&
                    ceil_div(plan->N, nchunk_dir()) < 65536,
                "too many node chunks for one launch");
   TARL_REQUIRE(((uintptr_t)f->hdp | (uintptr_t)f->rec1 | (uintptr_t)f->st0) % 16 == 0 &&
@@ -1864,18 +1911,33 @@ static int launch_direction(dim3 grid, unsigned threads, hipStream_t s, const ta
   return TARL_OK;
 }
 
-// rows per lane of the row pass (TARL_NCHUNK = 1, 2 or 4)
+// rows per lane of the row pass (TARL_NCHUNK = 1, 2 or 4); on a graph whose rows group by their out-edge targets (plan
+// row_siblings) the four-row form walks the plan's row-chunk table instead of consecutive rows (TARL_ROWS_SIBLINGS=0 keeps
+// the consecutive chunks: developer knob)
+static bool rows_sib(const tarl_plan* plan) {
+  static const bool ok = !(getenv("TARL_ROWS_SIBLINGS") && atoi(getenv("TARL_ROWS_SIBLINGS")) == 0);
+  return ok && nchunk() == 4 && plan->row_siblings && plan->row_chunks;
+}
+static int64_t num_row_chunks(const tarl_plan* plan) { return rows_sib(plan) ? plan->num_row_chunks : num_chunks(plan); }
 static int launch_rows(dim3 grid, unsigned threads, hipStream_t s, const tarl_plan* plan, const tarl_fused* f,
                        const FusedBufs& fb, int Nmax, int64_t B, float* agent_features, int64_t A, int64_t a_bstride,
                        float time, const FrameOut& out) {
-#define ROWS_LAUNCH(NCH)                                                                                              \
-  hipLaunchKernelGGL(k_fused_rows<NCH>, grid, dim3(threads), 0, s, (const NodeRec*)f->node_rec,                          \
-                     (const int32_t*)f->out_pad, plan->out_ptr, plan->out_dst, (const uint32_t*)f->post, Nmax,            \
-                     (uint32_t)B, (uint32_t)plan->N, fb, agent_features, A, a_bstride, time, out)
+#define ROWS_LAUNCH(NCH, SIB)                                                                                              \
+  hipLaunchKernelGGL((k_fused_rows<NCH, SIB>), grid, dim3(threads), 0, s, (const NodeRec*)f->node_rec,                          \
+                     (const int32_t*)f->out_pad, plan->out_ptr, plan->out_dst, (const RowChunk*)plan->row_chunks,         \
+                     (const uint32_t*)f->post, Nmax, (uint32_t)B, (uint32_t)plan->N, fb, agent_features, A, a_bstride,    \
+                     time, out)
+  grid.y = (unsigned)num_row_chunks(plan);
   switch (nchunk()) {
-    case 1: ROWS_LAUNCH(1); break;
-    case 2: ROWS_LAUNCH(2); break;
-    default: ROWS_LAUNCH(4); break;
+    case 1: ROWS_LAUNCH(1, false); break;
+    case 2: ROWS_LAUNCH(2, false); break;
+    default:
+      if (rows_sib(plan)) {
+        ROWS_LAUNCH(4, true);
+      } else {
+        ROWS_LAUNCH(4, false);
+      }
+      break;
   }
 #undef ROWS_LAUNCH
   TARL_LAUNCH_CHECK();
@@ -2138,14 +2200,23 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
     if (ahead) {
       // TARL_INSERT_PAIR=0 keeps one wave per environment (developer knob)
       static const bool pair_ok = !(getenv("TARL_INSERT_PAIR") && atoi(getenv("TARL_INSERT_PAIR")) == 0);
-      // environments per wave of the insert kernel (TARL_INSERT_EPW = 1, 2, 4 or 8). Default: by the size of the
-      // population — a frame's window holds the agents due in it, and an environment's share of the wave (64 / EPW lanes,
-      // INS_CAP / EPW list entries) should take them in one step: 8 up to 20 000 agents (BASELINE config 4: ~5 due per
-      // frame) when the launch is large (8 at 16 384 environments: 36 us against 40 with 4; at 4 096: 21 against 18),
-      // 4 up to 32 768, 2 up to 65 536, one wave per environment beyond (config 5: 262 144 agents, ~70 per frame)
+      // environments per wave of the insert kernel (TARL_INSERT_EPW = 1, 2, 4 or 8). A frame's window holds the agents due
+      // in it, and an environment's share of the wave (64 / EPW lanes, INS_CAP / EPW list entries) should take them in one
+      // step: an environment with more candidates than its share of the list sits the packed part out and is served
+      // alone afterwards, one after the other (measured with ~27 due per frame and EPW = 8: 260 us per launch instead of
+      // 36). With the schedule's due rate known (tarl_fused.due_rate, from pack): the largest EPW whose list share holds
+      // twice the expected candidates of a frame. Without it, by the size of the population: 8 up to 20 000 agents
+      // (BASELINE config 4: ~5 due per frame) when the launch is large (8 at 16 384 environments: 36 us against 40 with 4;
+      // at 4 096: 21 against 18), 4 up to 32 768, 2 up to 65 536, one wave per environment beyond (config 5: 262 144
+      // agents, ~70 per frame).
       static const int epw_env = getenv("TARL_INSERT_EPW") ? atoi(getenv("TARL_INSERT_EPW")) : 0;
-      const int epw = epw_env == 1 || epw_env == 2 || epw_env == 4 || epw_env == 8 ? epw_env
-                                                                                     : (A <= 20000 && B >= 12288 ? 8 : (A <= 32768 ? 4 : (A <= 65536 ? 2 : 1)));
+      int epw = A <= 20000 && B >= 12288 ? 8 : (A <= 32768 ? 4 : (A <= 65536 ? 2 : 1));
+      if (f->due_rate > 0.0f) {
+        const float dt = T > 1 ? times_host[1] - times_host[0] : 1.0f;
+        const float per_frame = f->due_rate * (dt > 0.0f ? dt : 1.0f);
+        while (epw > 1 && 2.0f * per_frame > (float)(INS_CAP / epw)) epw >>= 1;
+      }
+      if (epw_env == 1 || epw_env == 2 || epw_env == 4 || epw_env == 8) epw = epw_env;
       if (pair_ok && epw > 1 && f->a_order && f->a_win) {
         hipLaunchKernelGGL(epw == 8 ? k_fused_insert2<8> : (epw == 4 ? k_fused_insert2<4> : k_fused_insert2<2>), dim3((unsigned)ceil_div(B, epw)), dim3(INSB), 0, s, (int)Nmax, B, N, fbt, P, sel_t,
                            agent_features, A, a_bstride, use_cong, time, ins_scratch, entropy1, reward_t, out, lp_t, ent_t);

@@ -6,6 +6,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <map>
 #include <vector>
 
 #include "tarl_common.h"
@@ -127,12 +128,40 @@ extern "C" int tarl_plan_create(const int64_t* ei, int64_t E, int64_t N, const i
     }
     p->siblings4 = sib ? 1 : 0;
   }
+  // Row chunks of the row pass: rows grouped by their ordered out-edge target list, four per chunk (a group's remainder
+  // makes a partial chunk, padded with -1). Groups in order of their first row, rows ascending inside a group. Worth using
+  // when the table is not much longer than N / 4 chunks, i.e. when most rows share their targets with three others.
+  std::vector<int32_t> row_chunks;
+  {
+    std::map<std::vector<int32_t>, int32_t> group_of_list;
+    std::vector<std::vector<int32_t>> groups;
+    for (int64_t n = 0; n < N; ++n) {
+      std::vector<int32_t> key(out_dst.begin() + out_ptr[n], out_dst.begin() + out_ptr[n + 1]);
+      auto it = group_of_list.find(key);
+      if (it == group_of_list.end()) {
+        group_of_list.emplace(std::move(key), (int32_t)groups.size());
+        groups.emplace_back(1, (int32_t)n);
+      } else {
+        groups[it->second].push_back((int32_t)n);
+      }
+    }
+    for (const auto& g : groups)
+      for (size_t k = 0; k < g.size(); k += 4) {
+        for (size_t r = 0; r < 4; ++r) row_chunks.push_back(k + r < g.size() ? g[k + r] : -1);
+        const int32_t n0 = g[k];
+        for (int32_t q = 0; q < 4; ++q)   // beyond the out-degree: the row itself (valid, ignored by the readers), as NodeRec::out4
+          row_chunks.push_back(q < out_ptr[n0 + 1] - out_ptr[n0] ? out_dst[out_ptr[n0] + q] : n0);
+      }
+    p->num_row_chunks = (int64_t)(row_chunks.size() / 8);
+    p->row_siblings = (N >= 8 && p->num_row_chunks * 4 <= N + N / 4) ? 1 : 0;
+  }
   int rc;
 #define UP(field, vec)                       \
   if ((rc = upload(&p->field, vec)) != TARL_OK) { \
     tarl_plan_destroy(p);                    \
     return rc;                               \
   }
+  UP(row_chunks, row_chunks)
   UP(in_ptr, in_ptr)
   UP(in_src, in_src)
   UP(in_eid, in_eid)
@@ -150,7 +179,7 @@ extern "C" int tarl_plan_create(const int64_t* ei, int64_t E, int64_t N, const i
 
 extern "C" void tarl_plan_destroy(tarl_plan* p) {
   if (!p) return;
-  int32_t* arrs[] = {p->in_ptr, p->in_src, p->in_eid, p->out_ptr, p->out_dst, p->out_eid, p->src, p->dst,
+  int32_t* arrs[] = {p->row_chunks, p->in_ptr, p->in_src, p->in_eid, p->out_ptr, p->out_dst, p->out_eid, p->src, p->dst,
                      p->group_of_node, p->node_of_group};
   for (int32_t* a : arrs)
     if (a) (void)hipFree(a);

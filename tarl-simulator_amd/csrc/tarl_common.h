@@ -44,7 +44,12 @@ struct tarl_plan {
   int32_t dst_sorted;      // 1 when CSC order == original order
   int32_t siblings4;       // 1 when nodes 4c .. 4c + 3 have the same first four in-edge sources for every c (N % 4 == 0):
                            // the roads leaving one intersection; the Direction gather then reads the upstream rows once
+  int32_t row_siblings;    // 1 when the row-chunk table below is worth using (see row_chunks)
+  int64_t num_row_chunks;
   // device arrays (int32)
+  int32_t* row_chunks;     // [num_row_chunks][8] = {row[4] (-1: none), out4[4]}: rows with the SAME ordered out-edge target list
+                           // (on a road network: the roads that ENTER one intersection) grouped four at a time, so that the row
+                           // pass gathers their downstream post words once per chunk instead of once per row
   int32_t* in_ptr;         // [N+1]  CSC by destination
   int32_t* in_src;         // [E]    source node of the k-th in-edge
   int32_t* in_eid;         // [E]    original edge id (ascending inside a destination)

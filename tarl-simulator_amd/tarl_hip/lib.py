@@ -10,7 +10,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtarl_hip.so")
+# TARL_HIP_LIB (developer knob): another build of the same library, e.g. an A/B variant under tmp_ab/ (tools/ab.sh)
+LIB_PATH = os.environ.get("TARL_HIP_LIB") or os.path.join(_HERE, "libtarl_hip.so")
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -102,7 +103,8 @@ class FusedStruct(C.Structure):
                 [(n, C.c_void_p) for n in ("sel8", "sel", "node_rec", "in_rec", "out_pad", "acc_lp", "acc_n", "acc_w", "a_origin", "a_dest",
                                            "a_dep", "a_status", "a_order", "cur_lo", "a_dep_sorted", "a_win", "a_ins",
                                            "a_rank")] +
-                [("acc_slots", C.c_int64), ("flags", C.c_void_p), ("env_base", C.c_int64)])
+                [("acc_slots", C.c_int64), ("flags", C.c_void_p), ("env_base", C.c_int64), ("due_rate", C.c_float),
+                 ("reserved_", C.c_int32)])
 
 
 FLAG_COUNT_AT_NMAX, FLAG_AMBIGUOUS_EDGES, FLAG_PACK_RANGE, FLAG_CHOICE_OVERFLOW = 1, 2, 4, 8

@@ -683,7 +683,7 @@ class FusedState:
                                        self.acc_lp.data_ptr(), self.acc_n.data_ptr(), self.acc_w.data_ptr(),
                                        self.a_origin.data_ptr(), self.a_dest.data_ptr(), self.a_dep.data_ptr(),
                                        self.a_status.data_ptr(), None, self.cur_lo.data_ptr(), None, None, None, None,
-                                       self.acc_slots, self.flags.data_ptr(), int(env_base))
+                                       self.acc_slots, self.flags.data_ptr(), int(env_base), 0.0, 0)
         self.B, self.N, self.A, self.Nmax, self.env_base = B, N, A, Nmax, int(env_base)
 
     # -- unpacked views of the dense words (tests / debugging; torch plumbing, never on a hot path) ----------------------
@@ -717,6 +717,13 @@ class FusedState:
         self.struct.a_win = self.a_win.data_ptr()       # filled by tarl_fused_pack
         self.struct.a_ins = self.a_ins.data_ptr()
         self.struct.a_rank = self.a_rank.data_ptr()
+        # hint for the insert kernel's geometry: departures per second and environment at the busiest second of the
+        # schedule (the never-departing dummy, 48 h, is left out). One histogram over all environments: set-up plumbing.
+        real = self.a_dep_sorted[self.a_dep_sorted < 86400.0 * 1.5]
+        if real.numel() > 0:
+            lo, hi = float(real.min()), float(real.max())
+            bins = max(1, min(1 << 20, int(hi - lo) + 1))
+            self.struct.due_rate = float(torch.histc(real, bins=bins, min=lo, max=lo + bins).max()) / self.B
         self.order_valid = True
 
     def check_flags(self):
