@@ -12,12 +12,17 @@ import torch
 import torch.nn.functional as Fn
 
 
+# Floor of the advantage's standard deviation in average_gae (csrc/ppo.hip: TARL_ADV_STD_FLOOR — see the note there: SURVEY
+# §3.4 says 1e-6, torchrl 0.5.0's GAE may use 1e-4; unverifiable offline, immaterial unless std(A) < 1e-4).
+ADV_STD_FLOOR = 1e-6
+
+
 def gae(reward, value, next_value, done, terminated, gamma=0.99, lmbda=0.95, average_gae=True):
     """torchrl ``GAE(gamma=.99, lmbda=.95, average_gae=True)`` over time-major tensors ``(T, ...)``.
 
     delta_t = r_t + gamma * V_{t+1} * (1 - terminated_t) - V_t
     A_t     = delta_t + gamma * lmbda * (1 - done_t) * A_{t+1}
-    value_target = A + V_t (before normalisation); then A <- (A - mean) / max(std, 1e-6) with the unbiased std.
+    value_target = A + V_t (before normalisation); then A <- (A - mean) / max(std, ADV_STD_FLOOR) with the unbiased std.
     Returns (advantage, value_target)."""
     T = reward.size(0)
     not_term = 1.0 - terminated.to(reward.dtype)
@@ -30,7 +35,7 @@ def gae(reward, value, next_value, done, terminated, gamma=0.99, lmbda=0.95, ave
         adv[t] = run
     target = adv + value
     if average_gae:
-        adv = (adv - adv.mean()) / adv.std().clamp_min(1e-6)
+        adv = (adv - adv.mean()) / adv.std().clamp_min(ADV_STD_FLOOR)
     return adv, target
 
 

@@ -625,11 +625,15 @@ __device__ __forceinline__ bool edge_admissible(uint32_t cj, int32_t rk, const f
 // Every read-only array is its own `const __restrict__` kernel argument: topology, statics and edge constants are
 // wave-uniform and must compile to SCALAR loads (through a struct member the compiler has to assume they alias the post
 // stores and falls back to dependent vector loads — measured: 48 -> 85 us per launch).
-template <int NCH, bool SIB>
+// CNT: the row's own count comes from a byte per (row, environment) — in a rollout the count buffer's slice of the frame
+// before, which the row pass and the insert kernel have just written — instead of its 8-byte head words: of its own row the
+// dense pass needs the count and the tail word only (12 -> 5 bytes per pair).
+template <int NCH, bool SIB, bool CNT>
 __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fused_direction(
     const NodeRec* __restrict__ nodes, const InRec* __restrict__ in_rec, const int32_t* __restrict__ in_eid,
     const float* __restrict__ log_edge_attr, const uint2* __restrict__ hdp, const uint32_t* __restrict__ tl,
-    const uint2* __restrict__ rec1, const uint8_t* __restrict__ sel8, const float* __restrict__ sel_raw,
+    const uint8_t* __restrict__ cnt8, const uint2* __restrict__ rec1, const uint8_t* __restrict__ sel8,
+    const float* __restrict__ sel_raw,
     const float* __restrict__ gumbel, float* __restrict__ dtt, uint32_t* __restrict__ post, float log_eps, float t,
     float t_prev, uint64_t seed, uint64_t counter, uint32_t E, uint32_t B, uint32_t N, FrameOut out, uint64_t env_base) {
   __shared__ int32_t s_n;
@@ -646,7 +650,8 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
   // arithmetic per request are what counts: one node record + one base address fetch a row's statics.
   bool raw_seen = false;
   if (valid) {
-    uint2 me[NCH], hj[NCH][4];
+    uint2 hj[NCH][4];
+    uint32_t ncnt[NCH];   // the row's own count
     uint32_t tlw[NCH], cj[NCH][4];
     // SIB: sibling rows — the roads that leave one intersection — have the same upstream rows. When every chunk's rows
     // list the same first four sources (checked once per graph, tarl_plan::siblings4), the upstream words are gathered
@@ -655,7 +660,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     for (int r = 0; r < NCH; ++r) {
       const uint32_t i = (i0 + r < N) ? i0 + r : N - 1;
       const uint32_t row = i * B + b;
-      me[r] = hdp[row];
+      ncnt[r] = CNT ? (uint32_t)cnt8[row] : (hdp[row].x & 255u);
       tlw[r] = tl[row];
       const InRec* ir = nodes[i].in4;   // the first four in-edge records travel in the node record
 #pragma unroll
@@ -678,7 +683,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         const NodeRec& nr = nodes[i];
         const InRec* ir4 = nr.in4;
         const InRec* ir = in_rec + nr.in0;
-        const float max_i = nr.maxn, n_i = (float)(me[r].x & 255u), road_i = nr.road;
+        const float max_i = nr.maxn, n_i = (float)ncnt[r], road_i = nr.road;
         float P = 0.0f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -700,7 +705,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         // nobody chosen (pass 2 overwrites). A row that idled in the last frame (tail word without TLF_AUTH) still holds
         // exactly this word from the frame before: whatever changes a row's tail, empties or fills it, or hands it an
         // arrival makes it an event row, and event rows and inserts set the flag
-        if (tlw[r] & TLF_AUTH) post[row] = (tlw[r] & ~0xFFu) | ((me[r].x & 255u) ? PF_NONEMPTY : 0u) | PF_TLAUTH;
+        if (tlw[r] & TLF_AUTH) post[row] = (tlw[r] & ~0xFFu) | (ncnt[r] ? PF_NONEMPTY : 0u) | PF_TLAUTH;
         if (P > 0.0f) s_item[atomicAdd(&s_n, 1)] = (uint16_t)(r * TILE + threadIdx.x);
       }
     }
@@ -1884,25 +1889,37 @@ extern "C" int tarl_fused_policy_prepare(const tarl_plan* plan, const tarl_fused
 }
 
 // rows per lane of the Direction gather (TARL_NCHUNK_DIR = 1, 2 or 4)
+// cnt8: a byte per (row, environment) holding every row's current count (a rollout's count slice of the frame before), or NULL
 static int launch_direction(dim3 grid, unsigned threads, hipStream_t s, const tarl_plan* plan, const tarl_fused* f,
                             const float* edge_attr, const float* log_edge_attr, const uint8_t* sel8, const float* gumbel,
                             float* dtt, float log_eps, float time, float prev_time, uint64_t seed, uint64_t counter,
-                            int64_t B, const FrameOut& out) {
-#define DIR_LAUNCH(NCH, SIB)                                                                                              \
-  hipLaunchKernelGGL((k_fused_direction<NCH, SIB>), grid, dim3(threads), 0, s, (const NodeRec*)f->node_rec,                    \
+                            int64_t B, const FrameOut& out, const uint8_t* cnt8 = nullptr) {
+#define DIR_LAUNCH(NCH, SIB, CNT)                                                                                         \
+  hipLaunchKernelGGL((k_fused_direction<NCH, SIB, CNT>), grid, dim3(threads), 0, s, (const NodeRec*)f->node_rec,               \
                      (const InRec*)f->in_rec, plan->in_eid, log_edge_attr, (const uint2*)f->hdp, (const uint32_t*)f->tl,  \
-                     (const uint2*)f->rec1, sel8, (const float*)f->sel, gumbel, dtt, (uint32_t*)f->post, log_eps, time,   \
+                     cnt8, (const uint2*)f->rec1, sel8, (const float*)f->sel, gumbel, dtt, (uint32_t*)f->post, log_eps, time,   \
                      prev_time, seed, counter, (uint32_t)plan->E, (uint32_t)B, (uint32_t)plan->N, out, (uint64_t)f->env_base)
   // TARL_DIR_SIBLINGS=0 keeps the per-row gathers on a sibling graph (developer knob)
   static const bool sib_ok = !(getenv("TARL_DIR_SIBLINGS") && atoi(getenv("TARL_DIR_SIBLINGS")) == 0);
+  // TARL_DIR_COUNT_BYTE=0 keeps the head words as the count's source (developer knob)
+  static const bool cnt_ok = !(getenv("TARL_DIR_COUNT_BYTE") && atoi(getenv("TARL_DIR_COUNT_BYTE")) == 0);
+  if (!cnt_ok) cnt8 = nullptr;
   switch (nchunk_dir()) {
-    case 1: DIR_LAUNCH(1, false); break;
-    case 2: DIR_LAUNCH(2, false); break;
+    case 1: DIR_LAUNCH(1, false, false); break;
+    case 2: DIR_LAUNCH(2, false, false); break;
     default:
       if (sib_ok && plan->siblings4) {
-        DIR_LAUNCH(4, true);
+        if (cnt8) {
+          DIR_LAUNCH(4, true, true);
+        } else {
+          DIR_LAUNCH(4, true, false);
+        }
       } else {
-        DIR_LAUNCH(4, false);
+        if (cnt8) {
+          DIR_LAUNCH(4, false, true);
+        } else {
+          DIR_LAUNCH(4, false, false);
+        }
       }
       break;
   }
@@ -2188,7 +2205,8 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
       TARL_CHECK_HIP(hipStreamWaitEvent(s, side->done[t == 0 ? 0 : 1 + (t - CHOICE_FIRST) / CHOICE_CHUNK], 0));
     const bool timed = tarl_prof_mark(s, 0) != nullptr;
     rc = launch_direction(grid_d, threads, s, plan, f, edge_attr, log_edge_attr, sel_t, nullptr, nullptr, log_eps, time,
-                          t > 0 ? times_host[t - 1] : prev_time, seed, counter0 + (uint64_t)t, B, out);
+                          t > 0 ? times_host[t - 1] : prev_time, seed, counter0 + (uint64_t)t, B, out,
+                          (counts && t > 0) ? counts + (t - 1) * NB : nullptr);   // the counts after frame t - 1
     if (rc) return rc;
     if (timed) (void)tarl_prof_mark(s, 1);
     rc = launch_rows(grid, threads, s, plan, f, fbt, (int)Nmax, B, agent_features, A, a_bstride, time, out);

@@ -74,7 +74,12 @@ __global__ void k_stats_final(const double* __restrict__ partial, int nblocks, i
   stats[2] = (double)n;
 }
 
-// A <- (A - mean) / max(std, 1e-6), unbiased std, from (possibly all-reduced) stats = {sum, sumsq, count}
+// Floor of the advantage's standard deviation in average_gae's standardisation (src/rl/ppo_trainer.py:35 configures torchrl
+// 0.5.0's GAE(average_gae=True)). SURVEY §3.4 restates it as clamp_min(1e-6); the round-2 review recalls 1e-4 for GAE and
+// 1e-6 for ClipPPOLoss(normalize_advantage) in that release — the wheel is not in this image, so neither can be checked
+// ("parity unpinned"). Immaterial unless std(A) < 1e-4; one named constant here and in oracle/ppo.py.
+#define TARL_ADV_STD_FLOOR 1e-6f
+// A <- (A - mean) / max(std, TARL_ADV_STD_FLOOR), unbiased std, from (possibly all-reduced) stats = {sum, sumsq, count}
 __global__ __launch_bounds__(PPO_BLOCK) void k_normalize(float* __restrict__ a, int64_t n,
                                                          const double* __restrict__ stats) {
   const int64_t i = (int64_t)blockIdx.x * PPO_BLOCK + threadIdx.x;
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(PPO_BLOCK) void k_normalize(float* __restrict__ a, 
   double var = (stats[1] - cnt * mean * mean) / (cnt - 1.0);
   if (var < 0.0) var = 0.0;
   float sd = (float)sqrt(var);
-  if (sd < 1e-6f) sd = 1e-6f;
+  if (sd < TARL_ADV_STD_FLOOR) sd = TARL_ADV_STD_FLOOR;
   a[i] = (a[i] - (float)mean) / sd;
 }
 

@@ -40,3 +40,36 @@ def test_bench_line_contract():
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "env-steps/s" and c["sample"]
     assert d["congested_regime"]["value"] > 0
     assert d["state_dependent_policy"]["bf16"]["value"] > 0 and d["state_dependent_policy"]["fp32"]["value"] > 0
+    # round 3: the all-core CPU figure beside the fastest, the congested regime's own roofline objects, per-rank times
+    assert c["all_cores"]["cores"] == (os.cpu_count() or 1) and c["all_cores"]["value"] > 0
+    for key in ("roofline", "roofline_direction", "roofline_insert"):
+        r = d["congested_regime"][key]
+        assert r["bound"] == "hbm" and 0.0 <= r["frac"] <= 1.0 and r["avg_launch_us"] > 0
+    assert d["per_rank"]["timed_seconds"] == [pytest.approx(d["timed_seconds"], rel=0.2)] and len(d["per_rank"]["setup_seconds"]) == 1
+    assert d["world_size_seen_by_backend"] == 1
+
+
+def test_bench_starts_its_own_ranks():
+    """``python bench.py --gpus 2`` with no launcher around it: the parent (which never touches the GPU) starts the two
+    ranks through torch.distributed.run, relays rank 0's ONE JSON line and exits with the children's status. Here the two
+    ranks share the box's single GPU, so the process group runs on gloo (RCCL refuses two ranks on one device); on an
+    8-GPU node the same command shape runs one rank per GPU over RCCL."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TARL_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                          "--envs", "128", "--cpu-seconds", "0", "--congested-window", "0", "--policy-envs", "0"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size_seen_by_backend"] == 2 and d["dist_backend"] == "gloo"
+    assert len(d["per_rank"]["timed_seconds"]) == 2 and all(v > 0 for v in d["per_rank"]["timed_seconds"])
+    assert abs(d["value"] - 2 * 128 * 256 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6      # both ranks' frames / slowest rank
+    assert "cpu_baseline" not in d                                                             # N = 1 only
+    # a failing rank makes the whole command fail (no silent half-result)
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--envs", "128", "--rollout-steps", "0", "--cpu-seconds", "0", "--congested-window", "0", "--policy-envs", "0"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith('{"metric"')]
