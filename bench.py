@@ -46,6 +46,7 @@ for p in (ROOT, os.path.join(ROOT, "tarl-simulator_amd")):
 
 import torch  # noqa: E402
 
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy kernel achieves
 LATE_FRAME = 200          # the roofline window: frames >= 200 of an iteration (traffic and live time alike)
 # written by tools/pmc_bench.py from --pmc passes of this script (one record per workload: the default line and the
@@ -161,8 +162,11 @@ def cpu_baseline(args, net):
     best_nt, best_rate, by_threads = 1, 0.0, {}
     for nt in sorted({1, min(8, ncpu), min(16, ncpu), ncpu}):
         torch.set_num_threads(nt)
-        rollout(net.x.clone(), synth.population(args.agents, N, seed=args.seed), 21540, 0.3, 2)       # warm up
-        st, el = rollout(net.x.clone(), synth.population(args.agents, N, seed=args.seed), 21540, 1.0, 64)
+        # (on a many-core host the all-core setting is slower by orders of magnitude — the oracle's ops are a few thousand
+        # elements each —: one warm-up step and at most two probe steps there)
+        many = nt > 16
+        rollout(net.x.clone(), synth.population(args.agents, N, seed=args.seed), 21540, 0.3, 1 if many else 2)       # warm up
+        st, el = rollout(net.x.clone(), synth.population(args.agents, N, seed=args.seed), 21540, 1.0, 2 if many else 64)
         by_threads[str(nt)] = st / el
         if st / el > best_rate:
             best_nt, best_rate = nt, st / el
@@ -316,6 +320,8 @@ def main():
                                  edge_mlp_params=[mm[0].weight, mm[0].bias, mm[2].weight, mm[2].bias, mm[4].weight,
                                                   mm[4].bias])
             tr_p.train_iteration()
+            if not args.no_kernel_timing:
+                L.tarl_prof_enable(T)      # HIP events around the per-edge MLP launch of the first timed iteration's frames
             dist_utils.barrier()
             torch.cuda.synchronize()
             t2_ = time.perf_counter()
@@ -325,8 +331,20 @@ def main():
             torch.cuda.synchronize()
             dist_utils.barrier()
             pel = dist_utils.allreduce_max_float(time.perf_counter() - t2_, device)
+            p_all, p_late, p_nfr = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int64 * 2)()
+            lib.check(L.tarl_prof_collect(0, p_all, p_late, p_nfr))
+            L.tarl_prof_enable(0)
             tr_p.check_flags()
-            policy_lines[tag] = {"value": pf * world / pel, "unit": "env-steps/s", "envs_per_gpu": Bp,
+            mlp_s = p_all[0] / max(1, p_nfr[0]) * 1e-3
+            # MPNNPolicyNet.edge_mlp per edge: 2 * (33*64 + 64*32 + 32) flop (src/agents/mpnn_agent.py:35-41); the matrix
+            # cores are the bound of this kernel: dense MFMA peaks from MI355X_MICROARCH.md (bf16 2.5 PFLOP/s, fp32 157.3 TF)
+            flops = 2.0 * (33 * 64 + 64 * 32 + 32) * Bp * E
+            peak = MFMA_PEAK_TFLOPS["bf16" if bf else "f32"]
+            mlp_roof = ({"bound": "mfma", "kernel": "k_edge_mlp_fwd" + ("_bf16" if bf else "") + " (per-edge MLP 33->64->32->1)",
+                         "achieved": flops / mlp_s / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flops / mlp_s / 1e12 / peak,
+                         "traffic": None, "avg_launch_us": mlp_s * 1e6, "launches_timed": int(p_nfr[0]),
+                         "flop_per_launch": flops} if mlp_s > 0 else None)
+            policy_lines[tag] = {"value": pf * world / pel, "unit": "env-steps/s", "envs_per_gpu": Bp, "roofline": mlp_roof,
                                  "steps": args.policy_steps, "ms_per_step": pel / args.policy_steps * 1e3,
                                  "edge_mlp_edges_per_sec": pf * world / pel * E,
                                  "rollout_logits": "bf16 MFMA (v_mfma_f32_32x32x16_bf16)" if bf else

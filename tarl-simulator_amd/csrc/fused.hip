@@ -2340,9 +2340,12 @@ extern "C" int tarl_fused_rollout_policy(const tarl_plan* plan, const tarl_fused
         TARL_LAUNCH_CHECK();
       }
     }
+    // (live timing, bench.py: HIP events around the per-edge MLP of the timed frames — slot 0 of tarl_prof_collect)
+    const bool timed = tarl_prof_mark(s, 0) != nullptr;
     rc = tarl_policy_edge_mlp_fwd(plan, obs_scratch, B, edge_attr, w1, b1, w2, b2, w3, b3, precision == 1 ? 2 : 0,
                                   logits_scratch, stream);
     if (rc) return rc;
+    if (timed) (void)tarl_prof_mark(s, 1);
     rc = tarl_graphdist_rollout_at(plan, logits_scratch, B, temperature, nullptr, policy_seed,
                                    policy_counter0 + (uint64_t)t, dist_scratch, nullptr,
                                    choice8 ? choice8 + t * NB : nullptr, f->sel8, log_prob ? log_prob + t * B : nullptr,
