@@ -826,8 +826,14 @@ struct RowHead {      // what phase A derives from a row's dense words and hands
   bool pop;
 };
 
+// the statics of a row that phase A needs, loaded (scalar) at the head of the kernel instead of where they are used, behind
+// the waits for the vector loads (one dependent scalar round per row there: -2 % on the pass)
+struct RowStat {
+  int32_t out_deg, out0;
+  float tt0, maxn;
+};
 // phase A of one row: returns true when the row is an event row (nothing written), false when it was idle (words written)
-__device__ __forceinline__ bool row_phase_a(uint32_t i, uint32_t b, const NodeRec& nr, const uint32_t* __restrict__ post,
+__device__ __forceinline__ bool row_phase_a(uint32_t i, uint32_t b, const RowStat nr, const uint32_t* __restrict__ post,
                                             uint32_t pa, uint2 hp, uint32_t tlw, const uint32_t (&pj4)[4], int Nmax,
                                             uint32_t B, uint32_t N, const FusedBufs& fb, int64_t A, float t,
                                             const FrameOut& out, bool* pop_out, float* n_out) {
@@ -1059,6 +1065,12 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
       ri[r] = live[r] ? (int32_t)(i0 + r) : (int32_t)(N - 1);   // clamped: the tail rows are loaded twice, used once
     }
   }
+  RowStat rs[NCH];
+#pragma unroll
+  for (int r = 0; r < NCH; ++r) {
+    const NodeRec& nr = nodes[ri[r]];
+    rs[r] = RowStat{nr.out_deg, nr.out0, nr.tt0, nr.maxn};
+  }
   if (threadIdx.x == 0) s_cnt = 0;
   __syncthreads();
   float nsum = 0.0f;
@@ -1104,7 +1116,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         bool pop;
         float n = 0.0f;
         const uint32_t i = (uint32_t)ri[r];
-        if (row_phase_a(i, b, nodes[i], post, pa[r], hp[r], tlw[r], pj[r], Nmax, B, N, fb, A, t, out, &pop, &n)) {
+        if (row_phase_a(i, b, rs[r], post, pa[r], hp[r], tlw[r], pj[r], Nmax, B, N, fb, A, t, out, &pop, &n)) {
           const int32_t pos = atomicAdd(&s_cnt, 1);
           if (pos < EV_CAP) {
             s_item[pos] = (uint16_t)((r << 9) | (pop ? 256 : 0) | threadIdx.x);
