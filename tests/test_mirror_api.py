@@ -105,3 +105,17 @@ def test_synthetic_scenarios():
     assert bool((indeg == 4).all()) and bool((net.edge_attr == 0.25).all())
     pop = synth.population(100, 256, seed=1)
     assert pop.shape == (101, 9) and float(pop[0, 2]) == 48 * 3600
+
+
+def test_fused_path_supported_is_decided_from_the_topology():
+    """ppo_train picks the packed path or the unfused entry points from the graph alone (every rank takes the same
+    branch): Nmax <= 127, out-degree <= 126, no parallel dual edges."""
+    import torch
+    from tarl_hip import ops
+    ring = torch.tensor([[0, 1, 2, 3], [1, 2, 3, 0]])
+    assert ops.fused_path_supported(ring, 15) and not ops.fused_path_supported(ring, 128)
+    parallel = torch.tensor([[0, 0, 1], [1, 1, 0]])                  # two dual edges 0 -> 1
+    assert not ops.fused_path_supported(parallel, 15)
+    star = torch.stack([torch.zeros(127, dtype=torch.long), torch.arange(1, 128)])      # out-degree 127
+    assert not ops.fused_path_supported(star, 15)
+    assert ops.fused_path_supported(star[:, :126], 15)
