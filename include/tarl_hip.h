@@ -60,6 +60,10 @@ int tarl_plan_create(const int64_t* edge_index_host, int64_t num_edges, int64_t 
 void tarl_plan_destroy(tarl_plan* plan);
 /* info[0..5] = num_nodes, num_edges, num_groups (distinct sources), max_in_degree, max_out_degree, src_sorted */
 int tarl_plan_info(const tarl_plan* plan, int64_t* info6_host);
+/* launch-geometry facts of the plan (diagnostics / tests): info3_host = {siblings4: the rows 4c .. 4c+3 share their first
+ * four in-edge sources for every c (Direction gather reads them once per chunk), row_siblings: the row pass walks the
+ * row-chunk table (rows grouped by their out-edge targets), num_row_chunks} */
+int tarl_plan_geometry(const tarl_plan* plan, int64_t* info3_host);
 
 /* ---- traffic-flow step ---------------------------------------------------------------------------------------
  * tarl_direction_step == DirectionMPNN.forward: message + aggregate + update (src/direction_mpnn.py:44-196,210-236).

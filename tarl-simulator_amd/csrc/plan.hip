@@ -186,6 +186,14 @@ extern "C" void tarl_plan_destroy(tarl_plan* p) {
   delete p;
 }
 
+extern "C" int tarl_plan_geometry(const tarl_plan* p, int64_t* info) {
+  TARL_REQUIRE(p != nullptr && info != nullptr, "null argument");
+  info[0] = p->siblings4;
+  info[1] = p->row_siblings;
+  info[2] = p->num_row_chunks;
+  return TARL_OK;
+}
+
 extern "C" int tarl_plan_info(const tarl_plan* p, int64_t* info) {
   TARL_REQUIRE(p != nullptr && info != nullptr, "null argument");
   info[0] = p->N;

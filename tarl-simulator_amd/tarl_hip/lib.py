@@ -28,6 +28,7 @@ SIGNATURES = {
     "tarl_plan_create": (C.c_int, [_p, _i64, _i64, _p, C.POINTER(_p)]),
     "tarl_plan_destroy": (None, [_p]),
     "tarl_plan_info": (C.c_int, [_p, C.POINTER(_i64)]),
+    "tarl_plan_geometry": (C.c_int, [_p, C.POINTER(_i64)]),
     "tarl_direction_step": (C.c_int, [_p] + _STATE + [_i64, _p, _p, _f32, _p, _f32, _p, _u64, _u64, _p, _p, _p, _p]),
     "tarl_response_step": (C.c_int, [_p] + _STATE + [_i64, _p, _p, _p]),
     "tarl_core_step": (C.c_int, [_p] + _STATE + [_i64, _p, _p, _f32, _p, _f32, _p, _u64, _u64, _p, _p, _p, _p, _p, _p]),

@@ -74,6 +74,9 @@ class Plan:
         _lib.check(L.tarl_plan_info(handle, info))
         self.num_nodes, self.num_edges, self.num_groups, self.max_in, self.max_out, src_sorted = [int(v) for v in info]
         self.src_sorted = bool(src_sorted)
+        geo = (C.c_int64 * 3)()
+        _lib.check(L.tarl_plan_geometry(handle, geo))
+        self.siblings4, self.row_siblings, self.num_row_chunks = bool(geo[0]), bool(geo[1]), int(geo[2])
         self.device = torch.device("cuda", torch.cuda.current_device())
 
     @property

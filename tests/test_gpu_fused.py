@@ -46,26 +46,47 @@ def check_records(ops, plan, fs, x, Nmax, ag, cc, ec):
     assert int((((fs.tl & 1) == 0) | (fs.rec1[..., 1] > 0)).sum()) > 0
 
 
-@pytest.mark.parametrize("W,H,het,B,A,frames,with_cc,Nmax,tiny,dt", [
-    (3, 3, True, 3, 1500, 60, True, None, False, 1),
-    (4, 4, False, 2, 600, 80, True, None, False, 1),
-    (2, 3, True, 2, 300, 40, False, None, False, 1),
-    (3, 2, False, 70, 200, 30, True, 40, False, 1),
-    (2, 2, True, 3, 400, 40, True, 100, False, 1),
-    (3, 3, True, 3, 1500, 40, True, None, True, 15)])
-def test_fused_equals_unfused_frame_by_frame(ops, W, H, het, B, A, frames, with_cc, Nmax, tiny, dt):
+@pytest.mark.parametrize("W,H,het,B,A,frames,with_cc,Nmax,tiny,dt,prune", [
+    (3, 3, True, 3, 1500, 60, True, None, False, 1, 0.0),
+    (4, 4, False, 2, 600, 80, True, None, False, 1, 0.0),
+    (2, 3, True, 2, 300, 40, False, None, False, 1, 0.0),
+    (3, 2, False, 70, 200, 30, True, 40, False, 1, 0.0),
+    (2, 2, True, 3, 400, 40, True, 100, False, 1, 0.0),
+    (3, 3, True, 3, 1500, 40, True, None, True, 15, 0.0),
+    (4, 3, True, 5, 900, 60, True, None, False, 1, 0.35),
+    (6, 6, True, 4, 1500, 60, True, None, False, 1, 0.01)])
+def test_fused_equals_unfused_frame_by_frame(ops, W, H, het, B, A, frames, with_cc, Nmax, tiny, dt, prune):
     """tiny: every third road holds at most 2 or 3 agents (MAX_NUMBER_OF_AGENT <= CONGESTION_FILE) and the clock advances
     15 s per frame: such a road never receives anybody, but EMPTY it passes the Direction gather's second test (its garbage
     head is overdue by more than 10 s) and its id-0 head competes in the Gumbel race — the one reader of an empty row's
-    head departure, which the row pass therefore keeps storing for these rows and for no others."""
+    head departure, which the row pass therefore keeps storing for these rows and for no others.
+    prune: that fraction of the dual edges removed at random (every road keeps one out-edge): rows no longer group four by
+    four by their out-edge targets and in-degrees run from zero to four. With a third removed the row pass falls back to
+    consecutive chunks (its chunk table would be mostly padding); with 1 % removed it walks the table, whose groups of one
+    to four rows make PARTIAL chunks."""
     from tarl_hip import synth
     net = synth.torus_network(W, H, heterogeneous=het, seed=W + 10 * H, Nmax=Nmax)
+    if prune:
+        gp = torch.Generator().manual_seed(5)
+        Eall = net.edge_index.size(1)
+        keep = torch.rand(Eall, generator=gp) > prune
+        keep[torch.arange(0, Eall, 4) + torch.randint(0, 4, (Eall // 4,), generator=gp)] = True   # one out-edge per road stays
+        net.edge_index, net.edge_attr = net.edge_index[:, keep].contiguous(), net.edge_attr[keep].contiguous()
+        out_lists = {}
+        for e in range(net.edge_index.size(1)):
+            out_lists.setdefault(int(net.edge_index[0, e]), []).append(int(net.edge_index[1, e]))
+        sizes = {}
+        for lst in out_lists.values():
+            sizes[tuple(lst)] = sizes.get(tuple(lst), 0) + 1
+        assert len(set(sizes.values())) > 1 and any(v % 4 for v in sizes.values())      # mixed groups, partial chunks
     if tiny:
         nm = net.Nmax
         net.x[::3, 3 * nm + 0] = torch.tensor([2.0, 3.0]).repeat(net.num_roads)[:net.x[::3].size(0)]
         net.congestion_constant = net.x[:, 3 * nm + 2] * (net.x[:, 3 * nm + 0] + 10 - net.critical_number)
     N, Nmax, E = net.num_roads, net.Nmax, net.edge_index.size(1)
     plan = ops.Plan(net.edge_index, N)
+    if prune:
+        assert plan.row_siblings == (prune < 0.02) and plan.num_row_chunks > N // 4 and not plan.siblings4
     ec = ops.EdgeConst(net.edge_attr, "cuda")
     cc = dev(net.congestion_constant) if with_cc else None
     pops = torch.stack([synth.population(A, N, seed=40 + b, t0=100, t1=130) for b in range(B)])
