@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_obs16_packed(const int32_t* __restrict_
       const long long head = (long long)(hd >> 8);
       const float* arow = ag + b * a_bstride + ((head >= 0 && head < A) ? head : 0) * AG_COLS;
       float4* o = reinterpret_cast<float4*>(sm + bl * OB_LD + il * 16);
-      o[0] = make_float4(st.x, (float)(hd & 255u), st.y, xs[L.col_maxn() + 3]);
+      o[0] = make_float4(st.x, (float)(hd & HD_CNT), st.y, xs[L.col_maxn() + 3]);
       o[1] = make_float4(xs[L.col_maxflow()], sel_value(fb, out_ptr, out_dst, i, gid), st.z, arow[0]);
       o[2] = make_float4(arow[1], arow[2], arow[3], arow[4]);
       o[3] = make_float4(arow[5], arow[6], arow[7], arow[8]);
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_obs16_packed_bf16(const int32_t* __rest
       const float* xs = x0 + i * L.ldx;
       const long long head = (long long)(hd >> 8);
       const float* arow = ag + b * a_bstride + ((head >= 0 && head < A) ? head : 0) * AG_COLS;
-      const float v[16] = {st.x, (float)(hd & 255u), st.y, xs[L.col_maxn() + 3], xs[L.col_maxflow()],
+      const float v[16] = {st.x, (float)(hd & HD_CNT), st.y, xs[L.col_maxn() + 3], xs[L.col_maxflow()],
                            sel_value(fb, out_ptr, out_dst, i, gid), st.z, arow[0], arow[1], arow[2], arow[3], arow[4],
                            arow[5], arow[6], arow[7], arow[8]};
       uint4* o = reinterpret_cast<uint4*>(sm + bl * OBB_LD + il * 8);
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(FB) void k_obs16_rows(const int32_t* __restrict__ o
   const long long head = (long long)(hd >> 8);
   const float* arow = ag + b * a_bstride + ((head >= 0 && head < A) ? head : 0) * AG_COLS;
   float4* o = reinterpret_cast<float4*>(keep + ((int64_t)slot[blockIdx.y] * N + i) * 16);
-  o[0] = make_float4(st.x, (float)(hd & 255u), st.y, xs[L.col_maxn() + 3]);
+  o[0] = make_float4(st.x, (float)(hd & HD_CNT), st.y, xs[L.col_maxn() + 3]);
   o[1] = make_float4(xs[L.col_maxflow()], sel_value(fb, out_ptr, out_dst, i, gid), st.z, arow[0]);
   o[2] = make_float4(arow[1], arow[2], arow[3], arow[4]);
   o[3] = make_float4(arow[5], arow[6], arow[7], arow[8]);

@@ -61,9 +61,14 @@ __global__ __launch_bounds__(FB) void k_pack_nodes(const float* __restrict__ x, 
   const int q = (int)n;
   const float tail = (q >= 1 && q <= Nmax) ? xi[q - 1] : 0.0f;
   const float head = xi[0];
-  if (q < 0 || q > 255 || !(head >= 0.0f && head < 16777216.0f) || !(tail >= 0.0f && tail < 16777216.0f))
+  if (q < 0 || q > 127 || !(head >= 0.0f && head < 16777216.0f) || !(tail >= 0.0f && tail < 16777216.0f))
     atomicOr(fb.flags, FLAG_PACK_RANGE);
-  fb.hdp[gid] = make_uint2(((uint32_t)head << 8) | (uint32_t)(q & 255), __float_as_uint(xi[2 * Nmax]));
+  // HD_DIRTY: a non-zero dead slot (at or above the count: no garbage is pending after a pack), or a FIFO that has reached
+  // its last slot
+  bool dirty = q >= Nmax - 1;
+  for (int sidx = q < 0 ? 0 : q; sidx < Nmax; ++sidx)
+    dirty = dirty || xi[sidx] != 0.0f || xi[Nmax + sidx] != 0.0f || xi[2 * Nmax + sidx] != 0.0f;
+  fb.hdp[gid] = make_uint2(((uint32_t)head << 8) | (uint32_t)(q & (int)HD_CNT) | (dirty ? HD_DIRTY : 0u), __float_as_uint(xi[2 * Nmax]));
   fb.tl[gid] = tl_word((uint32_t)tail, 0, TLF_AUTH);
   fb.rec1[gid] = make_uint2(__float_as_uint(xi[Nmax]), r1_code(-1));
   fb.post[gid] = ((uint32_t)tail << 8) | (q > 0 ? PF_NONEMPTY : 0u);
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(FB) void k_export_rows(float* __restrict__ x, Layou
   float* xi = x + b * L.bstride + i * L.ldx;
   const uint32_t hd = fb.hdp[row].x;
   const uint32_t code = fb.rec1[row].y;
-  const int n = (int)(hd & 255u);
+  const int n = (int)(hd & HD_CNT);
   const uint32_t tlw = fb.tl[row];
   const int g = pending_g(tlw, n, code, Nmax);
   const float* sl = fb.slots + row * fb.lds + 3 * phys(tl_hoff(tlw), sidx, Nmax);  // un-rotate the ring buffer
@@ -221,6 +226,10 @@ __global__ __launch_bounds__(FB) void k_export_rows(float* __restrict__ x, Layou
     xi[sidx] = 0.0f;
     xi[Nmax + sidx] = t_last;
     xi[2 * Nmax + sidx] = t_last + tt;
+  } else if (!(hd & HD_DIRTY) && sidx >= n) {  // clean row: its dead slots are zero, whatever the store still holds there
+    xi[sidx] = 0.0f;
+    xi[Nmax + sidx] = 0.0f;
+    xi[2 * Nmax + sidx] = 0.0f;
   } else {
     xi[sidx] = sl[0];
     xi[Nmax + sidx] = sl[1];
@@ -232,6 +241,46 @@ __global__ __launch_bounds__(FB) void k_export_rows(float* __restrict__ x, Layou
     xi[L.col_sel()] = sv;
     fb.sel[row] = sv;
   }
+}
+
+// ---- clean rows <-> exact slot store (hand-over to / from code that maintains every dead slot physically) ------------------
+// tarl_fused_dead_slots(materialise = 1): write the zeros a clean row's dead slots stand for into the store (the slot at the
+// count only when no garbage is pending there): afterwards the store is exact for every row. (materialise = 0): set each
+// row's HD_DIRTY from the store — a non-zero dead slot, or a FIFO at its last slot — as pack does from x. The LDS-resident
+// rollout kernel (rollout_env.hip), which keeps the reference's slot-by-slot bookkeeping, runs between the two.
+__global__ __launch_bounds__(FB) void k_dead_slots(int64_t B, int64_t N, int Nmax, FusedBufs fb, int materialise) {
+  const int64_t row = (int64_t)blockIdx.x * FB + threadIdx.x;
+  if (row >= B * N) return;
+  const uint32_t hd = fb.hdp[row].x, tlw = fb.tl[row];
+  const int n = (int)(hd & HD_CNT), hoff = tl_hoff(tlw);
+  const int g = pending_g(tlw, n, fb.rec1[row].y, Nmax);
+  float* sl = fb.slots + row * fb.lds;
+  const int first = (g >= 0) ? n + 1 : n;       // the slot at the count holds the pending garbage (never stored) or is dead
+  if (materialise) {
+    if (hd & HD_DIRTY) return;
+    for (int sidx = first; sidx < Nmax; ++sidx) {
+      float* z = sl + 3 * phys(hoff, sidx, Nmax);
+      z[0] = 0.0f;
+      z[1] = 0.0f;
+      z[2] = 0.0f;
+    }
+  } else {
+    bool dirty = n >= Nmax - 1;
+    for (int sidx = first; sidx < Nmax; ++sidx) {
+      const float* z = sl + 3 * phys(hoff, sidx, Nmax);
+      dirty = dirty || z[0] != 0.0f || z[1] != 0.0f || z[2] != 0.0f;
+    }
+    fb.hdp[row].x = (hd & ~HD_DIRTY) | (dirty ? HD_DIRTY : 0u);
+  }
+}
+
+int tarl_fused_dead_slots(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, int materialise,
+                          tarl_stream stream) {
+  if (plan->N == 0) return TARL_OK;
+  hipLaunchKernelGGL(k_dead_slots, dim3((unsigned)ceil_div(B * plan->N, FB)), dim3(FB), 0, (hipStream_t)stream, B, plan->N,
+                     (int)Nmax, tarl_to_bufs(f), materialise);
+  TARL_LAUNCH_CHECK();
+  return TARL_OK;
 }
 
 // ---- policy tables ------------------------------------------------------------------------------------------------------
@@ -615,7 +664,7 @@ __device__ __forceinline__ bool edge_admissible(uint32_t cj, int32_t rk, const f
                                                 uint2 hj, float max_j, float road_i, float n_i, float max_i, float t) {
   bool heads_here = cj == (uint32_t)rk;   // ranks are < SEL_RAW: a raw code never matches here
   if (EXACT && cj == SEL_RAW) heads_here = sel_raw[jrow] == road_i;
-  const float dep = __uint_as_float(hj.y), n_j = (float)(hj.x & 255u);
+  const float dep = __uint_as_float(hj.y), n_j = (float)(hj.x & HD_CNT);
   const bool m1 = (dep <= t) && (n_i < max_i - TARL_CONGESTION_FILE) && heads_here && (n_j > 0.0f);
   const bool m2 = ((dep - t) < -10.0f) && ((max_j - TARL_CONGESTION_FILE) <= n_j) && ((max_j - n_j) <= (max_i - n_i)) &&
                   heads_here;
@@ -660,7 +709,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     for (int r = 0; r < NCH; ++r) {
       const uint32_t i = (i0 + r < N) ? i0 + r : N - 1;
       const uint32_t row = i * B + b;
-      ncnt[r] = CNT ? (uint32_t)cnt8[row] : (hdp[row].x & 255u);
+      ncnt[r] = CNT ? (uint32_t)cnt8[row] : (hdp[row].x & HD_CNT);
       tlw[r] = tl[row];
       const InRec* ir = nodes[i].in4;   // the first four in-edge records travel in the node record
 #pragma unroll
@@ -715,7 +764,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     for (uint32_t i = i0; i < i0 + NCH && i < N; ++i) {
       const uint32_t row = i * B + b;
       const uint2 mw = hdp[row];
-      const bool lazy_i = (mw.x & 255u) == 0u && !(tl[row] & TLF_AUTH);   // empty and idle in the last frame: its garbage
+      const bool lazy_i = (mw.x & HD_CNT) == 0u && !(tl[row] & TLF_AUTH);   // empty and idle in the last frame: its garbage
       const float arr_i = lazy_i ? t_prev : __uint_as_float(rec1[row].x);  // head arrived at that frame's clock and
       const float dep_i = lazy_i ? t_prev + nodes[i].tt0 : __uint_as_float(mw.y);   // departs tt0 later (never stored)
       const float d = (dep_i - arr_i) - nodes[i].ff;
@@ -731,7 +780,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         const uint2 mw = hdp[row];
         const NodeRec& nr = nodes[i];
         const InRec* ir = in_rec + nr.in0;
-        const float max_i = nr.maxn, n_i = (float)(mw.x & 255u), road_i = nr.road;
+        const float max_i = nr.maxn, n_i = (float)(mw.x & HD_CNT), road_i = nr.road;
         float P = 0.0f;
         for (int32_t q = 0; q < nr.in_deg; ++q) {
           const int32_t j = ir[q].src;
@@ -743,7 +792,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
             P = P + ir[q].ea * (m ? 1.0f : 0.0f);
           }
           if (dtt) {   // per-edge side output of DirectionMPNN.message (src/direction_mpnn.py:94-96): a property of j
-            const bool lazy_j = (hx.x & 255u) == 0u && !(tl[jrow] & TLF_AUTH);
+            const bool lazy_j = (hx.x & HD_CNT) == 0u && !(tl[jrow] & TLF_AUTH);
             const float arr_j = lazy_j ? t_prev : __uint_as_float(rec1[jrow].x);
             const float dep_j = lazy_j ? t_prev + nodes[j].tt0 : __uint_as_float(hx.y);
             const float d = (dep_j - arr_j) - nodes[j].ff;
@@ -764,7 +813,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     const uint2 mw = hdp[row];
     const NodeRec& nr = nodes[i];
     const int32_t in0 = nr.in0, in_deg = nr.in_deg;
-    const float max_i = nr.maxn, n_i = (float)(mw.x & 255u), road_i = nr.road;
+    const float max_i = nr.maxn, n_i = (float)(mw.x & HD_CNT), road_i = nr.road;
     float P = 0.0f, best = -FLT_MAX;
     uint32_t best_id = 0u;
     PhiloxRun rng;
@@ -838,7 +887,7 @@ __device__ __forceinline__ bool row_phase_a(uint32_t i, uint32_t b, const RowSta
                                             uint32_t B, uint32_t N, const FusedBufs& fb, int64_t A, float t,
                                             const FrameOut& out, bool* pop_out, float* n_out) {
   const uint32_t row = i * B + b;   // 32-bit row indices: N * B < 2^31 (host check)
-  const uint32_t n0i = hp.x & 255u, head_id0 = hp.x >> 8;
+  const uint32_t n0i = hp.x & HD_CNT, head_id0 = hp.x >> 8;
   const uint32_t arrived = pa & PF_ARRIVED;
   const uint32_t who = arrived ? (pa >> 8) : 0u;   // the agent the Direction update enqueues
   // Response message + max-aggregate from the post words (state after the Direction update of every row)
@@ -871,7 +920,7 @@ __device__ __forceinline__ bool row_phase_a(uint32_t i, uint32_t b, const RowSta
   // Direction gather's tests need an agent in the row or MAX_NUMBER_OF_AGENT <= 3 (rows that small keep the eager word),
   // export and delta_travel_time derive it from the clock. The tail word changes only when its flag has to go.
   if (n0i == 0u && nr.maxn <= TARL_CONGESTION_FILE)
-    fb.hdp[row] = make_uint2((head_id << 8) | ni, __float_as_uint(head_dep));
+    fb.hdp[row] = make_uint2((head_id << 8) | ni | (hp.x & HD_DIRTY), __float_as_uint(head_dep));
   if (tlw & TLF_AUTH) {
     fb.tl[row] = tlw & ~TLF_AUTH;      // tail and ring offset stay
     // ... and the post word's mirror of the flag goes with it (other workgroups may be gathering this word for their
@@ -897,11 +946,16 @@ __device__ __forceinline__ float2 row_phase_b(uint32_t i, uint32_t b, bool pop, 
   const PlanOut P{out_ptr, out_dst};
   const uint32_t row = i * B + b;
   const float4 st = make_float4(nr.maxn, nr.ff, nr.road, nr.cong);
-  const uint32_t n0i = hp.x & 255u, head_id0 = hp.x >> 8, tail0 = tlw >> 8;
+  const uint32_t n0i = hp.x & HD_CNT, head_id0 = hp.x >> 8, tail0 = tlw >> 8;
   const uint32_t arrived = pa & PF_ARRIVED;
   const uint32_t who = arrived ? (pa >> 8) : 0u;
   const float n0 = (float)n0i;
   const int q = (int)n0i;
+  // exact, slot-by-slot bookkeeping of the dead slots: rows that are dirty already, and from the moment the FIFO touches
+  // its last slot (count >= Nmax - 1: no dead slot is left above the one this update writes, so nothing has to be
+  // materialised at the transition). A clean row's dead slots are zero by the invariant (fused_common.h) whatever the
+  // store holds: its pops and withdraws neither read nor write them.
+  const bool exact = (hp.x & HD_DIRTY) != 0u || q >= Nmax - 1;
   // Direction update (every row, also when nothing was chosen): one 12-byte store — or, for a row that received
   // nobody, nothing at all (lazy garbage slot, see the file header).
   const float dep_new = t + entry_tt(st, n0);
@@ -928,12 +982,14 @@ __device__ __forceinline__ float2 row_phase_b(uint32_t i, uint32_t b, bool pop, 
     // front becomes the new logical last slot, so it receives a copy of the old last slot; then the head advances.
     int shift = 0;
     if (pop) {
-      const float* last = sl + 3 * phys(hoff, Nmax - 1, Nmax);
-      const float l0 = last[0], l1 = last[1], l2 = last[2];
-      float* front = sl + 3 * hoff;
-      front[0] = l0;
-      front[1] = l1;
-      front[2] = l2;
+      if (exact) {
+        const float* last = sl + 3 * phys(hoff, Nmax - 1, Nmax);
+        const float l0 = last[0], l1 = last[1], l2 = last[2];
+        float* front = sl + 3 * hoff;
+        front[0] = l0;
+        front[1] = l1;
+        front[2] = l2;
+      }
       hoff = phys(hoff, 1, Nmax);
       shift = 1;
       n = n - 1;
@@ -973,7 +1029,7 @@ __device__ __forceinline__ float2 row_phase_b(uint32_t i, uint32_t b, bool pop, 
       }
     }
     // withdraw = logical shift by c with zero fill: the c slots that fall off the front become the zeroed tail
-    for (int k = 0; k < c; ++k) {
+    for (int k = 0; exact && k < c; ++k) {
       float* z = sl + 3 * phys(hoff, k, Nmax);
       z[0] = 0.0f;
       z[1] = 0.0f;
@@ -989,6 +1045,10 @@ __device__ __forceinline__ float2 row_phase_b(uint32_t i, uint32_t b, bool pop, 
         head_id = 0u;
         head_arr = t;
         head_dep = dep_new;
+      } else if (!exact && n == 0) {   // a clean row emptied by the pop of the agent it has just received: a dead slot, zero
+        head_id = 0u;
+        head_arr = 0.0f;
+        head_dep = 0.0f;
       } else {
         const float* hd = sl + 3 * hoff;
         head_id = (uint32_t)(long long)hd[0];
@@ -997,7 +1057,7 @@ __device__ __forceinline__ float2 row_phase_b(uint32_t i, uint32_t b, bool pop, 
       }
       tail_id = (n >= 1 && n <= Nmax) ? (uint32_t)(long long)sl[3 * phys(hoff, n - 1, Nmax)] : 0u;
     }
-    fb.hdp[row] = make_uint2((head_id << 8) | (uint32_t)n, __float_as_uint(head_dep));
+    fb.hdp[row] = make_uint2((head_id << 8) | (uint32_t)n | (exact ? HD_DIRTY : 0u), __float_as_uint(head_dep));
     fb.tl[row] = tl_word(tail_id, hoff, TLF_AUTH);
     if (arr_new) fb.rec1[row].x = __float_as_uint(head_arr);   // otherwise the head, and its arrival, are unchanged
     fb.rec1[row].y = r1_code(lazy ? q : -1);
@@ -1161,7 +1221,7 @@ __device__ __forceinline__ bool fused_target(const FusedBufs& fb, PlanOut P, con
   const uint32_t c = sel8[orow] & 0x7Fu;
   const long long r = (long long)(c == SEL_RAW ? fb.sel[orow] : (float)P.out_dst[P.out_ptr[origin] + (int32_t)c]);
   if (r < 0 || r >= N) return false;
-  const long long room = (long long)(fb.st0[r].x - TARL_CONGESTION_FILE - (float)(fb.hdp[r * B + b].x & 255u));
+  const long long room = (long long)(fb.st0[r].x - TARL_CONGESTION_FILE - (float)(fb.hdp[r * B + b].x & HD_CNT));
   *road = (int32_t)r;
   *cap = (int32_t)(room > 0x7fffffff ? 0x7fffffff : room);
   return room > 0;
@@ -1187,7 +1247,7 @@ __device__ __forceinline__ bool fused_target_words(const FusedBufs& fb, PlanOut 
   if (r < 0 || r >= N) return false;
   const uint32_t hd = fb.hdp[r * B + b].x;
   *tl_out = fb.tl[r * B + b];
-  const long long room = (long long)(fb.st0[r].x - TARL_CONGESTION_FILE - (float)(hd & 255u));
+  const long long room = (long long)(fb.st0[r].x - TARL_CONGESTION_FILE - (float)(hd & HD_CNT));
   *road = (int32_t)r;
   *hd_out = hd;
   return room > 0;
@@ -1349,7 +1409,7 @@ __device__ __forceinline__ void fused_insert_body(InsLds& L, int64_t b, int Nmax
       const int64_t rrow = (int64_t)r * B + b;
       const float4 str = fb.st0[r];
       const uint32_t hd = s_un_hd[idx];
-      const uint32_t n0i = hd & 255u;
+      const uint32_t n0i = hd & HD_CNT;
       const float n0 = (float)n0i;
       const long long cap = (long long)(str.x - TARL_CONGESTION_FILE - n0);
       if (rank < cap) {
@@ -1371,7 +1431,7 @@ __device__ __forceinline__ void fused_insert_body(InsLds& L, int64_t b, int Nmax
         if (rank == 0) {
           const uint32_t cnt = n0i + (uint32_t)m;      // n0 + m <= MAX - 3 < 255
           if (n0i == 0u) {   // new head: id + departure, arrival
-            fb.hdp[rrow] = make_uint2(((uint32_t)a << 8) | cnt, __float_as_uint(t + tt));
+            fb.hdp[rrow] = make_uint2(((uint32_t)a << 8) | cnt | (hd & HD_DIRTY), __float_as_uint(t + tt));
             fb.rec1[rrow] = make_uint2(__float_as_uint(t), r1_code(-1));
           } else {
             fb.hdp[rrow].x = hd + (uint32_t)m;
@@ -1440,7 +1500,7 @@ __device__ __forceinline__ void fused_insert_body(InsLds& L, int64_t b, int Nmax
     const int64_t rrow = (int64_t)r * B + b;
     const float4 str = fb.st0[r];
     const uint32_t hd = fb.hdp[rrow].x;
-    const uint32_t n0i = hd & 255u;
+    const uint32_t n0i = hd & HD_CNT;
     const float n0 = (float)n0i;
     const long long cap = (long long)(str.x - TARL_CONGESTION_FILE - n0);
     int32_t commit = 0;
@@ -1460,7 +1520,7 @@ __device__ __forceinline__ void fused_insert_body(InsLds& L, int64_t b, int Nmax
       fb.a_status[b * A + a] = 1;
       if (fb.a_ins) fb.a_ins[b * A + fb.a_rank[b * A + a]] = 1;
       if (rank == 0 && n0i == 0u) {   // new head: id + departure (count byte unchanged), arrival
-        fb.hdp[rrow] = make_uint2(((uint32_t)a << 8) | n0i, __float_as_uint(t + tt));
+        fb.hdp[rrow] = make_uint2(((uint32_t)a << 8) | n0i | (hd & HD_DIRTY), __float_as_uint(t + tt));
         fb.rec1[rrow].x = __float_as_uint(t);
       }
       if (rank == m - 1) fb.tl[rrow] = tl_word((uint32_t)a, hoff, TLF_AUTH);  // new tail; rec1 authoritative from here on
@@ -1478,8 +1538,8 @@ __device__ __forceinline__ void fused_insert_body(InsLds& L, int64_t b, int Nmax
       fb.rec1[rrow].y = r1_code(-1);
       const uint32_t hd = fb.hdp[rrow].x + (uint32_t)cmt;   // count byte: n0 + cmt <= MAX - 3 < 255
       fb.hdp[rrow].x = hd;
-      if (out.counts8) out.counts8[rrow] = (uint8_t)(hd & 255u);
-      if (out.countsf) out.countsf[rrow] = (float)(hd & 255u);
+      if (out.counts8) out.counts8[rrow] = (uint8_t)(hd & HD_CNT);
+      if (out.countsf) out.countsf[rrow] = (float)(hd & HD_CNT);
       atomicAdd(&s_adm, cmt);
     }
   }
@@ -1640,7 +1700,7 @@ __global__ __launch_bounds__(INSB) void k_fused_insert2(int Nmax, int64_t B, int
       const int64_t rrow = (int64_t)r * B + b;
       const float4 str = fb.st0[r];
       const uint32_t hd = L.un_hd[base + idx];
-      const uint32_t n0i = hd & 255u;
+      const uint32_t n0i = hd & HD_CNT;
       const float n0 = (float)n0i;
       const long long cap = (long long)(str.x - TARL_CONGESTION_FILE - n0);
       if (rank < cap) {
@@ -1662,7 +1722,7 @@ __global__ __launch_bounds__(INSB) void k_fused_insert2(int Nmax, int64_t B, int
         if (rank == 0) {
           const uint32_t cnt = n0i + (uint32_t)m;      // n0 + m <= MAX - 3 < 255
           if (n0i == 0u) {   // new head: id + departure, arrival
-            fb.hdp[rrow] = make_uint2(((uint32_t)a << 8) | cnt, __float_as_uint(t + tt));
+            fb.hdp[rrow] = make_uint2(((uint32_t)a << 8) | cnt | (hd & HD_DIRTY), __float_as_uint(t + tt));
             fb.rec1[rrow] = make_uint2(__float_as_uint(t), r1_code(-1));
           } else {
             fb.hdp[rrow].x = hd + (uint32_t)m;

@@ -39,6 +39,17 @@
 //   rec1 uint2  {bits of head_arr, g + 1}                    g = count at the pending (unmaterialised) garbage write or -1.
 //                                                            WRITE-ONLY in the frame kernels (the event path never waits
 //                                                            for it: the ring offset it needs travels in tl)
+// Count byte of hdp.x: NUMBER_OF_AGENT in bits 0..6 (the fused path requires Nmax <= 127) and HD_DIRTY in bit 7.
+// A CLEAN row (bit clear) obeys the dead-slot invariant of the reference's own bookkeeping: every logical slot above the
+// count is ZERO (the slot at the count itself: the pending garbage triple, or zero when none is pending) — a pop duplicates
+// the last slot (zero) into the slot that falls off the front, a withdraw zero-fills, the Direction update and the insert
+// only ever write at the count. For a clean row the frame kernels therefore do not maintain the dead slots physically (no
+// read of the last slot + store of the vacated one per pop, no zero-fill stores per withdraw: two of the five scattered
+// slot accesses of a moving agent) and tarl_fused_export writes zeros for them. A row becomes DIRTY when pack finds a
+// non-zero dead slot in x or when its FIFO reaches its last slot (count >= Nmax - 1: the last slot then holds a value a
+// later pop has to duplicate); from then on it is maintained exactly, slot by slot, as before.
+#define HD_DIRTY 0x80u
+#define HD_CNT 0x7Fu
 #define TLF_AUTH 1u
 #define PF_ARRIVED 1u
 #define PF_NONEMPTY 2u
@@ -160,6 +171,8 @@ __device__ __forceinline__ float entry_tt(const float4 st, float n) {
 // fused.hip
 FusedBufs tarl_to_bufs(const tarl_fused* f);
 int tarl_check_fused_core(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax);
+int tarl_fused_dead_slots(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, int materialise,
+                          tarl_stream stream);   // clean rows <-> exact slot store (see k_dead_slots)
 hipEvent_t tarl_prof_mark(hipStream_t s, int tag);
 // dist.hip: tarl_graphdist_rollout with the batch's global environment offset
 int tarl_graphdist_rollout_at(const tarl_plan* plan, const float* logits, int64_t B, float temperature,

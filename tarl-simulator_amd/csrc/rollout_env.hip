@@ -183,7 +183,7 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
     const uint32_t tlw = fb.tl[row];
     const uint2 q1 = fb.rec1[row];
     const uint32_t pw = fb.post[row];
-    const int n = (int)(hp.x & 255u);
+    const int n = (int)(hp.x & HD_CNT);   // (HD_DIRTY, bit 7, is re-derived from the store after the rollout: tarl_fused_dead_slots)
     // an idle empty row's head arrived at the previous frame's clock and departs tt0 later (the frame kernels do not store
     // that departure); its pending garbage count is its count
     const bool lazy_row = n == 0 && !(tlw & TLF_AUTH);
@@ -734,6 +734,10 @@ extern "C" int tarl_rollout_env(const tarl_plan* plan, const tarl_fused* f, int6
   const EnvPlan P{plan->in_ptr, plan->in_src, plan->in_eid, plan->out_ptr, plan->out_dst, plan->out_eid,
                   plan->group_of_node, plan->N, plan->E, plan->G, ie, oe, op};
   const EnvOut out{choice, log_prob, entropy, reward, counts, metrics_envs, dtt_node, events, leg};
+  // this kernel keeps the reference's slot-by-slot bookkeeping of the dead slots: the zeros the frame kernels' clean rows
+  // stand for (fused_common.h: HD_DIRTY) go into the store first, and the rows' flags are derived from the store afterwards
+  int rc_d = tarl_fused_dead_slots(plan, f, B, Nmax, 1, stream);
+  if (rc_d) return rc_d;
   if (plan->N <= 512) {
     hipLaunchKernelGGL(k_rollout_env<256>, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, P, B, (int)Nmax,
                        tarl_to_bufs(f), thresholds, (const long long*)log_probs, entropy1, edge_attr, log_edge_attr, log_eps, use_cong,
@@ -756,5 +760,5 @@ extern "C" int tarl_rollout_env(const tarl_plan* plan, const tarl_fused* f, int6
                        a_bstride, ins_scratch, out);
   }
   TARL_LAUNCH_CHECK();
-  return TARL_OK;
+  return tarl_fused_dead_slots(plan, f, B, Nmax, 0, stream);
 }

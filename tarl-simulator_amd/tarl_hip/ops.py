@@ -16,7 +16,7 @@ from . import lib as _lib
 EPS_GUMBEL = 1e-12   # src/direction_mpnn.py:136
 # revision of the fused path's packed HBM layout / kernel set: a PMC traffic record (profiles/*_pmc_traffic.json) only
 # applies to the revision it was measured on
-FUSED_LAYOUT = "v9"
+FUSED_LAYOUT = "v10"
 
 
 def _check_dev(t: torch.Tensor, dtype, name: str):
@@ -692,7 +692,7 @@ class FusedState:
     # -- unpacked views of the dense words (tests / debugging; torch plumbing, never on a hot path) ----------------------
     @property
     def count(self):
-        return (self.hdp[..., 0] & 255).to(torch.float32)
+        return (self.hdp[..., 0] & 127).to(torch.float32)      # (bit 7 of the count byte: HD_DIRTY, csrc/fused_common.h)
 
     @property
     def head_id(self):

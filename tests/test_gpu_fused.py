@@ -27,8 +27,10 @@ def check_records(ops, plan, fs, x, Nmax, ag, cc, ec):
     ops.fused_pack(plan, ref, x, Nmax, ag, cc, ec=ec)
     # head id, count, head departure — the departure of an empty row that was idle in the last frame (tail word without
     # TLF_AUTH) is derived from the clock by its readers and not stored
-    live = ((fs.hdp[..., 0] & 255) > 0) | ((fs.tl & 1) != 0)
-    assert torch.equal(fs.hdp[..., 0], ref.hdp[..., 0]) and torch.equal(fs.hdp[..., 1][live], ref.hdp[..., 1][live])
+    live = ((fs.hdp[..., 0] & 127) > 0) | ((fs.tl & 1) != 0)
+    # (bit 7 of the count byte, HD_DIRTY, is bookkeeping state: a row stays dirty once its FIFO has touched its last slot,
+    # while a fresh pack derives the flag from the exported x, where the pending garbage triple sits in a dead slot)
+    assert torch.equal(fs.hdp[..., 0] & ~0x80, ref.hdp[..., 0] & ~0x80) and torch.equal(fs.hdp[..., 1][live], ref.hdp[..., 1][live])
     assert torch.equal(fs.sel, ref.sel)
     assert torch.equal(fs.sel8 & 0x7F, ref.sel8 & 0x7F) and torch.equal(fs.in_rec, ref.in_rec) and torch.equal(fs.node_rec, ref.node_rec)
     nz = ref.count > 0
@@ -478,3 +480,69 @@ def test_fused_overflow_paths_equal_unfused(ops):
             busiest = max(busiest, float(((n_col > 0) & (dep_col <= e2.time)).float().mean()))
     assert float(e2.agents[:, :, 7].sum() + e2.agents[:, :, 8].sum()) > 300 * B      # > 256 admitted per environment
     assert busiest > 0.45, busiest                     # > 384 of a workgroup's 1024 pairs are event rows in some frame
+
+
+@pytest.mark.parametrize("W,H,A,window,frames", [(2, 3, 600, 20, 400), (2, 2, 400, 10, 200)])
+def test_rows_that_fill_to_their_last_slot_equal_unfused(ops, W, H, A, window, frames):
+    """The fused store keeps no physical dead slots for a CLEAN row (count byte bit 7, HD_DIRTY, clear): its pops and
+    withdraws skip the last-slot copy and the zero fill, and the export writes zeros there. A row turns dirty for good when
+    its FIFO reaches Nmax - 1 agents (the shift then drags the last slot's content in). A small homogeneous torus (Nmax 15)
+    with hundreds of agents due within seconds: gridlock relief pushes counts to Nmax - 1 without reaching Nmax, so some
+    rows cross that line mid-run while others stay clean. Fused frames with device noise against the per-op kernels:
+    actions, rewards, counts, agents every frame and the exported state every few frames, bit-identical; then the
+    LDS-resident rollout and the frame loop continue from there and still agree."""
+    from tarl_hip import synth
+    from tarl_hip.engine import SimEngine
+    net = synth.torus_network(W, H, heterogeneous=False, seed=3)
+    N, B, Nmax = net.num_roads, 4, net.Nmax
+    pops = torch.stack([synth.population(A, N, seed=b, t0=21540, t1=21540 + window) for b in range(B)])
+    mk = lambda fused: SimEngine(dev(net.x.unsqueeze(0).repeat(B, 1, 1)), net.edge_index, net.edge_attr, Nmax,
+                                 dev(pops.clone()), congestion_constant=net.congestion_constant, seed=5, fused=fused)
+    e1, e2 = mk(False), mk(True)
+    e1.reset()
+    e2.reset()
+    emb = torch.randn(N, generator=torch.Generator().manual_seed(1)).cuda()
+    e2.prepare_policy(emb)
+    assert int((e2.fs.hdp[..., 0] & 0x80).sum()) == 0                     # a fresh network: every row starts clean
+    ch2 = torch.empty((N, B), dtype=torch.int32, device="cuda")
+    rw2, c2 = torch.empty(B, device="cuda"), torch.empty((N, B), device="cuda")
+    fullest = 0
+    for s in range(frames):
+        logits = ops.policy_edge_logits(e1.plan, e1.node_features, emb)
+        p = ops.graphdist_softmax(e1.plan, logits)
+        _, ch1 = ops.graphdist_sample(e1.plan, p, seed=e2.seed ^ 0x5DEECE66D, counter=s + 1, want_onehot=False,
+                                      want_choice=True)
+        e1.step(choice=ch1)
+        e2.frame_fused(choice=ch2, reward=rw2, counts=c2)
+        assert torch.equal(ch1, ch2.t()), f"actions frame {s}"
+        assert torch.equal(e1.reward, rw2) and torch.equal(e1.counts, c2.t()), f"reward / counts frame {s}"
+        assert torch.equal(e1.agents, e2.agents), f"agents frame {s}"
+        fullest = max(fullest, int(c2.max()))
+        if s % 5 == 4 or s == frames - 1:
+            assert torch.equal(e1.x, e2.x), f"state frame {s}"
+    e2.fs.check_flags()                                                   # nobody reached Nmax (outside the domain)
+    dirty = (e2.fs.hdp[..., 0] & 0x80) != 0
+    assert fullest == Nmax - 1 and 0 < int(dirty.sum()) < dirty.numel(), (fullest, int(dirty.sum()))
+    # hand the mixed clean / dirty state to the LDS-resident rollout and back
+    T = 20
+    chB, rwB = torch.zeros((T, B, N), dtype=torch.uint8, device="cuda"), torch.zeros((T, B), device="cuda")
+    ctB = torch.zeros((T + 1, B, N), dtype=torch.uint8, device="cuda")
+    assert e2.env_rollout_supported
+    e2.rollout_env(T, choice=chB, log_prob=None, reward=rwB, counts=ctB)
+    for t in range(T):
+        logits = ops.policy_edge_logits(e1.plan, e1.node_features, emb)
+        p = ops.graphdist_softmax(e1.plan, logits)
+        _, ch1 = ops.graphdist_sample(e1.plan, p, seed=e2.seed ^ 0x5DEECE66D, counter=frames + t + 1, want_onehot=False,
+                                      want_choice=True)
+        e1.step(choice=ch1)
+        assert torch.equal(e1.reward, rwB[t]), f"rollout reward frame {t}"
+    assert torch.equal(e1.x, e2.x) and torch.equal(e1.agents, e2.agents)
+    for t in range(10):
+        logits = ops.policy_edge_logits(e1.plan, e1.node_features, emb)
+        p = ops.graphdist_softmax(e1.plan, logits)
+        _, ch1 = ops.graphdist_sample(e1.plan, p, seed=e2.seed ^ 0x5DEECE66D, counter=frames + T + t + 1,
+                                      want_onehot=False, want_choice=True)
+        e1.step(choice=ch1)
+        e2.frame_fused(choice=ch2, reward=rw2)
+        assert torch.equal(ch1, ch2.t()) and torch.equal(e1.reward, rw2), f"continuation frame {t}"
+    assert torch.equal(e1.x, e2.x) and torch.equal(e1.agents, e2.agents)
