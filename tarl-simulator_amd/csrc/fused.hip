@@ -1055,12 +1055,19 @@ __device__ __forceinline__ float2 row_phase_b(uint32_t i, uint32_t b, bool pop, 
         head_arr = hd[1];
         head_dep = hd[2];
       }
-      tail_id = (n >= 1 && n <= Nmax) ? (uint32_t)(long long)sl[3 * phys(hoff, n - 1, Nmax)] : 0u;
+      // the agents that stay keep their order: the tail is who it was (the arrival, or the tail word's id) unless nobody
+      // stays. (A count at Nmax is outside the domain and flagged; the store is re-read there as the reference would.)
+      if (n == 0)
+        tail_id = 0u;
+      else if (n >= Nmax)
+        tail_id = (n == Nmax) ? (uint32_t)(long long)sl[3 * phys(hoff, n - 1, Nmax)] : 0u;
     }
     fb.hdp[row] = make_uint2((head_id << 8) | (uint32_t)n | (exact ? HD_DIRTY : 0u), __float_as_uint(head_dep));
     fb.tl[row] = tl_word(tail_id, hoff, TLF_AUTH);
-    if (arr_new) fb.rec1[row].x = __float_as_uint(head_arr);   // otherwise the head, and its arrival, are unchanged
-    fb.rec1[row].y = r1_code(lazy ? q : -1);
+    if (arr_new)      // one 8-byte store; otherwise the head, and its arrival, are unchanged
+      fb.rec1[row] = make_uint2(__float_as_uint(head_arr), r1_code(lazy ? q : -1));
+    else
+      fb.rec1[row].y = r1_code(lazy ? q : -1);
     // per-node count before insertion (the insert kernel adds this frame's arrivals)
     if (out.counts8) out.counts8[row] = (uint8_t)n;
     if (out.countsf) out.countsf[row] = (float)n;
