@@ -2364,6 +2364,37 @@ __global__ __launch_bounds__(FB) void k_obs_keep(const float4* __restrict__ obs,
   keep[(int64_t)slot[blockIdx.y] * row4 + j] = obs[(int64_t)env[blockIdx.y] * row4 + j];
 }
 
+// The per-frame sampler of the state-dependent policy runs one workgroup per environment and writes its action bytes
+// env-major (choice8 [B][N], coalesced); the frame kernels read SELECTED_ROAD env-minor (sel8 [N][B]). Written from the
+// sampler, the env-minor copy is one scattered byte store per (road, environment) — a partial-line store each, most of that
+// kernel's time. This kernel turns 64 x 64 byte tiles through LDS instead: both sides move whole 64-byte runs. A road that
+// drew nothing (bit 7 set by the sampler, which does not see the env-minor column any more) keeps its previous value: the
+// code is completed here from the old sel8 byte and written back to the action buffer as well (rare).
+__global__ __launch_bounds__(256) void k_sel8_from_choice8(uint8_t* __restrict__ choice8, uint8_t* __restrict__ sel8,
+                                                           int64_t B, int64_t N) {
+  __shared__ uint8_t tile[64][68];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t b0 = (int64_t)blockIdx.x * 64, i0 = (int64_t)blockIdx.y * 64;
+#pragma unroll 4
+  for (int r = w; r < 64; r += 4) {            // row r = environment b0 + r, lanes along the roads
+    const int64_t b = b0 + r, i = i0 + lane;
+    tile[r][lane] = (b < B && i < N) ? choice8[b * N + i] : (uint8_t)0;
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int r = w; r < 64; r += 4) {            // row r = road i0 + r, lanes along the environments
+    const int64_t i = i0 + r, b = b0 + lane;
+    if (b < B && i < N) {
+      uint32_t c = tile[lane][r];
+      if (c & SEL_CARRIED) {
+        c = (sel8[i * B + b] & 0x7Fu) | SEL_CARRIED;
+        choice8[b * N + i] = (uint8_t)c;
+      }
+      sel8[i * B + b] = (uint8_t)c;
+    }
+  }
+}
+
 extern "C" int tarl_fused_rollout_policy(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, int64_t T,
                                          const float* times_host, float prev_time, const float* x, int64_t x_bstride,
                                          int64_t ldx, float* agent_features, int64_t A, int64_t a_bstride,
@@ -2427,9 +2458,14 @@ extern "C" int tarl_fused_rollout_policy(const tarl_plan* plan, const tarl_fused
     if (timed) (void)tarl_prof_mark(s, 1);
     rc = tarl_graphdist_rollout_at(plan, logits_scratch, B, temperature, nullptr, policy_seed,
                                    policy_counter0 + (uint64_t)t, dist_scratch, nullptr,
-                                   choice8 ? choice8 + t * NB : nullptr, f->sel8, log_prob ? log_prob + t * B : nullptr,
-                                   f->env_base, stream);
+                                   choice8 ? choice8 + t * NB : nullptr, choice8 ? nullptr : f->sel8,
+                                   log_prob ? log_prob + t * B : nullptr, f->env_base, stream);
     if (rc) return rc;
+    if (choice8) {      // SELECTED_ROAD column of the frame kernels = the transposed action bytes
+      hipLaunchKernelGGL(k_sel8_from_choice8, dim3((unsigned)ceil_div(B, 64), (unsigned)ceil_div(N, 64)), dim3(256), 0, s,
+                         choice8 + t * NB, f->sel8, B, N);
+      TARL_LAUNCH_CHECK();
+    }
     const float time = times_host[t];
     const int64_t m = metrics_envs;
     const FrameOut out{counts ? counts + t * NB : nullptr,
