@@ -485,6 +485,14 @@ int tarl_rollout_env(const tarl_plan* plan, const tarl_fused* f, int64_t B, int3
                      void* static_scratch, uint8_t* choice, float* log_prob, float* entropy, float* reward,
                      uint8_t* counts, int32_t metrics_envs, float* dtt_node, uint8_t* events, int32_t* leg,
                      tarl_stream stream);
+/* tarl_fused_set_actions: load one frame's ENV-MAJOR action bytes (choice8 uint8 [B][N]: rank of the chosen out-edge in the
+ *   road's CSR list, as tarl_graphdist_rollout / tarl_rollout_env / tarl_fused_rollout_policy write them) as the SELECTED_ROAD
+ *   column of the packed state (tarl_fused.sel8, env-minor) — apply_action (src/transportation_simulator.py:411-414) for
+ *   recorded or externally sampled actions, as 64 x 64 byte tiles turned through LDS. A byte with bit 7 set means "this road
+ *   drew nothing": the road keeps its previous SELECTED_ROAD, and the completed code (previous rank | 0x80) is written back
+ *   into choice8. tarl_fused_rollout_policy uses it after every frame's draw. */
+int tarl_fused_set_actions(const tarl_plan* plan, const tarl_fused* f, int64_t B, uint8_t* choice8, tarl_stream stream);
+
 /* tarl_fused_rollout_policy: T consecutive frames of SimulatorEnv._step under a STATE-DEPENDENT policy — the per-edge MLP
  *   head (MPNNPolicyNet.edge_mlp, src/agents/mpnn_agent.py:35-41, 227-231) — in one foreign call. Nothing of
  *   GraphDistribution can be hoisted out of the frame; per frame the call queues, on the caller's stream,

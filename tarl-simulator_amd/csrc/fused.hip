@@ -2395,6 +2395,17 @@ __global__ __launch_bounds__(256) void k_sel8_from_choice8(uint8_t* __restrict__
   }
 }
 
+extern "C" int tarl_fused_set_actions(const tarl_plan* plan, const tarl_fused* f, int64_t B, uint8_t* choice8,
+                                      tarl_stream stream) {
+  TARL_REQUIRE(plan && f && f->sel8 && choice8, "null argument");
+  TARL_REQUIRE(B >= 1, "bad batch size");
+  if (plan->N == 0) return TARL_OK;
+  hipLaunchKernelGGL(k_sel8_from_choice8, dim3((unsigned)ceil_div(B, 64), (unsigned)ceil_div(plan->N, 64)), dim3(256), 0,
+                     (hipStream_t)stream, choice8, f->sel8, B, plan->N);
+  TARL_LAUNCH_CHECK();
+  return TARL_OK;
+}
+
 extern "C" int tarl_fused_rollout_policy(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, int64_t T,
                                          const float* times_host, float prev_time, const float* x, int64_t x_bstride,
                                          int64_t ldx, float* agent_features, int64_t A, int64_t a_bstride,
@@ -2462,9 +2473,8 @@ extern "C" int tarl_fused_rollout_policy(const tarl_plan* plan, const tarl_fused
                                    log_prob ? log_prob + t * B : nullptr, f->env_base, stream);
     if (rc) return rc;
     if (choice8) {      // SELECTED_ROAD column of the frame kernels = the transposed action bytes
-      hipLaunchKernelGGL(k_sel8_from_choice8, dim3((unsigned)ceil_div(B, 64), (unsigned)ceil_div(N, 64)), dim3(256), 0, s,
-                         choice8 + t * NB, f->sel8, B, N);
-      TARL_LAUNCH_CHECK();
+      rc = tarl_fused_set_actions(plan, f, B, choice8 + t * NB, stream);
+      if (rc) return rc;
     }
     const float time = times_host[t];
     const int64_t m = metrics_envs;

@@ -77,6 +77,7 @@ SIGNATURES = {
     "tarl_fused_rollout": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _f32, _p, _p, _p, _u64, _u64, _p, _i64, _i64, _p, _p,
                                      _f32, C.c_int, _u64, _u64] + [_p] * 9 + [_i32, _p, _p, _p, _p]),
     "tarl_fused_rollout_scratch_ints": (_i64, [_p, _i64, _i64]),
+    "tarl_fused_set_actions": (C.c_int, [_p, _p, _i64, _p, _p]),
     "tarl_fused_rollout_policy": (C.c_int, [_p, _p, _i64, _i32, _i64, _p, _f32, _p, _i64, _i64, _p, _i64, _i64, _p, _p,
                                             _f32, C.c_int] + [_p] * 6 + [C.c_int, _f32, _u64, _u64, _u64, _u64] +
                                   [_p] * 12 + [_i32, _p, _p, _p, _p]),

@@ -481,6 +481,17 @@ def fused_obs16_rows(plan: Plan, fs, x, Nmax, agent_features, env, slot, out):
     return out
 
 
+def fused_set_actions(plan: Plan, fs, choice8):
+    """Env-major action bytes ``choice8`` (B, N) uint8 -> the SELECTED_ROAD column of the packed state (env-minor). A byte
+    with bit 7 set keeps the road's previous value; the completed code is written back into ``choice8``."""
+    L = _lib.load()
+    _contig(choice8, torch.uint8, "choice8")
+    if choice8.dim() != 2 or choice8.size(0) != fs.B or choice8.size(1) != plan.num_nodes:
+        raise ValueError(f"choice8 must be (B, N) = ({fs.B}, {plan.num_nodes})")
+    _lib.check(L.tarl_fused_set_actions(plan.handle, fs.ref, fs.B, choice8.data_ptr(), _lib.current_stream()))
+    return choice8
+
+
 def policy_edge_mlp(plan: Plan, obs16, ec: EdgeConst, w: EdgeMlpWeights, *, bf16=False, out=None):
     """obs16 (M, N, 16) -> logits (M, E) of the per-edge MLP head (fp32 MFMA, or bf16 MFMA with ``bf16=True``);
     ``obs16`` in torch.bfloat16 (fused_obs16_bf16) selects the bf16 MFMA kernel that reads bf16 observations."""

@@ -365,3 +365,37 @@ def test_mirror_policy_net_with_edge_mlp_head_golden_and_cli(tmp_path, monkeypat
     fresh = MPNNPolicyNet(r.policy_net.edge_index, r.policy_net.num_nodes, None, device="cuda")
     assert not torch.equal(fresh.edge_mlp[4].weight, r.policy_net.edge_mlp[4].weight)      # the head trained
     assert torch.equal(fresh.nodes_embedding.weight, r.policy_net.nodes_embedding.weight)   # the embedding is off the path
+
+
+@pytest.mark.parametrize("W,H,B", [(5, 4, 96), (3, 3, 1), (7, 5, 130), (8, 8, 64)])
+def test_set_actions_turns_env_major_bytes_into_the_selected_road_column(W, H, B):
+    """tarl_fused_set_actions: choice8 (B, N) -> sel8 (N, B), 64 x 64 byte tiles (ragged on both sides here); a byte with
+    bit 7 set ("drew nothing") keeps the road's previous rank and comes back completed. Afterwards the exported
+    SELECTED_ROAD column names the chosen out-edge's target."""
+    from tarl_hip import ops, synth
+    from tarl_hip.engine import SimEngine
+    net = synth.torus_network(W, H, heterogeneous=True, seed=2)
+    N = net.num_roads
+    pops = torch.stack([synth.population(50, N, seed=b) for b in range(B)])
+    e = SimEngine(net.x.cuda().unsqueeze(0).repeat(B, 1, 1).contiguous(), net.edge_index, net.edge_attr, net.Nmax,
+                  pops.cuda(), congestion_constant=net.congestion_constant, seed=1)
+    e.reset()
+    g = torch.Generator().manual_seed(B + N)
+    first = torch.randint(0, 4, (B, N), generator=g, dtype=torch.uint8).cuda()
+    ops.fused_set_actions(e.plan, e.fs, first)
+    assert torch.equal(e.fs.sel8, first.t())
+    second = torch.randint(0, 4, (B, N), generator=g, dtype=torch.uint8)
+    carried = torch.rand((B, N), generator=g) < 0.2
+    second[carried] = 0x80
+    second = second.cuda()
+    want = torch.where(carried.cuda(), first | 0x80, second)
+    ops.fused_set_actions(e.plan, e.fs, second)
+    assert torch.equal(second, want) and torch.equal(e.fs.sel8, want.t())
+    assert int(carried.sum()) > 0 or B * N < 20
+    # the reference's view of it: SELECTED_ROAD = target of the out-edge with that rank
+    e._x_stale = True
+    sel = e.x[:, :, 3 * net.Nmax + 5]
+    src_sorted = torch.argsort(net.edge_index[0], stable=True)
+    dst_by_rank = net.edge_index[1][src_sorted].view(N, 4).cuda()           # a torus: four out-edges per road
+    assert torch.equal(sel, torch.gather(dst_by_rank.unsqueeze(0).expand(B, N, 4), 2,
+                                         (want & 0x7F).long().unsqueeze(2)).squeeze(2).float())
