@@ -490,7 +490,7 @@ int tarl_rollout_env(const tarl_plan* plan, const tarl_fused* f, int64_t B, int3
  *   column of the packed state (tarl_fused.sel8, env-minor) — apply_action (src/transportation_simulator.py:411-414) for
  *   recorded or externally sampled actions, as 64 x 64 byte tiles turned through LDS. A byte with bit 7 set means "this road
  *   drew nothing": the road keeps its previous SELECTED_ROAD, and the completed code (previous rank | 0x80) is written back
- *   into choice8. tarl_fused_rollout_policy uses it after every frame's draw. */
+ *   into choice8. */
 int tarl_fused_set_actions(const tarl_plan* plan, const tarl_fused* f, int64_t B, uint8_t* choice8, tarl_stream stream);
 
 /* tarl_fused_rollout_policy: T consecutive frames of SimulatorEnv._step under a STATE-DEPENDENT policy — the per-edge MLP

@@ -2364,12 +2364,11 @@ __global__ __launch_bounds__(FB) void k_obs_keep(const float4* __restrict__ obs,
   keep[(int64_t)slot[blockIdx.y] * row4 + j] = obs[(int64_t)env[blockIdx.y] * row4 + j];
 }
 
-// The per-frame sampler of the state-dependent policy runs one workgroup per environment and writes its action bytes
-// env-major (choice8 [B][N], coalesced); the frame kernels read SELECTED_ROAD env-minor (sel8 [N][B]). Written from the
-// sampler, the env-minor copy is one scattered byte store per (road, environment) — a partial-line store each, most of that
-// kernel's time. This kernel turns 64 x 64 byte tiles through LDS instead: both sides move whole 64-byte runs. A road that
-// drew nothing (bit 7 set by the sampler, which does not see the env-minor column any more) keeps its previous value: the
-// code is completed here from the old sel8 byte and written back to the action buffer as well (rare).
+// tarl_fused_set_actions: env-major action bytes (choice8 [B][N], what the samplers and the LDS-resident rollout write) ->
+// the SELECTED_ROAD column the frame kernels read (sel8 [N][B]): 64 x 64 byte tiles turned through LDS, whole 64-byte runs on
+// both sides. A road that drew nothing (bit 7) keeps its previous value: the code is completed from the old sel8 byte and
+// written back to the action buffer as well. (Measured as a replacement for the per-frame sampler's own scattered sel8
+// stores in tarl_fused_rollout_policy, B = 2048: sampler 102.7 -> 99.5 us, this kernel 8.9 us — not taken there.)
 __global__ __launch_bounds__(256) void k_sel8_from_choice8(uint8_t* __restrict__ choice8, uint8_t* __restrict__ sel8,
                                                            int64_t B, int64_t N) {
   __shared__ uint8_t tile[64][68];
@@ -2469,13 +2468,9 @@ extern "C" int tarl_fused_rollout_policy(const tarl_plan* plan, const tarl_fused
     if (timed) (void)tarl_prof_mark(s, 1);
     rc = tarl_graphdist_rollout_at(plan, logits_scratch, B, temperature, nullptr, policy_seed,
                                    policy_counter0 + (uint64_t)t, dist_scratch, nullptr,
-                                   choice8 ? choice8 + t * NB : nullptr, choice8 ? nullptr : f->sel8,
-                                   log_prob ? log_prob + t * B : nullptr, f->env_base, stream);
+                                   choice8 ? choice8 + t * NB : nullptr, f->sel8, log_prob ? log_prob + t * B : nullptr,
+                                   f->env_base, stream);
     if (rc) return rc;
-    if (choice8) {      // SELECTED_ROAD column of the frame kernels = the transposed action bytes
-      rc = tarl_fused_set_actions(plan, f, B, choice8 + t * NB, stream);
-      if (rc) return rc;
-    }
     const float time = times_host[t];
     const int64_t m = metrics_envs;
     const FrameOut out{counts ? counts + t * NB : nullptr,
