@@ -1,0 +1,13 @@
+#!/bin/bash
+# Developer tool: same-box A/B of one library under different environment knobs.
+# usage: tools/ab_env.sh [-r REPS] "VAR=a" "VAR=b" ...      BENCH_ARGS adds bench flags (e.g. --departure-window 600)
+cd "$(dirname "$0")/.."
+REPS=2
+if [ "$1" = "-r" ]; then REPS=$2; shift 2; fi
+Q="--steps 3 --warmup 1 --cpu-seconds 0 --policy-envs 0 --congested-window 0 $BENCH_ARGS"
+for i in $(seq $REPS); do
+  for kv in "$@"; do
+    printf "%-28s " "$kv"
+    env $kv python bench.py $Q 2>/dev/null | python tools/bench_brief.py
+  done
+done
