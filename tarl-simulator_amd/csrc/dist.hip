@@ -331,6 +331,9 @@ __global__ __launch_bounds__(ENV_BLOCK) void k_graphdist_rollout_reg(
     for (int q = 0; q < GDR_DEG; ++q) p[j][q] = q < deg[j] ? lb[eid[j][q]] / temperature : 0.0f;
   double base[J], inc[J];
   float un[J];
+  // (block-uniform) the wave's uniforms come out of shared Philox blocks: device noise, and the environment's first index a
+  // multiple of four (then so is every wave's first index of every chunk)
+  const bool share = !uniform && J <= 4 && ((idx_base + (uint64_t)(b * N)) & 3u) == 0;
   __shared__ double s_wave_j[J][ENV_BLOCK / 64];
   // per-node softmax (exp evaluated once per edge: the value the chain recomputes is the same function of the same
   // argument), per-group double sums, wave-level inclusive scans of all J chunks of 1 024 groups ...
@@ -364,18 +367,38 @@ __global__ __launch_bounds__(ENV_BLOCK) void k_graphdist_rollout_reg(
     }
     if (lane == 63) s_wave_j[j][wid] = v_inc;
     inc[j] = v_inc;
-    un[j] = g < N ? (uniform ? uniform[b * N + g] : philox_uniform(seed, counter, idx_base + (uint64_t)(b * N + g))) : 0.0f;
+    if (!share) un[j] = g < N ? (uniform ? uniform[b * N + g] : philox_uniform(seed, counter, idx_base + (uint64_t)(b * N + g))) : 0.0f;
+  }
+  if (share) {
+    // One Philox block holds the uniforms of four consecutive indices, and chunk j of this wave draws the 64 consecutive
+    // indices first + 1024 j + lane: 16 blocks per chunk. With the first index a multiple of four, lane L evaluates block
+    // (L & 15) of chunk (L >> 4) — one generator pass per wave instead of one per chunk — and lane l takes word (l & 3) from
+    // lane 16 j + (l >> 2). Same blocks, same words as philox_uniform(index).
+    const uint64_t first = idx_base + (uint64_t)(b * N) + (uint64_t)(64 * wid);
+    const int pj = lane >> 4;
+    const uint64_t blk = ((first + (uint64_t)ENV_BLOCK * (uint64_t)(pj < J ? pj : 0)) >> 2) + (uint64_t)(lane & 15);
+    uint32_t o[4];
+    philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)counter, (uint32_t)(counter >> 32), (uint32_t)seed,
+                  (uint32_t)(seed >> 32), o);
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int src = 16 * j + (lane >> 2);
+      const uint32_t w0 = __shfl(o[0], src), w1 = __shfl(o[1], src), w2 = __shfl(o[2], src), w3 = __shfl(o[3], src);
+      const int c = lane & 3;
+      un[j] = u01_open(c == 0 ? w0 : (c == 1 ? w1 : (c == 2 ? w2 : w3)));
+    }
   }
   __syncthreads();
   // ... then the cross-wave part of k_sample's scan, chunk after chunk (same additions in the same order)
   double running = 0.0;
 #pragma unroll
   for (int j = 0; j < J; ++j) {
+    // wbase = v0 + ... + v(wid-1) and tot = v0 + ... + v15, both left to right: one running sum serves both
     double wbase = 0.0, tot = 0.0;
+#pragma unroll
     for (int w = 0; w < ENV_BLOCK / 64; ++w) {
-      const double v = s_wave_j[j][w];
-      if (w < wid) wbase += v;
-      tot += v;
+      if (w == wid) wbase = tot;
+      tot += s_wave_j[j][w];
     }
     double exc = __shfl_up(inc[j], 1);
     if (lane == 0) exc = 0.0;

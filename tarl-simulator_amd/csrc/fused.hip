@@ -1144,6 +1144,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
   if (valid) {
     uint32_t pa[NCH], tlw[NCH], pj[NCH][4];
     uint2 hp[NCH];
+    uint32_t ovf = 0u;       // bit r: row r found the event list full; bit 4 + r: its pop flag
 #pragma unroll
     for (int r = 0; r < NCH; ++r) {
       const uint32_t row = (uint32_t)ri[r] * B + b;
@@ -1189,15 +1190,36 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
             s_item[pos] = (uint16_t)((r << 9) | (pop ? 256 : 0) | threadIdx.x);
             s_words[pos] = make_uint4(pa[r], hp[r].x, hp[r].y, tlw[r]);
           } else {
-            const float2 nc = row_phase_b(i, b, pop, pa[r], hp[r], tlw[r], nodes[i], out_ptr, out_dst, Nmax, B, N,
-                                          fb, ag, A, a_bstride, t, out);
-            nsum += nc.x;
-            if (nc.y != 0.0f) atomicAdd(&fb.acc_w[(int64_t)(blockIdx.y % (unsigned)fb.acc_slots) * B + b], nc.y);
+            ovf |= (1u << r) | (pop ? (16u << r) : 0u);   // the list is full: served in place below
           }
         } else {
           nsum += n;
         }
       }
+    // In-place fall-back for the pairs that found the list full (a loaded network; never in a filling one). ONE rolled copy
+    // of the event path behind the four rows, not one inside each row's body: with four inlined copies the idle path
+    // carried their registers and 145 spilled SGPRs (row pass 222 -> 208 us without them, timing-only build).
+    if (ovf != 0u) {
+#pragma unroll 1
+      for (int r = 0; r < NCH; ++r) {
+        if (!((ovf >> r) & 1u)) continue;
+        uint32_t pa_r = pa[0], tl_r = tlw[0];
+        uint2 hp_r = hp[0];
+        int32_t i_r = ri[0];
+#pragma unroll
+        for (int q = 1; q < NCH; ++q) {
+          pa_r = (r == q) ? pa[q] : pa_r;
+          tl_r = (r == q) ? tlw[q] : tl_r;
+          hp_r.x = (r == q) ? hp[q].x : hp_r.x;
+          hp_r.y = (r == q) ? hp[q].y : hp_r.y;
+          i_r = (r == q) ? ri[q] : i_r;
+        }
+        const float2 nc = row_phase_b((uint32_t)i_r, b, ((ovf >> (4 + r)) & 1u) != 0u, pa_r, hp_r, tl_r, nodes[i_r], out_ptr,
+                                      out_dst, Nmax, B, N, fb, ag, A, a_bstride, t, out);
+        nsum += nc.x;
+        if (nc.y != 0.0f) atomicAdd(&fb.acc_w[(int64_t)(blockIdx.y % (unsigned)fb.acc_slots) * B + b], nc.y);
+      }
+    }
   }
   // idle rows' share of the environment's count sum goes out now: a wave without a list entry is done after the barrier
   // (its slots go to the next workgroup while the event path, a chain of dependent loads a few lanes wide, runs on)

@@ -153,12 +153,15 @@ def test_rollout_with_gpu_sampling_matches_golden(ops):
         assert torch.equal(x.cpu(), g["x"][s]) and torch.equal(ag.cpu(), g["agents"][s])
 
 
-@pytest.mark.parametrize("case", ["golden_mid", "torus_philox", "torus_hot"])
+@pytest.mark.parametrize("case", ["golden_mid", "torus_philox", "torus_hot", "ring_philox"])
 def test_graphdist_rollout_one_launch_equals_the_chain(ops, case):
     """tarl_graphdist_rollout (softmax -> sample -> log_prob in one launch, probabilities never materialised) against the
     three-launch chain: identical actions, rank bytes, SELECTED_ROAD bytes and bit-identical log-probs — on the golden
     graph (unsorted edges, nodes without out-edges), on the 10k-edge torus with device noise, and with logits hot enough
-    that some nodes draw nothing (cumulative sum below u: the action is then not one edge per node, log_prob = -inf)."""
+    that some nodes draw nothing (cumulative sum below u: the action is then not one edge per node, log_prob = -inf).
+    ring_philox: 1 030 nodes with two out-edges each and device noise: the register sampler shares one Philox block between
+    the four lanes that draw consecutive indices when an environment's first index is a multiple of four — here every
+    second environment's is not (1 030 = 2 mod 4) and takes the block-per-node path: both must equal the chain."""
     from tarl_hip import synth
     gen = torch.Generator().manual_seed(11)
     if case == "golden_mid":
@@ -167,6 +170,12 @@ def test_graphdist_rollout_one_launch_equals_the_chain(ops, case):
         N = int(ei.max()) + 1
         B, T = 5, 0.8
         logits = torch.randn((B, ei.size(1)), generator=gen) * 3
+    elif case == "ring_philox":
+        N, B, T = 1030, 6, 0.7
+        src = torch.arange(N).repeat_interleave(2)
+        dst = torch.stack([(torch.arange(N) + 1) % N, (torch.arange(N) + 7) % N], 1).reshape(-1)
+        ei = torch.stack([src, dst])
+        logits = torch.randn((B, ei.size(1)), generator=gen) * 2
     else:
         net = synth.torus_network(25, 25)
         ei, N = net.edge_index, net.num_roads
@@ -176,7 +185,7 @@ def test_graphdist_rollout_one_launch_equals_the_chain(ops, case):
     E, G = ei.size(1), plan.num_groups
     logits = dev(logits)
     uniform = None
-    if case != "torus_philox":
+    if case not in ("torus_philox", "ring_philox"):
         uniform = torch.rand((B, G), generator=gen)
         if case == "torus_hot":
             uniform[:, ::7] = 0.99999994            # the largest fp32 below 1: beyond a rounded-down cumulative sum
