@@ -895,25 +895,26 @@ __device__ __forceinline__ bool row_phase_a(uint32_t i, uint32_t b, const RowSta
   {
     const uint32_t head = (n0i == 0u) ? who : head_id0;   // head after the Direction update
     const bool up = (n0i + arrived) > 0u;
+    // (bitwise on purpose: four lane masks and'ed / or'ed, no short-circuit control flow)
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      pop = pop || (q < nr.out_deg && up && (pj4[q] & PF_NONEMPTY) && (pj4[q] >> 8) == head);
+      pop = pop | ((q < nr.out_deg) & up & ((pj4[q] & PF_NONEMPTY) != 0u) & ((pj4[q] >> 8) == head));
     for (int32_t q = 4; q < nr.out_deg; ++q) {   // out-degree above four: the rest one by one
       const uint32_t pj = post[(uint32_t)fb.out_pad[nr.out0 + q] * B + b];
-      pop = pop || (up && (pj & PF_NONEMPTY) && (pj >> 8) == head);
+      pop = pop | (up & ((pj & PF_NONEMPTY) != 0u) & ((pj >> 8) == head));
     }
   }
   const int q = (int)n0i;
-  const bool lazy = (who == 0u) && (q < Nmax - 1);
+  const bool lazy = (who == 0u) & (q < Nmax - 1);
   const uint32_t ni = n0i + arrived;   // count after the Direction update
   if ((int)ni >= Nmax) atomicOr(fb.flags, FLAG_COUNT_AT_NMAX);
   const uint32_t head_id = (n0i == 0u) ? who : head_id0;
   // an empty row's head is this frame's garbage triple (0, t, t + tt): its departure needs the division only there
   const float head_dep = (n0i == 0u) ? t + nr.tt0 : __uint_as_float(hp.y);
   // is the (unpopped) head a withdraw candidate? (the first two tests of the withdraw scan, on registers)
-  const bool due = !pop && ni > 0u && (int64_t)head_id < A && (head_dep <= t);
+  const bool due = (!pop) & (ni > 0u) & ((int64_t)head_id < A) & (head_dep <= t);
   *pop_out = pop;
-  if (!(lazy && !pop && !due)) return true;
+  if (!(lazy & !pop & !due)) return true;
   // IDLE ROW: nothing moves, and (almost) nothing is written. With agents, the row keeps its head and count: its word
   // is already what a refresh would store. Empty, its garbage head departs at t + tt0, which changes every frame — but
   // nobody reads the departure of an empty row that was idle (tail word without TLF_AUTH): this pass recomputes it, the
