@@ -882,6 +882,9 @@ struct RowStat {
   float tt0, maxn;
 };
 // phase A of one row: returns true when the row is an event row (nothing written), false when it was idle (words written)
+// FAPI: the frame API's outputs (fp32 counts, env-major pop / withdraw masks) may be present; rollouts instantiate without
+// them (their null tests, addresses and registers leave the idle path)
+template <bool FAPI>
 __device__ __forceinline__ bool row_phase_a(uint32_t i, uint32_t b, const RowStat nr, const uint32_t* __restrict__ post,
                                             uint32_t pa, uint2 hp, uint32_t tlw, const uint32_t (&pj4)[4], int Nmax,
                                             uint32_t B, uint32_t N, const FusedBufs& fb, int64_t A, float t,
@@ -929,9 +932,9 @@ __device__ __forceinline__ bool row_phase_a(uint32_t i, uint32_t b, const RowSta
     fb.post[row] = pa & ~PF_TLAUTH;
   }
   if (out.counts8) __builtin_nontemporal_store((uint8_t)ni, &out.counts8[row]);
-  if (out.countsf) __builtin_nontemporal_store((float)ni, &out.countsf[row]);
-  if (out.popped) out.popped[(int64_t)b * N + i] = 0;
-  if (out.withdrawn) out.withdrawn[(int64_t)b * N + i] = 0;
+  if (FAPI && out.countsf) __builtin_nontemporal_store((float)ni, &out.countsf[row]);
+  if (FAPI && out.popped) out.popped[(int64_t)b * N + i] = 0;
+  if (FAPI && out.withdrawn) out.withdrawn[(int64_t)b * N + i] = 0;
   if (out.events && b < out.m_env) out.events[(int64_t)i * out.m_env + b] = 0;
   *n_out = (float)ni;
   return false;
@@ -939,6 +942,7 @@ __device__ __forceinline__ bool row_phase_a(uint32_t i, uint32_t b, const RowSta
 
 // phase B of one EVENT row (its dense words travel with the list entry): Direction update on the slot store,
 // Response pop, withdraw, refreshed dense words + event word. -> {count after the pass, agents withdrawn}
+template <bool FAPI>
 __device__ __forceinline__ float2 row_phase_b(uint32_t i, uint32_t b, bool pop, uint32_t pa, uint2 hp, uint32_t tlw,
                                               const NodeRec& nr, const int32_t* __restrict__ out_ptr,
                                               const int32_t* __restrict__ out_dst, int Nmax, uint32_t B, uint32_t N,
@@ -1071,9 +1075,9 @@ __device__ __forceinline__ float2 row_phase_b(uint32_t i, uint32_t b, bool pop, 
       fb.rec1[row].y = r1_code(lazy ? q : -1);
     // per-node count before insertion (the insert kernel adds this frame's arrivals)
     if (out.counts8) out.counts8[row] = (uint8_t)n;
-    if (out.countsf) out.countsf[row] = (float)n;
-    if (out.popped) out.popped[(int64_t)b * N + i] = pop ? 1 : 0;
-    if (out.withdrawn) out.withdrawn[(int64_t)b * N + i] = c > 0 ? 1 : 0;
+    if (FAPI && out.countsf) out.countsf[row] = (float)n;
+    if (FAPI && out.popped) out.popped[(int64_t)b * N + i] = pop ? 1 : 0;
+    if (FAPI && out.withdrawn) out.withdrawn[(int64_t)b * N + i] = c > 0 ? 1 : 0;
     if (out.events && b < out.m_env) out.events[(int64_t)i * out.m_env + b] = (uint8_t)((pop ? 1 : 0) | (c > 0 ? 2 : 0));
     return make_float2((float)n, (float)c);
   }
@@ -1096,7 +1100,7 @@ struct __attribute__((aligned(32))) RowChunk {
   int32_t row[4];    // -1: none (a group's remainder)
   int32_t out4[4];   // the shared first four out-edge targets
 };
-template <int NCH, bool SIB>
+template <int NCH, bool SIB, bool FAPI>
 __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fused_rows(const NodeRec* __restrict__ nodes,
                                                      const int32_t* __restrict__ out_pad,
                                                      const int32_t* __restrict__ out_ptr,
@@ -1185,7 +1189,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         bool pop;
         float n = 0.0f;
         const uint32_t i = (uint32_t)ri[r];
-        if (row_phase_a(i, b, rs[r], post, pa[r], hp[r], tlw[r], pj[r], Nmax, B, N, fb, A, t, out, &pop, &n)) {
+        if (row_phase_a<FAPI>(i, b, rs[r], post, pa[r], hp[r], tlw[r], pj[r], Nmax, B, N, fb, A, t, out, &pop, &n)) {
           const int32_t pos = atomicAdd(&s_cnt, 1);
           if (pos < EV_CAP) {
             s_item[pos] = (uint16_t)((r << 9) | (pop ? 256 : 0) | threadIdx.x);
@@ -1215,7 +1219,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
           hp_r.y = (r == q) ? hp[q].y : hp_r.y;
           i_r = (r == q) ? ri[q] : i_r;
         }
-        const float2 nc = row_phase_b((uint32_t)i_r, b, ((ovf >> (4 + r)) & 1u) != 0u, pa_r, hp_r, tl_r, nodes[i_r], out_ptr,
+        const float2 nc = row_phase_b<FAPI>((uint32_t)i_r, b, ((ovf >> (4 + r)) & 1u) != 0u, pa_r, hp_r, tl_r, nodes[i_r], out_ptr,
                                       out_dst, Nmax, B, N, fb, ag, A, a_bstride, t, out);
         nsum += nc.x;
         if (nc.y != 0.0f) atomicAdd(&fb.acc_w[(int64_t)(blockIdx.y % (unsigned)fb.acc_slots) * B + b], nc.y);
@@ -1236,7 +1240,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     int32_t i2 = ri[0];
 #pragma unroll
     for (int q = 1; q < NCH; ++q) i2 = (r == (uint32_t)q) ? ri[q] : i2;
-    const float2 nc = row_phase_b((uint32_t)i2, b2, (item & 256u) != 0u, wd.x, make_uint2(wd.y, wd.z), wd.w, nodes[i2],
+    const float2 nc = row_phase_b<FAPI>((uint32_t)i2, b2, (item & 256u) != 0u, wd.x, make_uint2(wd.y, wd.z), wd.w, nodes[i2],
                                   out_ptr, out_dst, Nmax, B, N, fb, ag, A, a_bstride, t, out);
     if (nc.x != 0.0f) atomicAdd(&fb.acc_n[bank0 + b2], nc.x);     // small integers: exact in fp32 in any order
     if (nc.y != 0.0f) atomicAdd(&fb.acc_w[bank0 + b2], nc.y);
@@ -2041,11 +2045,20 @@ static int64_t num_row_chunks(const tarl_plan* plan) { return rows_sib(plan) ? p
 static int launch_rows(dim3 grid, unsigned threads, hipStream_t s, const tarl_plan* plan, const tarl_fused* f,
                        const FusedBufs& fb, int Nmax, int64_t B, float* agent_features, int64_t A, int64_t a_bstride,
                        float time, const FrameOut& out) {
-#define ROWS_LAUNCH(NCH, SIB)                                                                                              \
-  hipLaunchKernelGGL((k_fused_rows<NCH, SIB>), grid, dim3(threads), 0, s, (const NodeRec*)f->node_rec,                          \
+#define ROWS_LAUNCH_(NCH, SIB, FAPI)                                                                                       \
+  hipLaunchKernelGGL((k_fused_rows<NCH, SIB, FAPI>), grid, dim3(threads), 0, s, (const NodeRec*)f->node_rec,                    \
                      (const int32_t*)f->out_pad, plan->out_ptr, plan->out_dst, (const RowChunk*)plan->row_chunks,         \
                      (const uint32_t*)f->post, Nmax, (uint32_t)B, (uint32_t)plan->N, fb, agent_features, A, a_bstride,    \
                      time, out)
+#define ROWS_LAUNCH(NCH, SIB)                                                                                              \
+  do {                                                                                                                     \
+    if (fapi) {                                                                                                            \
+      ROWS_LAUNCH_(NCH, SIB, true);                                                                                        \
+    } else {                                                                                                               \
+      ROWS_LAUNCH_(NCH, SIB, false);                                                                                       \
+    }                                                                                                                      \
+  } while (0)
+  const bool fapi = out.countsf || out.popped || out.withdrawn;
   grid.y = (unsigned)num_row_chunks(plan);
   switch (nchunk()) {
     case 1: ROWS_LAUNCH(1, false); break;
@@ -2059,6 +2072,7 @@ static int launch_rows(dim3 grid, unsigned threads, hipStream_t s, const tarl_pl
       break;
   }
 #undef ROWS_LAUNCH
+#undef ROWS_LAUNCH_
   TARL_LAUNCH_CHECK();
   return TARL_OK;
 }
