@@ -649,6 +649,20 @@ __global__ __launch_bounds__(ENVB) void k_choice_fixup(uint32_t B, uint32_t N, c
   if (threadIdx.x == 0) fix[0] = 0;
 }
 
+// element idx of a [node][env] array. O32: through a 32-bit BYTE offset from the (scalar) base — `global_load ... v_off,
+// s[base]` instead of a 64-bit address per lane (one to two vector instructions fewer per access; row pass 212 -> 204 us).
+// Valid while N * B * sizeof(T) < 2^32, i.e. N * B < 2^29 for the 8-byte words: launch_rows picks the instantiation.
+template <bool O32, class T>
+__device__ __forceinline__ T& at32(T* base, uint32_t idx) {
+  if (O32) return *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (size_t)(idx * (uint32_t)sizeof(T)));
+  return base[idx];
+}
+template <bool O32, class T>
+__device__ __forceinline__ const T& at32(const T* base, uint32_t idx) {
+  if (O32) return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (size_t)(idx * (uint32_t)sizeof(T)));
+  return base[idx];
+}
+
 // ---- Direction gather on the dense words (env-minor: lane = environment) ---------------------------------------------------
 // Two passes inside the workgroup. Pass 1 (every (node, environment) pair of the chunk): admissibility masks and the
 // summed turn probability P — no random numbers — and the default post word (nobody chosen). A pair needs the Gumbel
@@ -665,10 +679,10 @@ __device__ __forceinline__ bool edge_admissible(uint32_t cj, int32_t rk, const f
   bool heads_here = cj == (uint32_t)rk;   // ranks are < SEL_RAW: a raw code never matches here
   if (EXACT && cj == SEL_RAW) heads_here = sel_raw[jrow] == road_i;
   const float dep = __uint_as_float(hj.y), n_j = (float)(hj.x & HD_CNT);
-  const bool m1 = (dep <= t) && (n_i < max_i - TARL_CONGESTION_FILE) && heads_here && (n_j > 0.0f);
-  const bool m2 = ((dep - t) < -10.0f) && ((max_j - TARL_CONGESTION_FILE) <= n_j) && ((max_j - n_j) <= (max_i - n_i)) &&
-                  heads_here;
-  return m1 || m2;
+  // (bitwise on purpose: lane masks and'ed / or'ed by the scalar unit, no short-circuit control flow)
+  const bool m1 = (dep <= t) & (n_i < max_i - TARL_CONGESTION_FILE) & (n_j > 0.0f);
+  const bool m2 = ((dep - t) < -10.0f) & ((max_j - TARL_CONGESTION_FILE) <= n_j) & ((max_j - n_j) <= (max_i - n_i));
+  return heads_here & (m1 | m2);
 }
 
 // Every read-only array is its own `const __restrict__` kernel argument: topology, statics and edge constants are
@@ -677,7 +691,7 @@ __device__ __forceinline__ bool edge_admissible(uint32_t cj, int32_t rk, const f
 // CNT: the row's own count comes from a byte per (row, environment) — in a rollout the count buffer's slice of the frame
 // before, which the row pass and the insert kernel have just written — instead of its 8-byte head words: of its own row the
 // dense pass needs the count and the tail word only (12 -> 5 bytes per pair).
-template <int NCH, bool SIB, bool CNT>
+template <int NCH, bool SIB, bool CNT, bool O32>
 __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fused_direction(
     const NodeRec* __restrict__ nodes, const InRec* __restrict__ in_rec, const int32_t* __restrict__ in_eid,
     const float* __restrict__ log_edge_attr, const uint2* __restrict__ hdp, const uint32_t* __restrict__ tl,
@@ -709,8 +723,8 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     for (int r = 0; r < NCH; ++r) {
       const uint32_t i = (i0 + r < N) ? i0 + r : N - 1;
       const uint32_t row = i * B + b;
-      ncnt[r] = CNT ? (uint32_t)cnt8[row] : (hdp[row].x & HD_CNT);
-      tlw[r] = tl[row];
+      ncnt[r] = CNT ? (uint32_t)cnt8[row] : (at32<O32>(hdp, row).x & HD_CNT);
+      tlw[r] = at32<O32>(tl, row);
       const InRec* ir = nodes[i].in4;   // the first four in-edge records travel in the node record
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -719,7 +733,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
           cj[r][q] = cj[0][q];
         } else {
           const uint32_t jrow = (uint32_t)ir[q].src * B + b;
-          hj[r][q] = hdp[jrow];
+          hj[r][q] = at32<O32>(hdp, jrow);
           cj[r][q] = sel8[jrow] & 0x7Fu;
         }
       }
@@ -737,7 +751,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           if (q < nr.in_deg) {   // wave-uniform
-            raw_seen = raw_seen || (cj[r][q] == SEL_RAW);
+            raw_seen = raw_seen | (cj[r][q] == SEL_RAW);
             const bool m = edge_admissible<false>(cj[r][q], ir4[q].rank, sel_raw, 0, hj[r][q], ir4[q].max_src, road_i, n_i,
                                                   max_i, t);
             P = P + ir4[q].ea * (m ? 1.0f : 0.0f);
@@ -747,14 +761,14 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
           const uint32_t jrow = (uint32_t)ir[q].src * B + b;
           const uint2 hx = hdp[jrow];
           const uint32_t cx = sel8[jrow] & 0x7Fu;
-          raw_seen = raw_seen || (cx == SEL_RAW);
+          raw_seen = raw_seen | (cx == SEL_RAW);
           const bool m = edge_admissible<false>(cx, ir[q].rank, sel_raw, 0, hx, ir[q].max_src, road_i, n_i, max_i, t);
           P = P + ir[q].ea * (m ? 1.0f : 0.0f);
         }
         // nobody chosen (pass 2 overwrites). A row that idled in the last frame (tail word without TLF_AUTH) still holds
         // exactly this word from the frame before: whatever changes a row's tail, empties or fills it, or hands it an
         // arrival makes it an event row, and event rows and inserts set the flag
-        if (tlw[r] & TLF_AUTH) post[row] = (tlw[r] & ~0xFFu) | (ncnt[r] ? PF_NONEMPTY : 0u) | PF_TLAUTH;
+        if (tlw[r] & TLF_AUTH) at32<O32>(post, row) = (tlw[r] & ~0xFFu) | (ncnt[r] ? PF_NONEMPTY : 0u) | PF_TLAUTH;
         if (P > 0.0f) s_item[atomicAdd(&s_n, 1)] = (uint16_t)(r * TILE + threadIdx.x);
       }
     }
@@ -884,7 +898,7 @@ struct RowStat {
 // phase A of one row: returns true when the row is an event row (nothing written), false when it was idle (words written)
 // FAPI: the frame API's outputs (fp32 counts, env-major pop / withdraw masks) may be present; rollouts instantiate without
 // them (their null tests, addresses and registers leave the idle path)
-template <bool FAPI>
+template <bool FAPI, bool O32>
 __device__ __forceinline__ bool row_phase_a(uint32_t i, uint32_t b, const RowStat nr, const uint32_t* __restrict__ post,
                                             uint32_t pa, uint2 hp, uint32_t tlw, const uint32_t (&pj4)[4], int Nmax,
                                             uint32_t B, uint32_t N, const FusedBufs& fb, int64_t A, float t,
@@ -903,7 +917,7 @@ __device__ __forceinline__ bool row_phase_a(uint32_t i, uint32_t b, const RowSta
     for (int q = 0; q < 4; ++q)
       pop = pop | ((q < nr.out_deg) & up & ((pj4[q] & PF_NONEMPTY) != 0u) & ((pj4[q] >> 8) == head));
     for (int32_t q = 4; q < nr.out_deg; ++q) {   // out-degree above four: the rest one by one
-      const uint32_t pj = post[(uint32_t)fb.out_pad[nr.out0 + q] * B + b];
+      const uint32_t pj = at32<O32>(post, (uint32_t)fb.out_pad[nr.out0 + q] * B + b);
       pop = pop | (up & ((pj & PF_NONEMPTY) != 0u) & ((pj >> 8) == head));
     }
   }
@@ -924,14 +938,14 @@ __device__ __forceinline__ bool row_phase_a(uint32_t i, uint32_t b, const RowSta
   // Direction gather's tests need an agent in the row or MAX_NUMBER_OF_AGENT <= 3 (rows that small keep the eager word),
   // export and delta_travel_time derive it from the clock. The tail word changes only when its flag has to go.
   if (n0i == 0u && nr.maxn <= TARL_CONGESTION_FILE)
-    fb.hdp[row] = make_uint2((head_id << 8) | ni | (hp.x & HD_DIRTY), __float_as_uint(head_dep));
+    at32<O32>(fb.hdp, row) = make_uint2((head_id << 8) | ni | (hp.x & HD_DIRTY), __float_as_uint(head_dep));
   if (tlw & TLF_AUTH) {
-    fb.tl[row] = tlw & ~TLF_AUTH;      // tail and ring offset stay
+    at32<O32>(fb.tl, row) = tlw & ~TLF_AUTH;      // tail and ring offset stay
     // ... and the post word's mirror of the flag goes with it (other workgroups may be gathering this word for their
     // Response test right now: they look at PF_NONEMPTY and the tail id, which do not change)
-    fb.post[row] = pa & ~PF_TLAUTH;
+    at32<O32>(fb.post, row) = pa & ~PF_TLAUTH;
   }
-  if (out.counts8) __builtin_nontemporal_store((uint8_t)ni, &out.counts8[row]);
+  if (out.counts8) __builtin_nontemporal_store((uint8_t)ni, &at32<O32>(out.counts8, row));
   if (FAPI && out.countsf) __builtin_nontemporal_store((float)ni, &out.countsf[row]);
   if (FAPI && out.popped) out.popped[(int64_t)b * N + i] = 0;
   if (FAPI && out.withdrawn) out.withdrawn[(int64_t)b * N + i] = 0;
@@ -1100,7 +1114,7 @@ struct __attribute__((aligned(32))) RowChunk {
   int32_t row[4];    // -1: none (a group's remainder)
   int32_t out4[4];   // the shared first four out-edge targets
 };
-template <int NCH, bool SIB, bool FAPI>
+template <int NCH, bool SIB, bool FAPI, bool O32>
 __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fused_rows(const NodeRec* __restrict__ nodes,
                                                      const int32_t* __restrict__ out_pad,
                                                      const int32_t* __restrict__ out_ptr,
@@ -1153,12 +1167,12 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
 #pragma unroll
     for (int r = 0; r < NCH; ++r) {
       const uint32_t row = (uint32_t)ri[r] * B + b;
-      pa[r] = post[row];
+      pa[r] = at32<O32>(post, row);
       if (SIB) {
         if (r == 0) {
           const int32_t* od = rchunks[blockIdx.y].out4;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) pj[0][q] = post[(uint32_t)od[q] * B + b];
+          for (int q = 0; q < 4; ++q) pj[0][q] = at32<O32>(post, (uint32_t)od[q] * B + b);
         } else {
 #pragma unroll
           for (int q = 0; q < 4; ++q) pj[r][q] = pj[0][q];
@@ -1166,7 +1180,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
       } else {
         const int32_t* od = nodes[ri[r]].out4;   // the first four targets travel in the node record
 #pragma unroll
-        for (int q = 0; q < 4; ++q) pj[r][q] = post[(uint32_t)od[q] * B + b];
+        for (int q = 0; q < 4; ++q) pj[r][q] = at32<O32>(post, (uint32_t)od[q] * B + b);
       }
     }
     // The post word already says whether the row holds anybody (PF_NONEMPTY), receives somebody (PF_ARRIVED) or still
@@ -1179,8 +1193,8 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
       hp[r] = make_uint2(0u, 0u);
       tlw[r] = 0u;
       if (Nmax < 2 || (pa[r] & (PF_ARRIVED | PF_NONEMPTY | PF_TLAUTH))) {   // (a one-slot FIFO has no lazy garbage slot)
-        hp[r] = fb.hdp[row];
-        tlw[r] = fb.tl[row];
+        hp[r] = at32<O32>(fb.hdp, row);
+        tlw[r] = at32<O32>(fb.tl, row);
       }
     }
 #pragma unroll
@@ -1189,7 +1203,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         bool pop;
         float n = 0.0f;
         const uint32_t i = (uint32_t)ri[r];
-        if (row_phase_a<FAPI>(i, b, rs[r], post, pa[r], hp[r], tlw[r], pj[r], Nmax, B, N, fb, A, t, out, &pop, &n)) {
+        if (row_phase_a<FAPI, O32>(i, b, rs[r], post, pa[r], hp[r], tlw[r], pj[r], Nmax, B, N, fb, A, t, out, &pop, &n)) {
           const int32_t pos = atomicAdd(&s_cnt, 1);
           if (pos < EV_CAP) {
             s_item[pos] = (uint16_t)((r << 9) | (pop ? 256 : 0) | threadIdx.x);
@@ -2000,11 +2014,20 @@ static int launch_direction(dim3 grid, unsigned threads, hipStream_t s, const ta
                             const float* edge_attr, const float* log_edge_attr, const uint8_t* sel8, const float* gumbel,
                             float* dtt, float log_eps, float time, float prev_time, uint64_t seed, uint64_t counter,
                             int64_t B, const FrameOut& out, const uint8_t* cnt8 = nullptr) {
-#define DIR_LAUNCH(NCH, SIB, CNT)                                                                                         \
-  hipLaunchKernelGGL((k_fused_direction<NCH, SIB, CNT>), grid, dim3(threads), 0, s, (const NodeRec*)f->node_rec,               \
+#define DIR_LAUNCH_(NCH, SIB, CNT, O32)                                                                                   \
+  hipLaunchKernelGGL((k_fused_direction<NCH, SIB, CNT, O32>), grid, dim3(threads), 0, s, (const NodeRec*)f->node_rec,          \
                      (const InRec*)f->in_rec, plan->in_eid, log_edge_attr, (const uint2*)f->hdp, (const uint32_t*)f->tl,  \
                      cnt8, (const uint2*)f->rec1, sel8, (const float*)f->sel, gumbel, dtt, (uint32_t*)f->post, log_eps, time,   \
                      prev_time, seed, counter, (uint32_t)plan->E, (uint32_t)B, (uint32_t)plan->N, out, (uint64_t)f->env_base)
+#define DIR_LAUNCH(NCH, SIB, CNT)                                                                                         \
+  do {                                                                                                                     \
+    if (o32) {                                                                                                             \
+      DIR_LAUNCH_(NCH, SIB, CNT, true);                                                                                    \
+    } else {                                                                                                               \
+      DIR_LAUNCH_(NCH, SIB, CNT, false);                                                                                   \
+    }                                                                                                                      \
+  } while (0)
+  const bool o32 = plan->N * B < ((int64_t)1 << 29);      // 8-byte words addressed through 32-bit byte offsets (at32)
   // TARL_DIR_SIBLINGS=0 keeps the per-row gathers on a sibling graph (developer knob)
   static const bool sib_ok = !(getenv("TARL_DIR_SIBLINGS") && atoi(getenv("TARL_DIR_SIBLINGS")) == 0);
   // TARL_DIR_COUNT_BYTE=0 keeps the head words as the count's source (developer knob)
@@ -2030,6 +2053,7 @@ static int launch_direction(dim3 grid, unsigned threads, hipStream_t s, const ta
       break;
   }
 #undef DIR_LAUNCH
+#undef DIR_LAUNCH_
   TARL_LAUNCH_CHECK();
   return TARL_OK;
 }
@@ -2045,20 +2069,23 @@ static int64_t num_row_chunks(const tarl_plan* plan) { return rows_sib(plan) ? p
 static int launch_rows(dim3 grid, unsigned threads, hipStream_t s, const tarl_plan* plan, const tarl_fused* f,
                        const FusedBufs& fb, int Nmax, int64_t B, float* agent_features, int64_t A, int64_t a_bstride,
                        float time, const FrameOut& out) {
-#define ROWS_LAUNCH_(NCH, SIB, FAPI)                                                                                       \
-  hipLaunchKernelGGL((k_fused_rows<NCH, SIB, FAPI>), grid, dim3(threads), 0, s, (const NodeRec*)f->node_rec,                    \
+#define ROWS_LAUNCH_(NCH, SIB, FAPI, O32)                                                                                  \
+  hipLaunchKernelGGL((k_fused_rows<NCH, SIB, FAPI, O32>), grid, dim3(threads), 0, s, (const NodeRec*)f->node_rec,               \
                      (const int32_t*)f->out_pad, plan->out_ptr, plan->out_dst, (const RowChunk*)plan->row_chunks,         \
                      (const uint32_t*)f->post, Nmax, (uint32_t)B, (uint32_t)plan->N, fb, agent_features, A, a_bstride,    \
                      time, out)
 #define ROWS_LAUNCH(NCH, SIB)                                                                                              \
   do {                                                                                                                     \
     if (fapi) {                                                                                                            \
-      ROWS_LAUNCH_(NCH, SIB, true);                                                                                        \
+      ROWS_LAUNCH_(NCH, SIB, true, false);                                                                                 \
+    } else if (o32) {                                                                                                      \
+      ROWS_LAUNCH_(NCH, SIB, false, true);                                                                                 \
     } else {                                                                                                               \
-      ROWS_LAUNCH_(NCH, SIB, false);                                                                                       \
+      ROWS_LAUNCH_(NCH, SIB, false, false);                                                                                \
     }                                                                                                                      \
   } while (0)
   const bool fapi = out.countsf || out.popped || out.withdrawn;
+  const bool o32 = plan->N * B < ((int64_t)1 << 29);      // 8-byte words addressed through 32-bit byte offsets
   grid.y = (unsigned)num_row_chunks(plan);
   switch (nchunk()) {
     case 1: ROWS_LAUNCH(1, false); break;
