@@ -1128,7 +1128,10 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
   // the event list holds EV_CAP of the TILE * NCH pairs (a filling network lists ~2 %, a loaded one ~30 %); a pair that
   // finds it full runs its event path in place. 7 KB instead of 18: the workgroups a CU holds are bounded by its wave
   // slots, not by LDS, and the waves that have no list entry leave early
-  constexpr int EV_CAP = 384;
+#ifndef TARL_EV_CAP
+#define TARL_EV_CAP 384
+#endif
+  constexpr int EV_CAP = TARL_EV_CAP;
   __shared__ uint16_t s_item[EV_CAP];       // (row offset in the chunk) << 9 | pop << 8 | lane
   __shared__ uint4 s_words[EV_CAP];         // the listed row's {post word, hd, head_dep bits, tl}
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
