@@ -2011,6 +2011,13 @@ extern "C" int tarl_fused_policy_prepare(const tarl_plan* plan, const tarl_fused
   return TARL_OK;
 }
 
+// TARL_ADDR32=0 keeps 64-bit addresses in the frame kernels whatever the batch size (developer knob: the instantiations that
+// batches of 2^29 pairs and more run)
+static bool addr32_ok() {
+  static const bool ok = !(getenv("TARL_ADDR32") && atoi(getenv("TARL_ADDR32")) == 0);
+  return ok;
+}
+
 // rows per lane of the Direction gather (TARL_NCHUNK_DIR = 1, 2 or 4)
 // cnt8: a byte per (row, environment) holding every row's current count (a rollout's count slice of the frame before), or NULL
 static int launch_direction(dim3 grid, unsigned threads, hipStream_t s, const tarl_plan* plan, const tarl_fused* f,
@@ -2030,7 +2037,7 @@ static int launch_direction(dim3 grid, unsigned threads, hipStream_t s, const ta
       DIR_LAUNCH_(NCH, SIB, CNT, false);                                                                                   \
     }                                                                                                                      \
   } while (0)
-  const bool o32 = plan->N * B < ((int64_t)1 << 29);      // 8-byte words addressed through 32-bit byte offsets (at32)
+  const bool o32 = addr32_ok() && plan->N * B < ((int64_t)1 << 29);   // 8-byte words through 32-bit byte offsets (at32)
   // TARL_DIR_SIBLINGS=0 keeps the per-row gathers on a sibling graph (developer knob)
   static const bool sib_ok = !(getenv("TARL_DIR_SIBLINGS") && atoi(getenv("TARL_DIR_SIBLINGS")) == 0);
   // TARL_DIR_COUNT_BYTE=0 keeps the head words as the count's source (developer knob)
@@ -2088,7 +2095,7 @@ static int launch_rows(dim3 grid, unsigned threads, hipStream_t s, const tarl_pl
     }                                                                                                                      \
   } while (0)
   const bool fapi = out.countsf || out.popped || out.withdrawn;
-  const bool o32 = plan->N * B < ((int64_t)1 << 29);      // 8-byte words addressed through 32-bit byte offsets
+  const bool o32 = addr32_ok() && plan->N * B < ((int64_t)1 << 29);   // 8-byte words through 32-bit byte offsets
   grid.y = (unsigned)num_row_chunks(plan);
   switch (nchunk()) {
     case 1: ROWS_LAUNCH(1, false); break;
