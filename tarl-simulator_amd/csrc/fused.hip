@@ -754,6 +754,9 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         const bool a2 = ((dep - t) < -10.0f) & ((max_j - TARL_CONGESTION_FILE) <= n_j);
         x1[q] = a1 ? 0.0f : __uint_as_float(0x7fc00000u);
         slk[q] = a2 ? (max_j - n_j) : __uint_as_float(0x7fc00000u);
+        // a raw SELECTED_ROAD code upstream sends the workgroup to the exact pass; noted per upstream row, whatever the
+        // rows' in-degrees (a padding entry names row 0: at worst a repeat that was not needed)
+        raw_seen = raw_seen | (cj[0][q] == SEL_RAW);
       }
     }
 #pragma unroll
@@ -770,7 +773,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           if (q < nr.in_deg) {   // wave-uniform
-            raw_seen = raw_seen | (cj[r][q] == SEL_RAW);
+            if (!SIB) raw_seen = raw_seen | (cj[r][q] == SEL_RAW);
             bool m;
             if (SIB)
               m = (cj[0][q] == (uint32_t)ir4[q].rank) & (((n_i + x1[q]) < lim_i) | (slk[q] <= room_i));
