@@ -547,3 +547,53 @@ def test_rows_that_fill_to_their_last_slot_equal_unfused(ops, W, H, A, window, f
         e2.frame_fused(choice=ch2, reward=rw2)
         assert torch.equal(ch1, ch2.t()) and torch.equal(e1.reward, rw2), f"continuation frame {t}"
     assert torch.equal(e1.x, e2.x) and torch.equal(e1.agents, e2.agents)
+
+
+def test_raw_selected_road_codes_take_the_exact_direction_pass(ops):
+    """A packed state whose SELECTED_ROAD names none of a road's out-edges carries the raw value (code 0x7F); the Direction
+    gather's dense pass only notes such a code upstream and the workgroup repeats the pass in its exact form (the raw value
+    compared with ROAD_INDEX, as the reference does). Half of the roads of a torus get a valid neighbour, the others values
+    that are no neighbour (another road, -1, a value beyond the graph); no action is drawn afterwards (skip_choice), so the
+    codes stay. Fused frames against the per-op kernels on the reference layout: state and agents bit-identical."""
+    from tarl_hip import synth
+    from tarl_hip.engine import SimEngine
+    net = synth.torus_network(4, 4, heterogeneous=True, seed=5)
+    N, Nmax, B, A = net.num_roads, net.Nmax, 6, 400
+    assert ops.Plan(net.edge_index, N).siblings4
+    g = torch.Generator().manual_seed(3)
+    src_sorted = torch.argsort(net.edge_index[0], stable=True)
+    dst_by_rank = net.edge_index[1][src_sorted].view(N, 4)
+    sel = dst_by_rank[torch.arange(N), torch.randint(0, 4, (N,), generator=g)].float()
+    bogus = torch.tensor([-1.0, float(N + 3), 0.5])[torch.randint(0, 3, (N,), generator=g)]
+    other = ((torch.arange(N) + N // 2) % N).float()          # a road on the far side of the torus: not a neighbour
+    bogus = torch.where(torch.rand(N, generator=g) < 0.3, other, bogus)
+    raw = torch.rand(N, generator=g) < 0.5
+    x0 = net.x.unsqueeze(0).repeat(B, 1, 1).contiguous()
+    x0[:, :, 3 * Nmax + 5] = torch.where(raw, bogus, sel)
+    for b in range(B):                                         # not the same pattern in every environment
+        flip = torch.rand(N, generator=g) < 0.2
+        x0[b, flip, 3 * Nmax + 5] = sel[flip]
+    pops = torch.stack([synth.population(A, N, seed=70 + b, t0=21540, t1=21560) for b in range(B)])
+    mk = lambda fused: SimEngine(x0.clone().cuda(), net.edge_index, net.edge_attr, Nmax, pops.clone().cuda(),
+                                 congestion_constant=net.congestion_constant, seed=11, fused=fused)
+    e1, e2 = mk(False), mk(True)
+    assert int((e2.fs.sel8 & 0x7F == 0x7F).sum()) > N * B // 4          # raw codes are there
+    rw2 = torch.empty(B, device="cuda")
+    moved = 0
+    for s in range(60):
+        t = float(e1.time)
+        e1.noise_counter += 1
+        ops.core_step(e1.plan, e1.x, Nmax, e1.ec, t, congestion_constant=e1.cc, seed=e1.seed, counter=e1.noise_counter,
+                      chosen=e1.chosen, popped=e1.popped, status=e1.status)
+        ops.withdraw_step(e1.plan, e1.x, Nmax, e1.agents, t, want_mask=False)
+        ops.insert_step(e1.x, Nmax, e1.agents, t, congestion_constant=e1.cc, scratch=e1.ins_scratch, reward=e1.reward,
+                        counts=e1.counts)
+        e1.time += e1.timestep
+        e2.frame_fused(skip_choice=True, reward=rw2)
+        moved += int(e1.popped.sum())
+        assert torch.equal(e1.reward, rw2), f"reward frame {s}"
+        assert torch.equal(e1.agents, e2.agents), f"agents frame {s}"
+        if s % 5 == 4:
+            assert torch.equal(e1.x, e2.x), f"state frame {s}"
+    assert moved > 0 and float(e1.agents[:, :, 7].sum()) > 0          # agents entered and moved along the fixed choices
+    assert int((e2.fs.sel8 & 0x7F == 0x7F).sum()) > N * B // 4          # and the raw codes are still there
