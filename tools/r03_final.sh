@@ -14,7 +14,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_policy -o run --
 rm -f $O/*/run_kernel_trace.csv
 echo "[r03_final] kernel stats done"
 # 2. HBM traffic (PMC passes, default + congested) with the request counters beside FETCH_SIZE / WRITE_SIZE
-bash tools/r03_pmc.sh $TAG/pmc "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" > $O/pmc.log 2>&1
+bash tools/r03_pmc.sh $TAG/pmc "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_WAVE_CYCLES" > $O/pmc.log 2>&1
 cp $O/pmc/pmc_traffic.json profiles/r03_pmc_traffic.json
 cp $O/pmc/pmc_traffic_congested.json profiles/r03_pmc_traffic_congested.json
 echo "[r03_final] pmc done"
