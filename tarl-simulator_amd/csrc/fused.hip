@@ -1154,7 +1154,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
   // finds it full runs its event path in place. 7 KB instead of 18: the workgroups a CU holds are bounded by its wave
   // slots, not by LDS, and the waves that have no list entry leave early
 #ifndef TARL_EV_CAP
-#define TARL_EV_CAP 384
+#define TARL_EV_CAP 384      // (developer override through `make variant EXPFLAGS=-DTARL_EV_CAP=...`: 512 and 768 measure the same)
 #endif
   constexpr int EV_CAP = TARL_EV_CAP;
   __shared__ uint16_t s_item[EV_CAP];       // (row offset in the chunk) << 9 | pop << 8 | lane
