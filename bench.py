@@ -396,6 +396,12 @@ def main():
                    "compulsory_bytes_per_launch": comp,
                    "compulsory_frac": (comp / late_s / 1e9 / HBM_PEAK_GBS) if late_s > 0 else 0.0,
                    "traffic_over_compulsory": (traffic / comp) if (traffic is not None and comp > 0) else None}
+            if traffic is not None:
+                # frac = traffic / time / peak moves with BOTH terms: round 3 cut the row pass's traffic (1 289 -> 889 MB) by
+                # more than its time (245 -> 205 us), so the fraction fell while the kernel got faster; compulsory_frac and
+                # traffic_over_compulsory separate the two
+                out["note"] = ("frac falls when re-reads are removed faster than time: compare avg_launch_us and "
+                               "traffic_over_compulsory across rounds, not frac alone")
             if k and "raw_frac_bracket" in k:      # the same fraction with no correction / the guide's blanket 2x on FETCH_SIZE
                 out["frac_uncorrected_to_blanket_2x"] = [b_ / late_s / 1e9 / HBM_PEAK_GBS for b_ in k["raw_frac_bracket"]]
             if kernel in SURVEY_8D:
