@@ -39,6 +39,9 @@ import os
 import sys
 import time
 
+# before torch is imported (the HIP runtime reads it once): dmabuf IPC, which RCCL needs on hosts without legacy IPC — also
+# when the ranks come from an external `torchrun bench.py` (the driver's launch line) whose environment lacks it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "tarl-simulator_amd")):
     if p not in sys.path:
@@ -51,7 +54,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 T
 LATE_FRAME = 200          # the roofline window: frames >= 200 of an iteration (traffic and live time alike)
 # written by tools/pmc_bench.py from --pmc passes of this script (one record per workload: the default line and the
 # congested regime), with the per-kernel counter corrections measured by tools/pmc_cal.hip (profiles/r03_pmc_calibration.txt)
-PMC_RECORDS = (os.path.join("profiles", "r03_pmc_traffic.json"), os.path.join("profiles", "r03_pmc_traffic_congested.json"))
+PMC_RECORDS = (os.path.join("profiles", "r04_pmc_traffic.json"), os.path.join("profiles", "r04_pmc_traffic_congested.json"))
 # Compulsory HBM bytes per (road, environment) and launch of the packed env-minor layout: what each kernel
 # must read and write once, neighbour gathers served by the XCD's L2, statics / topology / policy tables through the
 # scalar cache (shared by all environments, not counted).
@@ -66,8 +69,9 @@ COMPULSORY = {
     "k_fused_insert": {"per_node_env": 0.0},
 }
 # SURVEY §8d's per-unit figures for the reference's AoS layout (kept as ``survey_8d_*`` keys only): Direction message +
-# aggregate 52 B/edge + 4 B/node; row pass = Direction update 32 B/node + Response message/aggregate 24 B/edge.
-SURVEY_8D = {"k_fused_direction": (52.0, 4.0), "k_fused_rows": (24.0, 32.0)}
+# aggregate 60 B/edge (8 indices + 4 edge_attr + 4 noise + 28 x_j + 12 x_i + 4 delta_tt out); row pass = Direction update
+# 32 B/node + Response message/aggregate 24 B/edge (its 344 B per popped road not counted).
+SURVEY_8D = {"k_fused_direction": (60.0, 0.0), "k_fused_rows": (24.0, 32.0)}
 
 
 def parse():
@@ -133,37 +137,105 @@ def build_trainer(args, rank, device):
     return net, engine, trainer
 
 
+def physical_cores_one_socket():
+    """Physical cores of socket 0 (unique core ids under physical id 0 in /proc/cpuinfo); the logical count if unknown."""
+    try:
+        cores, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = int(line.split(":")[1])
+            elif line.startswith("core id"):
+                core = int(line.split(":")[1])
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+        first = min(p for p, _ in cores)
+        n = len([1 for p, _ in cores if p == first])
+        if n > 0:
+            return min(n, os.cpu_count() or n)
+    except (OSError, ValueError):
+        pass
+    return os.cpu_count() or 1
+
+
 def cpu_baseline(args, net):
-    """Oracle rollout (policy logits -> GraphDistribution -> sample -> env step) of ONE environment at the bench's
-    config size on the host CPU; bounded by --cpu-seconds."""
-    from oracle import sim, dist, nets
+    """The oracle (CPU restatement of the reference path, torch CPU) on ONE environment at the bench's config size, on the
+    host's cores, bounded by --cpu-seconds: a rollout (policy logits -> GraphDistribution sample + log_prob -> env step)
+    that keeps what the collector keeps, then ONE PPO update on those frames as the reference's loop runs it
+    (src/rl/ppo_trainer.py:129-145: critic over all frames, GAE, a minibatch of --sub-batch frames, ClipPPOLoss, backward,
+    Adam) — ``value`` = frames / (rollout + update), like the GPU ``value``; ``value_rollout_only`` beside it."""
+    from oracle import sim, dist, nets, ppo
     from tarl_hip import synth
     N, Nmax, E = net.num_roads, net.Nmax, net.edge_index.size(1)
     adj = net.dense_adjacency()
-    w = torch.randn(N)
+    gen = torch.Generator().manual_seed(args.seed)
+    w = torch.randn(N, generator=gen)
 
-    def rollout(x, ag, t, budget_s, max_steps):
+    def rollout(x, ag, t, budget_s, max_steps, keep=None):
         steps, t0 = 0, time.perf_counter()
         while True:
-            d = dist.GraphDist(nets.policy_logits(sim.observe(x, Nmax)[0], net.edge_index, w), net.edge_index)
+            nf = sim.observe(x, Nmax)[0]
+            d = dist.GraphDist(nets.policy_logits(nf, net.edge_index, w), net.edge_index)
             a = d.sample()
-            d.log_prob(a)
-            sim.env_step(x, ag, net.edge_index, net.edge_attr, adj, a, t, Nmax,
-                         congestion_constant=net.congestion_constant)
+            lp = d.log_prob(a)
+            if keep is not None:
+                keep["counts"].append(nf[..., 1].reshape(-1).clone())
+                keep["action"].append(a.reshape(-1).clone())
+                keep["logp"].append(lp.reshape(-1)[0].clone())
+                keep["time"].append(float(t))
+            out = sim.env_step(x, ag, net.edge_index, net.edge_attr, adj, a, t, Nmax,
+                               congestion_constant=net.congestion_constant)
+            if keep is not None:
+                keep["reward"].append(-float(x[:, 3 * Nmax + 1].sum()))     # reward = -(agents in the network), as _step's
+            del out
             t += 1
             steps += 1
             el = time.perf_counter() - t0
             if el >= budget_s or steps >= max_steps:
+                if keep is not None:
+                    keep["counts"].append(sim.observe(x, Nmax)[0][..., 1].reshape(-1).clone())
+                    keep["time"].append(float(t))
                 return steps, el
 
-    # the oracle's ops are small: more threads can be slower. Probe a few thread counts (always including ALL cores of
-    # this host, the figure BASELINE.md promises), report each, time the long sample with the fastest.
-    ncpu = os.cpu_count() or 1
+    def update(keep):
+        """One PPO update on the kept frames: oracle/ppo.py + autograd, the reference's optimiser step."""
+        t0 = time.perf_counter()
+        T = len(keep["reward"])
+        counts = torch.stack(keep["counts"])                               # (T + 1, N)
+        times = torch.tensor(keep["time"], dtype=torch.float32)
+        nf_all = torch.zeros((T + 1, 1, N, 7))
+        nf_all[:, 0, :, 1] = counts
+        nf_all[:, 0, :, 6] = torch.arange(N, dtype=torch.float32)
+        g2 = torch.Generator().manual_seed(args.seed + 1)
+        cw = [torch.randn(s_, generator=g2) * 0.05 for s_ in ((64, N + 1), (64,), (64, 64), (64,), (1, 64), (1,))]
+        emb = w.clone().requires_grad_(True)
+        cw = [c.requires_grad_(True) for c in cw]
+        with torch.no_grad():
+            v_all = nets.critic_value(nf_all, times.view(T + 1, 1, 1), *cw).reshape(T + 1, 1)
+            reward = torch.tensor(keep["reward"], dtype=torch.float32).view(T, 1)
+            z = torch.zeros((T, 1))
+            adv, tgt = ppo.gae(reward, v_all[:T], v_all[1:], z, z, average_gae=T > 1)
+        M = min(args.sub_batch, T)
+        idx = torch.randperm(T, generator=g2)[:M]
+        onehot = torch.stack(keep["action"])[idx]
+        nf_mb = nf_all[idx, 0]
+        d = dist.GraphDist(nets.policy_logits(nf_mb, net.edge_index, emb), net.edge_index)
+        lp_new, ent = d.log_prob(onehot), d.entropy()
+        value = nets.critic_value(nf_mb, times[idx].view(M, 1), *cw).reshape(-1)
+        losses = ppo.clip_ppo_loss(lp_new, torch.stack(keep["logp"])[idx], adv.view(-1)[idx], value, tgt.view(-1)[idx], ent)
+        (losses["loss_objective"] + losses["loss_critic"] + losses["loss_entropy"]).backward()
+        for p in [emb] + cw:
+            ppo.adam_step(p.data, p.grad, torch.zeros_like(p), torch.zeros_like(p), 1)
+        return time.perf_counter() - t0
+
+    # the oracle's ops are small: more threads can be slower. Probe a few thread counts — up to the PHYSICAL cores of one
+    # socket (beyond that the probe measures oversubscription of a few-thousand-element ops, not the machine) — report each,
+    # time the long sample with the fastest.
+    ncpu, nsock = os.cpu_count() or 1, physical_cores_one_socket()
     best_nt, best_rate, by_threads = 1, 0.0, {}
-    for nt in sorted({1, min(8, ncpu), min(16, ncpu), ncpu}):
+    for nt in sorted({1, min(8, nsock), min(16, nsock), nsock}):
         torch.set_num_threads(nt)
-        # (on a many-core host the all-core setting is slower by orders of magnitude — the oracle's ops are a few thousand
-        # elements each —: one warm-up step and at most two probe steps there)
         many = nt > 16
         rollout(net.x.clone(), synth.population(args.agents, N, seed=args.seed), 21540, 0.3, 1 if many else 2)       # warm up
         st, el = rollout(net.x.clone(), synth.population(args.agents, N, seed=args.seed), 21540, 1.0, 2 if many else 64)
@@ -171,13 +243,27 @@ def cpu_baseline(args, net):
         if st / el > best_rate:
             best_nt, best_rate = nt, st / el
     torch.set_num_threads(best_nt)
-    steps, el = rollout(net.x.clone(), synth.population(args.agents, N, seed=args.seed), 21540, args.cpu_seconds, 8192)
-    return {"value": steps / el, "unit": "env-steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "all_cores": {"cores": ncpu, "value": by_threads[str(ncpu)], "unit": "env-steps/s",
-                          "sample": "1 s probe of the same rollout with torch.set_num_threads(all host cores)"},
+    # PPO iterations as the reference runs them (reset, collect rollout_steps frames, one update) until the budget is spent
+    steps, el, up, iters, t_all = 0, 0.0, 0.0, 0, time.perf_counter()
+    while True:
+        keep = {"counts": [], "action": [], "logp": [], "time": [], "reward": []}
+        left = max(0.05, args.cpu_seconds - (time.perf_counter() - t_all))
+        st_i, el_i = rollout(net.x.clone(), synth.population(args.agents, N, seed=args.seed + iters), 21540, left,
+                             args.rollout_steps, keep)
+        up += update(keep)
+        steps, el, iters = steps + st_i, el + el_i, iters + 1
+        if time.perf_counter() - t_all >= args.cpu_seconds:
+            break
+    return {"value": steps / (el + up), "unit": "env-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "value_rollout_only": steps / el, "update_seconds": up, "rollout_seconds": el,
+            "all_cores": {"cores": nsock, "value": by_threads[str(nsock)], "unit": "env-steps/s",
+                          "logical_cpus_of_the_host": ncpu,
+                          "sample": "1 s probe of the same rollout with torch.set_num_threads(physical cores of one socket)"},
             "by_threads_1s_probe": by_threads,
-            "sample": f"{steps} env steps of 1 environment (oracle rollout: policy logits, GraphDistribution sample + "
-                      f"log_prob, env step) on the {E}-edge / {args.agents}-agent workload, {el:.1f} s, torch CPU"}
+            "sample": f"{iters} PPO iteration(s) of 1 environment: {steps} env steps (oracle rollout: policy logits, "
+                      f"GraphDistribution sample + log_prob, env step; at most {args.rollout_steps} per iteration) + one update "
+                      f"per iteration (critic over all frames, GAE, minibatch of {args.sub_batch}, ClipPPOLoss, autograd "
+                      f"backward, Adam) on the {E}-edge / {args.agents}-agent workload, {el:.1f} s + {up:.2f} s, torch CPU"}
 
 
 def spawn_ranks(args):
@@ -246,11 +332,27 @@ def main():
     elapsed_rank = time.perf_counter() - t0
     elapsed = dist_utils.allreduce_max_float(elapsed_rank, device)
     per_rank = dist_utils.gather_floats([setup_s, elapsed_rank], device)     # [rank][setup_seconds, timed_seconds]
+    # data-parallel evidence (outside the timed region): after `steps` averaged-gradient Adam steps every replica must still
+    # hold rank 0's parameter bits
+    replica_diff = dist_utils.replica_max_abs_diff(trainer.flat.flat)
 
     ms_all, ms_late, nfr = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int64 * 2)()
     late0 = LATE_FRAME if T > LATE_FRAME else 0
     lib.check(L.tarl_prof_collect(late0, ms_all, ms_late, nfr))
     L.tarl_prof_enable(0)
+    trainer.check_flags()
+
+    # rollout-only figure (BASELINE.md §3 / SURVEY §8d: "rollout + update, and rollout-only"): the collector loop alone, timed
+    # the same way right behind the headline region
+    dist_utils.barrier()
+    torch.cuda.synchronize()
+    t_ro = time.perf_counter()
+    ro_frames = 0
+    for _ in range(min(args.steps, 3)):
+        ro_frames += trainer.collect()
+    torch.cuda.synchronize()
+    dist_utils.barrier()
+    ro_elapsed = dist_utils.allreduce_max_float(time.perf_counter() - t_ro, device)
     trainer.check_flags()
 
     # ---- second line of evidence: the congested regime -------------------------------------------------------------------
@@ -360,14 +462,18 @@ def main():
         NB = B * n_roads
 
         def pmc_record(window):
-            """The committed PMC record of this workload (config + layout revision must match), or None."""
+            """The committed PMC record of this workload, or None: the config must match AND the record must have been taken
+            on the very frame-kernel sources this run executes (sha256 of csrc/fused.hip + fused_common.h) — a kernel edit
+            without a fresh PMC pass falls back to the compulsory bytes instead of pairing new times with old bytes."""
+            from tarl_hip.ops import frame_kernel_source_hash
+            sha = frame_kernel_source_hash()
             want = {"edges": E, "agents": args.agents, "envs": B, "rollout_steps": T}
             if window:
                 want["departure_window"] = window
             for path in PMC_RECORDS:
                 try:
                     rec = json.load(open(os.path.join(ROOT, path)))
-                    if rec["config"] == want and rec.get("layout") == layout_tag:
+                    if rec["config"] == want and rec.get("source_sha16") == sha:
                         rec["path"] = path
                         return rec
                 except (OSError, KeyError, ValueError):
@@ -426,6 +532,7 @@ def main():
             congested["msgpass_pair_edges_per_sec"] = (B * E) / (c_dir_s + c_rows_s) if (c_dir_s + c_rows_s) > 0 else None
         out = {
             "metric": "ppo_env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
+            "value_rollout_only": ro_frames * world / ro_elapsed if ro_elapsed > 0 else None,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"mpnn+ppo train, {E}-edge synthetic torus dual graph ({n_roads} roads), "
@@ -441,6 +548,7 @@ def main():
             "setup_seconds": setup_s, "timed_seconds": elapsed,
             "per_rank": {"setup_seconds": [r_[0] for r_ in per_rank], "timed_seconds": [r_[1] for r_ in per_rank]},
             "world_size_seen_by_backend": dist_utils.world()[1], "dist_backend": dist_utils.backend_name(),
+            "replica_param_max_abs_diff": replica_diff,
             "congested_regime": congested,
             "state_dependent_policy": policy_lines,
         }

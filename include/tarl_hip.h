@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TARL_ABI_VERSION 3
+#define TARL_ABI_VERSION 4
 
 typedef enum {
   TARL_OK = 0,
@@ -294,12 +294,13 @@ int tarl_value_mpnn_bwd(const tarl_plan* plan, const float* node_features, int64
 /* ---- fused rollout frame (vectorised fast path; same results as the entry points above, 3-4 launches per frame) --------
  * ENV-MINOR layout: every per-(node, environment) buffer is stored [node][environment], so that a wavefront holds 64
  * environments of one node: topology / table loads are wave-uniform and record gathers are coalesced.
- * Caller-owned side buffers that mirror x / agent_features (all device memory, 16-byte aligned). Packed words ("v6"):
+ * Caller-owned side buffers that mirror x / agent_features (all device memory, 32-byte aligned). Packed words ("v11"):
  *   hdp  uint32 [N][B][2] = {head_id << 8 | NUMBER_OF_AGENT, bits of the head's departure time}
- *   tl   uint32 [N][B]    = tail_id << 8 | ring-buffer head offset << 1 | bit 0: rec1 is authoritative for the last frame
+ *   tl   uint32 [N][B]    = tail_id << 8 | ring-buffer head offset << 1 | bit 0: gc8 is authoritative for the last frame
  *   post uint32 [N][B]    = state after the Direction update: tail' << 8 | non-empty' << 1 | arrived
- *   rec1 uint32 [N][B][2] = {bits of the head's arrival time, pending-garbage count + 1}; only WRITTEN, and only by rows
- *                           where something moves in a frame
+ *   gc8  uint8  [N][B]    = pending-garbage count + 1; only WRITTEN, and only by rows where something moves in a frame
+ *                           (ABI version 4; version 3 kept an 8-byte word {head arrival, code} here: the head's arrival
+ *                           time is the arrival field of the head's slot record and is no longer stored twice)
  *   sel8 uint8  [N][B]    = SELECTED_ROAD as the rank of the chosen out-edge in the node's CSR list (bit 7: carried over
  *                           from the previous frame; 0x7F: the fp32 value in sel [N][B] is authoritative)
  *   static records built by pack and shared by all environments (read through the scalar cache): node_rec int32/fp32
@@ -310,7 +311,7 @@ int tarl_value_mpnn_bwd(const tarl_plan* plan, const float* node_features, int64
  *   out-edge (sizes are checked against csrc/fused_common.h by static_assert; tarl_hip/ops.py:FusedState allocates them)
  *   st0  [N][4]    = {MAX_NUMBER_OF_AGENT, FREE_FLOW_TIME_TRAVEL, ROAD_INDEX, congestion_constant} (static, shared)
  *   slots [N][B][ld_slots]: slot-interleaved FIFO store, slot s at floats 3s..3s+2 = {agent id, arrival, departure};
- *                  ld_slots >= 3*Nmax (pad to a multiple of 16 floats)
+ *                  ld_slots = tarl_fused_slot_floats(Nmax) (>= 3*Nmax, padded to a multiple of 16 floats)
  *   acc_lp int64 [acc_slots][B], acc_n / acc_w fp32 [acc_slots][B]: per-frame accumulator banks (log-prob in 2^-32 fixed
  *   point, sum of counts, agents withdrawn; zeroed by pack; acc_slots >= 1 banks spread the atomics of the many
  *   workgroups that serve one environment)
@@ -334,7 +335,7 @@ int tarl_value_mpnn_bwd(const tarl_plan* plan, const float* node_features, int64
 typedef struct tarl_fused {
   void* hdp;
   void* tl;
-  void* rec1;
+  uint8_t* gc8;
   void* post;
   float* st0;
   float* slots;
@@ -372,10 +373,13 @@ typedef struct tarl_fused {
   int32_t reserved_;
 } tarl_fused;
 
+/* floats per (node, environment) row of tarl_fused.slots for FIFOs of Nmax slots */
+int64_t tarl_fused_slot_floats(int32_t Nmax);
 int tarl_fused_pack(const tarl_plan* plan, const tarl_fused* f, const float* x, int64_t B, int64_t x_bstride,
                     int64_t ldx, int32_t Nmax, const float* congestion_constant, const float* edge_attr,
                     const float* agent_features, int64_t num_agents, int64_t a_bstride, tarl_stream stream);
-/* tarl_fused_reset == tarl_reset_state applied to the packed state (SimulatorEnv._reset): zero the FIFO store and the
+/* tarl_fused_reset == tarl_reset_state applied to the packed state (SimulatorEnv._reset): empty every FIFO (count 0, row
+ *   CLEAN: its slots are logically zero from here on, the store itself is not touched), zero the
  *   counters, keep SELECTED_ROAD, clear ON_WAY / DONE in agent_features (for the agents the status SoA marks as on the
  *   way / done, i.e. everything that changed since tarl_fused_pack) and the status SoA, re-arm the insert cursor. */
 int tarl_fused_reset(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, float* agent_features,

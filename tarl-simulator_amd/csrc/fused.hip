@@ -18,14 +18,17 @@
 //   * the live policy's sample is state-independent (see k_policy_tables): the choice phase is a table walk per
 //     (node, env) with Philox blocks shared across consecutive nodes;
 //   * ONE row pass applies Direction update + Response pop + withdraw. A row where nothing moves (nobody enqueued, no pop,
-//     head not due) touches nothing but its dense words; the EVENT-ONLY word rec1 = {head_arr, pending-garbage count,
-//     ring offset} and the FIFO store are read / written only by the rows that move something;
+//     head not due) touches nothing but its dense words; the EVENT-ONLY byte gc8 (pending-garbage count) and the FIFO
+//     store are written only by the rows that move something (the head's arrival time is never stored beside the dense
+//     words: it is the arrival field of the head's slot record, fused_common.h: head_arrival);
 //   * the FIFO contents live in a slot-interleaved store  slots[node][env][s] = {id, arrival, departure}: the Direction
-//     update's per-row write is ONE 12-byte store instead of three dwords in three DRAM sectors (+ counter);
+//     update's per-row write is ONE 12-byte store instead of three dwords in three DRAM sectors (+ counter). (32-byte
+//     records — a store then fills its sector, no read-modify-write at the memory side — were measured in round 4 and
+//     rejected: fused_common.h, TARL_SLW);
 //   * LAZY GARBAGE SLOT: a row that receives nobody still gets (0, t, t + tt) written into its first dead slot by the
 //     reference. That value is never read by the simulation, is overwritten by the next frame's update (or
 //     by an insertion) before anything can move it, and only shows in x. It is never stored: for a row that was idle in
-//     the last frame the count at the write is its count, otherwise rec1 holds it (TLF_AUTH), and the export kernel
+//     the last frame the count at the write is its count, otherwise gc8 holds it (TLF_AUTH), and the export kernel
 //     materialises the triple (same fp32 expression, same slot). The one case where the pop's "last slot keeps its value"
 //     rule would duplicate it (count == Nmax-1) is written eagerly;
 //   * RING-BUFFER FIFOs: the reference pops by shifting all Nmax slots (and withdraws with a zero-filled shift). Here a
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(FB) void k_pack_nodes(const float* __restrict__ x, 
     dirty = dirty || xi[sidx] != 0.0f || xi[Nmax + sidx] != 0.0f || xi[2 * Nmax + sidx] != 0.0f;
   fb.hdp[gid] = make_uint2(((uint32_t)head << 8) | (uint32_t)(q & (int)HD_CNT) | (dirty ? HD_DIRTY : 0u), __float_as_uint(xi[2 * Nmax]));
   fb.tl[gid] = tl_word((uint32_t)tail, 0, TLF_AUTH);
-  fb.rec1[gid] = make_uint2(__float_as_uint(xi[Nmax]), r1_code(-1));
+  fb.gc8[gid] = (uint8_t)r1_code(-1);
   fb.post[gid] = ((uint32_t)tail << 8) | (q > 0 ? PF_NONEMPTY : 0u);
   // SELECTED_ROAD: the rank of the out-edge it names, or the raw value when it names none of them
   const float sv = xi[L.col_sel()];
@@ -88,11 +91,7 @@ __global__ __launch_bounds__(FB) void k_pack_nodes(const float* __restrict__ x, 
     }
   }
   float* sl = fb.slots + gid * fb.lds;
-  for (int sidx = 0; sidx < Nmax; ++sidx) {
-    sl[3 * sidx + 0] = xi[sidx];
-    sl[3 * sidx + 1] = xi[Nmax + sidx];
-    sl[3 * sidx + 2] = xi[2 * Nmax + sidx];
-  }
+  for (int sidx = 0; sidx < Nmax; ++sidx) slot_store(sl + SLW * sidx, xi[sidx], xi[Nmax + sidx], xi[2 * Nmax + sidx]);
   if (b == 0 && st0_out) {
     const float maxn = xi[L.col_maxn()], ff = xi[L.col_ff()];
     float c;
@@ -178,7 +177,7 @@ __global__ __launch_bounds__(FB) void k_fused_reset_nodes(int64_t B, int64_t N, 
   if (gid >= B * N) return;
   fb.hdp[gid] = make_uint2(0u, 0u);
   fb.tl[gid] = TLF_AUTH;
-  fb.rec1[gid] = make_uint2(0u, r1_code(-1));
+  fb.gc8[gid] = (uint8_t)r1_code(-1);
   fb.post[gid] = 0u;
   if (gid < B) {
     for (int64_t sl_ = 0; sl_ < fb.acc_slots; ++sl_) {
@@ -216,11 +215,11 @@ __global__ __launch_bounds__(FB) void k_export_rows(float* __restrict__ x, Layou
   const int64_t i = row / B, b = row - i * B;
   float* xi = x + b * L.bstride + i * L.ldx;
   const uint32_t hd = fb.hdp[row].x;
-  const uint32_t code = fb.rec1[row].y;
+  const uint32_t code = fb.gc8[row];
   const int n = (int)(hd & HD_CNT);
   const uint32_t tlw = fb.tl[row];
   const int g = pending_g(tlw, n, code, Nmax);
-  const float* sl = fb.slots + row * fb.lds + 3 * phys(tl_hoff(tlw), sidx, Nmax);  // un-rotate the ring buffer
+  const float* sl = fb.slots + row * fb.lds + SLW * phys(tl_hoff(tlw), sidx, Nmax);  // un-rotate the ring buffer
   if (g >= 0 && sidx == n) {  // pending garbage write of the last Direction update -> first dead slot
     const float tt = entry_tt(fb.st0[i], (float)g);
     xi[sidx] = 0.0f;
@@ -253,21 +252,18 @@ __global__ __launch_bounds__(FB) void k_dead_slots(int64_t B, int64_t N, int Nma
   if (row >= B * N) return;
   const uint32_t hd = fb.hdp[row].x, tlw = fb.tl[row];
   const int n = (int)(hd & HD_CNT), hoff = tl_hoff(tlw);
-  const int g = pending_g(tlw, n, fb.rec1[row].y, Nmax);
+  const int g = pending_g(tlw, n, fb.gc8[row], Nmax);
   float* sl = fb.slots + row * fb.lds;
   const int first = (g >= 0) ? n + 1 : n;       // the slot at the count holds the pending garbage (never stored) or is dead
   if (materialise) {
     if (hd & HD_DIRTY) return;
     for (int sidx = first; sidx < Nmax; ++sidx) {
-      float* z = sl + 3 * phys(hoff, sidx, Nmax);
-      z[0] = 0.0f;
-      z[1] = 0.0f;
-      z[2] = 0.0f;
+      slot_store(sl + SLW * phys(hoff, sidx, Nmax), 0.0f, 0.0f, 0.0f);
     }
   } else {
     bool dirty = n >= Nmax - 1;
     for (int sidx = first; sidx < Nmax; ++sidx) {
-      const float* z = sl + 3 * phys(hoff, sidx, Nmax);
+      const float* z = sl + SLW * phys(hoff, sidx, Nmax);
       dirty = dirty || z[0] != 0.0f || z[1] != 0.0f || z[2] != 0.0f;
     }
     fb.hdp[row].x = (hd & ~HD_DIRTY) | (dirty ? HD_DIRTY : 0u);
@@ -695,7 +691,8 @@ template <int NCH, bool SIB, bool CNT, bool O32>
 __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fused_direction(
     const NodeRec* __restrict__ nodes, const InRec* __restrict__ in_rec, const int32_t* __restrict__ in_eid,
     const float* __restrict__ log_edge_attr, const uint2* __restrict__ hdp, const uint32_t* __restrict__ tl,
-    const uint8_t* __restrict__ cnt8, const uint2* __restrict__ rec1, const uint8_t* __restrict__ sel8,
+    const uint8_t* __restrict__ cnt8, const uint8_t* __restrict__ gc8, const float* __restrict__ slots, int64_t lds,
+    int Nmax, const uint8_t* __restrict__ sel8,
     const float* __restrict__ sel_raw,
     const float* __restrict__ gumbel, float* __restrict__ dtt, uint32_t* __restrict__ post, float log_eps, float t,
     float t_prev, uint64_t seed, uint64_t counter, uint32_t E, uint32_t B, uint32_t N, FrameOut out, uint64_t env_base) {
@@ -807,8 +804,9 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     for (uint32_t i = i0; i < i0 + NCH && i < N; ++i) {
       const uint32_t row = i * B + b;
       const uint2 mw = hdp[row];
-      const bool lazy_i = (mw.x & HD_CNT) == 0u && !(tl[row] & TLF_AUTH);   // empty and idle in the last frame: its garbage
-      const float arr_i = lazy_i ? t_prev : __uint_as_float(rec1[row].x);  // head arrived at that frame's clock and
+      const uint32_t tw = tl[row];
+      const bool lazy_i = (mw.x & HD_CNT) == 0u && !(tw & TLF_AUTH);   // empty and idle in the last frame: its garbage
+      const float arr_i = head_arrival(slots, lds, gc8, row, mw.x, tw, Nmax, t_prev);   // head arrived at that frame's clock and
       const float dep_i = lazy_i ? t_prev + nodes[i].tt0 : __uint_as_float(mw.y);   // departs tt0 later (never stored)
       const float d = (dep_i - arr_i) - nodes[i].ff;
       out.dtt_node[(int64_t)i * out.m_env + b] = d > 0.0f ? d : (d != d ? d : 0.0f);
@@ -835,8 +833,9 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
             P = P + ir[q].ea * (m ? 1.0f : 0.0f);
           }
           if (dtt) {   // per-edge side output of DirectionMPNN.message (src/direction_mpnn.py:94-96): a property of j
-            const bool lazy_j = (hx.x & HD_CNT) == 0u && !(tl[jrow] & TLF_AUTH);
-            const float arr_j = lazy_j ? t_prev : __uint_as_float(rec1[jrow].x);
+            const uint32_t tj = tl[jrow];
+            const bool lazy_j = (hx.x & HD_CNT) == 0u && !(tj & TLF_AUTH);
+            const float arr_j = head_arrival(slots, lds, gc8, jrow, hx.x, tj, Nmax, t_prev);
             const float dep_j = lazy_j ? t_prev + nodes[j].tt0 : __uint_as_float(hx.y);
             const float d = (dep_j - arr_j) - nodes[j].ff;
             dtt[(int64_t)b * E + in_eid[nr.in0 + q]] = d > 0.0f ? d : (d != d ? d : 0.0f);
@@ -987,143 +986,163 @@ __device__ __forceinline__ bool row_phase_a(uint32_t i, uint32_t b, const RowSta
 // Response pop, withdraw, refreshed dense words + event word. -> {count after the pass, agents withdrawn}
 template <bool FAPI>
 __device__ __forceinline__ float2 row_phase_b(uint32_t i, uint32_t b, bool pop, uint32_t pa, uint2 hp, uint32_t tlw,
-                                              const NodeRec& nr, const int32_t* __restrict__ out_ptr,
+                                              const NodeRec* __restrict__ nodes, const int32_t* __restrict__ out_ptr,
                                               const int32_t* __restrict__ out_dst, int Nmax, uint32_t B, uint32_t N,
                                               const FusedBufs& fb, float* __restrict__ ag, int64_t A, int64_t a_bstride,
                                               float t, const FrameOut& out) {
-  const PlanOut P{out_ptr, out_dst};
   const uint32_t row = i * B + b;
-  const float4 st = make_float4(nr.maxn, nr.ff, nr.road, nr.cong);
+  const NodeRec& nr = nodes[i];
   const uint32_t n0i = hp.x & HD_CNT, head_id0 = hp.x >> 8, tail0 = tlw >> 8;
   const uint32_t arrived = pa & PF_ARRIVED;
   const uint32_t who = arrived ? (pa >> 8) : 0u;
   const float n0 = (float)n0i;
   const int q = (int)n0i;
+  float* sl = fb.slots + (int64_t)row * fb.lds;  // slot s = sl[SLW s ..] = {id, arrival, departure}
+  int hoff = tl_hoff(tlw);     // (the event byte gc8 is write-only here: no load sits between the row and its slots)
+  const uint32_t ni = n0i + arrived;   // count after the Direction update
+  // ---- the loads whose address follows from the list entry alone AND that are certain to be needed are requested now,
+  // before anything is computed: the event path is a chain of dependent memory rounds a few lanes wide. (a) the record of
+  // the head a pop exposes (the second slot; not when that is the agent enqueued in this very frame: registers), (b) for an
+  // unpopped head that is DUE (the withdraw scan's first two tests, on registers): its destination and the out-edge
+  // targets the withdraw test compares it with. Nothing is requested on speculation: the pass is bound by the NUMBER of
+  // scattered requests as much as by their latency (round 4: a destination gather for every unpopped event row instead of
+  // the ~quarter that are due cost +15 % in the loaded network).
+  const bool pop_slot = pop & (n0i >= 2u);                       // new head = old logical slot 1, stored in an earlier frame
+  SlotRec nh{0.0f, 0.0f, 0.0f};
+  if (pop_slot) nh = slot_load(sl + SLW * phys(hoff, 1, Nmax));
+  const float4 st = make_float4(nr.maxn, nr.ff, nr.road, nr.cong);
+  const float dep_new = t + entry_tt(st, n0);
+  const uint32_t head_pre = (n0i == 0u) ? who : head_id0;
+  const float dep_pre = (n0i == 0u) ? dep_new : __uint_as_float(hp.y);
+  const bool due0 = (!pop) & (ni > 0u) & ((int64_t)head_pre < A) & (dep_pre <= t);
+  // the withdraw test "is the agent's destination an out-neighbour of this road" (src/agents/base.py:334-403) needs the
+  // out-edge targets of node ROAD_INDEX(i): the first four travel in that node's record (for a road row ROAD_INDEX(i) = i:
+  // this very record), one L2 round instead of the out_ptr -> out_dst -> compare chain; loaded when a candidate is due
+  const long long road = (long long)st.z;
+  const bool road_ok = road >= 0 && road < (long long)N;
+  const NodeRec& rr = nodes[road_ok ? road : (long long)i];
+  int32_t dest0 = -1, r_deg = 0, r_out0 = 0, r_o0 = 0, r_o1 = 0, r_o2 = 0, r_o3 = 0;
+  bool have_rr = false;
+  auto load_road = [&]() {
+    r_deg = road_ok ? rr.out_deg : 0;
+    r_out0 = rr.out0;
+    r_o0 = rr.out4[0];
+    r_o1 = rr.out4[1];
+    r_o2 = rr.out4[2];
+    r_o3 = rr.out4[3];
+    have_rr = true;
+  };
+  if (due0) {
+    dest0 = fb.a_dest[(int64_t)b * A + head_pre];
+    load_road();
+  }
   // exact, slot-by-slot bookkeeping of the dead slots: rows that are dirty already, and from the moment the FIFO touches
   // its last slot (count >= Nmax - 1: no dead slot is left above the one this update writes, so nothing has to be
   // materialised at the transition). A clean row's dead slots are zero by the invariant (fused_common.h) whatever the
   // store holds: its pops and withdraws neither read nor write them.
   const bool exact = (hp.x & HD_DIRTY) != 0u || q >= Nmax - 1;
-  // Direction update (every row, also when nothing was chosen): one 12-byte store — or, for a row that received
+  // Direction update (every row, also when nothing was chosen): one record store — or, for a row that received
   // nobody, nothing at all (lazy garbage slot, see the file header).
-  const float dep_new = t + entry_tt(st, n0);
   const bool lazy = (who == 0u) && (q < Nmax - 1);
-  const uint32_t ni = n0i + arrived;   // count after the Direction update
-  uint32_t head_id = (n0i == 0u) ? who : head_id0;
-  float head_dep = (n0i == 0u) ? dep_new : __uint_as_float(hp.y);
-  {
-    // The FIFO is a ring buffer: logical slot s lives at physical slot (hoff + s) mod Nmax.
-    float* sl = fb.slots + (int64_t)row * fb.lds;  // slot s = sl[3s .. 3s+2] = {id, arrival, departure}
-    int hoff = tl_hoff(tlw);     // (the event word rec1 is write-only here: no load sits between the row and its slots)
-    if (!lazy && q < Nmax) {
-      float* w = sl + 3 * phys(hoff, q, Nmax);
-      w[0] = (float)who;
-      w[1] = t;
-      w[2] = dep_new;
-    }
-    int n = (int)ni;
-    bool arr_new = n0i == 0u;    // the head's arrival changes: a new head, or the garbage triple of an empty row
-    float head_arr = t;
-    uint32_t tail_id = arrived ? who : tail0;
+  uint32_t head_id = head_pre;
+  float head_dep = dep_pre;
+  // The FIFO is a ring buffer: logical slot s lives at physical slot (hoff + s) mod Nmax.
+  if (!lazy && q < Nmax) slot_store(sl + SLW * phys(hoff, q, Nmax), (float)who, t, dep_new);
+  int n = (int)ni;
+  uint32_t tail_id = arrived ? who : tail0;
 
-    // Response pop: logical shift by one where the LAST slot keeps its value. Ring form: the slot that falls off the
-    // front becomes the new logical last slot, so it receives a copy of the old last slot; then the head advances.
-    int shift = 0;
-    if (pop) {
-      if (exact) {
-        const float* last = sl + 3 * phys(hoff, Nmax - 1, Nmax);
-        const float l0 = last[0], l1 = last[1], l2 = last[2];
-        float* front = sl + 3 * hoff;
-        front[0] = l0;
-        front[1] = l1;
-        front[2] = l2;
-      }
-      hoff = phys(hoff, 1, Nmax);
-      shift = 1;
-      n = n - 1;
+  // Response pop: logical shift by one where the LAST slot keeps its value. Ring form: the slot that falls off the
+  // front becomes the new logical last slot, so it receives a copy of the old last slot; then the head advances.
+  int shift = 0;
+  if (pop) {
+    if (exact) {
+      const SlotRec last = slot_load(sl + SLW * phys(hoff, Nmax - 1, Nmax));
+      slot_store(sl + SLW * hoff, last.id, last.arr, last.dep);
     }
-    // withdraw: leading run of the (popped) row
-    int c = 0;
-    if (n > 0) {
-      const long long road = (long long)st.z;
-      int32_t w0 = 0, w1 = 0;
-      if (road >= 0 && road < N) {
-        w0 = P.out_ptr[road];
-        w1 = P.out_ptr[road + 1];
-      }
-      for (int sx = 0; sx < Nmax && sx < n; ++sx) {
-        float idf, depf;
-        if (sx == 0 && shift == 0) {   // the head is in registers unless the pop just exposed a new one
-          idf = (float)head_id;
-          depf = head_dep;
-        } else {
-          const float* rd = sl + 3 * phys(hoff, sx, Nmax);
-          idf = rd[0];
-          depf = rd[2];
-        }
-        const long long id = (long long)idf;
-        if (id < 0 || id >= A) break;
-        if (!(depf <= t)) break;  // tested first: most heads are still travelling, and the lookup below is a gather
-        const long long dest = (long long)fb.a_dest[(int64_t)b * A + id];
-        bool conn = false;
-        for (int32_t k = w0; k < w1; ++k) conn = conn || ((long long)P.out_dst[k] == dest);
-        if (!conn) break;
-        float* a = ag + (int64_t)b * a_bstride + id * AG_COLS;
-        a[AG_DONE] = 1.0f;
-        a[AG_ON_WAY] = 0.0f;
-        a[AG_ARR] = t;
-        fb.a_status[(int64_t)b * A + id] = 2;
-        ++c;
-      }
-    }
-    // withdraw = logical shift by c with zero fill: the c slots that fall off the front become the zeroed tail
-    for (int k = 0; exact && k < c; ++k) {
-      float* z = sl + 3 * phys(hoff, k, Nmax);
-      z[0] = 0.0f;
-      z[1] = 0.0f;
-      z[2] = 0.0f;
-    }
-    if (c > 0) {
-      hoff = phys(hoff, c, Nmax);   // c <= Nmax
-      n = n - c;
-    }
-    if (shift + c > 0) {
-      arr_new = true;
-      if (lazy && n == 0) {  // the row emptied: its head slot is the (unmaterialised) garbage slot
-        head_id = 0u;
-        head_arr = t;
-        head_dep = dep_new;
-      } else if (!exact && n == 0) {   // a clean row emptied by the pop of the agent it has just received: a dead slot, zero
-        head_id = 0u;
-        head_arr = 0.0f;
-        head_dep = 0.0f;
-      } else {
-        const float* hd = sl + 3 * hoff;
-        head_id = (uint32_t)(long long)hd[0];
-        head_arr = hd[1];
-        head_dep = hd[2];
-      }
-      // the agents that stay keep their order: the tail is who it was (the arrival, or the tail word's id) unless nobody
-      // stays. (A count at Nmax is outside the domain and flagged; the store is re-read there as the reference would.)
-      if (n == 0)
-        tail_id = 0u;
-      else if (n >= Nmax)
-        tail_id = (n == Nmax) ? (uint32_t)(long long)sl[3 * phys(hoff, n - 1, Nmax)] : 0u;
-    }
-    fb.hdp[row] = make_uint2((head_id << 8) | (uint32_t)n | (exact ? HD_DIRTY : 0u), __float_as_uint(head_dep));
-    fb.tl[row] = tl_word(tail_id, hoff, TLF_AUTH);
-    if (arr_new)      // one 8-byte store; otherwise the head, and its arrival, are unchanged
-      fb.rec1[row] = make_uint2(__float_as_uint(head_arr), r1_code(lazy ? q : -1));
-    else
-      fb.rec1[row].y = r1_code(lazy ? q : -1);
-    // per-node count before insertion (the insert kernel adds this frame's arrivals)
-    if (out.counts8) out.counts8[row] = (uint8_t)n;
-    if (FAPI && out.countsf) out.countsf[row] = (float)n;
-    if (FAPI && out.popped) out.popped[(int64_t)b * N + i] = pop ? 1 : 0;
-    if (FAPI && out.withdrawn) out.withdrawn[(int64_t)b * N + i] = c > 0 ? 1 : 0;
-    if (out.events && b < out.m_env) out.events[(int64_t)i * out.m_env + b] = (uint8_t)((pop ? 1 : 0) | (c > 0 ? 2 : 0));
-    return make_float2((float)n, (float)c);
+    hoff = phys(hoff, 1, Nmax);
+    shift = 1;
+    n = n - 1;
   }
+  // withdraw: leading run of the (popped) row. `cid / cdep` = the record the scan looks at; it starts with the head —
+  // registers, or what the pop exposed (prefetched above; the agent enqueued in this frame when the row held one agent) —
+  // and every further record is the next slot. Whatever record the scan STOPS at is the row's new head: it is not read again.
+  float cid = (float)head_id, cdep = head_dep;
+  if (shift != 0 && n > 0) {
+    if (n0i >= 2u) {
+      cid = nh.id;
+      cdep = nh.dep;
+    } else {            // n0i == 1 and somebody arrived: the new head is the record stored above
+      cid = (float)who;
+      cdep = dep_new;
+    }
+  }
+  int c = 0;
+  if (n > 0) {
+    int32_t dest = dest0;
+    bool have_dest = due0;       // the prefetched destination belongs to the first candidate of an unpopped row
+    for (int sx = 0; sx < Nmax && sx < n; ++sx) {
+      if (sx > 0) {
+        const SlotRec rd = slot_load(sl + SLW * phys(hoff, sx, Nmax));
+        cid = rd.id;
+        cdep = rd.dep;
+        have_dest = false;
+      }
+      const long long id = (long long)cid;
+      if (id < 0 || id >= A) break;
+      if (!(cdep <= t)) break;  // tested first: most heads are still travelling, and the lookup below is a gather
+      if (!have_dest) dest = fb.a_dest[(int64_t)b * A + id];
+      if (!have_rr) load_road();
+      const long long dl = (long long)dest;
+      bool conn = ((r_deg > 0) & ((long long)r_o0 == dl)) | ((r_deg > 1) & ((long long)r_o1 == dl)) |
+                  ((r_deg > 2) & ((long long)r_o2 == dl)) | ((r_deg > 3) & ((long long)r_o3 == dl));
+      for (int32_t k = r_out0 + 4; k < r_out0 + r_deg; ++k) conn = conn || ((long long)out_dst[k] == dl);
+      if (!conn) break;
+      float* a = ag + (int64_t)b * a_bstride + id * AG_COLS;
+      a[AG_DONE] = 1.0f;
+      a[AG_ON_WAY] = 0.0f;
+      a[AG_ARR] = t;
+      fb.a_status[(int64_t)b * A + id] = 2;
+      ++c;
+    }
+  }
+  // withdraw = logical shift by c with zero fill: the c slots that fall off the front become the zeroed tail
+  for (int k = 0; exact && k < c; ++k) slot_store(sl + SLW * phys(hoff, k, Nmax), 0.0f, 0.0f, 0.0f);
+  if (c > 0) {
+    hoff = phys(hoff, c, Nmax);   // c <= Nmax
+    n = n - c;
+  }
+  if (shift + c > 0) {
+    if (lazy && n == 0) {  // the row emptied: its head slot is the (unmaterialised) garbage slot
+      head_id = 0u;
+      head_dep = dep_new;
+    } else if (!exact && n == 0) {   // a clean row emptied by the pop of the agent it has just received: a dead slot, zero
+      head_id = 0u;
+      head_dep = 0.0f;
+    } else if (n > 0 && c < Nmax) {  // the record the scan stopped at (it was looked at: the scan only ends early on a test)
+      head_id = (uint32_t)(long long)cid;
+      head_dep = cdep;
+    } else {                         // a dirty row that emptied (its dead slots are physical), or a FIFO beyond its domain
+      const SlotRec hd = slot_load(sl + SLW * hoff);
+      head_id = (uint32_t)(long long)hd.id;
+      head_dep = hd.dep;
+    }
+    // the agents that stay keep their order: the tail is who it was (the arrival, or the tail word's id) unless nobody
+    // stays. (A count at Nmax is outside the domain and flagged; the store is re-read there as the reference would.)
+    if (n == 0)
+      tail_id = 0u;
+    else if (n >= Nmax)
+      tail_id = (n == Nmax) ? (uint32_t)(long long)sl[SLW * phys(hoff, n - 1, Nmax)] : 0u;
+  }
+  fb.hdp[row] = make_uint2((head_id << 8) | (uint32_t)n | (exact ? HD_DIRTY : 0u), __float_as_uint(head_dep));
+  fb.tl[row] = tl_word(tail_id, hoff, TLF_AUTH);
+  fb.gc8[row] = (uint8_t)r1_code(lazy ? q : -1);
+  // per-node count before insertion (the insert kernel adds this frame's arrivals)
+  if (out.counts8) out.counts8[row] = (uint8_t)n;
+  if (FAPI && out.countsf) out.countsf[row] = (float)n;
+  if (FAPI && out.popped) out.popped[(int64_t)b * N + i] = pop ? 1 : 0;
+  if (FAPI && out.withdrawn) out.withdrawn[(int64_t)b * N + i] = c > 0 ? 1 : 0;
+  if (out.events && b < out.m_env) out.events[(int64_t)i * out.m_env + b] = (uint8_t)((pop ? 1 : 0) | (c > 0 ? 2 : 0));
+  return make_float2((float)n, (float)c);
 }
 
 // NCH rows per lane: ALL their loads (dense words, downstream post words) are issued before the first row is processed,
@@ -1265,7 +1284,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
           hp_r.y = (r == q) ? hp[q].y : hp_r.y;
           i_r = (r == q) ? ri[q] : i_r;
         }
-        const float2 nc = row_phase_b<FAPI>((uint32_t)i_r, b, ((ovf >> (4 + r)) & 1u) != 0u, pa_r, hp_r, tl_r, nodes[i_r], out_ptr,
+        const float2 nc = row_phase_b<FAPI>((uint32_t)i_r, b, ((ovf >> (4 + r)) & 1u) != 0u, pa_r, hp_r, tl_r, nodes, out_ptr,
                                       out_dst, Nmax, B, N, fb, ag, A, a_bstride, t, out);
         nsum += nc.x;
         if (nc.y != 0.0f) atomicAdd(&fb.acc_w[(int64_t)(blockIdx.y % (unsigned)fb.acc_slots) * B + b], nc.y);
@@ -1286,7 +1305,7 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     int32_t i2 = ri[0];
 #pragma unroll
     for (int q = 1; q < NCH; ++q) i2 = (r == (uint32_t)q) ? ri[q] : i2;
-    const float2 nc = row_phase_b<FAPI>((uint32_t)i2, b2, (item & 256u) != 0u, wd.x, make_uint2(wd.y, wd.z), wd.w, nodes[i2],
+    const float2 nc = row_phase_b<FAPI>((uint32_t)i2, b2, (item & 256u) != 0u, wd.x, make_uint2(wd.y, wd.z), wd.w, nodes,
                                   out_ptr, out_dst, Nmax, B, N, fb, ag, A, a_bstride, t, out);
     if (nc.x != 0.0f) atomicAdd(&fb.acc_n[bank0 + b2], nc.x);     // small integers: exact in fp32 in any order
     if (nc.y != 0.0f) atomicAdd(&fb.acc_w[bank0 + b2], nc.y);
@@ -1499,24 +1518,20 @@ __device__ __forceinline__ void fused_insert_body(InsLds& L, int64_t b, int Nmax
         const float tt = (t_cong != t_cong) ? t_cong : fmaxf(str.y, t_cong);
         const int hoff = tl_hoff(s_un_tl[idx]);
         if (slot >= 0 && slot < Nmax) {
-          float* sr = fb.slots + rrow * fb.lds + 3 * phys(hoff, (int)slot, Nmax);
-          sr[0] = (float)a;
-          sr[1] = t;
-          sr[2] = t + tt;
+          slot_store(fb.slots + rrow * fb.lds + SLW * phys(hoff, (int)slot, Nmax), (float)a, t, t + tt);
         }
         agb[(int64_t)a * AG_COLS + AG_ON_WAY] = 1.0f;
         fb.a_status[b * A + a] = 1;
         fb.a_ins[b * A + s_un_k[idx]] = 1;
-        if (rank == m - 1) fb.tl[rrow] = tl_word((uint32_t)a, hoff, TLF_AUTH);  // new tail; rec1 authoritative from here on
+        if (rank == m - 1) fb.tl[rrow] = tl_word((uint32_t)a, hoff, TLF_AUTH);  // new tail; gc8 authoritative from here on
         if (rank == 0) {
           const uint32_t cnt = n0i + (uint32_t)m;      // n0 + m <= MAX - 3 < 255
           if (n0i == 0u) {   // new head: id + departure, arrival
             fb.hdp[rrow] = make_uint2(((uint32_t)a << 8) | cnt | (hd & HD_DIRTY), __float_as_uint(t + tt));
-            fb.rec1[rrow] = make_uint2(__float_as_uint(t), r1_code(-1));
           } else {
             fb.hdp[rrow].x = hd + (uint32_t)m;
-            fb.rec1[rrow].y = r1_code(-1);   // the arrivals overwrote a pending garbage slot: none pending now
           }
+          fb.gc8[rrow] = (uint8_t)r1_code(-1);   // the arrivals overwrote a pending garbage slot: none pending now
           if (out.counts8) out.counts8[rrow] = (uint8_t)cnt;
           if (out.countsf) out.countsf[rrow] = (float)cnt;
           atomicAdd(&s_adm, (int32_t)m);
@@ -1566,7 +1581,7 @@ __device__ __forceinline__ void fused_insert_body(InsLds& L, int64_t b, int Nmax
   }
 
   // phase 2: rank within road (stable), admit the first min(count, capacity), write slots / dense words.
-  // Per admitted road: the rank-0 candidate owns hdp / rec1 (the count's byte of hd is committed after the barrier), the
+  // Per admitted road: the rank-0 candidate owns hdp / gc8 (the count's byte of hd is committed after the barrier), the
   // last admitted candidate owns tl. Everybody else only READS the count byte, which nobody changes in this phase.
   for (int32_t idx = tid; idx < Lc; idx += INSB) {
     const int32_t r = cand_road[idx];
@@ -1591,19 +1606,15 @@ __device__ __forceinline__ void fused_insert_body(InsLds& L, int64_t b, int Nmax
       const float tt = (t_cong != t_cong) ? t_cong : fmaxf(str.y, t_cong);
       const int hoff = tl_hoff(fb.tl[rrow]);   // the tail word's owner below rewrites it with the same offset
       if (slot >= 0 && slot < Nmax) {
-        float* sr = fb.slots + rrow * fb.lds + 3 * phys(hoff, (int)slot, Nmax);
-        sr[0] = (float)a;
-        sr[1] = t;
-        sr[2] = t + tt;
+        slot_store(fb.slots + rrow * fb.lds + SLW * phys(hoff, (int)slot, Nmax), (float)a, t, t + tt);
       }
       agb[(int64_t)a * AG_COLS + AG_ON_WAY] = 1.0f;
       fb.a_status[b * A + a] = 1;
       if (fb.a_ins) fb.a_ins[b * A + fb.a_rank[b * A + a]] = 1;
       if (rank == 0 && n0i == 0u) {   // new head: id + departure (count byte unchanged), arrival
         fb.hdp[rrow] = make_uint2(((uint32_t)a << 8) | n0i | (hd & HD_DIRTY), __float_as_uint(t + tt));
-        fb.rec1[rrow].x = __float_as_uint(t);
       }
-      if (rank == m - 1) fb.tl[rrow] = tl_word((uint32_t)a, hoff, TLF_AUTH);  // new tail; rec1 authoritative from here on
+      if (rank == m - 1) fb.tl[rrow] = tl_word((uint32_t)a, hoff, TLF_AUTH);  // new tail; gc8 authoritative from here on
       if (rank == 0) commit = (int32_t)m;
     }
     cand_agent[idx] = commit;
@@ -1615,7 +1626,7 @@ __device__ __forceinline__ void fused_insert_body(InsLds& L, int64_t b, int Nmax
     const int32_t cmt = cand_agent[idx];
     if (cmt > 0) {
       const int64_t rrow = (int64_t)cand_road[idx] * B + b;
-      fb.rec1[rrow].y = r1_code(-1);
+      fb.gc8[rrow] = (uint8_t)r1_code(-1);
       const uint32_t hd = fb.hdp[rrow].x + (uint32_t)cmt;   // count byte: n0 + cmt <= MAX - 3 < 255
       fb.hdp[rrow].x = hd;
       if (out.counts8) out.counts8[rrow] = (uint8_t)(hd & HD_CNT);
@@ -1790,24 +1801,20 @@ __global__ __launch_bounds__(INSB) void k_fused_insert2(int Nmax, int64_t B, int
         const float tt = (t_cong != t_cong) ? t_cong : fmaxf(str.y, t_cong);
         const int hoff = tl_hoff(L.un_tl[base + idx]);
         if (slot >= 0 && slot < Nmax) {
-          float* sr = fb.slots + rrow * fb.lds + 3 * phys(hoff, (int)slot, Nmax);
-          sr[0] = (float)a;
-          sr[1] = t;
-          sr[2] = t + tt;
+          slot_store(fb.slots + rrow * fb.lds + SLW * phys(hoff, (int)slot, Nmax), (float)a, t, t + tt);
         }
         agb[(int64_t)a * AG_COLS + AG_ON_WAY] = 1.0f;
         fb.a_status[b * A + a] = 1;
         fb.a_ins[b * A + L.un_k[base + idx]] = 1;
-        if (rank == m - 1) fb.tl[rrow] = tl_word((uint32_t)a, hoff, TLF_AUTH);  // new tail; rec1 authoritative from here on
+        if (rank == m - 1) fb.tl[rrow] = tl_word((uint32_t)a, hoff, TLF_AUTH);  // new tail; gc8 authoritative from here on
         if (rank == 0) {
           const uint32_t cnt = n0i + (uint32_t)m;      // n0 + m <= MAX - 3 < 255
           if (n0i == 0u) {   // new head: id + departure, arrival
             fb.hdp[rrow] = make_uint2(((uint32_t)a << 8) | cnt | (hd & HD_DIRTY), __float_as_uint(t + tt));
-            fb.rec1[rrow] = make_uint2(__float_as_uint(t), r1_code(-1));
           } else {
             fb.hdp[rrow].x = hd + (uint32_t)m;
-            fb.rec1[rrow].y = r1_code(-1);   // the arrivals overwrote a pending garbage slot: none pending now
           }
+          fb.gc8[rrow] = (uint8_t)r1_code(-1);   // the arrivals overwrote a pending garbage slot: none pending now
           if (out.counts8) out.counts8[rrow] = (uint8_t)cnt;
           if (out.countsf) out.countsf[rrow] = (float)cnt;
           atomicAdd(&L.adm2[h], (int32_t)m);
@@ -1886,7 +1893,7 @@ __global__ __launch_bounds__(TILE) void k_fused_insert_choice(ChoiceArgs C, int 
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
 FusedBufs tarl_to_bufs(const tarl_fused* f) {
-  return FusedBufs{(uint2*)f->hdp,        (uint32_t*)f->tl, (uint2*)f->rec1, (uint32_t*)f->post, (const float4*)f->st0,
+  return FusedBufs{(uint2*)f->hdp,        (uint32_t*)f->tl, f->gc8,          (uint32_t*)f->post, (const float4*)f->st0,
                    f->slots,              f->ld_slots,      f->sel8,         f->sel,             (const NodeRec*)f->node_rec,
                    (const InRec*)f->in_rec, f->out_pad,
                    (long long*)f->acc_lp, f->acc_n,         f->acc_w,        f->a_origin,        f->a_dest,
@@ -1930,7 +1937,7 @@ static int nchunk_choice() {
 
 int tarl_check_fused_core(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax) {
   TARL_REQUIRE(plan && f, "null argument");
-  TARL_REQUIRE(f->hdp && f->tl && f->rec1 && f->post && f->st0 && f->slots && f->sel8 && f->sel && f->acc_lp &&
+  TARL_REQUIRE(f->hdp && f->tl && f->gc8 && f->post && f->st0 && f->slots && f->sel8 && f->sel && f->acc_lp &&
                    f->acc_n && f->acc_w && f->flags && f->node_rec && f->in_rec && f->out_pad,
                "fused node buffers missing");
   TARL_REQUIRE(B >= 1 && B < ((int64_t)1 << 31) && Nmax >= 2, "bad sizes");
@@ -1939,11 +1946,11 @@ int tarl_check_fused_core(const tarl_plan* plan, const tarl_fused* f, int64_t B,
                             "Nmax must be <= 127 (use the unfused entry points for longer FIFOs)");
   TARL_REQUIRE(plan->max_out <= 126, "the fused path packs the chosen out-edge's rank into 7 bits: out-degree must be <= 126");
   TARL_REQUIRE(f->acc_slots >= 1 && f->acc_slots <= 4096, "acc_slots out of range");
-  TARL_REQUIRE(f->ld_slots >= 3 * (int64_t)Nmax, "slot row stride smaller than 3*Nmax");
+  TARL_REQUIRE(f->ld_slots >= SLW * (int64_t)Nmax && f->ld_slots % SLW_ALIGN == 0, "slot row stride smaller than SLW*Nmax or misaligned (tarl_fused_slot_floats)");
   TARL_REQUIRE(num_chunks(plan) < 65536 && plan->num_row_chunks < 65536 && ceil_div(plan->N, nchunk_choice()) < 65536 &&
                    ceil_div(plan->N, nchunk_dir()) < 65536,
                "too many node chunks for one launch");
-  TARL_REQUIRE(((uintptr_t)f->hdp | (uintptr_t)f->rec1 | (uintptr_t)f->st0) % 16 == 0 &&
+  TARL_REQUIRE(((uintptr_t)f->hdp | (uintptr_t)f->st0 | (uintptr_t)f->slots) % 32 == 0 &&
                    ((uintptr_t)f->tl | (uintptr_t)f->post) % 4 == 0,
                "fused records must be 16-byte aligned");
   return TARL_OK;
@@ -1960,6 +1967,10 @@ static int check_fused(const tarl_plan* plan, const tarl_fused* f, const float* 
 }
 
 static unsigned tile_threads(int64_t B) { return B >= TILE ? TILE : (unsigned)(ceil_div(B, 64) * 64); }
+
+extern "C" int64_t tarl_fused_slot_floats(int32_t Nmax) {
+  return SLW == 8 ? (int64_t)8 * Nmax : ((int64_t)SLW * Nmax + 15) / 16 * 16;   // 12-byte slots: rows padded to 64 bytes
+}
 
 extern "C" int tarl_fused_pack(const tarl_plan* plan, const tarl_fused* f, const float* x, int64_t B, int64_t x_bstride,
                                int64_t ldx, int32_t Nmax, const float* cong, const float* edge_attr,
@@ -2003,7 +2014,10 @@ extern "C" int tarl_fused_reset(const tarl_plan* plan, const tarl_fused* f, int6
   TARL_REQUIRE(agent_features && A >= 1 && f->a_status, "agents missing");
   const FusedBufs fb = tarl_to_bufs(f);
   hipStream_t s = (hipStream_t)stream;
-  TARL_CHECK_HIP(hipMemsetAsync(f->slots, 0, (size_t)(plan->N * B * f->ld_slots) * sizeof(float), s));
+  // The slot store is NOT zeroed: after the reset every row is empty and CLEAN (count byte 0), and a clean row's dead slots
+  // are zero by rule whatever the store holds (fused_common.h) — export, head_arrival and tarl_fused_dead_slots apply the
+  // rule, the frame kernels never read a clean row's dead slot. (The memset was 1.5 ms of every PPO iteration at 16 384
+  // environments with 12-byte slots; with 32-byte records it would be 4 ms.)
   if (plan->N > 0) {
     hipLaunchKernelGGL(k_fused_reset_nodes, dim3((unsigned)ceil_div(B * plan->N, FB)), dim3(FB), 0, s, B, plan->N, fb);
     TARL_LAUNCH_CHECK();
@@ -2052,11 +2066,12 @@ static bool addr32_ok() {
 static int launch_direction(dim3 grid, unsigned threads, hipStream_t s, const tarl_plan* plan, const tarl_fused* f,
                             const float* edge_attr, const float* log_edge_attr, const uint8_t* sel8, const float* gumbel,
                             float* dtt, float log_eps, float time, float prev_time, uint64_t seed, uint64_t counter,
-                            int64_t B, const FrameOut& out, const uint8_t* cnt8 = nullptr) {
+                            int64_t B, int Nmax, const FrameOut& out, const uint8_t* cnt8 = nullptr) {
 #define DIR_LAUNCH_(NCH, SIB, CNT, O32)                                                                                   \
   hipLaunchKernelGGL((k_fused_direction<NCH, SIB, CNT, O32>), grid, dim3(threads), 0, s, (const NodeRec*)f->node_rec,          \
                      (const InRec*)f->in_rec, plan->in_eid, log_edge_attr, (const uint2*)f->hdp, (const uint32_t*)f->tl,  \
-                     cnt8, (const uint2*)f->rec1, sel8, (const float*)f->sel, gumbel, dtt, (uint32_t*)f->post, log_eps, time,   \
+                     cnt8, (const uint8_t*)f->gc8, (const float*)f->slots, f->ld_slots, Nmax, sel8, (const float*)f->sel, gumbel, \
+                     dtt, (uint32_t*)f->post, log_eps, time,   \
                      prev_time, seed, counter, (uint32_t)plan->E, (uint32_t)B, (uint32_t)plan->N, out, (uint64_t)f->env_base)
 #define DIR_LAUNCH(NCH, SIB, CNT)                                                                                         \
   do {                                                                                                                     \
@@ -2188,7 +2203,7 @@ extern "C" int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int6
   const dim3 grid_d((unsigned)ceil_div(B, threads), (unsigned)ceil_div(plan->N, nchunk_dir()));
   const FrameOut out{nullptr, counts, popped, withdrawn, nullptr, nullptr, 0, nullptr};
   rc = launch_direction(grid_d, threads, s, plan, f, edge_attr, log_edge_attr, (const uint8_t*)f->sel8, gumbel,
-                        delta_travel_time, log_eps, time, prev_time, seed, counter, B, out);
+                        delta_travel_time, log_eps, time, prev_time, seed, counter, B, (int)Nmax, out);
   if (rc) return rc;
   if (timed) (void)tarl_prof_mark(s, 1);
   rc = launch_rows(grid, threads, s, plan, f, fb, (int)Nmax, B, agent_features, A, a_bstride, time, out);
@@ -2387,7 +2402,7 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
       TARL_CHECK_HIP(hipStreamWaitEvent(s, side->done[t == 0 ? 0 : 1 + (t - CHOICE_FIRST) / CHOICE_CHUNK], 0));
     const bool timed = tarl_prof_mark(s, 0) != nullptr;
     rc = launch_direction(grid_d, threads, s, plan, f, edge_attr, log_edge_attr, sel_t, nullptr, nullptr, log_eps, time,
-                          t > 0 ? times_host[t - 1] : prev_time, seed, counter0 + (uint64_t)t, B, out,
+                          t > 0 ? times_host[t - 1] : prev_time, seed, counter0 + (uint64_t)t, B, (int)Nmax, out,
                           (counts && t > 0) ? counts + (t - 1) * NB : nullptr);   // the counts after frame t - 1
     if (rc) return rc;
     if (timed) (void)tarl_prof_mark(s, 1);
@@ -2585,7 +2600,7 @@ extern "C" int tarl_fused_rollout_policy(const tarl_plan* plan, const tarl_fused
                        metrics_envs,
                        leg ? leg + t * 2 * B : nullptr};
     rc = launch_direction(grid_d, threads, s, plan, f, edge_attr, log_edge_attr, (const uint8_t*)f->sel8, nullptr, nullptr,
-                          log_eps, time, t > 0 ? times_host[t - 1] : prev_time, seed, counter0 + (uint64_t)t, B, out);
+                          log_eps, time, t > 0 ? times_host[t - 1] : prev_time, seed, counter0 + (uint64_t)t, B, (int)Nmax, out);
     if (rc) return rc;
     rc = launch_rows(grid, threads, s, plan, f, fb, (int)Nmax, B, agent_features, A, a_bstride, time, out);
     if (rc) return rc;

@@ -25,7 +25,7 @@
 //   hdp  uint2  {hd = head_id << 8 | n, bits of head_dep}   n = NUMBER_OF_AGENT (<= 255: the fused path requires Nmax <= 255),
 //                                                            ids < 2^24 (the reference keeps them in fp32: exact below 2^24)
 //   tl   u32    tail_id << 8 | hoff << 1 | TLF_AUTH          hoff = physical slot of logical slot 0 (ring buffer; < 128: the
-//                                                            fused path requires Nmax <= 127). TLF_AUTH: rec1 (head_arr,
+//                                                            fused path requires Nmax <= 127). TLF_AUTH: gc8 (the
 //                                                            pending-garbage count) is authoritative for the last frame;
 //                                                            clear = the row was idle in the last frame: the pending
 //                                                            garbage count is n itself and an empty row's head arrival is
@@ -35,10 +35,15 @@
 //                                                            Direction gather, gathered by the upstream rows' Response test
 //   sel8 u8     SELECTED_ROAD as the rank of the chosen out-edge in the node's CSR list (| SEL_CARRIED when the node drew
 //               nothing in this frame and keeps its previous value); SEL_RAW: the fp32 value in `sel` is authoritative
-// Event-only word, read / written by the rows that move something in a frame (a few percent):
-//   rec1 uint2  {bits of head_arr, g + 1}                    g = count at the pending (unmaterialised) garbage write or -1.
-//                                                            WRITE-ONLY in the frame kernels (the event path never waits
-//                                                            for it: the ring offset it needs travels in tl)
+// Event-only byte, written by the rows that move something in a frame:
+//   gc8  u8     g + 1                                        g = count at the pending (unmaterialised) garbage write or -1;
+//                                                            authoritative while tl carries TLF_AUTH. WRITE-ONLY in the
+//                                                            frame kernels. (Layout v11: the head's ARRIVAL time, which
+//                                                            the v10 event word rec1 carried beside it, is not stored
+//                                                            any more: it is the arrival field of the head's slot record,
+//                                                            or follows from the pending garbage / clean-row rules —
+//                                                            head_arrival() below; an 8-byte scattered store per event
+//                                                            row and frame became one byte.)
 // Count byte of hdp.x: NUMBER_OF_AGENT in bits 0..6 (the fused path requires Nmax <= 127) and HD_DIRTY in bit 7.
 // A CLEAN row (bit clear) obeys the dead-slot invariant of the reference's own bookkeeping: every logical slot above the
 // count is ZERO (the slot at the count itself: the pending garbage triple, or zero when none is pending) — a pop duplicates
@@ -95,7 +100,7 @@ static_assert(sizeof(NodeRec) == NODE_REC_WORDS * 4 && sizeof(InRec) == IN_REC_W
 struct FusedBufs {
   uint2* hdp;           // [N][B]
   uint32_t* tl;         // [N][B]
-  uint2* rec1;          // [N][B]
+  uint8_t* gc8;         // [N][B] pending-garbage code (g + 1)
   uint32_t* post;       // [N][B]
   const float4* st0;    // [N]    {maxn, ff, road_index, cong}
   float* slots;         // [N][B][lds] slot-interleaved FIFO store: slot s at floats 3s..3s+2 = {id, arrival, departure}
@@ -141,13 +146,47 @@ struct FrameOut {
 
 #define LP_FIX 4294967296.0  // 2^32
 
+// ---- slot records of the FIFO store ------------------------------------------------------------------------------------
+// slots[node][env][s] = one record of SLW floats {agent id, arrival, departure [, 0 ...]}. SLW = 3 (default): 12-byte
+// triples, 192 B per row at Nmax = 15. SLW = 8 (developer build, -DTARL_SLW=8): a record is ONE aligned 32-byte sector, so
+// the scattered store of an enqueue / insert fills its sector (no read-modify-write at the memory side: 13 ps per store
+// against 43 ps for a 12-byte triple in isolation, profiles/r03_pmc_calibration.txt). Measured in round 4 at 16 384
+// environments (same-box A/B, profiles/README.md): congested regime unchanged within the run-to-run noise, headline regime
+// row pass 187 -> 236 us (the store grows from 7.9 to 19.7 GB: the scattered accesses of the event tail pay for the larger
+// footprint, and the event tail is a latency chain, not a store-throughput problem). Not taken.
+#ifndef TARL_SLW
+#define TARL_SLW 3
+#endif
+#define SLW TARL_SLW
+#define SLW_ALIGN (SLW == 8 ? 8 : 1)
+__device__ __forceinline__ void slot_store(float* w, float id, float arr, float dep) {
+#if TARL_SLW == 8
+  reinterpret_cast<float4*>(w)[0] = make_float4(id, arr, dep, 0.0f);
+  reinterpret_cast<float4*>(w)[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#else
+  w[0] = id;
+  w[1] = arr;
+  w[2] = dep;
+#endif
+}
+struct SlotRec {
+  float id, arr, dep;
+};
+__device__ __forceinline__ SlotRec slot_load(const float* r) {
+#if TARL_SLW == 8
+  const float4 v = *reinterpret_cast<const float4*>(r);
+  return SlotRec{v.x, v.y, v.z};
+#else
+  return SlotRec{r[0], r[1], r[2]};
+#endif
+}
 __device__ __forceinline__ uint32_t r1_code(int g) { return (uint32_t)(g + 1); }
 __device__ __forceinline__ int r1_g(uint32_t code) { return (int)code - 1; }
 __device__ __forceinline__ int tl_hoff(uint32_t tlw) { return (int)((tlw >> 1) & 127u); }
 __device__ __forceinline__ uint32_t tl_word(uint32_t tail_id, int hoff, uint32_t auth) {
   return (tail_id << 8) | ((uint32_t)hoff << 1) | auth;
 }
-// pending garbage count of a row from its dense words (+ rec1 when it is authoritative)
+// pending garbage count of a row from its dense words (+ gc8 when it is authoritative)
 __device__ __forceinline__ int pending_g(uint32_t tlw, int n, uint32_t code, int Nmax) {
   return (tlw & TLF_AUTH) ? r1_g(code) : (n < Nmax - 1 ? n : -1);
 }
@@ -156,6 +195,18 @@ __device__ __forceinline__ int phys(int hoff, int s, int Nmax) {
   int p = hoff + s;
   return p >= Nmax ? p - Nmax : p;
 }
+// Arrival time of the row's head slot (the reference's x[i, Nmax + 0]; read by delta_travel_time only) from the packed
+// state: the head's slot record while the row holds somebody; the head slot of an EMPTY row is the pending garbage triple
+// (arrival = the last frame's clock t_last), a dead slot of a clean row (zero), or whatever the store holds (dirty rows).
+__device__ __forceinline__ float head_arrival(const float* __restrict__ slots, int64_t lds, const uint8_t* __restrict__ gc8,
+                                              int64_t row, uint32_t hd, uint32_t tlw, int Nmax, float t_last) {
+  if ((hd & HD_CNT) == 0u) {
+    if (pending_g(tlw, 0, (uint32_t)gc8[row], Nmax) >= 0) return t_last;
+    if (!(hd & HD_DIRTY)) return 0.0f;
+  }
+  return slots[row * lds + SLW * tl_hoff(tlw) + 1];
+}
+
 // SELECTED_ROAD value of a sel8 code (node i)
 __device__ __forceinline__ float sel_value(const FusedBufs& fb, const int32_t* __restrict__ out_ptr,
                                            const int32_t* __restrict__ out_dst, int64_t i, int64_t row) {

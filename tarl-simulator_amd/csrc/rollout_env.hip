@@ -181,7 +181,7 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
     const int64_t row = (int64_t)i * B + b;
     const uint2 hp = fb.hdp[row];
     const uint32_t tlw = fb.tl[row];
-    const uint2 q1 = fb.rec1[row];
+    const uint32_t gcode = fb.gc8[row];
     const uint32_t pw = fb.post[row];
     const int n = (int)(hp.x & HD_CNT);   // (HD_DIRTY, bit 7, is re-derived from the store after the rollout: tarl_fused_dead_slots)
     // an idle empty row's head arrived at the previous frame's clock and departs tt0 later (the frame kernels do not store
@@ -189,8 +189,8 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
     const bool lazy_row = n == 0 && !(tlw & TLF_AUTH);
     const float dep0 = lazy_row ? prev_time + entry_tt(fb.st0[i], 0.0f) : __uint_as_float(hp.y);
     r0[i] = make_float4((float)(hp.x >> 8), dep0, (float)n, (float)(tlw >> 8));
-    const float arr = lazy_row ? prev_time : __uint_as_float(q1.x);
-    r1[i] = make_float2(arr, l1_code((float)pending_g(tlw, n, q1.y, Nmax), tl_hoff(tlw)));
+    const float arr = head_arrival(fb.slots, fb.lds, fb.gc8, row, hp.x, tlw, Nmax, prev_time);
+    r1[i] = make_float2(arr, l1_code((float)pending_g(tlw, n, gcode, Nmax), tl_hoff(tlw)));
     const bool arrived = (pw & PF_ARRIVED) != 0u;
     pA[i] = make_float2(arrived ? (float)(n + 1) : (float)n, (float)(pw >> 8));
     who_l[i] = arrived ? (float)(pw >> 8) : 0.0f;
@@ -400,10 +400,7 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
       const bool lazy = (who == 0.0f) && (q >= 0) && (q < Nmax - 1);
       if ((int)pa.x >= Nmax) atomicOr(fb.flags, FLAG_COUNT_AT_NMAX);
       if (!lazy && q >= 0 && q < Nmax) {
-        float* w = sl + 3 * phys(hoff, q, Nmax);
-        w[0] = who;
-        w[1] = t;
-        w[2] = dep_new;
+        slot_store(sl + SLW * phys(hoff, q, Nmax), who, t, dep_new);
       }
       float n = pa.x;
       float head_id = (n0 == 0.0f) ? who : q0.x;
@@ -412,12 +409,8 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
       float tail_id = pa.y;
       int shift = 0;
       if (pop) {
-        const float* last = sl + 3 * phys(hoff, Nmax - 1, Nmax);
-        const float l0 = last[0], l1 = last[1], l2 = last[2];
-        float* front = sl + 3 * hoff;
-        front[0] = l0;
-        front[1] = l1;
-        front[2] = l2;
+        const SlotRec last = slot_load(sl + SLW * phys(hoff, Nmax - 1, Nmax));
+        slot_store(sl + SLW * hoff, last.id, last.arr, last.dep);
         hoff = phys(hoff, 1, Nmax);
         shift = 1;
         n = n - 1.0f;
@@ -431,9 +424,9 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
             idf = head_id;
             depf = head_dep;
           } else {
-            const float* rd = sl + 3 * phys(hoff, sx, Nmax);
-            idf = rd[0];
-            depf = rd[2];
+            const SlotRec rd = slot_load(sl + SLW * phys(hoff, sx, Nmax));
+            idf = rd.id;
+            depf = rd.dep;
           }
           const long long id = (long long)idf;
           if (id < 0 || id >= A) break;
@@ -459,10 +452,7 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
         }
       }
       for (int k = 0; k < c; ++k) {
-        float* z = sl + 3 * phys(hoff, k, Nmax);
-        z[0] = 0.0f;
-        z[1] = 0.0f;
-        z[2] = 0.0f;
+        slot_store(sl + SLW * phys(hoff, k, Nmax), 0.0f, 0.0f, 0.0f);
       }
       if (c > 0) {
         hoff = phys(hoff, c, Nmax);
@@ -474,13 +464,13 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
           head_arr = t;
           head_dep = dep_new;
         } else {
-          const float* hd = sl + 3 * hoff;
-          head_id = hd[0];
-          head_arr = hd[1];
-          head_dep = hd[2];
+          const SlotRec hd = slot_load(sl + SLW * hoff);
+          head_id = hd.id;
+          head_arr = hd.arr;
+          head_dep = hd.dep;
         }
         const int qn = (int)n;
-        tail_id = (qn >= 1 && qn <= Nmax) ? sl[3 * phys(hoff, qn - 1, Nmax)] : 0.0f;
+        tail_id = (qn >= 1 && qn <= Nmax) ? sl[SLW * phys(hoff, qn - 1, Nmax)] : 0.0f;
       }
       r0[i] = make_float4(head_id, head_dep, n, tail_id);
       r1[i] = make_float2(head_arr, l1_code(lazy ? n0 : -1.0f, hoff));
@@ -608,10 +598,7 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
           const float tt = (t_cong != t_cong) ? t_cong : fmaxf(str.y, t_cong);
           const float code = r1[r].y;   // nobody writes r1.y before the barrier below
           if (slot >= 0 && slot < Nmax) {
-            float* sr = fb.slots + rrow * fb.lds + 3 * phys(l1_hoff(code), (int)slot, Nmax);
-            sr[0] = (float)a;
-            sr[1] = t;
-            sr[2] = t + tt;
+            slot_store(fb.slots + rrow * fb.lds + SLW * phys(l1_hoff(code), (int)slot, Nmax), (float)a, t, t + tt);
           }
           agb[(int64_t)a * AG_COLS + AG_ON_WAY] = 1.0f;
           fb.a_status[b * A + a] = 1;
@@ -668,7 +655,7 @@ __global__ __launch_bounds__(RE_THREADS) void k_rollout_env(EnvPlan P, int64_t B
     const float2 q1 = r1[i];
     fb.hdp[row] = make_uint2(((uint32_t)q0.x << 8) | (uint32_t)q0.z, __float_as_uint(q0.y));
     fb.tl[row] = tl_word((uint32_t)q0.w, l1_hoff(q1.y), TLF_AUTH);
-    fb.rec1[row] = make_uint2(__float_as_uint(q1.x), r1_code((int)l1_g(q1.y)));
+    fb.gc8[row] = (uint8_t)r1_code((int)l1_g(q1.y));
     const float who = who_l[i];
     fb.post[row] = ((uint32_t)pA[i].y << 8) | (pA[i].x > 0.0f ? PF_NONEMPTY : 0u) | (who != 0.0f ? PF_ARRIVED : 0u);
     // SELECTED_ROAD back as a rank of this road's out-list (the raw value where it names none of them, as pack does)

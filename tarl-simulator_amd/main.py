@@ -6,6 +6,9 @@ import argparse
 import os
 import sys
 
+# before anything imports torch (the HIP runtime reads it once): dmabuf IPC, which RCCL needs on hosts without legacy IPC —
+# also when the ranks were started by an external `torchrun main.py` whose environment lacks it. A launcher's value wins.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from src.runner import Runner, RunnerArgs  # noqa: E402

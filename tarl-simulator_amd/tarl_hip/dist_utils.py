@@ -8,7 +8,11 @@ from __future__ import annotations
 
 import os
 
-import torch
+# dmabuf IPC: what RCCL (and device-tensor sharing across processes) needs on hosts whose driver has no legacy IPC; must be in
+# the environment before the HIP runtime starts, i.e. before torch is imported. A launcher's own setting wins.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 import torch.distributed as dist
 
 
@@ -60,6 +64,19 @@ def gather_floats(vals, device):
     out = [torch.empty_like(t) for _ in range(world()[1])]
     dist.all_gather(out, t)
     return [o.tolist() for o in out]
+
+
+def replica_max_abs_diff(t: torch.Tensor) -> float:
+    """max over ranks and elements of |t - rank 0's t|: 0.0 exactly when every replica holds rank 0's bits (one broadcast
+    of a copy + one MAX all-reduce; 0.0 for a single process). The data-parallel contract: replicated
+    parameters, one averaged gradient, the same Adam step on every rank."""
+    if world()[1] == 1:
+        return 0.0
+    ref = t.detach().clone()
+    dist.broadcast(ref, src=0)
+    d = (t.detach() - ref).abs().max().to(torch.float64).reshape(1)
+    dist.all_reduce(d, op=dist.ReduceOp.MAX)
+    return float(d.item())
 
 
 def backend_name() -> str:

@@ -67,6 +67,7 @@ SIGNATURES = {
     "tarl_critic_mlp_fwd_u8": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64] + [_p] * 6 + [_p, _p, _p, _p]),
     "tarl_critic_mlp_fwd_slabs_u8": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64] + [_p] * 6 + [_p, _p, _p]),
     "tarl_critic_split_scratch_bytes": (_i64, [_i64]),
+    "tarl_fused_slot_floats": (_i64, [_i32]),
     "tarl_fused_pack": (C.c_int, [_p, _p] + _STATE + [_p, _p, _p, _i64, _i64, _p]),
     "tarl_fused_reset": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _i64, _p]),
     "tarl_fused_export": (C.c_int, [_p, _p] + _STATE + [_f32, _p]),
@@ -100,7 +101,7 @@ SIGNATURES = {
 
 class FusedStruct(C.Structure):
     """``tarl_fused`` of include/tarl_hip.h."""
-    _fields_ = ([(n, C.c_void_p) for n in ("hdp", "tl", "rec1", "post", "st0", "slots")] +
+    _fields_ = ([(n, C.c_void_p) for n in ("hdp", "tl", "gc8", "post", "st0", "slots")] +
                 [("ld_slots", C.c_int64)] +
                 [(n, C.c_void_p) for n in ("sel8", "sel", "node_rec", "in_rec", "out_pad", "acc_lp", "acc_n", "acc_w", "a_origin", "a_dest",
                                            "a_dep", "a_status", "a_order", "cur_lo", "a_dep_sorted", "a_win", "a_ins",

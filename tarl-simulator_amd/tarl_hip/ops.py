@@ -7,6 +7,7 @@ strides), mutated in place like the reference does.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 
 import torch
@@ -16,7 +17,19 @@ from . import lib as _lib
 EPS_GUMBEL = 1e-12   # src/direction_mpnn.py:136
 # revision of the fused path's packed HBM layout / kernel set: a PMC traffic record (profiles/*_pmc_traffic.json) only
 # applies to the revision it was measured on
-FUSED_LAYOUT = "v10"
+FUSED_LAYOUT = "v11"
+
+
+def frame_kernel_source_hash() -> str:
+    """sha256 (first 16 hex digits) of the frame kernels' sources, csrc/fused.hip + csrc/fused_common.h: a PMC traffic record
+    (tools/pmc_bench.py -> profiles/*.json) is only paired with kernel times measured on the very code it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
+    for name in ("fused.hip", "fused_common.h"):
+        with open(os.path.join(csrc, name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def _check_dev(t: torch.Tensor, dtype, name: str):
@@ -648,7 +661,7 @@ def adam_step_(param, grad, exp_avg, exp_avg_sq, step, *, lr=1e-3, beta1=0.9, be
 # ---- fused rollout frame ----------------------------------------------------------------------------------------------
 class FusedState:
     """Side buffers of the fused path (``tarl_fused`` in include/tarl_hip.h), ENV-MINOR ([node][env]): the packed dense
-    words (hdp, tl, post, sel8), the event-only word rec1, static node records, the slot-interleaved FIFO store and the
+    words (hdp, tl, post, sel8), the event-only byte gc8, static node records, the slot-interleaved FIFO store and the
     agent SoA. They hold the state between :func:`fused_pack` and :func:`fused_export`."""
 
     def __init__(self, plan: Plan, B: int, A: int, device, Nmax: int = 15, env_base: int = 0):
@@ -662,11 +675,12 @@ class FusedState:
                                  f"{plan.max_out}); construct SimEngine(..., fused=False) for this graph")
         f32 = dict(dtype=torch.float32, device=device)
         i32 = dict(dtype=torch.int32, device=device)
-        self.ld_slots = ((3 * Nmax + 15) // 16) * 16
+        # Never zeroed after this: a CLEAN row's dead slots are zero by rule, whatever the store holds (csrc/fused_common.h)
+        self.ld_slots = int(L.tarl_fused_slot_floats(Nmax))
         self.slots = torch.zeros((N, B, self.ld_slots), **f32)
         self.hdp = torch.zeros((N, B, 2), **i32)
         self.tl = torch.zeros((N, B), **i32)
-        self.rec1 = torch.zeros((N, B, 2), **i32)
+        self.gc8 = torch.zeros((N, B), dtype=torch.uint8, device=device)     # pending-garbage code (event-only byte)
         self.post = torch.zeros((N, B), **i32)
         self.st0 = torch.zeros((N, 4), **f32)
         self.sel8 = torch.zeros((N, B), dtype=torch.uint8, device=device)
@@ -690,7 +704,7 @@ class FusedState:
         self.a_rank = torch.zeros((B, A), **i32)
         self.flags = torch.zeros(1, **i32)
         self.order_valid = False
-        self.struct = _lib.FusedStruct(self.hdp.data_ptr(), self.tl.data_ptr(), self.rec1.data_ptr(),
+        self.struct = _lib.FusedStruct(self.hdp.data_ptr(), self.tl.data_ptr(), self.gc8.data_ptr(),
                                        self.post.data_ptr(), self.st0.data_ptr(), self.slots.data_ptr(), self.ld_slots,
                                        self.sel8.data_ptr(), self.sel.data_ptr(), self.node_rec.data_ptr(),
                                        self.in_rec.data_ptr(), self.out_pad.data_ptr(),
@@ -717,6 +731,15 @@ class FusedState:
     @property
     def tail_id(self):
         return ((self.tl >> 8) & 0xFFFFFF).to(torch.float32)
+
+    @property
+    def head_slot_arrival(self):
+        """Arrival field of the slot record at every row's ring offset: the head's arrival time where the row holds
+        somebody (csrc/fused_common.h: head_arrival)."""
+        hoff = ((self.tl >> 1) & 127).long().unsqueeze(-1)
+        w = 8 if int(_lib.load().tarl_fused_slot_floats(1)) == 8 else 3    # (developer build -DTARL_SLW=8: 32-byte records)
+        arr = self.slots[..., :w * self.Nmax].reshape(self.N, self.B, self.Nmax, w)[..., 1]
+        return torch.gather(arr, 2, hoff).squeeze(-1)
 
     def sort_agents(self, agent_features):
         """Departure-time order of every environment's population (static while DEPARTURE_TIME is not edited): lets the

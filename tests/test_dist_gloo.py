@@ -38,6 +38,10 @@ def _worker(rank, world, port, q):
     wts = torch.full((5,), float(rank))
     dist_utils.broadcast_(wts, src=0)
     mx = dist_utils.allreduce_max_float(1.0 + rank, "cpu")
+    # (4) the replica check bench.py reports (replica_param_max_abs_diff): 0.0 exactly for identical replicas, the largest
+    # deviation from rank 0 otherwise — the same number on every rank
+    assert dist_utils.replica_max_abs_diff(wts) == 0.0
+    assert dist_utils.replica_max_abs_diff(torch.full((7,), float(rank))) == float(world - 1)
     dist_utils.barrier()
     # numpy arrays pickle by value (torch tensors travel as file descriptors that die with this process)
     q.put((rank, grad.numpy(), stats.numpy(), adv.numpy(), wts.numpy(), mx))

@@ -41,12 +41,14 @@ def test_bench_line_contract():
     assert d["congested_regime"]["value"] > 0
     assert d["state_dependent_policy"]["bf16"]["value"] > 0 and d["state_dependent_policy"]["fp32"]["value"] > 0
     # round 3: the all-core CPU figure beside the fastest, the congested regime's own roofline objects, per-rank times
-    assert c["all_cores"]["cores"] == (os.cpu_count() or 1) and c["all_cores"]["value"] > 0
+    assert 1 <= c["all_cores"]["cores"] <= (os.cpu_count() or 1) and c["all_cores"]["value"] > 0      # physical cores of one socket
+    assert c["all_cores"]["logical_cpus_of_the_host"] == (os.cpu_count() or 1)
+    assert c["value_rollout_only"] >= c["value"] > 0 and c["update_seconds"] > 0                       # update included in value
     for key in ("roofline", "roofline_direction", "roofline_insert"):
         r = d["congested_regime"][key]
         assert r["bound"] == "hbm" and 0.0 <= r["frac"] <= 1.0 and r["avg_launch_us"] > 0
     assert d["per_rank"]["timed_seconds"] == [pytest.approx(d["timed_seconds"], rel=0.2)] and len(d["per_rank"]["setup_seconds"]) == 1
-    assert d["world_size_seen_by_backend"] == 1
+    assert d["world_size_seen_by_backend"] == 1 and d["replica_param_max_abs_diff"] == 0.0
 
 
 def test_bench_starts_its_own_ranks():
@@ -65,6 +67,7 @@ def test_bench_starts_its_own_ranks():
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["world_size_seen_by_backend"] == 2 and d["dist_backend"] == "gloo"
+    assert d["replica_param_max_abs_diff"] == 0.0      # after the timed Adam steps both replicas still hold rank 0's bits
     assert len(d["per_rank"]["timed_seconds"]) == 2 and all(v > 0 for v in d["per_rank"]["timed_seconds"])
     assert abs(d["value"] - 2 * 128 * 256 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6      # both ranks' frames / slowest rank
     assert "cpu_baseline" not in d                                                             # N = 1 only

@@ -35,7 +35,7 @@ def check_records(ops, plan, fs, x, Nmax, ag, cc, ec):
     assert torch.equal(fs.sel8 & 0x7F, ref.sel8 & 0x7F) and torch.equal(fs.in_rec, ref.in_rec) and torch.equal(fs.node_rec, ref.node_rec)
     nz = ref.count > 0
     assert torch.equal(fs.tail_id[nz], ref.tail_id[nz])
-    assert torch.equal(fs.rec1[..., 0][nz], ref.rec1[..., 0][nz])              # head arrival (event-only word)
+    assert torch.equal(fs.head_slot_arrival[nz], ref.head_slot_arrival[nz])    # head arrival (read from the head's slot record)
     assert torch.equal(fs.a_status, ref.a_status) and torch.equal(fs.st0, ref.st0)
     # insert cursor: nobody before it is still waiting
     pos = torch.arange(fs.A, device=x.device).unsqueeze(0)
@@ -45,7 +45,7 @@ def check_records(ops, plan, fs, x, Nmax, ag, cc, ec):
     assert torch.equal(fs.a_ins, (st_sorted != 0).to(torch.uint8)) and torch.equal(fs.a_win, ref.a_win)
     assert torch.equal(torch.gather(fs.a_rank, 1, fs.a_order.long()), pos.expand(fs.B, -1).to(torch.int32))
     # some rows carry a pending (lazy, never stored) garbage slot: idle in the last frame, or an event row that received nobody
-    assert int((((fs.tl & 1) == 0) | (fs.rec1[..., 1] > 0)).sum()) > 0
+    assert int((((fs.tl & 1) == 0) | (fs.gc8 > 0)).sum()) > 0
 
 
 @pytest.mark.parametrize("W,H,het,B,A,frames,with_cc,Nmax,tiny,dt,prune", [

@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--note", type=str, default="")
     ap.add_argument("--out", type=str, default=None)
     a = ap.parse_args()
-    from tarl_hip.ops import FUSED_LAYOUT
+    from tarl_hip.ops import FUSED_LAYOUT, frame_kernel_source_hash
     allc = per_kernel_all(a.dirs)
     if "FETCH_SIZE" not in allc or "WRITE_SIZE" not in allc:
         raise SystemExit("FETCH_SIZE and WRITE_SIZE passes are required")
@@ -93,7 +93,9 @@ def main():
                     "128-B request per triple) — so the factor 2 holds for every load these kernels issue; WRITE_SIZE is exact for stores "
                     "that fill 64-byte lines and tallies a partial-line store at 32 B per request. "
                     f"Mean over the last iteration's frames >= {a.first_frame}. " + a.note).strip(),
-           "config": cfg, "layout": FUSED_LAYOUT, "first_frame": a.first_frame, "kernels": {}}
+           "config": cfg, "layout": FUSED_LAYOUT, "source_sha16": frame_kernel_source_hash(),
+           "source_sha16_of": "tarl-simulator_amd/csrc/fused.hip + fused_common.h (bench.py ignores a record taken on other code)",
+           "first_frame": a.first_frame, "kernels": {}}
     for k, per_iter in ROLLOUT_KERNELS.items():
         if k not in allc["FETCH_SIZE"] or k not in allc["WRITE_SIZE"]:
             print(f"warning: {k} not in the traces ({sorted(allc['FETCH_SIZE'])[:12]} ...)", file=sys.stderr)
