@@ -959,6 +959,10 @@ __device__ __forceinline__ bool row_phase_a(uint32_t i, uint32_t b, const RowSta
   // is the (unpopped) head a withdraw candidate? (the first two tests of the withdraw scan, on registers)
   const bool due = (!pop) & (ni > 0u) & ((int64_t)head_id < A) & (head_dep <= t);
   *pop_out = pop;
+  // the row's count after the pass is ni - pop - (agents withdrawn): all but the last term is known here, so the row's
+  // share of the environment's count sum rides on the idle rows' coalesced atomic; the event path adds only what it
+  // withdraws (rare) instead of one scattered global atomic per event row
+  *n_out = (float)(ni - (pop ? 1u : 0u));
   if (!(lazy & !pop & !due)) return true;
   // IDLE ROW: nothing moves, and (almost) nothing is written. With agents, the row keeps its head and count: its word
   // is already what a refresh would store. Empty, its garbage head departs at t + tt0, which changes every frame — but
@@ -978,171 +982,144 @@ __device__ __forceinline__ bool row_phase_a(uint32_t i, uint32_t b, const RowSta
   if (FAPI && out.popped) out.popped[(int64_t)b * N + i] = 0;
   if (FAPI && out.withdrawn) out.withdrawn[(int64_t)b * N + i] = 0;
   if (out.events && b < out.m_env) out.events[(int64_t)i * out.m_env + b] = 0;
-  *n_out = (float)ni;
   return false;
 }
 
 // phase B of one EVENT row (its dense words travel with the list entry): Direction update on the slot store,
 // Response pop, withdraw, refreshed dense words + event word. -> {count after the pass, agents withdrawn}
+// Round 4, measured and rejected on this function and its caller (same-box A/B at 16 384 environments, profiles/README.md):
+// (1) every load whose address follows from the list entry requested at the head of the function — the record a pop
+// exposes, the destination of the scan's first candidate, the withdraw test's out-edge targets from the node record — for
+// every event row: row pass +7 % / +15 % (headline / loaded network), 7 M more scattered requests per launch; the same only
+// for heads that are due and without re-reading the record the scan stopped at: +2 % / +1 %, 14 spilled VGPRs in the hot
+// idle path. (2) DENSE rows: for a wave-row with >= 4 / 8 / 16 event lanes the refreshed words handed back through the
+// list and stored by the owning lanes as FULL 64-byte lines after a second barrier (re-read from L2, flag clears of the idle
+// lanes folded in): loaded network +14 % / +15 % / +2 % slower, and the extra LDS table and live state put scratch traffic
+// into the idle path (headline 181 -> 312 us). (3) 32-byte slot records (full-sector stores): fused_common.h, TARL_SLW.
+// What did pay: one store fewer per event row (the 8-byte event word rec1 became the byte gc8: -10 % / -17 %).
 template <bool FAPI>
 __device__ __forceinline__ float2 row_phase_b(uint32_t i, uint32_t b, bool pop, uint32_t pa, uint2 hp, uint32_t tlw,
-                                              const NodeRec* __restrict__ nodes, const int32_t* __restrict__ out_ptr,
+                                              const NodeRec& nr, const int32_t* __restrict__ out_ptr,
                                               const int32_t* __restrict__ out_dst, int Nmax, uint32_t B, uint32_t N,
                                               const FusedBufs& fb, float* __restrict__ ag, int64_t A, int64_t a_bstride,
                                               float t, const FrameOut& out) {
+  const PlanOut P{out_ptr, out_dst};
   const uint32_t row = i * B + b;
-  const NodeRec& nr = nodes[i];
+  const float4 st = make_float4(nr.maxn, nr.ff, nr.road, nr.cong);
   const uint32_t n0i = hp.x & HD_CNT, head_id0 = hp.x >> 8, tail0 = tlw >> 8;
   const uint32_t arrived = pa & PF_ARRIVED;
   const uint32_t who = arrived ? (pa >> 8) : 0u;
   const float n0 = (float)n0i;
   const int q = (int)n0i;
-  float* sl = fb.slots + (int64_t)row * fb.lds;  // slot s = sl[SLW s ..] = {id, arrival, departure}
-  int hoff = tl_hoff(tlw);     // (the event byte gc8 is write-only here: no load sits between the row and its slots)
-  const uint32_t ni = n0i + arrived;   // count after the Direction update
-  // ---- the loads whose address follows from the list entry alone AND that are certain to be needed are requested now,
-  // before anything is computed: the event path is a chain of dependent memory rounds a few lanes wide. (a) the record of
-  // the head a pop exposes (the second slot; not when that is the agent enqueued in this very frame: registers), (b) for an
-  // unpopped head that is DUE (the withdraw scan's first two tests, on registers): its destination and the out-edge
-  // targets the withdraw test compares it with. Nothing is requested on speculation: the pass is bound by the NUMBER of
-  // scattered requests as much as by their latency (round 4: a destination gather for every unpopped event row instead of
-  // the ~quarter that are due cost +15 % in the loaded network).
-  const bool pop_slot = pop & (n0i >= 2u);                       // new head = old logical slot 1, stored in an earlier frame
-  SlotRec nh{0.0f, 0.0f, 0.0f};
-  if (pop_slot) nh = slot_load(sl + SLW * phys(hoff, 1, Nmax));
-  const float4 st = make_float4(nr.maxn, nr.ff, nr.road, nr.cong);
-  const float dep_new = t + entry_tt(st, n0);
-  const uint32_t head_pre = (n0i == 0u) ? who : head_id0;
-  const float dep_pre = (n0i == 0u) ? dep_new : __uint_as_float(hp.y);
-  const bool due0 = (!pop) & (ni > 0u) & ((int64_t)head_pre < A) & (dep_pre <= t);
-  // the withdraw test "is the agent's destination an out-neighbour of this road" (src/agents/base.py:334-403) needs the
-  // out-edge targets of node ROAD_INDEX(i): the first four travel in that node's record (for a road row ROAD_INDEX(i) = i:
-  // this very record), one L2 round instead of the out_ptr -> out_dst -> compare chain; loaded when a candidate is due
-  const long long road = (long long)st.z;
-  const bool road_ok = road >= 0 && road < (long long)N;
-  const NodeRec& rr = nodes[road_ok ? road : (long long)i];
-  int32_t dest0 = -1, r_deg = 0, r_out0 = 0, r_o0 = 0, r_o1 = 0, r_o2 = 0, r_o3 = 0;
-  bool have_rr = false;
-  auto load_road = [&]() {
-    r_deg = road_ok ? rr.out_deg : 0;
-    r_out0 = rr.out0;
-    r_o0 = rr.out4[0];
-    r_o1 = rr.out4[1];
-    r_o2 = rr.out4[2];
-    r_o3 = rr.out4[3];
-    have_rr = true;
-  };
-  if (due0) {
-    dest0 = fb.a_dest[(int64_t)b * A + head_pre];
-    load_road();
-  }
   // exact, slot-by-slot bookkeeping of the dead slots: rows that are dirty already, and from the moment the FIFO touches
   // its last slot (count >= Nmax - 1: no dead slot is left above the one this update writes, so nothing has to be
   // materialised at the transition). A clean row's dead slots are zero by the invariant (fused_common.h) whatever the
   // store holds: its pops and withdraws neither read nor write them.
   const bool exact = (hp.x & HD_DIRTY) != 0u || q >= Nmax - 1;
-  // Direction update (every row, also when nothing was chosen): one record store — or, for a row that received
+  // Direction update (every row, also when nothing was chosen): one 12-byte store — or, for a row that received
   // nobody, nothing at all (lazy garbage slot, see the file header).
+  const float dep_new = t + entry_tt(st, n0);
   const bool lazy = (who == 0u) && (q < Nmax - 1);
-  uint32_t head_id = head_pre;
-  float head_dep = dep_pre;
-  // The FIFO is a ring buffer: logical slot s lives at physical slot (hoff + s) mod Nmax.
-  if (!lazy && q < Nmax) slot_store(sl + SLW * phys(hoff, q, Nmax), (float)who, t, dep_new);
-  int n = (int)ni;
-  uint32_t tail_id = arrived ? who : tail0;
+  const uint32_t ni = n0i + arrived;   // count after the Direction update
+  uint32_t head_id = (n0i == 0u) ? who : head_id0;
+  float head_dep = (n0i == 0u) ? dep_new : __uint_as_float(hp.y);
+  {
+    // The FIFO is a ring buffer: logical slot s lives at physical slot (hoff + s) mod Nmax.
+    float* sl = fb.slots + (int64_t)row * fb.lds;  // slot s = sl[3s .. 3s+2] = {id, arrival, departure}
+    int hoff = tl_hoff(tlw);     // (the event byte gc8 is write-only here: no load sits between the row and its slots)
+    if (!lazy && q < Nmax) {
+      slot_store(sl + SLW * phys(hoff, q, Nmax), (float)who, t, dep_new);
+    }
+    int n = (int)ni;
+    uint32_t tail_id = arrived ? who : tail0;
 
-  // Response pop: logical shift by one where the LAST slot keeps its value. Ring form: the slot that falls off the
-  // front becomes the new logical last slot, so it receives a copy of the old last slot; then the head advances.
-  int shift = 0;
-  if (pop) {
-    if (exact) {
-      const SlotRec last = slot_load(sl + SLW * phys(hoff, Nmax - 1, Nmax));
-      slot_store(sl + SLW * hoff, last.id, last.arr, last.dep);
-    }
-    hoff = phys(hoff, 1, Nmax);
-    shift = 1;
-    n = n - 1;
-  }
-  // withdraw: leading run of the (popped) row. `cid / cdep` = the record the scan looks at; it starts with the head —
-  // registers, or what the pop exposed (prefetched above; the agent enqueued in this frame when the row held one agent) —
-  // and every further record is the next slot. Whatever record the scan STOPS at is the row's new head: it is not read again.
-  float cid = (float)head_id, cdep = head_dep;
-  if (shift != 0 && n > 0) {
-    if (n0i >= 2u) {
-      cid = nh.id;
-      cdep = nh.dep;
-    } else {            // n0i == 1 and somebody arrived: the new head is the record stored above
-      cid = (float)who;
-      cdep = dep_new;
-    }
-  }
-  int c = 0;
-  if (n > 0) {
-    int32_t dest = dest0;
-    bool have_dest = due0;       // the prefetched destination belongs to the first candidate of an unpopped row
-    for (int sx = 0; sx < Nmax && sx < n; ++sx) {
-      if (sx > 0) {
-        const SlotRec rd = slot_load(sl + SLW * phys(hoff, sx, Nmax));
-        cid = rd.id;
-        cdep = rd.dep;
-        have_dest = false;
+    // Response pop: logical shift by one where the LAST slot keeps its value. Ring form: the slot that falls off the
+    // front becomes the new logical last slot, so it receives a copy of the old last slot; then the head advances.
+    int shift = 0;
+    if (pop) {
+      if (exact) {
+        const SlotRec last = slot_load(sl + SLW * phys(hoff, Nmax - 1, Nmax));
+        slot_store(sl + SLW * hoff, last.id, last.arr, last.dep);
       }
-      const long long id = (long long)cid;
-      if (id < 0 || id >= A) break;
-      if (!(cdep <= t)) break;  // tested first: most heads are still travelling, and the lookup below is a gather
-      if (!have_dest) dest = fb.a_dest[(int64_t)b * A + id];
-      if (!have_rr) load_road();
-      const long long dl = (long long)dest;
-      bool conn = ((r_deg > 0) & ((long long)r_o0 == dl)) | ((r_deg > 1) & ((long long)r_o1 == dl)) |
-                  ((r_deg > 2) & ((long long)r_o2 == dl)) | ((r_deg > 3) & ((long long)r_o3 == dl));
-      for (int32_t k = r_out0 + 4; k < r_out0 + r_deg; ++k) conn = conn || ((long long)out_dst[k] == dl);
-      if (!conn) break;
-      float* a = ag + (int64_t)b * a_bstride + id * AG_COLS;
-      a[AG_DONE] = 1.0f;
-      a[AG_ON_WAY] = 0.0f;
-      a[AG_ARR] = t;
-      fb.a_status[(int64_t)b * A + id] = 2;
-      ++c;
+      hoff = phys(hoff, 1, Nmax);
+      shift = 1;
+      n = n - 1;
     }
-  }
-  // withdraw = logical shift by c with zero fill: the c slots that fall off the front become the zeroed tail
-  for (int k = 0; exact && k < c; ++k) slot_store(sl + SLW * phys(hoff, k, Nmax), 0.0f, 0.0f, 0.0f);
-  if (c > 0) {
-    hoff = phys(hoff, c, Nmax);   // c <= Nmax
-    n = n - c;
-  }
-  if (shift + c > 0) {
-    if (lazy && n == 0) {  // the row emptied: its head slot is the (unmaterialised) garbage slot
-      head_id = 0u;
-      head_dep = dep_new;
-    } else if (!exact && n == 0) {   // a clean row emptied by the pop of the agent it has just received: a dead slot, zero
-      head_id = 0u;
-      head_dep = 0.0f;
-    } else if (n > 0 && c < Nmax) {  // the record the scan stopped at (it was looked at: the scan only ends early on a test)
-      head_id = (uint32_t)(long long)cid;
-      head_dep = cdep;
-    } else {                         // a dirty row that emptied (its dead slots are physical), or a FIFO beyond its domain
-      const SlotRec hd = slot_load(sl + SLW * hoff);
-      head_id = (uint32_t)(long long)hd.id;
-      head_dep = hd.dep;
+    // withdraw: leading run of the (popped) row
+    int c = 0;
+    if (n > 0) {
+      const long long road = (long long)st.z;
+      int32_t w0 = -1, w1 = 0;   // out-list of this row's road: fetched only when a head is actually due
+      for (int sx = 0; sx < Nmax && sx < n; ++sx) {
+        float idf, depf;
+        if (sx == 0 && shift == 0) {   // the head is in registers unless the pop just exposed a new one
+          idf = (float)head_id;
+          depf = head_dep;
+        } else {
+          const SlotRec rd = slot_load(sl + SLW * phys(hoff, sx, Nmax));
+          idf = rd.id;
+          depf = rd.dep;
+        }
+        const long long id = (long long)idf;
+        if (id < 0 || id >= A) break;
+        if (!(depf <= t)) break;  // tested first: most heads are still travelling, and the lookup below is a gather
+        const long long dest = (long long)fb.a_dest[(int64_t)b * A + id];
+        if (w0 < 0) {
+          w0 = 0;
+          if (road >= 0 && road < N) {
+            w0 = P.out_ptr[road];
+            w1 = P.out_ptr[road + 1];
+          }
+        }
+        bool conn = false;
+        for (int32_t k = w0; k < w1; ++k) conn = conn || ((long long)P.out_dst[k] == dest);
+        if (!conn) break;
+        float* a = ag + (int64_t)b * a_bstride + id * AG_COLS;
+        a[AG_DONE] = 1.0f;
+        a[AG_ON_WAY] = 0.0f;
+        a[AG_ARR] = t;
+        fb.a_status[(int64_t)b * A + id] = 2;
+        ++c;
+      }
     }
-    // the agents that stay keep their order: the tail is who it was (the arrival, or the tail word's id) unless nobody
-    // stays. (A count at Nmax is outside the domain and flagged; the store is re-read there as the reference would.)
-    if (n == 0)
-      tail_id = 0u;
-    else if (n >= Nmax)
-      tail_id = (n == Nmax) ? (uint32_t)(long long)sl[SLW * phys(hoff, n - 1, Nmax)] : 0u;
+    // withdraw = logical shift by c with zero fill: the c slots that fall off the front become the zeroed tail
+    for (int k = 0; exact && k < c; ++k) {
+      slot_store(sl + SLW * phys(hoff, k, Nmax), 0.0f, 0.0f, 0.0f);
+    }
+    if (c > 0) {
+      hoff = phys(hoff, c, Nmax);   // c <= Nmax
+      n = n - c;
+    }
+    if (shift + c > 0) {
+      if (lazy && n == 0) {  // the row emptied: its head slot is the (unmaterialised) garbage slot
+        head_id = 0u;
+        head_dep = dep_new;
+      } else if (!exact && n == 0) {   // a clean row emptied by the pop of the agent it has just received: a dead slot, zero
+        head_id = 0u;
+        head_dep = 0.0f;
+      } else {
+        const SlotRec hd = slot_load(sl + SLW * hoff);
+        head_id = (uint32_t)(long long)hd.id;
+        head_dep = hd.dep;
+      }
+      // the agents that stay keep their order: the tail is who it was (the arrival, or the tail word's id) unless nobody
+      // stays. (A count at Nmax is outside the domain and flagged; the store is re-read there as the reference would.)
+      if (n == 0)
+        tail_id = 0u;
+      else if (n >= Nmax)
+        tail_id = (n == Nmax) ? (uint32_t)(long long)sl[SLW * phys(hoff, n - 1, Nmax)] : 0u;
+    }
+    fb.hdp[row] = make_uint2((head_id << 8) | (uint32_t)n | (exact ? HD_DIRTY : 0u), __float_as_uint(head_dep));
+    fb.tl[row] = tl_word(tail_id, hoff, TLF_AUTH);
+    fb.gc8[row] = (uint8_t)r1_code(lazy ? q : -1);
+    // per-node count before insertion (the insert kernel adds this frame's arrivals)
+    if (out.counts8) out.counts8[row] = (uint8_t)n;
+    if (FAPI && out.countsf) out.countsf[row] = (float)n;
+    if (FAPI && out.popped) out.popped[(int64_t)b * N + i] = pop ? 1 : 0;
+    if (FAPI && out.withdrawn) out.withdrawn[(int64_t)b * N + i] = c > 0 ? 1 : 0;
+    if (out.events && b < out.m_env) out.events[(int64_t)i * out.m_env + b] = (uint8_t)((pop ? 1 : 0) | (c > 0 ? 2 : 0));
+    return make_float2((float)n, (float)c);
   }
-  fb.hdp[row] = make_uint2((head_id << 8) | (uint32_t)n | (exact ? HD_DIRTY : 0u), __float_as_uint(head_dep));
-  fb.tl[row] = tl_word(tail_id, hoff, TLF_AUTH);
-  fb.gc8[row] = (uint8_t)r1_code(lazy ? q : -1);
-  // per-node count before insertion (the insert kernel adds this frame's arrivals)
-  if (out.counts8) out.counts8[row] = (uint8_t)n;
-  if (FAPI && out.countsf) out.countsf[row] = (float)n;
-  if (FAPI && out.popped) out.popped[(int64_t)b * N + i] = pop ? 1 : 0;
-  if (FAPI && out.withdrawn) out.withdrawn[(int64_t)b * N + i] = c > 0 ? 1 : 0;
-  if (out.events && b < out.m_env) out.events[(int64_t)i * out.m_env + b] = (uint8_t)((pop ? 1 : 0) | (c > 0 ? 2 : 0));
-  return make_float2((float)n, (float)c);
 }
 
 // NCH rows per lane: ALL their loads (dense words, downstream post words) are issued before the first row is processed,
@@ -1254,7 +1231,9 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
         bool pop;
         float n = 0.0f;
         const uint32_t i = (uint32_t)ri[r];
-        if (row_phase_a<FAPI, O32>(i, b, rs[r], post, pa[r], hp[r], tlw[r], pj[r], Nmax, B, N, fb, A, t, out, &pop, &n)) {
+        const bool ev = row_phase_a<FAPI, O32>(i, b, rs[r], post, pa[r], hp[r], tlw[r], pj[r], Nmax, B, N, fb, A, t, out, &pop, &n);
+        nsum += n;
+        if (ev) {
           const int32_t pos = atomicAdd(&s_cnt, 1);
           if (pos < EV_CAP) {
             s_item[pos] = (uint16_t)((r << 9) | (pop ? 256 : 0) | threadIdx.x);
@@ -1262,8 +1241,6 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
           } else {
             ovf |= (1u << r) | (pop ? (16u << r) : 0u);   // the list is full: served in place below
           }
-        } else {
-          nsum += n;
         }
       }
     // In-place fall-back for the pairs that found the list full (a loaded network; never in a filling one). ONE rolled copy
@@ -1284,9 +1261,9 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
           hp_r.y = (r == q) ? hp[q].y : hp_r.y;
           i_r = (r == q) ? ri[q] : i_r;
         }
-        const float2 nc = row_phase_b<FAPI>((uint32_t)i_r, b, ((ovf >> (4 + r)) & 1u) != 0u, pa_r, hp_r, tl_r, nodes, out_ptr,
+        const float2 nc = row_phase_b<FAPI>((uint32_t)i_r, b, ((ovf >> (4 + r)) & 1u) != 0u, pa_r, hp_r, tl_r, nodes[i_r], out_ptr,
                                       out_dst, Nmax, B, N, fb, ag, A, a_bstride, t, out);
-        nsum += nc.x;
+        nsum -= nc.y;
         if (nc.y != 0.0f) atomicAdd(&fb.acc_w[(int64_t)(blockIdx.y % (unsigned)fb.acc_slots) * B + b], nc.y);
       }
     }
@@ -1305,10 +1282,12 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     int32_t i2 = ri[0];
 #pragma unroll
     for (int q = 1; q < NCH; ++q) i2 = (r == (uint32_t)q) ? ri[q] : i2;
-    const float2 nc = row_phase_b<FAPI>((uint32_t)i2, b2, (item & 256u) != 0u, wd.x, make_uint2(wd.y, wd.z), wd.w, nodes,
+    const float2 nc = row_phase_b<FAPI>((uint32_t)i2, b2, (item & 256u) != 0u, wd.x, make_uint2(wd.y, wd.z), wd.w, nodes[i2],
                                   out_ptr, out_dst, Nmax, B, N, fb, ag, A, a_bstride, t, out);
-    if (nc.x != 0.0f) atomicAdd(&fb.acc_n[bank0 + b2], nc.x);     // small integers: exact in fp32 in any order
-    if (nc.y != 0.0f) atomicAdd(&fb.acc_w[bank0 + b2], nc.y);
+    if (nc.y != 0.0f) {      // withdrawn agents leave the count sum (small integers: exact in fp32 in any order)
+      atomicAdd(&fb.acc_n[bank0 + b2], -nc.y);
+      atomicAdd(&fb.acc_w[bank0 + b2], nc.y);
+    }
   }
 }
 

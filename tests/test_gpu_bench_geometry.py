@@ -220,6 +220,36 @@ def test_config5_training_leg_matches_oracle_autograd():
     n_emb = emb.grad.numel()
     close(g[:n_emb], emb.grad.reshape(-1), "grad emb", 8 * Q)
     assert float(emb.grad.abs().max()) > 0
+    # ---- fp64 referee for the actor side (round-3 verdict) ------------------------------------------------------------------
+    # The ulp-sized bounds above compare two fp32 evaluations with each other. Here both are compared with the SAME quantities
+    # evaluated once in float64 on the CPU (the reference's formulas, src/reinforcement_learning.py:82-92, on double inputs):
+    # the HIP result must be no farther from the exact value than twice the fp32 oracle's own distance, plus 1e-4 of the
+    # quantity's scale — i.e. the ulp-sized slack is the fp32 format's, shared by the reference, not the kernels'.
+    emb64 = emb0.double().clone().requires_grad_(True)
+    d64 = dist.GraphDist(nets.policy_logits(nf_mb.double(), net.edge_index, emb64), net.edge_index)
+    lp64 = d64.log_prob(onehot)
+    assert lp64.dtype == torch.float64
+
+    def referee(hip, orc, exact, what):
+        scale = max(1.0, float(exact.abs().max()))
+        e_hip, e_orc = float((hip.double() - exact).abs().max()), float((orc.double() - exact).abs().max())
+        assert e_hip <= 2.0 * e_orc + 1e-4 * scale, f"{what}: |hip - fp64| = {e_hip:.3e}, |oracle fp32 - fp64| = {e_orc:.3e}, scale {scale:.3e}"
+        return e_hip, e_orc
+
+    with torch.no_grad():
+        lp_or32 = dist.GraphDist(nets.policy_logits(nf_mb, net.edge_index, emb0), net.edge_index).log_prob(onehot)
+    e_hip, e_orc = referee(lp_old, lp_or32, lp64.detach(), "sample_log_prob")
+    # the rollout sums its log-prob terms in 2^-32 fixed point: the stored value is the correctly rounded sum of its fp32
+    # terms (half an ulp + the terms' own rounding), at least as close to the exact value as the fp32 tree sum
+    assert e_hip <= 2 * Q
+    # surrogate loss and embedding gradient with the stored behaviour log-prob, exact arithmetic elsewhere
+    adv64, lpo64 = adv_mb.double(), lp_old.double()
+    lw = lp64 - lpo64
+    gain = torch.min(lw.exp() * adv64, lw.clamp(math.log1p(-0.2), math.log1p(0.2)).exp() * adv64)
+    obj64 = -gain.mean()
+    (obj64 + (-0.01) * d64.entropy().mean()).backward()
+    referee(o[0].double().reshape(1), losses["loss_objective"].detach().reshape(1), obj64.detach().reshape(1), "loss_objective")
+    referee(g[:n_emb], emb.grad.reshape(-1), emb64.grad.reshape(-1), "grad emb")
     off = n_emb
     for name, ref in [(f"critic{i}", c.grad) for i, c in enumerate(cw)]:
         n = ref.numel()
