@@ -347,30 +347,35 @@ __global__ __launch_bounds__(CR_THREADS) void k_split_w1(const float* __restrict
   w3[2 * CR_H * Kpad + idx] = lo;
 }
 
+// CT column tiles of 32 environments per wave: a workgroup owns 128 * CT environments of one frame. The three weight pieces
+// of a k-tile (12 KB) are read from L2 once per workgroup and k-tile whatever CT is, the count bytes are 4 KB * CT: with
+// CT = 1 (round 3) the pass moved 3 bytes of weights through the L2 for every byte of counts from HBM — 32 GB of L2 -> LDS
+// traffic beside the 10.5 GB stream at 16 384 environments, 1.9 TB/s of HBM; CT = 4 cuts the weight traffic by four.
+template <int CT>
 __global__ __launch_bounds__(CR_THREADS) void k_critic_fwd_slab_u8x3(const uint8_t* __restrict__ counts, int64_t rps,
                                                                      int64_t M, int64_t N, int64_t Kpad,
                                                                      const float* __restrict__ time_rows,
                                                                      int64_t rows_per_time,
                                                                      const uint16_t* __restrict__ w3, CriticParams P,
                                                                      float* __restrict__ value) {
-  // staging: 2 x (Xs [128 envs][36] bytes + Wb [3][64][40] bf16); the epilogue reuses the space as Hs [64][129] + W2s [64][65] f32
-  __shared__ __attribute__((aligned(16))) uint8_t lds_raw[(CR_H * (CR_BM + 1) + CR_H * (CR_H + 1)) * 4];
-  const int XB = CR_BM * CB_XLD, WB = 3 * CR_H * CB_WLD * 2, BUF = XB + WB;   // bytes
-  static_assert(2 * (CR_BM * CB_XLD + 3 * CR_H * CB_WLD * 2) <= (CR_H * (CR_BM + 1) + CR_H * (CR_H + 1)) * 4, "LDS plan");
+  // staging: 2 x (Xs [128 CT envs][36] bytes + Wb [3][64][40] bf16); the epilogue reuses the space as Hs [64][129] + W2s [64][65] f32
+  constexpr int XB = CT * CR_BM * CB_XLD, WB = 3 * CR_H * CB_WLD * 2, BUF = XB + WB;   // bytes
+  constexpr int EPI = (CR_H * (CR_BM + 1) + CR_H * (CR_H + 1)) * 4;
+  __shared__ __attribute__((aligned(16))) uint8_t lds_raw[2 * BUF > EPI ? 2 * BUF : EPI];
   static_assert(CR_BK == 32 && CR_BM == 128 && CR_THREADS == 256 && (CR_BM * CB_XLD) % 16 == 0, "X staging plan");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t row0 = (int64_t)blockIdx.x * CR_BM;
+  const int64_t row0 = (int64_t)blockIdx.x * (CR_BM * CT);
   const int64_t ldw = N + 1;
   const uint8_t* xbase = counts + (row0 / rps) * (N * rps) + (row0 % rps);   // element (env r, node k) at xbase[k * rps + r]
   const int64_t WP = CR_H * Kpad;      // one weight piece
 
   // Two register stages: the tile of iteration i + 2 is requested while tile i is multiplied and tile i + 1 (requested one
-  // iteration earlier) is written to LDS — an iteration is 12 MFMAs (~0.2 us), far less than a load's round trip, so one
+  // iteration earlier) is written to LDS — an iteration is 12 CT MFMAs, far less than a load's round trip, so one
   // tile ahead left the matrix cores waiting. Loads are unconditional (a k past the end re-reads the last row: its weight
   // pieces are zero padding; a tile past the end re-reads the last tile): no divergent control flow, exact wait counts.
   struct Stage {
-    uint32_t xr[4];    // 4 environments (4 * (tid & 31) ..) of 4 consecutive k (4 * (tid >> 5) ..)
-    uint4 wr[3];       // 8 bf16 of each piece: j = tid >> 2, k = 8 * (tid & 3) ..
+    uint32_t xr[CT][4];    // per 128-environment block c: 4 environments (4 * (tid & 31) ..) of 4 consecutive k (4 * (tid >> 5) ..)
+    uint4 wr[3];           // 8 bf16 of each piece: j = tid >> 2, k = 8 * (tid & 3) ..
   };
   const int64_t NIT = (N + CR_BK - 1) / CR_BK;
   auto fetch = [&](Stage& st, int64_t it) {
@@ -379,7 +384,9 @@ __global__ __launch_bounds__(CR_THREADS) void k_critic_fwd_slab_u8x3(const uint8
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int64_t k = k0 + 4 * kg + i;
-      st.xr[i] = *reinterpret_cast<const uint32_t*>(xbase + (k < N ? k : N - 1) * rps + 4 * eg);
+      const uint8_t* xk = xbase + (k < N ? k : N - 1) * rps + 4 * eg;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) st.xr[c][i] = *reinterpret_cast<const uint32_t*>(xk + CR_BM * c);
     }
     const int j = tid >> 2, q = tid & 3;
 #pragma unroll
@@ -391,17 +398,25 @@ __global__ __launch_bounds__(CR_THREADS) void k_critic_fwd_slab_u8x3(const uint8
     uint16_t* Wb = reinterpret_cast<uint16_t*>(Xs + XB);
     const int kg = tid >> 5, eg = tid & 31;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {      // byte e of the four k-rows -> one dword [env 4 eg + e][k 4 kg .. 4 kg + 3]
-      const uint32_t v = ((st.xr[0] >> (8 * e)) & 0xFFu) | (((st.xr[1] >> (8 * e)) & 0xFFu) << 8) |
-                         (((st.xr[2] >> (8 * e)) & 0xFFu) << 16) | (((st.xr[3] >> (8 * e)) & 0xFFu) << 24);
-      *reinterpret_cast<uint32_t*>(Xs + (4 * eg + e) * CB_XLD + 4 * kg) = v;
-    }
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {      // byte e of the four k-rows -> one dword [env 128 c + 4 eg + e][k 4 kg .. 4 kg + 3]
+        const uint32_t v = ((st.xr[c][0] >> (8 * e)) & 0xFFu) | (((st.xr[c][1] >> (8 * e)) & 0xFFu) << 8) |
+                           (((st.xr[c][2] >> (8 * e)) & 0xFFu) << 16) | (((st.xr[c][3] >> (8 * e)) & 0xFFu) << 24);
+        *reinterpret_cast<uint32_t*>(Xs + (CR_BM * c + 4 * eg + e) * CB_XLD + 4 * kg) = v;
+      }
     const int j = tid >> 2, q = tid & 3;
 #pragma unroll
     for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<uint4*>(Wb + (pc * CR_H + j) * CB_WLD + 8 * q) = st.wr[pc];
   };
 
-  f32x16 acc0 = {0}, acc1 = {0};     // D^T: rows j (0..31 / 32..63), cols = this wave's 32 environments
+  // D^T: rows j (0..31 / 32..63), cols = 32 environments; the wave's tile c covers environments 128 c + 32 wave .. + 31
+  f32x16 acc0[CT], acc1[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    acc0[c] = (f32x16){0};
+    acc1[c] = (f32x16){0};
+  }
   const int r32 = lane & 31, h8 = (lane >> 5) * 8;
   auto multiply = [&](int buf) {
     const uint8_t* Xs = lds_raw + buf * BUF;
@@ -409,22 +424,29 @@ __global__ __launch_bounds__(CR_THREADS) void k_critic_fwd_slab_u8x3(const uint8
 #pragma unroll
     for (int s = 0; s < CR_BK / 16; ++s) {
       // B fragment: lane (col r32 = env, half h) holds X^T[k = 16 s + 8 h + j][env], j = 0..7: small integers, exact in bf16
-      const uint32_t* xw = reinterpret_cast<const uint32_t*>(Xs + (wave * 32 + r32) * CB_XLD + 16 * s + h8);
-      const uint32_t x0 = xw[0], x1 = xw[1];
-      uint32_t bw[4];
+      cbf16x8 bx[CT];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {      // two counts -> two bf16 (the top halves of their fp32 images: exact below 256)
-        const uint32_t xs = j < 2 ? x0 : x1;
-        const float c0 = (float)((xs >> (16 * (j & 1))) & 0xFFu), c1 = (float)((xs >> (16 * (j & 1) + 8)) & 0xFFu);
-        bw[j] = (__float_as_uint(c0) >> 16) | (__float_as_uint(c1) & 0xFFFF0000u);
+      for (int c = 0; c < CT; ++c) {
+        const uint32_t* xw = reinterpret_cast<const uint32_t*>(Xs + (CR_BM * c + wave * 32 + r32) * CB_XLD + 16 * s + h8);
+        const uint32_t x0 = xw[0], x1 = xw[1];
+        uint32_t bw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {      // two counts -> two bf16 (the top halves of their fp32 images: exact below 256)
+          const uint32_t xs = j < 2 ? x0 : x1;
+          const float c0 = (float)((xs >> (16 * (j & 1))) & 0xFFu), c1 = (float)((xs >> (16 * (j & 1) + 8)) & 0xFFu);
+          bw[j] = (__float_as_uint(c0) >> 16) | (__float_as_uint(c1) & 0xFFFF0000u);
+        }
+        bx[c] = __builtin_bit_cast(cbf16x8, bw);
       }
-      const cbf16x8 bx = __builtin_bit_cast(cbf16x8, bw);
 #pragma unroll
       for (int pc = 0; pc < 3; ++pc) {
         const cbf16x8 a0 = *reinterpret_cast<const cbf16x8*>(Wb + (pc * CR_H + r32) * CB_WLD + 16 * s + h8);
         const cbf16x8 a1 = *reinterpret_cast<const cbf16x8*>(Wb + (pc * CR_H + 32 + r32) * CB_WLD + 16 * s + h8);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bx, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bx, acc1, 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          acc0[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bx[c], acc0[c], 0, 0, 0);
+          acc1[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bx[c], acc1[c], 0, 0, 0);
+        }
       }
     }
   };
@@ -444,62 +466,68 @@ __global__ __launch_bounds__(CR_THREADS) void k_critic_fwd_slab_u8x3(const uint8
     __syncthreads();
   }
 
-  // epilogue: + time * W1[:, N] + b1, ReLU -> Hs [j][env]; then the second and third layer exactly as k_critic_fwd_slab
+  // epilogue, one 128-environment block c at a time through the same LDS: + time * W1[:, N] + b1, ReLU -> Hs [j][env]; then
+  // the second and third layer exactly as k_critic_fwd_slab
   float* Hs = reinterpret_cast<float*>(lds_raw);     // [j][row], stride 129
   float* W2s = Hs + CR_H * (CR_BM + 1);              // [k][j],  stride 65
-  {
-    const int lr = wave * 32 + r32;                  // this lane's environment (column of D^T)
-    const int64_t gr = row0 + lr;
-    const float tm = (gr < M) ? time_rows[gr / rows_per_time] : 0.0f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int j = mfma_row(r, lane);               // row of D^T = hidden unit
-      float v0 = acc0[r] + tm * P.w1[(int64_t)j * ldw + N] + P.b1[j];
-      float v1 = acc1[r] + tm * P.w1[(int64_t)(j + 32) * ldw + N] + P.b1[j + 32];
-      Hs[j * (CR_BM + 1) + lr] = v0 > 0.0f ? v0 : 0.0f;
-      Hs[(j + 32) * (CR_BM + 1) + lr] = v1 > 0.0f ? v1 : 0.0f;
-    }
-  }
 #pragma unroll
   for (int it = 0; it < (CR_H * CR_H) / CR_THREADS; ++it) {
     const int idx = it * CR_THREADS + tid;
     const int j = idx >> 6, k = idx & 63;
     W2s[k * (CR_H + 1) + j] = P.w2[j * CR_H + k];
   }
-  __syncthreads();
-  f32x16 c0 = {0}, c1 = {0};
 #pragma unroll
-  for (int kk = 0; kk < CR_H; kk += 2) {
-    const int k = kk + (lane >> 5);
-    const float a = Hs[k * (CR_BM + 1) + wave * 32 + (lane & 31)];
-    const float b0 = W2s[k * (CR_H + 1) + (lane & 31)];
-    const float b1 = W2s[k * (CR_H + 1) + 32 + (lane & 31)];
-    c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, c1, 0, 0, 0);
-  }
-  __syncthreads();
-  {
-    const int j0 = lane & 31;
-    const float bb0 = P.b2[j0], bb1 = P.b2[j0 + 32];
+  for (int c = 0; c < CT; ++c) {
+    const int64_t rowc = row0 + CR_BM * c;           // first row of this 128-environment block
+    {
+      const int lr = wave * 32 + r32;                // this lane's environment (column of D^T)
+      const int64_t gr = rowc + lr;
+      const float tm = (gr < M) ? time_rows[gr / rows_per_time] : 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int lr = wave * 32 + mfma_row(r, lane);
-      float v0 = c0[r] + bb0, v1 = c1[r] + bb1;
-      v0 = v0 > 0.0f ? v0 : 0.0f;
-      v1 = v1 > 0.0f ? v1 : 0.0f;
-      Hs[j0 * (CR_BM + 1) + lr] = v0;
-      Hs[(j0 + 32) * (CR_BM + 1) + lr] = v1;
+      for (int r = 0; r < 16; ++r) {
+        const int j = mfma_row(r, lane);             // row of D^T = hidden unit
+        float v0 = acc0[c][r] + tm * P.w1[(int64_t)j * ldw + N] + P.b1[j];
+        float v1 = acc1[c][r] + tm * P.w1[(int64_t)(j + 32) * ldw + N] + P.b1[j + 32];
+        Hs[j * (CR_BM + 1) + lr] = v0 > 0.0f ? v0 : 0.0f;
+        Hs[(j + 32) * (CR_BM + 1) + lr] = v1 > 0.0f ? v1 : 0.0f;
+      }
     }
-  }
-  __syncthreads();
-  if (tid < CR_BM) {
-    const int64_t gr = row0 + tid;
-    if (gr < M) {
-      float sacc = 0.0f;
+    __syncthreads();
+    f32x16 c0 = {0}, c1 = {0};
+#pragma unroll
+    for (int kk = 0; kk < CR_H; kk += 2) {
+      const int k = kk + (lane >> 5);
+      const float a = Hs[k * (CR_BM + 1) + wave * 32 + (lane & 31)];
+      const float b0 = W2s[k * (CR_H + 1) + (lane & 31)];
+      const float b1 = W2s[k * (CR_H + 1) + 32 + (lane & 31)];
+      c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, c1, 0, 0, 0);
+    }
+    __syncthreads();
+    {
+      const int j0 = lane & 31;
+      const float bb0 = P.b2[j0], bb1 = P.b2[j0 + 32];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lr = wave * 32 + mfma_row(r, lane);
+        float v0 = c0[r] + bb0, v1 = c1[r] + bb1;
+        v0 = v0 > 0.0f ? v0 : 0.0f;
+        v1 = v1 > 0.0f ? v1 : 0.0f;
+        Hs[j0 * (CR_BM + 1) + lr] = v0;
+        Hs[(j0 + 32) * (CR_BM + 1) + lr] = v1;
+      }
+    }
+    __syncthreads();
+    if (tid < CR_BM) {
+      const int64_t gr = rowc + tid;
+      if (gr < M) {
+        float sacc = 0.0f;
 #pragma unroll 8
-      for (int j = 0; j < CR_H; ++j) sacc += Hs[j * (CR_BM + 1) + tid] * P.w3[j];
-      value[gr] = sacc + P.b3[0];
+        for (int j = 0; j < CR_H; ++j) sacc += Hs[j * (CR_BM + 1) + tid] * P.w3[j];
+        value[gr] = sacc + P.b3[0];
+      }
     }
+    __syncthreads();      // the next block's activations overwrite Hs
   }
 }
 
@@ -783,8 +811,24 @@ extern "C" int tarl_critic_mlp_fwd_slabs_u8(const uint8_t* counts, int64_t rows_
   hipLaunchKernelGGL(k_split_w1, dim3((unsigned)ceil_div(CR_H * Kpad, CR_THREADS)), dim3(CR_THREADS), 0, s, w1, N, Kpad,
                      (uint16_t*)split_scratch);
   TARL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_critic_fwd_slab_u8x3, dim3((unsigned)(M / CR_BM)), dim3(CR_THREADS), 0, s, counts, rows_per_slab, M,
-                     N, Kpad, time_rows, rows_per_time, (const uint16_t*)split_scratch, P, value);
+  // environments per workgroup: 256 when the slab divides and the launch still fills the chip several times over, else 128.
+  // Measured at 16 384 environments x 257 frames x 2 500 nodes (10.5 GB of count bytes; tools/time_phases.py, whole GAE pass):
+  // 5.76 ms with 128, 4.82 ms with 256, 5.22 ms with 512 (368 registers: one workgroup per CU left).
+  // (TARL_CRITIC_CT = 1 | 2 | 4: developer / test override, read at every call)
+  const int ct_env = getenv("TARL_CRITIC_CT") ? atoi(getenv("TARL_CRITIC_CT")) : 0;
+  int ct = 1;
+  if (rows_per_slab % (2 * CR_BM) == 0 && M / (2 * CR_BM) >= 1024) ct = 2;
+  if ((ct_env == 1 || ct_env == 2 || ct_env == 4) && rows_per_slab % (ct_env * CR_BM) == 0) ct = ct_env;
+  const dim3 grid((unsigned)(M / (CR_BM * ct)));
+  if (ct == 4)
+    hipLaunchKernelGGL(k_critic_fwd_slab_u8x3<4>, grid, dim3(CR_THREADS), 0, s, counts, rows_per_slab, M, N, Kpad, time_rows,
+                       rows_per_time, (const uint16_t*)split_scratch, P, value);
+  else if (ct == 2)
+    hipLaunchKernelGGL(k_critic_fwd_slab_u8x3<2>, grid, dim3(CR_THREADS), 0, s, counts, rows_per_slab, M, N, Kpad, time_rows,
+                       rows_per_time, (const uint16_t*)split_scratch, P, value);
+  else
+    hipLaunchKernelGGL(k_critic_fwd_slab_u8x3<1>, grid, dim3(CR_THREADS), 0, s, counts, rows_per_slab, M, N, Kpad, time_rows,
+                       rows_per_time, (const uint16_t*)split_scratch, P, value);
   TARL_LAUNCH_CHECK();
   return TARL_OK;
 }

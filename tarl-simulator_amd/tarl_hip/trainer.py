@@ -108,8 +108,12 @@ class VecPPOTrainer:
         self.values = torch.zeros((self.T + 1, B), dtype=torch.float32, device=dev)
         # every rank draws its own minibatches / action noise; rank_offset=False (test hook) makes replicas identical
         off = self.rank if rank_offset else 0
-        self.gen = torch.Generator(device=dev)
-        self.gen.manual_seed(int(seed) + 7919 * off)
+        # minibatch draw: M distinct frames out of T * B (the reference's SamplerWithoutReplacement hands out sub-batches of a
+        # shuffled buffer). Drawn on the HOST in O(M) (numpy's Floyd sampler) and copied behind the launches already queued:
+        # a device randperm of T * B = 4.2 M keys was a radix sort + scatter of ~6 ms per optimiser step inside the timed
+        # iteration (profiles/r03_default_kernel_stats.txt: elementwise_kernel_manual_unroll / _scatter_gather_elementwise)
+        import numpy as np
+        self.np_rng = np.random.Generator(np.random.Philox(key=int(seed) + 7919 * off))
         self.seed = int(seed) + off
         self.sample_counter = 0
         self.last = {}
@@ -143,14 +147,15 @@ class VecPPOTrainer:
         self.counts[0].zero_()
         M = min(self.M, T * B)
         if self.obs_idx is not None:                    # test hook: these frames instead of a random draw
-            self._mb_idx = [self.obs_idx.to(eng.device)]
+            host = [self.obs_idx.cpu()]
         else:
-            self._mb_idx = [torch.randperm(T * B, generator=self.gen, device=eng.device)[:M] for _ in range(self.num_epochs)]
-        flat = torch.cat(self._mb_idx)
+            host = [self.draw_frames(T * B, M, device=False) for _ in range(self.num_epochs)]
+        self._mb_idx = [h.pin_memory().to(eng.device, non_blocking=True) for h in host]
+        flat = torch.cat(host)      # (the frame list stays on the host: no device round trip before the rollout)
         order = torch.argsort(flat, stable=True)
         t_sorted = torch.div(flat[order], B, rounding_mode="floor").tolist()
-        keep_env = (flat[order] % B).to(torch.int32).contiguous()
-        keep_slot = order.to(torch.int32).contiguous()
+        keep_env = (flat[order] % B).to(torch.int32).to(eng.device)
+        keep_slot = order.to(torch.int32).to(eng.device)
         self.obs_mb = torch.empty((flat.numel(), N, 16), dtype=torch.float32, device=eng.device)
         w = self._edge_mlp()
         pseed = self.seed ^ 0x5DEECE66D
@@ -272,6 +277,11 @@ class VecPPOTrainer:
                           if any(done) else None)
         return T * eng.B
 
+    def draw_frames(self, n, M, device=True):
+        """M distinct flat frame indices t * B + b out of n, uniform, int64 (host draw; device=True: asynchronous copy)."""
+        idx = torch.from_numpy(self.np_rng.choice(n, size=M, replace=False, shuffle=True).astype("int64"))
+        return idx.pin_memory().to(self.eng.device, non_blocking=True) if device else idx
+
     def poll_flags(self):
         """Raise if a finished rollout flagged a domain exit (non-blocking)."""
         if self._flag_event is not None and self._flag_event.query():
@@ -322,7 +332,7 @@ class VecPPOTrainer:
             obs_mb = self.obs_mb[off:off + M]
             self._epoch += 1
         elif idx is None:
-            idx = torch.randperm(T * B, generator=self.gen, device=eng.device)[:M]
+            idx = self.draw_frames(T * B, M)
         else:
             idx = idx.to(eng.device)
             M = idx.numel()

@@ -236,6 +236,28 @@ def test_critic_slab_mode_matches_row_major(ops):
     assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
 
 
+@pytest.mark.parametrize("ct", [2, 4])
+def test_critic_slab_wide_tiles_equal_the_128_environment_tiles(ops, monkeypatch, ct):
+    """k_critic_fwd_slab_u8x3<CT>: 256 / 512 environments per workgroup (the weight pieces of a k-tile are fetched once for all
+    of them) — every environment's value is the same chain of MFMAs in the same k order as with 128: bit-identical. The
+    launcher picks the wide tiles only for large batches; TARL_CRITIC_CT forces them here."""
+    gen = torch.Generator().manual_seed(11)
+    S, N, R = 3, 333, 1024
+    c8 = torch.randint(0, 16, (S, N, R), generator=gen).to(torch.uint8).cuda()
+    times = (torch.arange(S).float() + 21540.0).cuda()
+    lin = [torch.nn.Linear(N + 1, 64), torch.nn.Linear(64, 64), torch.nn.Linear(64, 1)]
+    cw = ops.CriticWeights(*(t.detach().cuda().contiguous() for t in (lin[0].weight, lin[0].bias, lin[1].weight,
+                                                                     lin[1].bias, lin[2].weight.reshape(-1), lin[2].bias)))
+    monkeypatch.setenv("TARL_CRITIC_CT", "1")
+    v1 = ops.critic_forward_slabs(cw, c8, times)
+    monkeypatch.setenv("TARL_CRITIC_CT", str(ct))
+    vw = ops.critic_forward_slabs(cw, c8, times)
+    assert torch.equal(v1, vw)
+    rows = c8.float().permute(0, 2, 1).contiguous().view(S * R, N)
+    v_rows, _, _ = ops.critic_forward(cw, rows, times, rows_per_time=R)
+    assert float((vw - v_rows).abs().max()) <= 1e-5 * max(1.0, float(v_rows.abs().max()))
+
+
 @pytest.mark.parametrize("B,T,merge", [(5, 30, "1"), (5, 30, "0"), (70, 7, "1"), (3, 1, "1"), (130, 2, "1"),
                                        (130, 3, "1"), (300, 5, "1"), (5, 70, "2"), (300, 33, "2"), (3, 1, "2")])
 def test_rollout_launcher_equals_frame_loop(ops, monkeypatch, B, T, merge):
