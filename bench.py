@@ -409,7 +409,11 @@ def main():
                           net.Nmax, pops, congestion_constant=net.congestion_constant, device=device,
                           seed=args.seed + rank)
         policy_lines = {}
-        for tag, bf in (("fp32", False), ("bf16", True)):
+        # "fp32": rollout logits at fp32 accuracy (the north star's 1e-4 contract) on the bf16 pipe — operands split into
+        # exact bf16 pieces, k_edge_mlp_fwd_x3; "fp32_mfma": the same contract on the fp32 matrix pipe (exact fp32 products,
+        # round 3's "fp32" line); "bf16": bf16 logits on bf16 observations (BASELINE config 5's "bf16 MPNN features")
+        for tag, prec in (("fp32", "x3"), ("fp32_mfma", "fp32"), ("bf16", "bf16")):
+            bf = prec == "bf16"
             torch.manual_seed(args.seed)
             pol = MPNNPolicyNet(net.edge_index, net.num_roads, None, device=str(device))
             val = MPNNValueNetSimple(net.edge_index, net.num_roads, device=str(device))
@@ -418,7 +422,7 @@ def main():
                                  [l[0].weight, l[0].bias, l[2].weight, l[2].bias, l[4].weight, l[4].bias],
                                  rollout_steps=T, num_epochs=args.epochs, sub_batch_size=args.sub_batch,
                                  extra_params=[p for n, p in pol.named_parameters() if not n.startswith("nodes_embedding")],
-                                 seed=args.seed, policy="edge_mlp", policy_bf16=bf, temperature=args.policy_temperature,
+                                 seed=args.seed, policy="edge_mlp", policy_precision=prec, temperature=args.policy_temperature,
                                  edge_mlp_params=[mm[0].weight, mm[0].bias, mm[2].weight, mm[2].bias, mm[4].weight,
                                                   mm[4].bias])
             tr_p.train_iteration()
@@ -441,16 +445,26 @@ def main():
             # MPNNPolicyNet.edge_mlp per edge: 2 * (33*64 + 64*32 + 32) flop (src/agents/mpnn_agent.py:35-41); the matrix
             # cores are the bound of this kernel: dense MFMA peaks from MI355X_MICROARCH.md (bf16 2.5 PFLOP/s, fp32 157.3 TF)
             flops = 2.0 * (33 * 64 + 64 * 32 + 32) * Bp * E
-            peak = MFMA_PEAK_TFLOPS["bf16" if bf else "f32"]
-            mlp_roof = ({"bound": "mfma", "kernel": "k_edge_mlp_fwd" + ("_bf16" if bf else "") + " (per-edge MLP 33->64->32->1)",
+            # x3: the kernel ISSUES six bf16 piece products per multiply-add of the head (hi hi, hi mid, mid hi, hi lo, mid mid,
+            # lo hi; the edge_attr / bias k-step once): achieved / frac are the HEAD's flops over the bf16 peak,
+            # issued_* the piece products the matrix cores actually execute
+            peak = MFMA_PEAK_TFLOPS["f32" if prec == "fp32" else "bf16"]
+            kname = {"x3": "k_edge_mlp_fwd_x3", "fp32": "k_edge_mlp_fwd_f32", "bf16": "k_edge_mlp_fwd_bf16"}[prec]
+            mlp_roof = ({"bound": "mfma", "kernel": kname + " (per-edge MLP 33->64->32->1)",
                          "achieved": flops / mlp_s / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flops / mlp_s / 1e12 / peak,
                          "traffic": None, "avg_launch_us": mlp_s * 1e6, "launches_timed": int(p_nfr[0]),
                          "flop_per_launch": flops} if mlp_s > 0 else None)
+            if mlp_roof and prec == "x3":
+                issued = 2.0 * 32 * 32 * 16 * 50 * (Bp * E / 32.0)      # 50 MFMAs of 32x32x16 per 32 edges
+                mlp_roof["issued_tflops"] = issued / mlp_s / 1e12
+                mlp_roof["issued_frac"] = issued / mlp_s / 1e12 / peak
             policy_lines[tag] = {"value": pf * world / pel, "unit": "env-steps/s", "envs_per_gpu": Bp, "roofline": mlp_roof,
                                  "steps": args.policy_steps, "ms_per_step": pel / args.policy_steps * 1e3,
                                  "edge_mlp_edges_per_sec": pf * world / pel * E,
-                                 "rollout_logits": "bf16 MFMA (v_mfma_f32_32x32x16_bf16)" if bf else
-                                                   "fp32 MFMA (v_mfma_f32_32x32x2_f32)"}
+                                 "rollout_logits": {"bf16": "bf16 MFMA (v_mfma_f32_32x32x16_bf16) on bf16 observations",
+                                                    "fp32": "fp32 MFMA (v_mfma_f32_32x32x2_f32), exact fp32 products",
+                                                    "x3": "fp32-accurate on the bf16 pipe: operands in three exact bf16 "
+                                                          "pieces, six products per multiply-add (v_mfma_f32_32x32x16_bf16)"}[prec]}
             del tr_p
         policy_lines["note"] = ("policy_head=edge_mlp: per-frame observation + 33->64->32->1 MLP per edge + GraphDistribution "
                                 "softmax / sample / log_prob (no table hoist), then the simulation frame; "

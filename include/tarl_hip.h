@@ -47,6 +47,10 @@ typedef struct tarl_plan tarl_plan; /* opaque static per-graph plan */
 typedef void* tarl_stream;          /* hipStream_t */
 
 int tarl_abi_version(void);
+/* The experiment flags (-DTARL_EXP_... of `make variant`) this library was built with; "" for the product build. The test
+ * suite refuses to run against a library that reports any (tests/conftest.py): a timing-only developer build must never
+ * stand in for the product in a parity run. */
+const char* tarl_build_flags(void);
 const char* tarl_last_error(void);
 
 /* ---- static plan ---------------------------------------------------------------------------------------------
@@ -183,7 +187,9 @@ int tarl_policy_edge_logits_bwd(const tarl_plan* plan, const float* road_index, 
  * precision 0: fp32 MFMA (v_mfma_f32_32x32x2_f32; exact fp32 products); 1: bf16 MFMA (v_mfma_f32_32x32x16_bf16; inputs,
  *   weights and the first hidden activation rounded to bf16, fp32 accumulation) — BASELINE config 5's bf16 features;
  *   2: as 1 with obs16 pointing at bf16 observations, uint16 [M][N][16] (tarl_fused_obs16_bf16): same values, half the
- *   bytes gathered, deeper prefetch.
+ *   bytes gathered, deeper prefetch; 3: fp32 ACCURACY on the bf16 pipe — fp32 observations, weights and the first hidden
+ *   activation each split into three exact bf16 pieces, the six piece products of order >= 2^-16 accumulated in fp32
+ *   (logits within a few fp32 ulp of precision 0's; 50 bf16 MFMAs instead of 66 fp32 MFMAs of twice the passes).
  * tarl_policy_edge_mlp_bwd ACCUMULATES (+=) the gradients of sum(grad_logits * logits) into gw1 [64][33], gb1 [64],
  *   gw2 [32][64], gb2 [32], gw3 [32], gb3 [1] (fp32, fixed reduction order); scratch: fp32
  *   [tarl_policy_edge_mlp_bwd_scratch_floats(plan, M)]. Observations receive no gradient. */
@@ -510,7 +516,10 @@ int tarl_fused_set_actions(const tarl_plan* plan, const tarl_fused* f, int64_t B
  *   Scratch (device): obs_scratch fp32 [B][N][16] (16-byte aligned), logits_scratch fp32 [B][E], dist_scratch
  *   (tarl_graphdist_rollout_scratch_bytes), ins_scratch int32 [B][2A].
  *   Outputs, frame-major, nullable: choice8 uint8 [T][B][N] (ENV-MAJOR rank bytes, bit 7: nothing drawn), log_prob /
- *   reward fp32 [T][B], counts uint8 [T][N][B] (env-minor, after frame t), and the per-step logs of tarl_fused_rollout. */
+ *   reward fp32 [T][B], counts uint8 [T][N][B] (env-minor, after frame t), and the per-step logs of tarl_fused_rollout.
+ *   precision (of the rollout's logits; the PPO update always evaluates the head with exact fp32 products): 0 = fp32 MFMA
+ *   (tarl_policy_edge_mlp_fwd precision 0), 1 = bf16 MFMA on bf16 observations (its precision 2), 2 = fp32-accurate on the
+ *   bf16 pipe (its precision 3: operands split into exact bf16 pieces). */
 int tarl_fused_rollout_policy(const tarl_plan* plan, const tarl_fused* f, int64_t B, int32_t Nmax, int64_t T,
                               const float* times_host, float prev_time, const float* x, int64_t x_bstride, int64_t ldx,
                               float* agent_features, int64_t num_agents, int64_t a_bstride, const float* edge_attr,

@@ -554,6 +554,182 @@ __global__ __launch_bounds__(EMR_WAVES * 64) void k_edge_mlp_fwd_bf16(const int3
   }
 }
 
+// ---- fp32 accuracy on the bf16 pipe: v_mfma_f32_32x32x16_bf16 on operands split into exact bf16 pieces -------------------
+// An fp32 number is the exact sum of three bf16 numbers (8 + 8 + 8 significand bits: hi = bf16(v), mid = bf16(v - hi),
+// lo = bf16(v - hi - mid), every subtraction exact), and the product of two bf16 numbers is exact in fp32. Inputs, weights
+// AND the first hidden activation are split; of the nine piece products of x * w the six of order >= 2^-16 are
+// accumulated (hi hi, hi mid, mid hi, hi lo, mid mid, lo hi) and the three of order <= 2^-24 — below the rounding of the
+// fp32 accumulation itself — dropped: the logits equal the fp32 chain's to a few ulp of the accumulated magnitude
+// (contract: 1e-4 of the logits' scale, tests/test_gpu_edge_mlp.py), at 6 bf16 MFMAs of 8 passes per 16 k where the fp32
+// MFMA needs 8 of 16 passes: 2.7x the matrix rate. Layout exactly as k_edge_mlp_fwd_f32 / _bf16: weights as A operands
+// in registers for the wave's life, edges as columns, layer 2 walking the hidden units in accumulator order.
+//   layer 1, k-steps of 16: [x_src 0..15] [x_dst 0..15], 6 MFMAs each per 32-row tile, then ONE k-step per tile for
+//   edge_attr and the bias: B = {ea_h, ea_h, ea_h, ea_m, ea_m, ea_l, 1, 1 | 1, 0 ...} against
+//   A = {w_h, w_m, w_l, w_h, w_m, w_h, b_h, b_m | b_l, 0 ...} (w = W1[:, 32], b = b1, both split): 26 MFMAs;
+//   layer 2: 4 k-steps x 6 = 24 MFMAs, b2 as the initial fp32 accumulator; layer 3 in fp32 on the vector ALU.
+struct Split3 {
+  uint32_t h, m, l;      // two bf16 each (low half = first value)
+};
+// Pieces by TRUNCATION (the top 16 bits of the fp32 word are a bf16): hi = v & 0xFFFF0000, mid = (v - hi) & 0xFFFF0000,
+// lo = v - hi - mid — 8 + 8 + 8 significand bits, every subtraction exact, hi + mid + lo == v exactly, and nothing but
+// full-rate integer / add instructions (v_and, v_sub, v_perm): with v_cvt_pk_bf16_f32 (round to nearest even) for the
+// three pieces: 946 -> 866 us per 20.5 M edges.
+__device__ __forceinline__ uint32_t emr_pack_hi16(float a, float b) {      // {bf16 bits of a, bf16 bits of b}, truncated
+  return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+__device__ __forceinline__ Split3 emr_split2(float a, float b) {
+  Split3 r;
+  r.h = emr_pack_hi16(a, b);
+  const float ra = a - __uint_as_float(__float_as_uint(a) & 0xFFFF0000u), rb = b - __uint_as_float(__float_as_uint(b) & 0xFFFF0000u);
+  r.m = emr_pack_hi16(ra, rb);
+  const float sa = ra - __uint_as_float(__float_as_uint(ra) & 0xFFFF0000u), sb = rb - __uint_as_float(__float_as_uint(rb) & 0xFFFF0000u);
+  r.l = emr_pack_hi16(sa, sb);
+  return r;
+}
+__device__ __forceinline__ void emr_split_host3(float v, uint16_t* h, uint16_t* m, uint16_t* l) {
+  *h = f32_to_bf16_rne(v);
+  const float r1 = v - __uint_as_float((uint32_t)*h << 16);
+  *m = f32_to_bf16_rne(r1);
+  *l = f32_to_bf16_rne(r1 - __uint_as_float((uint32_t)*m << 16));
+}
+struct Frag3 {
+  bf16x8 h, m, l;
+};
+// eight floats -> their three piece fragments
+__device__ __forceinline__ Frag3 emr_split8(const float (&v)[8]) {
+  u32x4 ph, pm, pl;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const Split3 sp = emr_split2(v[2 * q], v[2 * q + 1]);
+    ph[q] = sp.h;
+    pm[q] = sp.m;
+    pl[q] = sp.l;
+  }
+  return Frag3{__builtin_bit_cast(bf16x8, ph), __builtin_bit_cast(bf16x8, pm), __builtin_bit_cast(bf16x8, pl)};
+}
+// acc += W x with both operands in pieces: the six products of order >= 2^-16, small ones first
+__device__ __forceinline__ f32x16 emr_mma6(const Frag3& w, const Frag3& x, f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.l, x.h, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, x.l, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.m, x.m, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.m, x.h, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, x.m, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, x.h, acc, 0, 0, 0);
+  return acc;
+}
+
+#define EMX_W1 (2 * 2 * 3)     // W1 fragments: [tile][k-step][piece]
+#define EMX_W2 (4 * 3)         // W2 fragments: [k-step][piece]
+__global__ __launch_bounds__(EMR_WAVES * 64) void k_edge_mlp_fwd_x3(const int32_t* __restrict__ src,
+                                                                    const int32_t* __restrict__ dst, int64_t E,
+                                                                    int64_t N, int64_t M,
+                                                                    const float* __restrict__ obs,
+                                                                    const float* __restrict__ edge_attr, EdgeMlpW W,
+                                                                    float* __restrict__ logits) {
+  // fragment-ordered weight pieces, built once per workgroup in LDS and copied to registers
+  __shared__ __attribute__((aligned(16))) uint16_t W1f[EMX_W1 * 64 * 8];
+  __shared__ __attribute__((aligned(16))) uint16_t WEf[2 * 64 * 8];          // the edge_attr / bias k-step, per tile
+  __shared__ __attribute__((aligned(16))) uint16_t W2f[EMX_W2 * 64 * 8];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, j = lane & 31;
+  for (int idx = tid; idx < 2 * 2 * 64 * 8; idx += EMR_WAVES * 64) {
+    const int q = idx & 7, l = (idx >> 3) & 63, f = idx >> 9;           // f = tile * 2 + k-step
+    const int a = f >> 1, ks = f & 1, u = 32 * a + (l & 31), hh = l >> 5;
+    uint16_t ph, pm, pl;
+    emr_split_host3(W.w1[u * EM_IN + 16 * ks + 8 * hh + q], &ph, &pm, &pl);
+    W1f[((f * 3 + 0) * 64 + l) * 8 + q] = ph;
+    W1f[((f * 3 + 1) * 64 + l) * 8 + q] = pm;
+    W1f[((f * 3 + 2) * 64 + l) * 8 + q] = pl;
+  }
+  for (int idx = tid; idx < 2 * 64 * 8; idx += EMR_WAVES * 64) {
+    const int q = idx & 7, l = (idx >> 3) & 63, a = idx >> 9;
+    const int u = 32 * a + (l & 31), hh = l >> 5;
+    uint16_t wh, wm, wl, bh, bm, bl;
+    emr_split_host3(W.w1[u * EM_IN + 32], &wh, &wm, &wl);
+    emr_split_host3(W.b1[u], &bh, &bm, &bl);
+    const uint16_t lo8[8] = {wh, wm, wl, wh, wm, wh, bh, bm};
+    WEf[idx] = hh == 0 ? lo8[q] : (q == 0 ? bl : (uint16_t)0);
+  }
+  for (int idx = tid; idx < 4 * 64 * 8; idx += EMR_WAVES * 64) {
+    const int q = idx & 7, l = (idx >> 3) & 63, ks = idx >> 9;
+    const int u = 32 * (ks >> 1) + emr_unit(8 * (ks & 1) + q, l >> 5);
+    uint16_t ph, pm, pl;
+    emr_split_host3(W.w2[(l & 31) * EM_H1 + u], &ph, &pm, &pl);
+    W2f[((ks * 3 + 0) * 64 + l) * 8 + q] = ph;
+    W2f[((ks * 3 + 1) * 64 + l) * 8 + q] = pm;
+    W2f[((ks * 3 + 2) * 64 + l) * 8 + q] = pl;
+  }
+  __syncthreads();
+  // The 26 weight fragments (104 registers) stay in LDS and are read where they are used (a lane's 16 bytes are consecutive:
+  // conflict-free ds_read_b128): 119 registers instead of 224, i.e. four waves per SIMD instead of two (866 against 892 us
+  // per 20.5 M edges). Measured and rejected (tools/time_edge_mlp.py): a three-chunk software pipeline that
+  // puts one chunk's MFMAs beside another's vector work inside the wave (937 us: tools/mfma_valu_overlap.hip shows that
+  // independent MFMA and vector streams of one wave take 0.89 of the SUM of their times on this chip, not the maximum).
+  auto lw1 = [&](int a, int ks) {
+    const int f = a * 2 + ks;
+    return Frag3{*reinterpret_cast<const bf16x8*>(W1f + ((f * 3 + 0) * 64 + lane) * 8),
+                 *reinterpret_cast<const bf16x8*>(W1f + ((f * 3 + 1) * 64 + lane) * 8),
+                 *reinterpret_cast<const bf16x8*>(W1f + ((f * 3 + 2) * 64 + lane) * 8)};
+  };
+  auto lw2 = [&](int ks) {
+    return Frag3{*reinterpret_cast<const bf16x8*>(W2f + ((ks * 3 + 0) * 64 + lane) * 8),
+                 *reinterpret_cast<const bf16x8*>(W2f + ((ks * 3 + 1) * 64 + lane) * 8),
+                 *reinterpret_cast<const bf16x8*>(W2f + ((ks * 3 + 2) * 64 + lane) * 8)};
+  };
+  auto lwe = [&](int a) { return *reinterpret_cast<const bf16x8*>(WEf + (a * 64 + lane) * 8); };
+  f32x16 b2r;
+  float w3r[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    b2r[r] = W.b2[emr_unit(r, h)];
+    w3r[r] = W.w3[emr_unit(r, h)];
+  }
+  const float b3 = W.b3[0];
+  const f32x16 zero = {0};
+  ChunkWalk cw;
+  if (!cw.init(E, M, wave)) return;
+  EdgeIn nxt = emr_load(src, dst, edge_attr, obs, (int32_t)E, N, cw.mn, cw.cn, lane);
+  for (; cw.g < cw.g1; ++cw.g) {
+    const EdgeIn cur = nxt;
+    cw.step();
+    if (cw.g + 1 < cw.g1) nxt = emr_load(src, dst, edge_attr, obs, (int32_t)E, N, cw.mn, cw.cn, lane);
+    asm volatile("" ::: "memory");      // keeps the LDS fragments out of loop-invariant registers
+    const float vs[8] = {cur.s0.x, cur.s0.y, cur.s0.z, cur.s0.w, cur.s1.x, cur.s1.y, cur.s1.z, cur.s1.w};
+    const float vd[8] = {cur.d0.x, cur.d0.y, cur.d0.z, cur.d0.w, cur.d1.x, cur.d1.y, cur.d1.z, cur.d1.w};
+    const Frag3 xs = emr_split8(vs), xd = emr_split8(vd);
+    // the edge_attr / bias k-step: {ea_h, ea_h, ea_h, ea_m, ea_m, ea_l, 1, 1} in the lower half-wave, {1, 0 ...} in the upper
+    const Split3 se = emr_split2(cur.ea, 0.0f);
+    const uint32_t eh = se.h & 0xFFFFu, em = se.m & 0xFFFFu, el = se.l & 0xFFFFu, one = 0x3F80u;
+    u32x4 pe;
+    pe[0] = h == 0 ? (eh | (eh << 16)) : one;
+    pe[1] = h == 0 ? (eh | (em << 16)) : 0u;
+    pe[2] = h == 0 ? (em | (el << 16)) : 0u;
+    pe[3] = h == 0 ? (one | (one << 16)) : 0u;
+    const bf16x8 xe = __builtin_bit_cast(bf16x8, pe);
+    f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lwe(0), xe, zero, 0, 0, 0);
+    f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lwe(1), xe, zero, 0, 0, 0);
+    acc0 = emr_mma6(lw1(0, 0), xs, acc0);
+    acc1 = emr_mma6(lw1(1, 0), xs, acc1);
+    acc0 = emr_mma6(lw1(0, 1), xd, acc0);
+    acc1 = emr_mma6(lw1(1, 1), xd, acc1);
+    f32x16 c0 = b2r;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float hv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) hv[q] = emr_relu((ks < 2 ? acc0 : acc1)[8 * (ks & 1) + q]);
+      c0 = emr_mma6(lw2(ks), emr_split8(hv), c0);
+    }
+    float part = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part = fmaf(emr_relu(c0[r]), w3r[r], part);
+    const float tot = part + __shfl_xor(part, 32);
+    const int32_t e = cw.c * 32 + j;
+    if (h == 0 && e < (int32_t)E) logits[(int64_t)cw.m * E + e] = tot + b3;
+  }
+}
+
 // ---- backward -------------------------------------------------------------------------------------------------------------
 // stage 1, on the matrix cores: the forward's register-resident recomputation per 32 edges (exact fp32 products), then
 // dh2 = g w3 (masked by the second pre-activation) on the lane's own sixteen units and dh1^T [64][32] = W2^T dh2^T as
@@ -797,8 +973,8 @@ extern "C" int tarl_policy_edge_mlp_fwd(const tarl_plan* plan, const float* obs1
                                         tarl_stream stream) {
   TARL_REQUIRE(plan && obs16 && edge_attr && w1 && b1 && w2 && b2 && w3 && b3 && logits, "null argument");
   TARL_REQUIRE(M >= 1 && M < 65536, "bad batch size");
-  TARL_REQUIRE(precision >= 0 && precision <= 2,
-               "precision: 0 = fp32 MFMA, 1 = bf16 MFMA, 2 = bf16 MFMA on bf16 observations");
+  TARL_REQUIRE(precision >= 0 && precision <= 3,
+               "precision: 0 = fp32 MFMA, 1 = bf16 MFMA, 2 = bf16 MFMA on bf16 observations, 3 = fp32-accurate bf16x3 MFMA");
   TARL_REQUIRE(((uintptr_t)obs16) % 16 == 0, "obs16 must be 16-byte aligned");
   if (plan->E == 0) return TARL_OK;
   const EdgeMlpW W{w1, b1, w2, b2, w3, b3};
@@ -808,9 +984,15 @@ extern "C" int tarl_policy_edge_mlp_fwd(const tarl_plan* plan, const float* obs1
                "edge MLP: batch x edges too large");
   int64_t blocks = ceil_div(chunks, (int64_t)EMR_WAVES * 16);          // >= 16 chunks per wave
   // workgroups the chip holds at once (VGPR-bound): fp32 2 per CU, bf16 on fp32 rows 3, bf16 on bf16 rows 4
-  const int64_t resident = 256 * (precision == 0 ? 2 : (precision == 2 ? 4 : 3));
+  const int64_t resident = 256 * (precision == 0 || precision == 3 ? 2 : (precision == 2 ? 4 : 3));
   if (blocks > resident) blocks = resident;                             // one round: no tail
-  if (precision == 0)
+  if (precision == 3) {
+    blocks = ceil_div(chunks, (int64_t)EMR_WAVES * 16);
+    if (blocks > 256 * 4) blocks = 256 * 4;      // 119 registers, 26 KB of LDS: four workgroups per CU, one round
+    hipLaunchKernelGGL(k_edge_mlp_fwd_x3, dim3((unsigned)blocks), dim3(EMR_WAVES * 64), 0, (hipStream_t)stream,
+                       plan->src, plan->dst, plan->E, plan->N, M, obs16, edge_attr, W, logits);
+  }
+  else if (precision == 0)
     hipLaunchKernelGGL(k_edge_mlp_fwd_f32, dim3((unsigned)blocks), dim3(EMR_WAVES * 64), 0, (hipStream_t)stream,
                        plan->src, plan->dst, plan->E, plan->N, M, obs16, edge_attr, W, logits);
   else if (precision == 1)

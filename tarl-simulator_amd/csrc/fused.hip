@@ -2520,7 +2520,8 @@ extern "C" int tarl_fused_rollout_policy(const tarl_plan* plan, const tarl_fused
   TARL_REQUIRE(T >= 1 && times_host, "bad frame count / times");
   TARL_REQUIRE(x && obs_scratch && logits_scratch && dist_scratch, "observation / logits / sampler scratch missing");
   TARL_REQUIRE(!keep_ptr_host || (keep_env && keep_slot && obs_keep), "keep list without its arrays");
-  TARL_REQUIRE(precision == 0 || precision == 1, "precision: 0 = fp32 logits, 1 = bf16 logits on bf16 observations");
+  TARL_REQUIRE(precision >= 0 && precision <= 2,
+               "precision: 0 = fp32 MFMA logits, 1 = bf16 logits on bf16 observations, 2 = fp32-accurate logits on the bf16 pipe (bf16x3)");
   rc = check_frame_args(plan, f, B, agent_features, A, a_bstride, ins_scratch, edge_attr, log_edge_attr);
   if (rc) return rc;
   TARL_REQUIRE(metrics_envs >= 0 && metrics_envs <= B, "metrics_envs out of range");
@@ -2559,8 +2560,8 @@ extern "C" int tarl_fused_rollout_policy(const tarl_plan* plan, const tarl_fused
     }
     // (live timing, bench.py: HIP events around the per-edge MLP of the timed frames — slot 0 of tarl_prof_collect)
     const bool timed = tarl_prof_mark(s, 0) != nullptr;
-    rc = tarl_policy_edge_mlp_fwd(plan, obs_scratch, B, edge_attr, w1, b1, w2, b2, w3, b3, precision == 1 ? 2 : 0,
-                                  logits_scratch, stream);
+    rc = tarl_policy_edge_mlp_fwd(plan, obs_scratch, B, edge_attr, w1, b1, w2, b2, w3, b3,
+                                  precision == 1 ? 2 : (precision == 2 ? 3 : 0), logits_scratch, stream);
     if (rc) return rc;
     if (timed) (void)tarl_prof_mark(s, 1);
     rc = tarl_graphdist_rollout_at(plan, logits_scratch, B, temperature, nullptr, policy_seed,

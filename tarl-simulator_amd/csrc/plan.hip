@@ -22,6 +22,11 @@ void tarl_set_error(const char* fmt, ...) {
 
 extern "C" const char* tarl_last_error(void) { return g_err; }
 extern "C" int tarl_abi_version(void) { return TARL_ABI_VERSION; }
+// the experiment flags this library was built with (`make variant EXPFLAGS=...`); empty for the product build
+#ifndef TARL_BUILD_FLAGS
+#define TARL_BUILD_FLAGS ""
+#endif
+extern "C" const char* tarl_build_flags(void) { return TARL_BUILD_FLAGS; }
 
 static int upload(int32_t** dptr, const std::vector<int32_t>& h) {
   const size_t bytes = (h.empty() ? 1 : h.size()) * sizeof(int32_t);

@@ -201,13 +201,14 @@ class SimEngine:
             self.check_flags()
         return times
 
-    def rollout_policy(self, T, weights, *, bf16, temperature, policy_seed, policy_counter0, choice8, log_prob, reward,
+    def rollout_policy(self, T, weights, *, bf16=False, temperature, policy_seed, policy_counter0, choice8, log_prob, reward,
                        counts, keep=None, obs_keep=None, metrics_envs=0, dtt_node=None, events=None, leg=None,
-                       check=True):
+                       check=True, precision=None):
         """``T`` frames under the per-edge MLP head (``weights``: ops.EdgeMlpWeights) in one foreign call: per frame
         observation -> logits -> GraphDistribution sample + log-prob -> the simulation frame. ``choice8`` (T,B,N) uint8
         (ENV-MAJOR rank bytes), ``counts`` (T+1,N,B) uint8 (counts[t + 1] = after frame t), ``log_prob`` / ``reward`` (T,B).
-        Frame t draws its action with Philox counter ``policy_counter0 + t``. Returns the list of clock values."""
+        Frame t draws its action with Philox counter ``policy_counter0 + t``. ``precision`` of the rollout's logits: "fp32"
+        (fp32 MFMA), "bf16" (= ``bf16=True``) or "x3" (fp32-accurate on the bf16 pipe). Returns the list of clock values."""
         if self._packed_stale:
             self.resync()
         if counts.dtype != torch.uint8 or tuple(counts.shape) != (T + 1, self.N, self.B) or not counts.is_contiguous():
@@ -223,7 +224,7 @@ class SimEngine:
                                  policy_counter0=policy_counter0, seed=self.seed, counter0=self.noise_counter + 1,
                                  scratch=self.ins_scratch, prev_time=self._last_step_time, keep=keep, obs_keep=obs_keep,
                                  choice8=choice8, log_prob=log_prob, reward=reward, counts=counts[1:],
-                                 metrics_envs=metrics_envs, dtt_node=dtt_node, events=events, leg=leg)
+                                 metrics_envs=metrics_envs, dtt_node=dtt_node, events=events, leg=leg, precision=precision)
         self.sample_counter += T
         self.noise_counter += T
         self._last_step_time = times[-1]

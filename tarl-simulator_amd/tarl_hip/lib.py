@@ -24,6 +24,7 @@ _f64 = C.c_double
 _STATE = [_p, _i64, _i64, _i64, _i32]  # x, B, x_bstride, ldx, Nmax
 SIGNATURES = {
     "tarl_abi_version": (C.c_int, []),
+    "tarl_build_flags": (C.c_char_p, []),
     "tarl_last_error": (C.c_char_p, []),
     "tarl_plan_create": (C.c_int, [_p, _i64, _i64, _p, C.POINTER(_p)]),
     "tarl_plan_destroy": (None, [_p]),

@@ -505,9 +505,23 @@ def fused_set_actions(plan: Plan, fs, choice8):
     return choice8
 
 
-def policy_edge_mlp(plan: Plan, obs16, ec: EdgeConst, w: EdgeMlpWeights, *, bf16=False, out=None):
-    """obs16 (M, N, 16) -> logits (M, E) of the per-edge MLP head (fp32 MFMA, or bf16 MFMA with ``bf16=True``);
-    ``obs16`` in torch.bfloat16 (fused_obs16_bf16) selects the bf16 MFMA kernel that reads bf16 observations."""
+EDGE_MLP_PRECISIONS = ("fp32", "bf16", "x3")
+
+
+def _edge_mlp_precision(bf16, precision):
+    """``precision``: "fp32" = fp32 MFMA (exact fp32 products), "bf16" = bf16 MFMA, "x3" = fp32 accuracy on the bf16 pipe
+    (operands split into three exact bf16 pieces). ``bf16=True`` is the older spelling of precision="bf16"."""
+    if precision is None:
+        precision = "bf16" if bf16 else "fp32"
+    if precision not in EDGE_MLP_PRECISIONS:
+        raise ValueError(f"precision must be one of {EDGE_MLP_PRECISIONS}")
+    return precision
+
+
+def policy_edge_mlp(plan: Plan, obs16, ec: EdgeConst, w: EdgeMlpWeights, *, bf16=False, precision=None, out=None):
+    """obs16 (M, N, 16) -> logits (M, E) of the per-edge MLP head: fp32 MFMA (default), bf16 MFMA (``bf16=True`` /
+    ``precision="bf16"``) or fp32-accurate on the bf16 pipe (``precision="x3"``); ``obs16`` in torch.bfloat16
+    (fused_obs16_bf16) selects the bf16 MFMA kernel that reads bf16 observations."""
     L = _lib.load()
     if obs16.dtype == torch.bfloat16:
         _contig(obs16, torch.bfloat16, "obs16")
@@ -523,8 +537,9 @@ def policy_edge_mlp(plan: Plan, obs16, ec: EdgeConst, w: EdgeMlpWeights, *, bf16
     if obs16.shape[1:] != (plan.num_nodes, 16):
         raise ValueError("obs16 must be (M, num_nodes, 16)")
     logits = out if out is not None else torch.empty((M, plan.num_edges), dtype=torch.float32, device=obs16.device)
+    code = {"fp32": 0, "bf16": 1, "x3": 3}[_edge_mlp_precision(bf16, precision)]
     _lib.check(L.tarl_policy_edge_mlp_fwd(plan.handle, obs16.data_ptr(), M, ec.edge_attr.data_ptr(), *w.ptrs(),
-                                          1 if bf16 else 0, logits.data_ptr(), _lib.current_stream()))
+                                          code, logits.data_ptr(), _lib.current_stream()))
     return logits
 
 
@@ -941,9 +956,9 @@ def fused_rollout(plan: Plan, fs: FusedState, tables: PolicyTables, agent_featur
 
 
 def fused_rollout_policy(plan: Plan, fs: FusedState, x, agent_features, ec: EdgeConst, w: EdgeMlpWeights, times, *,
-                         use_cong, bf16, temperature, policy_seed, policy_counter0, seed, counter0, scratch, prev_time=None,
-                         keep=None, obs_keep=None, choice8=None, log_prob=None, reward=None, counts=None, metrics_envs=0,
-                         dtt_node=None, events=None, leg=None):
+                         use_cong, bf16=False, temperature, policy_seed, policy_counter0, seed, counter0, scratch,
+                         prev_time=None, keep=None, obs_keep=None, choice8=None, log_prob=None, reward=None, counts=None,
+                         metrics_envs=0, dtt_node=None, events=None, leg=None, precision=None):
     """``T = len(times)`` frames under the per-edge MLP policy in one foreign call (tarl_fused_rollout_policy).
     ``keep`` = (ptr, env, slot): ``ptr`` a Python list of T + 1 offsets, ``env`` / ``slot`` int32 device tensors — the
     observations (frame t, environment env[j]) for ptr[t] <= j < ptr[t + 1] are copied to ``obs_keep[slot[j]]``
@@ -977,7 +992,8 @@ def fused_rollout_policy(plan: Plan, fs: FusedState, x, agent_features, ec: Edge
     _lib.check(L.tarl_fused_rollout_policy(
         plan.handle, fs.ref, B, fs.Nmax, T, tarr, float(times[0] - 1 if prev_time is None else prev_time), x.data_ptr(),
         bs, ldx, agent_features.data_ptr(), A, abs_, ec.edge_attr.data_ptr(), ec.log_edge_attr.data_ptr(), ec.log_eps,
-        1 if use_cong else 0, *w.ptrs(), 1 if bf16 else 0, float(temperature), int(policy_seed), int(policy_counter0),
+        1 if use_cong else 0, *w.ptrs(), {"fp32": 0, "bf16": 1, "x3": 2}[_edge_mlp_precision(bf16, precision)],
+        float(temperature), int(policy_seed), int(policy_counter0),
         int(seed), int(counter0), kptr, _lib.ptr(kenv), _lib.ptr(kslot), _lib.ptr(obs_keep), fs.obs_scratch.data_ptr(),
         fs.logits_scratch.data_ptr(), fs.dist_scratch.data_ptr(), scratch.data_ptr(), _lib.ptr(choice8),
         _lib.ptr(log_prob), _lib.ptr(reward), _lib.ptr(counts), int(metrics_envs), _lib.ptr(dtt_node), _lib.ptr(events),

@@ -23,7 +23,7 @@ class VecPPOTrainer:
     def __init__(self, engine, emb_param, critic_params, *, rollout_steps, num_epochs=1, sub_batch_size=32, lr=1e-3,
                  gamma=0.99, lmbda=0.95, clip_epsilon=0.2, entropy_coef=0.01, critic_coef=1.0, temperature=1.0,
                  extra_params=(), seed=0, lazy_log_prob=False, rank_offset=True, rollout=None, metrics_envs=1,
-                 policy="embedding", edge_mlp_params=None, policy_bf16=False):
+                 policy="embedding", edge_mlp_params=None, policy_bf16=False, policy_precision=None):
         """``emb_param``: nn.Parameter (num_nodes, 1) — MPNNPolicyNet.nodes_embedding.weight;
         ``critic_params``: [w1 (64,N+1), b1, w2 (64,64), b2, w3 (1,64), b3] — MPNNValueNetSimple.final_mlp.{0,2,4};
         ``extra_params``: further actor/critic parameters that never receive gradient on the live path (the dormant
@@ -35,9 +35,14 @@ class VecPPOTrainer:
         # (src/agents/mpnn_agent.py:35-41,227-231): state-DEPENDENT, so every frame evaluates observation -> MLP (MFMA) ->
         # segment softmax -> sample -> log-prob before the simulation step. ``edge_mlp_params`` = [w1, b1, w2, b2, w3, b3]
         # (edge_mlp.{0,2,4}.{weight,bias}; they must also be in ``extra_params`` so that they live in the flat buffer);
-        # ``policy_bf16``: rollout logits on the bf16 MFMA path (the update always runs in fp32).
+        # ``policy_bf16``: rollout logits on the bf16 MFMA path (the update always runs in fp32). ``policy_precision``
+        # ("fp32" | "bf16" | "x3") names the rollout kernel outright; the default for a non-bf16 policy is "x3": logits
+        # within a few fp32 ulp of the fp32 MFMA kernel's (the north star's 1e-4 contract) at 2.7x its matrix rate.
         self.policy = policy
-        self.policy_bf16 = bool(policy_bf16)
+        self.policy_precision = policy_precision or ("bf16" if policy_bf16 else "x3")
+        if self.policy_precision not in ops.EDGE_MLP_PRECISIONS:
+            raise ValueError(f"policy_precision must be one of {ops.EDGE_MLP_PRECISIONS}")
+        self.policy_bf16 = self.policy_precision == "bf16"
         self.edge_mlp_params = list(edge_mlp_params) if edge_mlp_params is not None else None
         if policy == "edge_mlp":
             if engine.fs is None or self.edge_mlp_params is None or len(self.edge_mlp_params) != 6:
@@ -177,7 +182,7 @@ class VecPPOTrainer:
                 rel.append(pos - seg_lo)
             keep = (rel, keep_env[seg_lo:pos], keep_slot[seg_lo:pos]) if pos > seg_lo else None
             sl = slice(t0, t0 + seg)
-            times = eng.rollout_policy(seg, w, bf16=self.policy_bf16, temperature=self.temperature, policy_seed=pseed,
+            times = eng.rollout_policy(seg, w, precision=self.policy_precision, temperature=self.temperature, policy_seed=pseed,
                                        policy_counter0=self.sample_counter + 1, choice8=self.choice[sl],
                                        log_prob=self.logp[sl], reward=self.reward[sl],
                                        counts=self.counts[t0:t0 + seg + 1], keep=keep, obs_keep=self.obs_mb,

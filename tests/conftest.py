@@ -18,6 +18,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True, scope="session")
+def _product_build_only():
+    """Parity is judged on the product build only: a library built with experiment flags (`make variant EXPFLAGS=...`,
+    selected through TARL_HIP_LIB) — timing-only kernels, shortcuts whose results are wrong on purpose — is refused here.
+    (Round 3: a GPU abort in a bench-geometry test came from exactly such a build standing in for the product)
+    TARL_ALLOW_VARIANT=1 lifts the refusal for a developer who wants to see WHICH tests an experiment breaks."""
+    so = os.environ.get("TARL_HIP_LIB") or os.path.join(PKG, "tarl_hip", "libtarl_hip.so")
+    if os.path.exists(so) and os.environ.get("TARL_ALLOW_VARIANT") != "1":
+        from tarl_hip import lib
+        flags = lib.load().tarl_build_flags()
+        flags = flags.decode() if isinstance(flags, bytes) else (flags or "")
+        assert flags == "", f"{so} was built with experiment flags '{flags}': not the product build"
+    yield
+
+
 def load_golden(name):
     """npz fixture -> dict of torch tensors (0-d arrays become python scalars)."""
     z = np.load(os.path.join(GOLDEN, name + ".npz"))

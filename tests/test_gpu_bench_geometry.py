@@ -298,6 +298,7 @@ def test_config5_edge_mlp_bf16_on_100k_edges():
     ref = nets.edge_mlp_logits(obs.cpu(), net.edge_index, net.edge_attr.expand(B, -1, -1), *[p.detach().cpu() for p in ws])
     assert ref.shape == (B, E)
     close(ops.policy_edge_mlp(eng.plan, obs, eng.ec, w).cpu(), ref, "logits (fp32 MFMA, 100k edges)")
+    close(ops.policy_edge_mlp(eng.plan, obs, eng.ec, w, precision="x3").cpu(), ref, "logits (bf16x3 MFMA, 100k edges)")
     lb = ops.policy_edge_mlp(eng.plan, obs, eng.ec, w, bf16=True)
     close(lb.cpu(), ref, "logits (bf16 MFMA, 100k edges)", BF16_TOL)
     assert torch.equal(ops.policy_edge_mlp(eng.plan, obs_b, eng.ec, w), lb)          # bf16 rows in == fp32 rows rounded inside

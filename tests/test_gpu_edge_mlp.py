@@ -45,6 +45,17 @@ def test_edge_mlp_forward_and_gradients_golden(tag):
     lb = ops.policy_edge_mlp(plan, obs, ec, w, bf16=True)
     close(lb.cpu(), g[f"{tag}__logits"], "logits (bf16 MFMA)", BF16_TOL)
     assert not torch.equal(lb, logits)
+    # fp32 accuracy on the bf16 pipe (operands split into three exact bf16 pieces): the same 1e-4 contract against the
+    # reference's module, and as close to the fp64 evaluation of that module as the fp32 MFMA chain is (referee: the
+    # oracle's restatement of the head in float64)
+    l3 = ops.policy_edge_mlp(plan, obs, ec, w, precision="x3")
+    close(l3.cpu(), g[f"{tag}__logits"], "logits (bf16x3 MFMA)")
+    from oracle import nets
+    ws64 = [t.double() for t in (w.w1.cpu(), w.b1.cpu(), w.w2.cpu(), w.b2.cpu(), w.w3.cpu().view(1, -1), w.b3.cpu())]
+    ref64 = nets.edge_mlp_logits(ref_x.double(), ei, g["edge_attr"].double().reshape(1, E, 1).expand(ref_x.size(0), E, 1), *ws64)
+    scale = max(1.0, float(ref64.abs().max()))
+    e3, e32 = float((l3.cpu().double() - ref64).abs().max()), float((logits.cpu().double() - ref64).abs().max())
+    assert e3 <= 4 * e32 + 1e-6 * scale, (e3, e32, scale)
     grads = [torch.zeros_like(t) for t in (w.w1, w.b1, w.w2, w.b2, w.w3, w.b3)]
     ops.policy_edge_mlp_bwd(plan, obs, ec, w, g["coef"].cuda(), grads)
     for gr, name in zip(grads, ("0__weight", "0__bias", "2__weight", "2__bias", "4__weight", "4__bias")):
@@ -193,8 +204,8 @@ def test_ppo_update_with_edge_mlp_policy_matches_oracle_autograd(bf16_rollout):
         close(p_gpu.detach().cpu(), q, f"param {name}")
 
 
-@pytest.mark.parametrize("bf16", [False, True])
-def test_rollout_policy_call_equals_its_launches_one_by_one(bf16):
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "x3"])
+def test_rollout_policy_call_equals_its_launches_one_by_one(precision):
     """tarl_fused_rollout_policy (T frames of observation -> MLP -> sample + log-prob -> simulation frame queued by one
     foreign call) against the same entry points called one by one from Python on a twin engine: identical action bytes,
     log-probs, rewards, counts, kept observations and final state; the per-step logs add up."""
@@ -227,7 +238,7 @@ def test_rollout_policy_call_equals_its_launches_one_by_one(bf16):
     m = 2
     ch1, ct1, lp1, rw1, keep1 = z8(T, B, N), z8(T + 1, N, B), zf(T, B), zf(T, B), zf(20, N, 16)
     leg1, dtt1, ev1 = torch.zeros((T, B, 2), dtype=torch.int32, device="cuda"), zf(T, N, m), z8(T, N, m)
-    e1.rollout_policy(T, w, bf16=bf16, temperature=TEMP, policy_seed=77, policy_counter0=5, choice8=ch1, log_prob=lp1,
+    e1.rollout_policy(T, w, precision=precision, temperature=TEMP, policy_seed=77, policy_counter0=5, choice8=ch1, log_prob=lp1,
                       reward=rw1, counts=ct1, keep=(ptr, kenv, kslot), obs_keep=keep1, metrics_envs=m, dtt_node=dtt1,
                       events=ev1, leg=leg1)
     # twin: one entry point at a time
@@ -238,7 +249,7 @@ def test_rollout_policy_call_equals_its_launches_one_by_one(bf16):
         if ptr[t + 1] > ptr[t]:
             j = slice(ptr[t], ptr[t + 1])
             keep2.index_copy_(0, kslot[j].long(), obs.index_select(0, kenv[j].long()))
-        logits = ops.policy_edge_mlp(e2.plan, obs, e2.ec, w, bf16=bf16)
+        logits = ops.policy_edge_mlp(e2.plan, obs, e2.ec, w, precision=precision)
         ops.graphdist_rollout(e2.plan, logits, TEMP, seed=77, counter=5 + t, choice8=ch2[t], sel8=e2.fs.sel8,
                               log_prob=lp2[t])
         e2.frame_fused(skip_choice=True, reward=rw2[t], counts=cf)

@@ -20,4 +20,10 @@ for line in sys.stdin:
     p = d.get("state_dependent_policy")
     if p:
         s += f" | policy fp32 {p['fp32']['value'] / 1e6:5.2f} M bf16 {p['bf16']['value'] / 1e6:5.2f} M"
+        if "fp32_mfma" in p:
+            s += f" fp32-mfma {p['fp32_mfma']['value'] / 1e6:5.2f} M"
+        for k in ("fp32", "bf16"):
+            r = p[k].get("roofline")
+            if r:
+                s += f" mlp[{k}] {r['avg_launch_us']:.0f} us"
     print(s)
