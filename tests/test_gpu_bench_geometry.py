@@ -101,6 +101,53 @@ def test_config4_at_the_bench_batch_size_is_batch_independent():
     assert torch.equal(rw, -ct[1:].sum(dim=1, dtype=torch.float32))
 
 
+def test_config4_loaded_network_at_the_bench_batch_size_is_batch_independent():
+    """The bench's CONGESTED regime at its own geometry: every agent departs within 600 s, a whole rollout of 256 frames at
+    B = 16 384 — by its end each environment carries ~7 000 agents, a third of the (road, environment) pairs move something
+    in every frame, the row pass's event list overflows into its in-place fall-back in a share of the workgroups, the insert
+    kernel runs two environments per wave (due rate ~27 per frame) with blocked candidates queueing in its window, and the
+    Direction gather races a sixth of the pairs. Environments {0, 8 191, 16 383} must be bit-identical to the same
+    environments simulated ALONE under their global ids; domain invariants and reward = -sum(count bytes) for every
+    environment and frame. Reference semantics held: src/direction_mpnn.py:66-196, src/response_mpnn.py:86-127,
+    src/agents/base.py:244-403."""
+    from tarl_hip import synth
+    from tarl_hip.engine import EPISODE_START, SimEngine
+    B, A, T = 16384, 16384, 256
+    probe = [0, 8191, 16383]
+    net = synth.torus_network(25, 25)
+    N = net.num_roads
+    pops = synth.population_batch(A, N, B, seed=9, device="cuda", t1=EPISODE_START + 600)
+    emb = torch.randn(N, generator=torch.Generator().manual_seed(4)).cuda()
+    eng = SimEngine(net.x.cuda().unsqueeze(0).repeat(B, 1, 1).contiguous(), net.edge_index, net.edge_attr, net.Nmax,
+                    pops, congestion_constant=net.congestion_constant, seed=13)
+    eng.reset()
+    eng.prepare_policy(emb)
+    ch, ct, lp, rw, leg = _rollout(eng, T)
+    eng.check_flags()
+    # the network is loaded: thousands of agents on the way per environment, most rows hold somebody, and a large share of
+    # the pairs changed their count between the last two frames
+    on_way = float(-rw[-1].mean())
+    moved = float((ct[-1] != ct[-2]).float().mean())
+    assert on_way > 5000 and float((ct[-1] > 0).float().mean()) > 0.5 and moved > 0.1, (on_way, moved)
+    assert torch.equal(rw, -ct[1:].sum(dim=1, dtype=torch.float32))
+    xb = torch.stack([eng.x[b] for b in probe])
+    agb = torch.stack([eng.agents[b] for b in probe])
+    pidx = torch.tensor(probe, device="cuda")
+    _invariants(net, xb, agb, rw[-1, pidx], ct[-1][:, pidx].t(), eng.time)
+    for k, b in enumerate(probe):
+        solo = SimEngine(net.x.cuda().unsqueeze(0).contiguous(), net.edge_index, net.edge_attr, net.Nmax,
+                         pops[b:b + 1].clone(), congestion_constant=net.congestion_constant, seed=13, env_base=b)
+        solo.reset()
+        solo.prepare_policy(emb)
+        ch1, ct1, lp1, rw1, leg1 = _rollout(solo, T)
+        solo.check_flags()
+        assert torch.equal(ch1[:, :, 0], ch[:, :, b]), f"actions of environment {b}"
+        assert torch.equal(lp1[:, 0], lp[:, b]), f"log-probs of environment {b}"
+        assert torch.equal(rw1[:, 0], rw[:, b]) and torch.equal(leg1[:, 0], leg[:, b]), f"rewards / leg counts of environment {b}"
+        assert torch.equal(ct1[:, :, 0], ct[:, :, b]), f"counts of environment {b}"
+        assert torch.equal(solo.x[0], xb[k]) and torch.equal(solo.agents[0], agb[k]), f"final state of environment {b}"
+
+
 def test_two_half_batches_reproduce_the_whole_batch():
     """What two data-parallel ranks simulate (each its half of the environments, env_base = rank * B / 2, one seed) is
     bit-identical to one rank simulating all of them."""
