@@ -115,8 +115,8 @@ class VecPPOTrainer:
         off = self.rank if rank_offset else 0
         # minibatch draw: M distinct frames out of T * B (the reference's SamplerWithoutReplacement hands out sub-batches of a
         # shuffled buffer). Drawn on the HOST in O(M) (numpy's Floyd sampler) and copied behind the launches already queued:
-        # a device randperm of T * B = 4.2 M keys was a radix sort + scatter of ~6 ms per optimiser step inside the timed
-        # iteration (profiles/r03_default_kernel_stats.txt: elementwise_kernel_manual_unroll / _scatter_gather_elementwise)
+        # a device randperm of T * B = 4.2 M keys is seven radix-sort passes + key generation per optimiser step (0.3 ms and a
+        # dozen launches per iteration in profiles/r03_default_kernel_stats.csv) for 32 indices
         import numpy as np
         self.np_rng = np.random.Generator(np.random.Philox(key=int(seed) + 7919 * off))
         self.seed = int(seed) + off
