@@ -142,6 +142,11 @@ struct FrameOut {
   float* dtt_node;      // [N][m_env] metric environments: delta_travel_time of the node's out-edges
   int32_t m_env;        // environments 0 .. m_env-1 keep the per-node series
   int32_t* leg;         // [B][2] {agents departed (inserted), agents arrived (withdrawn)} in this frame
+  int32_t write_gc;     // store the event byte gc8 for every row that moves something. gc8 is read only BETWEEN calls (export,
+                        // the LDS-resident rollout, the next call's first delta_travel_time) and is authoritative for the last
+                        // frame alone: a rollout sets this in its last frame only, and the frames before store the byte just
+                        // for the metric environments (whose delta_travel_time reads it every frame) — one scattered
+                        // partial-line store into an array nothing else touches less per event row and frame
 };
 
 #define LP_FIX 4294967296.0  // 2^32
