@@ -27,6 +27,10 @@ Also reported on the same JSON line:
                         kept for continuity only (it charges every record once per out-edge: not a fraction of peak).
   roofline_direction  — the same for k_fused_direction (DirectionMPNN.message + aggregate, the scatter kernel the
                         north star names); roofline_insert — the insert launch (latency-bound).
+  state_dependent_policy — the same iteration with the per-edge MLP head (nothing hoisted): "fp32" = rollout logits at fp32
+                        accuracy on the bf16 matrix pipe (operands split into exact bf16 pieces), "fp32_mfma" = on the fp32
+                        matrix pipe (exact fp32 products), "bf16" = bf16 logits on bf16 observations; each with an MFMA
+                        roofline object for the MLP launch (live HIP-event time).
   cpu_baseline        — the oracle (CPU restatement of the reference path, torch CPU) timed on this host's cores on a
                         bounded sample of the same workload (rank 0, N=1 only). A reported baseline, not a target.
 """

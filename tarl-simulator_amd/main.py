@@ -34,7 +34,8 @@ OPTIONS = (
     ("--num-envs", dict(type=int, default=1, help="vectorised environments per GPU for mpnn+ppo training")),
     ("--policy-head", dict(choices=("embedding", "edge_mlp", "edge_mlp_bf16"), default="embedding",
                            help="mpnn / mpnn+ppo: the reference's live embedding head, or the per-edge MLP head it keeps "
-                                "as parameters (state-dependent; fp32 or bf16 MFMA)")),
+                                "as parameters (state-dependent; edge_mlp: rollout logits at fp32 accuracy on the bf16 matrix "
+                                "pipe — operands in exact bf16 pieces —, edge_mlp_bf16: bf16 logits; the PPO update runs in fp32)")),
 )
 
 
