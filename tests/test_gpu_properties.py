@@ -164,3 +164,56 @@ def test_drop_in_direction_mpnn_reports_the_domain_exit_without_stalling_the_ste
     with pytest.raises(IndexError, match="reached Nmax"):
         mp.check()
     mp.check()                                                             # reported once, then re-armed
+
+
+@pytest.mark.parametrize("B,T,case", [(1, 1, "nobody"), (3, 5, "nobody"), (1, 7, "one_agent"), (65, 3, "one_agent"),
+                                      (257, 2, "everybody_at_once")])
+def test_edge_cases_empty_traffic_single_frames_ragged_batches(B, T, case):
+    """The corners the reference's own tests poke at (tests/agents_test.py: an agent table where nobody is due, one agent;
+    tests/conftest.py: a three-road graph), on all three implementations of the frame at once — per-op kernels, the fused
+    frame kernels and the LDS-resident rollout must agree bit for bit on: NOBODY ever due (every row idle in every frame:
+    the state stays the reset state, rewards 0, log-probs finite), ONE agent in the whole network, EVERY agent due in the
+    first frame (the insert's backlog path: most are refused for lack of room), batch sizes 1 / 65 / 257 (partial waves and
+    partial workgroups), one-frame rollouts (no previous count slice)."""
+    from tarl_hip import ops, synth
+    from tarl_hip.engine import EPISODE_START, SimEngine
+    net = synth.torus_network(3, 4, heterogeneous=True, seed=7)
+    N = net.num_roads
+    A = {"nobody": 40, "one_agent": 1, "everybody_at_once": 600}[case]
+    t0 = EPISODE_START + (10_000_000 if case == "nobody" else 0)
+    t1 = t0 + (1 if case != "one_agent" else 3)
+    pops = torch.stack([synth.population(A, N, seed=90 + b, t0=t0, t1=t1) for b in range(B)]).cuda()
+    emb = torch.randn(N, generator=torch.Generator().manual_seed(3)).cuda()
+
+    def engine(fused):
+        e = SimEngine(net.x.cuda().unsqueeze(0).repeat(B, 1, 1).contiguous(), net.edge_index, net.edge_attr, net.Nmax,
+                      pops.clone(), congestion_constant=net.congestion_constant, seed=5, fused=fused)
+        e.reset()
+        if fused:
+            e.prepare_policy(emb)
+        return e
+    ef, ee, eu = engine(True), engine(True), engine(False)
+    chf, lpf, rwf, ctf = _rollout(ef, T, "frames")
+    che, lpe, rwe, cte = _rollout(ee, T, "env")
+    assert torch.equal(chf, che) and torch.equal(lpf, lpe) and torch.equal(rwf, rwe) and torch.equal(ctf, cte)
+    assert torch.equal(ef.x, ee.x) and torch.equal(ef.agents, ee.agents) and ef.time == ee.time
+    # the per-op kernels, frame by frame, with the same draws (the engine's own Philox streams)
+    for t in range(T):
+        logits = ops.policy_edge_logits(eu.plan, eu.node_features, emb)
+        p = ops.graphdist_softmax(eu.plan, logits)
+        eu.sample_counter += 1
+        _, choice = ops.graphdist_sample(eu.plan, p, seed=eu.seed ^ 0x5DEECE66D, counter=eu.sample_counter, want_onehot=False,
+                                         want_choice=True)
+        reward, _ = eu.step(choice=choice)
+        assert torch.equal(choice, chf[t]) and torch.equal(reward, rwf[t]) and torch.equal(eu.counts, ctf[t + 1]), f"frame {t}"
+    assert torch.equal(eu.x, ef.x) and torch.equal(eu.agents, ef.agents)
+    ef.check_flags()
+    ee.check_flags()
+    assert bool(torch.isfinite(lpf).all())
+    if case == "nobody":
+        assert float(rwf.abs().sum()) == 0.0 and float(ctf.sum()) == 0.0 and float(ef.agents[:, :, 7:].sum()) == 0.0
+    elif case == "one_agent":
+        assert float(ef.agents[:, :, 7].sum() + ef.agents[:, :, 8].sum()) == (B if T >= 4 else float(ef.agents[:, :, 7].sum()))
+    else:
+        on_way = ef.agents[:, :, 7].sum(dim=1)
+        assert bool((on_way > 0).all()) and bool((on_way < A).all())      # some got in, most found no room
