@@ -11,26 +11,32 @@ DirectionMPNN, ResponseMPNN, withdraw, insert, reward) followed by ``epochs`` x 
 advantage normalisation, minibatch, clipped PPO loss, backward, gradient all-reduce, Adam).
 What is hoisted: the live policy's logits are state-independent (embedding of the target road), so its segment softmax,
 inverse-CDF thresholds, log-probabilities and entropy are evaluated once per parameter update, not per frame (bit-identical
-to evaluating them per frame; ``--policy edge_mlp`` runs the state-dependent head with per-frame logits instead).
+to evaluating them per frame; the ``state_dependent_policy`` lines run the per-edge MLP head with per-frame logits instead).
 Workload: BASELINE.json config 4 — 10k-edge synthetic torus dual graph, 16k agents, rollout-steps 256 — with ``--envs``
 vectorised environments per GPU (weak scaling: per-GPU work is fixed). Inputs are resident in HBM before the timed
 region. The timed region is bracketed by barrier + synchronize on both sides; the slowest rank's time is used.
 
-Also reported on the same JSON line:
+ONE JSON line on stdout, numbers only and below 4 KB (the driver keeps the line's tail); every descriptive field — what a
+kernel does, where a traffic figure comes from, the CPU sample in words — goes to the sidecar
+``gpurun_out/bench_details.json`` (and its path to stderr). Objects on the line:
   roofline            — the DOMINANT kernel of a frame, k_fused_rows (DirectionMPNN.update + ResponseMPNN message /
-                        aggregate / update + withdraw): HBM bytes per launch from the PMC counters (2*FETCH_SIZE +
-                        WRITE_SIZE, rocprofv3 --pmc passes of THIS script reduced by tools/pmc_bench.py over frames >= 200
-                        of an iteration and committed under profiles/) / the kernel's average launch duration over the
-                        same frames, measured live with HIP events on the launch stream, vs the 8 TB/s HBM peak.
-                        ``compulsory_*``: the same with the bytes the packed layout must move instead of
-                        the counter bytes; ``survey_8d_*``: SURVEY §8d's per-edge figure for the reference's AoS layout,
-                        kept for continuity only (it charges every record once per out-edge: not a fraction of peak).
+                        aggregate / update + withdraw): ``traffic`` = HBM bytes per launch from the PMC counters
+                        (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc passes of THIS script reduced by tools/pmc_bench.py
+                        over frames >= 200 of an iteration, committed under profiles/ and matched by the sha256 of the
+                        frame-kernel sources) / the kernel's average launch duration over the same frames, measured live
+                        with HIP events on the launch stream, vs the 8 TB/s HBM peak. ``compulsory_frac``: the same with
+                        the bytes the packed layout must move; ``rd_req`` / ``wr_req``: memory-side
+                        read / write requests per launch (TCC_EA0_RDREQ / WRREQ).
   roofline_direction  — the same for k_fused_direction (DirectionMPNN.message + aggregate, the scatter kernel the
                         north star names); roofline_insert — the insert launch (latency-bound).
-  state_dependent_policy — the same iteration with the per-edge MLP head (nothing hoisted): "fp32" = rollout logits at fp32
-                        accuracy on the bf16 matrix pipe (operands split into exact bf16 pieces), "fp32_mfma" = on the fp32
-                        matrix pipe (exact fp32 products), "bf16" = bf16 logits on bf16 observations; each with an MFMA
-                        roofline object for the MLP launch (live HIP-event time).
+  config5             — BASELINE config 5 (100k route edges, 262 144 agents) at ``--config5-envs`` environments: one or two
+                        PPO iterations, its own three roofline objects, and the bf16 per-edge MLP line at that size.
+  update_path         — the same iteration with ``--update-epochs`` x ``--update-sub-batch`` (the update at a size where
+                        its kernels exist): HIP-event time and algorithmic bytes per update stage.
+  congested_regime    — every agent departs within ``--congested-window`` seconds (the loaded network).
+  state_dependent_policy — the per-edge MLP head (nothing hoisted): "fp32" = rollout logits on the fp32 matrix pipe (exact
+                        fp32 products), "fp32_x3" = fp32 accuracy on the bf16 pipe (operands in exact bf16 pieces),
+                        "bf16" = bf16 logits on bf16 observations; each with an MFMA roofline object for the MLP launch.
   cpu_baseline        — the oracle (CPU restatement of the reference path, torch CPU) timed on this host's cores on a
                         bounded sample of the same workload (rank 0, N=1 only). A reported baseline, not a target.
 """
@@ -56,26 +62,35 @@ import torch  # noqa: E402
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy kernel achieves
 LATE_FRAME = 200          # the roofline window: frames >= 200 of an iteration (traffic and live time alike)
-# written by tools/pmc_bench.py from --pmc passes of this script (one record per workload: the default line and the
-# congested regime), with the per-kernel counter corrections measured by tools/pmc_cal.hip (profiles/r03_pmc_calibration.txt)
-PMC_RECORDS = (os.path.join("profiles", "r04_pmc_traffic.json"), os.path.join("profiles", "r04_pmc_traffic_congested.json"))
+# written by tools/pmc_bench.py from --pmc passes of this script (one record per workload), matched by config + source hash
+PMC_RECORDS = tuple(os.path.join("profiles", n) for n in
+                    ("r05_pmc_traffic.json", "r05_pmc_traffic_congested.json", "r05_pmc_traffic_c5.json"))
 # Compulsory HBM bytes per (road, environment) and launch of the packed env-minor layout: what each kernel
 # must read and write once, neighbour gathers served by the XCD's L2, statics / topology / policy tables through the
 # scalar cache (shared by all environments, not counted).
 COMPULSORY = {
-    # head words 8 + tail word 4 + SELECTED_ROAD byte 1 in; post word 4 out
-    "k_fused_direction": {"per_node_env": 13.0 + 4.0},
-    # post word 4 + head words 8 + tail word 4 in; count byte 1 out (an idle row's words already hold what a refresh would
-    # store: head / tail words, event word, slot store and agent rows are written only where something moves)
-    "k_fused_rows": {"per_node_env": 16.0 + 1.0},
-    # insert(t): departure window, a few words per admitted agent, the accumulator banks (the actions of all frames are
-    # drawn on a side stream: k_fused_choice_all, 1 byte per (frame, road, environment))
-    "k_fused_insert": {"per_node_env": 0.0},
+    "k_fused_direction": 13.0 + 4.0,   # head words 8 + tail word 4 + SELECTED_ROAD byte 1 in; post word 4 out
+    "k_fused_rows": 16.0 + 1.0,        # post word 4 + head words 8 + tail word 4 in; count byte 1 out
+    "k_fused_insert": 0.0,             # departure window, a few words per admitted agent, the accumulator banks
 }
-# SURVEY §8d's per-unit figures for the reference's AoS layout (kept as ``survey_8d_*`` keys only): Direction message +
-# aggregate 60 B/edge (8 indices + 4 edge_attr + 4 noise + 28 x_j + 12 x_i + 4 delta_tt out); row pass = Direction update
-# 32 B/node + Response message/aggregate 24 B/edge (its 344 B per popped road not counted).
-SURVEY_8D = {"k_fused_direction": (60.0, 0.0), "k_fused_rows": (24.0, 32.0)}
+KERNEL_WHAT = {
+    "k_fused_rows": "DirectionMPNN.update + ResponseMPNN message / aggregate / update + withdraw; the dominant kernel",
+    "k_fused_direction": "DirectionMPNN message + aggregate on the packed dense words (the scatter kernel)",
+    "k_fused_insert": "insert_agent_into_network + reward; a latency chain, several environments per wave",
+}
+
+
+def sig(x, n=4):
+    return float(f"{x:.{n}g}") if isinstance(x, float) else x
+
+
+def compact(o, key=None):
+    """Numbers at four significant digits, five for the throughput figures (the line must stay below 4 KB)."""
+    if isinstance(o, dict):
+        return {k: compact(v, k) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [compact(v, key) for v in o]
+    return sig(o, 5 if key in ("value", "value_rollout_only", "ms_per_step") else 4)
 
 
 def parse():
@@ -97,11 +112,18 @@ def parse():
                     help="also time --congested-steps iterations with every agent departing within this many seconds "
                          "(0 = skip); reported under congested_regime")
     ap.add_argument("--congested-steps", type=int, default=2)
+    ap.add_argument("--update-epochs", type=int, default=8,
+                    help="update_path object: epochs per iteration (0 = skip); with --update-sub-batch frames per minibatch")
+    ap.add_argument("--update-sub-batch", type=int, default=4096)
+    ap.add_argument("--update-steps", type=int, default=2)
+    ap.add_argument("--config5-envs", type=int, default=2048,
+                    help="environments per GPU of the config5 object (BASELINE config 5: 100k edges, 262 144 agents; 0 = skip)")
+    ap.add_argument("--config5-steps", type=int, default=2)
     ap.add_argument("--policy-envs", type=int, default=2048,
-                    help="environments per GPU of the state-dependent-policy line (policy_head=edge_mlp; 0 = skip)")
+                    help="environments per GPU of the state-dependent-policy lines (policy_head=edge_mlp; 0 = skip)")
     ap.add_argument("--policy-steps", type=int, default=2)
     ap.add_argument("--policy-temperature", type=float, default=2000.0,
-                    help="GraphDistribution temperature of the state-dependent-policy line: the head reads raw features "
+                    help="GraphDistribution temperature of the state-dependent-policy lines: the head reads raw features "
                          "(clock times ~2e4), so an untrained head at temperature 1 is near-deterministic, drives every "
                          "agent down the same turn and gridlocks the network out of the reference's domain")
     ap.add_argument("--metrics-envs", type=int, default=1,
@@ -109,35 +131,51 @@ def parse():
                          "masks); the per-frame leg histogram is kept for all of them")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true",
-                    help="do not bracket the Direction kernel with HIP events (lets small batches use the graph replay)")
+                    help="do not bracket the frame kernels with HIP events (PMC / kernel-trace passes)")
+    ap.add_argument("--details", type=str, default=os.path.join("gpurun_out", "bench_details.json"),
+                    help="sidecar file with every descriptive field (relative to the repo root; '' = stderr only)")
     return ap.parse_args()
 
 
-def build_trainer(args, rank, device):
+def make_network(edges):
+    from tarl_hip import synth
+    W, H = synth.torus_for_edges(edges)
+    return synth.torus_network(W, H)
+
+
+def build_trainer(args, rank, device, net=None, *, agents=None, envs=None, window=None, seed_off=0, **trainer_kw):
+    """Engine + trainer of one workload: every environment of every rank gets its own population, drawn on the device."""
     from tarl_hip import synth
     from tarl_hip.engine import SimEngine
     from tarl_hip.trainer import VecPPOTrainer
     from src.agents.mpnn_agent import MPNNPolicyNet, MPNNValueNetSimple
 
-    W, H = synth.torus_for_edges(args.edges)
-    net = synth.torus_network(W, H)
+    net = net if net is not None else make_network(args.edges)
+    agents = args.agents if agents is None else agents
+    envs = args.envs if envs is None else envs
+    window = args.departure_window if window is None else window
     N = net.num_roads
-    # every environment of every rank gets its own population, drawn on the device (seed + rank)
-    pops = synth.population_batch(args.agents, N, args.envs, seed=args.seed + 1000 * rank, device=device,
-                                  t1=args.departure_window + synth.EPISODE_START if args.departure_window else synth.EPISODE_END)
-    engine = SimEngine(net.x.to(device).unsqueeze(0).repeat(args.envs, 1, 1).contiguous(), net.edge_index,
+    pops = synth.population_batch(agents, N, envs, seed=args.seed + 1000 * rank + seed_off, device=device,
+                                  t1=window + synth.EPISODE_START if window else synth.EPISODE_END)
+    engine = SimEngine(net.x.to(device).unsqueeze(0).repeat(envs, 1, 1).contiguous(), net.edge_index,
                        net.edge_attr, net.Nmax, pops, congestion_constant=net.congestion_constant,
                        device=device, seed=args.seed + rank)
     torch.manual_seed(args.seed)       # identical initial weights on every rank (also broadcast by the trainer)
-    ff = net.x[:, 3 * net.Nmax + 2][net.edge_index[1]]
+    head = trainer_kw.get("policy") == "edge_mlp"
+    ff = None if head else net.x[:, 3 * net.Nmax + 2][net.edge_index[1]]
     pol = MPNNPolicyNet(net.edge_index, N, ff, device=str(device))
     val = MPNNValueNetSimple(net.edge_index, N, device=str(device))
-    l = val.final_mlp
-    dormant = [p for n, p in pol.named_parameters() if not n.startswith("nodes_embedding")]
+    l, mm = val.final_mlp, pol.edge_mlp
+    if head:
+        trainer_kw["edge_mlp_params"] = [mm[0].weight, mm[0].bias, mm[2].weight, mm[2].bias, mm[4].weight, mm[4].bias]
+    trainer_kw.setdefault("num_epochs", args.epochs)
+    trainer_kw.setdefault("sub_batch_size", args.sub_batch)
+    trainer_kw.setdefault("metrics_envs", args.metrics_envs)
     trainer = VecPPOTrainer(engine, pol.nodes_embedding.weight,
                             [l[0].weight, l[0].bias, l[2].weight, l[2].bias, l[4].weight, l[4].bias],
-                            rollout_steps=args.rollout_steps, num_epochs=args.epochs, sub_batch_size=args.sub_batch,
-                            extra_params=dormant, seed=args.seed, metrics_envs=args.metrics_envs)
+                            rollout_steps=args.rollout_steps,
+                            extra_params=[p for n, p in pol.named_parameters() if not n.startswith("nodes_embedding")],
+                            seed=args.seed, **trainer_kw)
     return net, engine, trainer
 
 
@@ -259,15 +297,10 @@ def cpu_baseline(args, net):
         if time.perf_counter() - t_all >= args.cpu_seconds:
             break
     return {"value": steps / (el + up), "unit": "env-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{iters} PPO iter x 1 env: {steps} oracle env steps + 1 update each, {el:.1f}+{up:.2f} s",
             "value_rollout_only": steps / el, "update_seconds": up, "rollout_seconds": el,
-            "all_cores": {"cores": nsock, "value": by_threads[str(nsock)], "unit": "env-steps/s",
-                          "logical_cpus_of_the_host": ncpu,
-                          "sample": "1 s probe of the same rollout with torch.set_num_threads(physical cores of one socket)"},
-            "by_threads_1s_probe": by_threads,
-            "sample": f"{iters} PPO iteration(s) of 1 environment: {steps} env steps (oracle rollout: policy logits, "
-                      f"GraphDistribution sample + log_prob, env step; at most {args.rollout_steps} per iteration) + one update "
-                      f"per iteration (critic over all frames, GAE, minibatch of {args.sub_batch}, ClipPPOLoss, autograd "
-                      f"backward, Adam) on the {E}-edge / {args.agents}-agent workload, {el:.1f} s + {up:.2f} s, torch CPU"}
+            "all_cores": {"cores": nsock, "value": by_threads[str(nsock)], "logical_cpus_of_the_host": ncpu},
+            "by_threads_1s_probe": by_threads}
 
 
 def spawn_ranks(args):
@@ -300,6 +333,220 @@ def spawn_ranks(args):
     sys.exit(rc)
 
 
+def time_iterations(trainer, steps, L, T, prof, device, run=None):
+    """``steps`` iterations bracketed by barrier + synchronize; HIP events around the frame kernels of the first one.
+    -> (frames, slowest rank's seconds, this rank's seconds, (ms_all[3], ms_late[3], frames[2]))"""
+    from tarl_hip import dist_utils, lib
+    if prof:
+        L.tarl_prof_enable(T)
+    dist_utils.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    frames = 0
+    for _ in range(steps):
+        frames += (run or trainer.train_iteration)()
+    torch.cuda.synchronize()
+    dist_utils.barrier()
+    mine = time.perf_counter() - t0
+    elapsed = dist_utils.allreduce_max_float(mine, device)
+    ms_all, ms_late, nfr = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int64 * 2)()
+    lib.check(L.tarl_prof_collect(LATE_FRAME if T > LATE_FRAME else 0, ms_all, ms_late, nfr))
+    L.tarl_prof_enable(0)
+    trainer.check_flags()
+    return frames, elapsed, mine, (list(ms_all), list(ms_late), list(nfr))
+
+
+def pmc_record(cfg):
+    """The committed PMC record of a workload, or None: the config must match AND the record must have been taken on the
+    very frame-kernel sources this run executes (sha256 of csrc/fused.hip + fused_common.h) — a kernel edit without a fresh
+    PMC pass falls back to the compulsory bytes instead of pairing new times with old bytes."""
+    from tarl_hip.ops import frame_kernel_source_hash
+    sha = frame_kernel_source_hash()
+    for path in PMC_RECORDS:
+        try:
+            rec = json.load(open(os.path.join(ROOT, path)))
+            if rec["config"] == cfg and rec.get("source_sha16") == sha:
+                rec["path"] = path
+                return rec
+        except (OSError, KeyError, ValueError):
+            pass
+    return None
+
+
+def rooflines(cfg, NB, prof, T, full_first=True, want_req=True):
+    """The three frame kernels' roofline objects of one workload: (compact objects for the line, verbose ones for the
+    sidecar, {kernel: late seconds}). achieved = HBM bytes per launch (PMC counters of this script's own rollout, frames >=
+    LATE_FRAME; without a matching record: the compulsory bytes, ``traffic`` null) / the live average launch duration."""
+    ms_all, ms_late, nfr = prof
+    pmc = pmc_record(cfg)
+    late0 = LATE_FRAME if T > LATE_FRAME else 0
+    line, detail, secs = {}, {}, {}
+    for key, slot, kernel in (("roofline", 1, "k_fused_rows"), ("roofline_direction", 0, "k_fused_direction"),
+                              ("roofline_insert", 2, "k_fused_insert")):
+        n_late, n_all = max(1, nfr[1]), max(1, nfr[0])
+        late_s, all_s = ms_late[slot] / n_late * 1e-3, ms_all[slot] / n_all * 1e-3
+        comp = COMPULSORY[kernel] * NB
+        k = pmc["kernels"].get(kernel) if pmc else None
+        traffic = k["hbm_bytes_per_launch"] if k else None
+        byts = traffic if traffic is not None else comp
+        achieved = byts / late_s / 1e9 if late_s > 0 else 0.0
+        o = {"kernel": kernel, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+             "avg_launch_us": late_s * 1e6, "avg_launch_us_all_frames": all_s * 1e6,
+             "bytes_basis": "pmc" if traffic is not None else "compulsory",
+             "compulsory_frac": (comp / late_s / 1e9 / HBM_PEAK_GBS) if late_s > 0 else 0.0,
+             "traffic_over_compulsory": (traffic / comp) if (traffic is not None and comp > 0) else None}
+        if k and "TCC_EA0_RDREQ_sum" in k:
+            o["rd_req"], o["wr_req"] = k["TCC_EA0_RDREQ_sum"], k.get("TCC_EA0_WRREQ_sum")
+        full = {"bound": "hbm", "kernel": kernel, "achieved": o["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": o["frac"], "traffic": traffic, **{a: b for a, b in o.items() if a not in ("kernel", "achieved", "frac", "traffic")}}
+        if key == "roofline" and full_first:      # the contract's object: bound / achieved / peak / unit / frac / traffic
+            line[key] = full
+        else:                                     # the other kernels / workloads: the same numbers under fewer keys (the 4 KB line)
+            line[key] = {"frac": o["frac"], "achieved": o["achieved"], "traffic": traffic, "avg_launch_us": o["avg_launch_us"],
+                         "us_all": o["avg_launch_us_all_frames"], "t_over_c": o["traffic_over_compulsory"]}
+            if want_req and "rd_req" in o:
+                line[key]["req"] = [o["rd_req"], o["wr_req"]]
+        detail[key] = dict(full, what=KERNEL_WHAT[kernel], frames_timed=int(nfr[1]),
+                           first_frame=late0, compulsory_bytes_per_launch=comp,
+                           traffic_source=(f"{pmc['path']}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, mean over "
+                                           f"frames >= {LATE_FRAME}; bytes = {k.get('formula', '2*FETCH_SIZE + WRITE_SIZE')}") if k else None,
+                           note="frac falls when re-reads are removed faster than time: compare avg_launch_us and "
+                                "traffic_over_compulsory across rounds, not frac alone")
+        secs[kernel] = late_s
+    return line, detail, secs
+
+
+def update_path(args, trainer, engine, world, L, T, device):
+    """The update at a size where its kernels exist (the reference's loop shape, src/rl/ppo_trainer.py:129-145, with more
+    epochs and a larger sub-batch): env-steps/s of the iteration, and per update stage the HIP-event time per call plus its
+    algorithmic bytes (what the stage must read + write once)."""
+    from tarl_hip.trainer import NoStageTimer, StageTimer
+    B, N, E = engine.B, engine.N, engine.E
+    M = min(args.update_sub_batch, T * B)
+    saved = trainer.num_epochs, trainer.M
+    trainer.num_epochs, trainer.M = args.update_epochs, M
+    trainer.train_iteration()                                   # warm-up at this shape (scratch allocations)
+    trainer.stage = st = StageTimer()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    up_s, frames = 0.0, 0
+    for _ in range(args.update_steps):
+        frames += trainer.collect()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        trainer.update()
+        torch.cuda.synchronize()
+        up_s += time.perf_counter() - t1
+    el = time.perf_counter() - t0
+    ms = st.ms()
+    trainer.stage = NoStageTimer()
+    trainer.num_epochs, trainer.M = saved
+    trainer.check_flags()
+    P = trainer.flat.numel
+    K = N + 1
+    # algorithmic bytes per call of each stage (fp32 unless noted): inputs read once + outputs written once
+    byts = {"critic_all_frames": (T + 1) * B * N + 3 * 64 * K * 2 + (T + 1) * B * 4,     # count bytes + W1 pieces + values
+            "gae": T * B * 4 * 5,
+            "minibatch_gather": M * N * (1 + 1 + 4 + 4),                                  # action / count bytes in, ids / fp32 rows out
+            "actor_logits_fwd": M * E * 4 + N * 4,
+            "graphdist_fwd": M * E * 4 * 3 + M * N * 4,
+            "critic_fwd": M * K * 4 + 64 * K * 4 + M * 64 * 4 * 2,
+            "ppo_loss": M * 4 * 9,
+            "graphdist_bwd": M * E * 4 * 2 + M * N * 4,
+            "actor_logits_bwd": M * E * 4 + N * 4,
+            "critic_bwd": M * K * 4 + 2 * 64 * K * 4 + M * 64 * 4 * 2,
+            "grad_allreduce": P * 4 * 2, "adam": P * 4 * 7}
+    stages = {k: {"us": v[0] / v[1] * 1e3, "GBs": byts.get(k, 0) / (v[0] / v[1] * 1e-3) / 1e9 if v[0] > 0 else None}
+              for k, v in ms.items()}
+    n_up = args.update_steps * args.update_epochs
+    slow = max((k for k in stages if k != "critic_all_frames"), key=lambda k: stages[k]["us"])
+    line = {"value": frames * world / el, "epochs": args.update_epochs, "sub_batch": M, "ms_per_step": el / args.update_steps * 1e3,
+            "update_frac": up_s / el, "ms_per_minibatch_step": (up_s / n_up) * 1e3,
+            "stage_us": {k: v["us"] for k, v in stages.items()}, "slowest_minibatch_stage": slow,
+            "slowest_GBs": stages[slow]["GBs"]}
+    detail = dict(line, stages={k: dict(v, bytes_per_call=byts.get(k)) for k, v in stages.items()}, update_seconds=up_s,
+                  note="HIP events on the launch stream around each stage of VecPPOTrainer.advantages / minibatch_step; "
+                       "bytes = algorithmic (inputs once + outputs once)")
+    return line, detail
+
+
+def policy_lines(args, net, rank, world, device, L, T, envs, precisions, steps, seed_off=31, agents=None):
+    """The state-dependent policy (per-edge MLP head 33 -> 64 -> 32 -> 1 on cat(x[src], x[dst], edge_attr); the reference
+    keeps it as parameters, src/agents/mpnn_agent.py:35-41,227-231): NOTHING is hoisted — every frame builds the
+    observation from the packed state, runs the MLP on the matrix cores, the segment softmax, the sample and the log-prob,
+    then the simulation frame; the update runs the MLP forward / backward."""
+    from tarl_hip import dist_utils, lib
+    E = net.edge_index.size(1)
+    out, detail, eng_p = {}, {}, None
+    for tag, prec in precisions:
+        if eng_p is None:
+            _, eng_p, tr_p = build_trainer(args, rank, device, net, agents=agents, envs=envs, window=0, seed_off=seed_off,
+                                           policy="edge_mlp", policy_precision=prec, temperature=args.policy_temperature,
+                                           metrics_envs=1)
+        else:
+            tr_p = rebuild_policy_trainer(args, eng_p, net, device, prec)
+        tr_p.train_iteration()
+        if not args.no_kernel_timing:
+            L.tarl_prof_enable(T)      # HIP events around the per-edge MLP launch of the first timed iteration's frames
+        dist_utils.barrier()
+        torch.cuda.synchronize()
+        t2_ = time.perf_counter()
+        pf = 0
+        for _ in range(steps):
+            pf += tr_p.train_iteration()
+        torch.cuda.synchronize()
+        dist_utils.barrier()
+        pel = dist_utils.allreduce_max_float(time.perf_counter() - t2_, device)
+        p_all, p_late, p_nfr = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int64 * 2)()
+        lib.check(L.tarl_prof_collect(0, p_all, p_late, p_nfr))
+        L.tarl_prof_enable(0)
+        tr_p.check_flags()
+        mlp_s = p_all[0] / max(1, p_nfr[0]) * 1e-3
+        # MPNNPolicyNet.edge_mlp per edge: 2 * (33*64 + 64*32 + 32) flop (src/agents/mpnn_agent.py:35-41); the matrix
+        # cores are the bound of this kernel: dense MFMA peaks from MI355X_MICROARCH.md (bf16 2.5 PFLOP/s, fp32 157.3 TF)
+        flops = 2.0 * (33 * 64 + 64 * 32 + 32) * envs * E
+        peak = MFMA_PEAK_TFLOPS["f32" if prec == "fp32" else "bf16"]
+        kname = {"x3": "k_edge_mlp_fwd_x3", "fp32": "k_edge_mlp_fwd_f32", "bf16": "k_edge_mlp_fwd_bf16"}[prec]
+        roof = None
+        if mlp_s > 0:
+            roof = {"bound": "mfma", "kernel": kname, "achieved": flops / mlp_s / 1e12, "peak": peak, "unit": "TFLOP/s",
+                    "frac": flops / mlp_s / 1e12 / peak, "traffic": None, "avg_launch_us": mlp_s * 1e6}
+            if prec == "x3":
+                # the kernel ISSUES six bf16 piece products per multiply-add of the head: issued_frac = the piece products the
+                # matrix cores actually execute (50 MFMAs of 32x32x16 per 32 edges) over the bf16 peak
+                roof["issued_frac"] = 2.0 * 32 * 32 * 16 * 50 * (envs * E / 32.0) / mlp_s / 1e12 / peak
+        out[tag] = {"value": pf * world / pel, "ms_per_step": pel / steps * 1e3,
+                    "roofline": {k: roof[k] for k in ("bound", "achieved", "frac", "avg_launch_us", "issued_frac") if k in roof} if roof else None}
+        detail[tag] = dict(out[tag], roofline=roof, unit="env-steps/s", envs_per_gpu=envs, steps=steps, edge_mlp_edges_per_sec=pf * world / pel * E,
+                           launches_timed=int(p_nfr[0]), flop_per_launch=flops,
+                           rollout_logits={"bf16": "bf16 MFMA (v_mfma_f32_32x32x16_bf16) on bf16 observations",
+                                           "fp32": "fp32 MFMA (v_mfma_f32_32x32x2_f32), exact fp32 products",
+                                           "x3": "fp32-accurate on the bf16 pipe: operands in three exact bf16 pieces, six "
+                                                 "products per multiply-add (v_mfma_f32_32x32x16_bf16)"}[prec])
+        del tr_p
+    out["envs_per_gpu"], out["temperature"] = envs, args.policy_temperature
+    detail["note"] = ("policy_head=edge_mlp: per-frame observation + 33->64->32->1 MLP per edge + GraphDistribution softmax / "
+                      f"sample / log_prob (no table hoist), then the simulation frame; GraphDistribution temperature {args.policy_temperature:g}")
+    del eng_p
+    torch.cuda.empty_cache()
+    return out, detail
+
+
+def rebuild_policy_trainer(args, eng_p, net, device, prec):
+    from tarl_hip.trainer import VecPPOTrainer
+    from src.agents.mpnn_agent import MPNNPolicyNet, MPNNValueNetSimple
+    torch.manual_seed(args.seed)
+    pol = MPNNPolicyNet(net.edge_index, net.num_roads, None, device=str(device))
+    val = MPNNValueNetSimple(net.edge_index, net.num_roads, device=str(device))
+    l, mm = val.final_mlp, pol.edge_mlp
+    return VecPPOTrainer(eng_p, pol.nodes_embedding.weight,
+                         [l[0].weight, l[0].bias, l[2].weight, l[2].bias, l[4].weight, l[4].bias],
+                         rollout_steps=args.rollout_steps, num_epochs=args.epochs, sub_batch_size=args.sub_batch,
+                         extra_params=[p for n, p in pol.named_parameters() if not n.startswith("nodes_embedding")],
+                         seed=args.seed, policy="edge_mlp", policy_precision=prec, temperature=args.policy_temperature,
+                         edge_mlp_params=[mm[0].weight, mm[0].bias, mm[2].weight, mm[2].bias, mm[4].weight, mm[4].bias])
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -314,56 +561,37 @@ def main():
     if world > 1:     # N ranks share the host: keep each rank's CPU-side set-up (population generation) in its share
         torch.set_num_threads(max(1, (os.cpu_count() or 1) // world))
     L = lib.load()
+    prof = not args.no_kernel_timing
 
     t_setup = time.perf_counter()
     net, engine, trainer = build_trainer(args, rank, device)
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t_setup
-    E, B, T = engine.E, engine.B, args.rollout_steps
+    E, B, T, n_roads = engine.E, engine.B, args.rollout_steps, engine.N
+    NB = B * n_roads
+    layout_tag, rollout_mode = trainer.layout_tag, trainer.rollout
 
+    # ---- the headline: `steps` PPO iterations of BASELINE's workload ----------------------------------------------------------
     for _ in range(args.warmup):
         trainer.train_iteration()
-    if not args.no_kernel_timing:
-        L.tarl_prof_enable(T)      # HIP events around the two message-passing kernels of the first timed iteration's frames
-    dist_utils.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    frames = 0
-    for _ in range(args.steps):
-        frames += trainer.train_iteration()
-    torch.cuda.synchronize()
-    dist_utils.barrier()
-    elapsed_rank = time.perf_counter() - t0
-    elapsed = dist_utils.allreduce_max_float(elapsed_rank, device)
+    frames, elapsed, elapsed_rank, prof_main = time_iterations(trainer, args.steps, L, T, prof, device)
     per_rank = dist_utils.gather_floats([setup_s, elapsed_rank], device)     # [rank][setup_seconds, timed_seconds]
     # data-parallel evidence (outside the timed region): after `steps` averaged-gradient Adam steps every replica must still
     # hold rank 0's parameter bits
     replica_diff = dist_utils.replica_max_abs_diff(trainer.flat.flat)
+    # rollout-only figure (BASELINE.md §3 / SURVEY §8d: "rollout + update, and rollout-only"): the collector loop alone
+    ro_frames, ro_elapsed, _, _ = time_iterations(trainer, min(args.steps, 3), L, T, False, device, run=trainer.collect)
 
-    ms_all, ms_late, nfr = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int64 * 2)()
-    late0 = LATE_FRAME if T > LATE_FRAME else 0
-    lib.check(L.tarl_prof_collect(late0, ms_all, ms_late, nfr))
-    L.tarl_prof_enable(0)
-    trainer.check_flags()
+    # ---- the update at a size where its kernels exist -----------------------------------------------------------------------------
+    upd = upd_detail = None
+    if args.update_epochs > 0 and not args.departure_window and world == 1:      # (N = 1 only: a multi-rank run times the headline)
+        upd, upd_detail = update_path(args, trainer, engine, world, L, T, device)
 
-    # rollout-only figure (BASELINE.md §3 / SURVEY §8d: "rollout + update, and rollout-only"): the collector loop alone, timed
-    # the same way right behind the headline region
-    dist_utils.barrier()
-    torch.cuda.synchronize()
-    t_ro = time.perf_counter()
-    ro_frames = 0
-    for _ in range(min(args.steps, 3)):
-        ro_frames += trainer.collect()
-    torch.cuda.synchronize()
-    dist_utils.barrier()
-    ro_elapsed = dist_utils.allreduce_max_float(time.perf_counter() - t_ro, device)
-    trainer.check_flags()
-
-    # ---- second line of evidence: the congested regime -------------------------------------------------------------------
+    # ---- the congested regime: every agent departs within --congested-window seconds -----------------------------------------------
     # The headline workload spreads the departures over the 61-minute episode (BASELINE config), so the 256 timed frames see
-    # a filling network. Here every agent departs within --congested-window seconds: the FIFOs fill up, most rows pop /
-    # withdraw / enqueue in every frame. Same engine, same kernels, populations re-drawn and re-packed.
-    congested = None
+    # a filling network. Here the FIFOs fill up, most rows pop / withdraw / enqueue in every frame. Same engine, same kernels,
+    # populations re-drawn and re-packed.
+    congested = cong_detail = None
     if args.congested_window > 0 and not args.departure_window:
         from tarl_hip import synth
         engine.agents.copy_(synth.population_batch(args.agents, engine.N, B, seed=args.seed + 1000 * rank + 17,
@@ -371,208 +599,112 @@ def main():
         engine.fs.order_valid = False
         engine._packed_stale = True
         trainer.train_iteration()                       # warm-up (re-pack, re-sort)
-        if not args.no_kernel_timing:
-            L.tarl_prof_enable(T)
-        dist_utils.barrier()
-        torch.cuda.synchronize()
-        t1_ = time.perf_counter()
-        cf = 0
-        for _ in range(args.congested_steps):
-            cf += trainer.train_iteration()
-        torch.cuda.synchronize()
-        dist_utils.barrier()
-        cel = dist_utils.allreduce_max_float(time.perf_counter() - t1_, device)
-        c_all, c_late, c_nfr = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int64 * 2)()
-        lib.check(L.tarl_prof_collect(late0, c_all, c_late, c_nfr))
-        L.tarl_prof_enable(0)
-        trainer.check_flags()
-        on_way = float(engine.agents[:, :, 7].sum()) / B
-        arrived = float(engine.agents[:, :, 8].sum()) / B
-        congested = {"value": cf * world / cel, "unit": "env-steps/s", "steps": args.congested_steps,
-                     "ms_per_step": cel / args.congested_steps * 1e3, "departure_window_s": args.congested_window,
-                     "agents_on_the_way_at_the_end_per_env": on_way, "agents_arrived_per_env": arrived,
-                     "note": "all agents depart within the window: the network is loaded for most of the rollout"}
+        cf, cel, _, prof_c = time_iterations(trainer, args.congested_steps, L, T, prof, device)
+        congested = {"value": cf * world / cel, "ms_per_step": cel / args.congested_steps * 1e3,
+                     "departure_window_s": args.congested_window,
+                     "agents_on_the_way_at_the_end_per_env": float(engine.agents[:, :, 7].sum()) / B}
+        cong_detail = dict(congested, unit="env-steps/s", steps=args.congested_steps,
+                           agents_arrived_per_env=float(engine.agents[:, :, 8].sum()) / B,
+                           note="all agents depart within the window: the network is loaded for most of the rollout")
+        if prof:
+            cfg_c = {"edges": E, "agents": args.agents, "envs": B, "rollout_steps": T, "departure_window": args.congested_window}
+            rl, rd, secs = rooflines(cfg_c, NB, prof_c, T, full_first=False)
+            congested.update(rl)
+            cong_detail.update(rd)
+            pair = secs["k_fused_direction"] + secs["k_fused_rows"]
+            congested["msgpass_pair_edges_per_sec"] = (B * E) / pair if pair > 0 else None
+    del trainer, engine
+    torch.cuda.empty_cache()
 
-    # ---- third line of evidence: the state-dependent policy ---------------------------------------------------------------
-    # The per-edge MLP head (33 -> 64 -> 32 -> 1 on cat(x[src], x[dst], edge_attr); the reference keeps it as parameters,
-    # src/agents/mpnn_agent.py:35-41,227-231) reads the dynamic state, so NOTHING is hoisted: every frame builds the
-    # observation from the packed state, runs the MLP on the matrix cores (fp32 and bf16 variants), the segment softmax,
-    # the sample and the log-prob, then the four-launch simulation frame; the update runs the MLP forward / backward.
-    policy_lines = None
-    layout_tag, rollout_mode, n_roads = trainer.layout_tag, trainer.rollout, engine.N
-    if args.policy_envs > 0:
+    # ---- BASELINE config 5: 100k route edges, 262 144 agents ("HBM-bound scatter stress") --------------------------------------------
+    c5 = c5_detail = None
+    if args.config5_envs > 0 and world == 1 and not args.departure_window and (E, args.agents) == (10000, 16384):
         from tarl_hip import synth
-        from tarl_hip.engine import SimEngine
-        from tarl_hip.trainer import VecPPOTrainer
-        from src.agents.mpnn_agent import MPNNPolicyNet, MPNNValueNetSimple
-        Bp = args.policy_envs
-        del trainer, engine
+        B5, A5 = args.config5_envs, 262144
+        net5 = synth.torus_network(25, 250)
+        E5, N5 = net5.edge_index.size(1), net5.num_roads
+        t5 = time.perf_counter()
+        _, eng5, tr5 = build_trainer(args, rank, device, net5, agents=A5, envs=B5, window=0, seed_off=53)
+        tr5.train_iteration()
+        torch.cuda.synchronize()
+        setup5 = time.perf_counter() - t5
+        f5, el5, _, prof5 = time_iterations(tr5, args.config5_steps, L, T, prof, device)
+        c5 = {"value": f5 * world / el5, "ms_per_step": el5 / args.config5_steps * 1e3, "envs_per_gpu": B5,
+              "edges": E5, "agents": A5, "msgpass_edges_per_sec": f5 * world / el5 * E5}
+        c5_detail = dict(c5, unit="env-steps/s", roads=N5, steps=args.config5_steps, setup_seconds=setup5,
+                         rollout_kernels=tr5.rollout,
+                         workload="BASELINE config 5: mpnn+ppo train, 100 000-edge torus dual graph, 262 144 agents per environment")
+        if prof:
+            rl, rd, secs = rooflines({"edges": E5, "agents": A5, "envs": B5, "rollout_steps": T}, B5 * N5, prof5, T, full_first=False, want_req=False)
+            c5.update(rl)
+            c5_detail.update(rd)
+            pair = secs["k_fused_direction"] + secs["k_fused_rows"]
+            c5["msgpass_pair_edges_per_sec"] = (B5 * E5) / pair if pair > 0 else None
+            # picoseconds per (road, environment) pair of the Direction + row pass pair: config 4's figure beside it
+            c5["ps_per_pair"] = pair / (B5 * N5) * 1e12
+        del tr5, eng5
         torch.cuda.empty_cache()
-        pops = synth.population_batch(args.agents, net.num_roads, Bp, seed=args.seed + 1000 * rank + 31, device=device)
-        eng_p = SimEngine(net.x.to(device).unsqueeze(0).repeat(Bp, 1, 1).contiguous(), net.edge_index, net.edge_attr,
-                          net.Nmax, pops, congestion_constant=net.congestion_constant, device=device,
-                          seed=args.seed + rank)
-        policy_lines = {}
-        # "fp32": rollout logits at fp32 accuracy (the north star's 1e-4 contract) on the bf16 pipe — operands split into
-        # exact bf16 pieces, k_edge_mlp_fwd_x3; "fp32_mfma": the same contract on the fp32 matrix pipe (exact fp32 products,
-        # round 3's "fp32" line); "bf16": bf16 logits on bf16 observations (BASELINE config 5's "bf16 MPNN features")
-        for tag, prec in (("fp32", "x3"), ("fp32_mfma", "fp32"), ("bf16", "bf16")):
-            bf = prec == "bf16"
-            torch.manual_seed(args.seed)
-            pol = MPNNPolicyNet(net.edge_index, net.num_roads, None, device=str(device))
-            val = MPNNValueNetSimple(net.edge_index, net.num_roads, device=str(device))
-            l, mm = val.final_mlp, pol.edge_mlp
-            tr_p = VecPPOTrainer(eng_p, pol.nodes_embedding.weight,
-                                 [l[0].weight, l[0].bias, l[2].weight, l[2].bias, l[4].weight, l[4].bias],
-                                 rollout_steps=T, num_epochs=args.epochs, sub_batch_size=args.sub_batch,
-                                 extra_params=[p for n, p in pol.named_parameters() if not n.startswith("nodes_embedding")],
-                                 seed=args.seed, policy="edge_mlp", policy_precision=prec, temperature=args.policy_temperature,
-                                 edge_mlp_params=[mm[0].weight, mm[0].bias, mm[2].weight, mm[2].bias, mm[4].weight,
-                                                  mm[4].bias])
-            tr_p.train_iteration()
-            if not args.no_kernel_timing:
-                L.tarl_prof_enable(T)      # HIP events around the per-edge MLP launch of the first timed iteration's frames
-            dist_utils.barrier()
-            torch.cuda.synchronize()
-            t2_ = time.perf_counter()
-            pf = 0
-            for _ in range(args.policy_steps):
-                pf += tr_p.train_iteration()
-            torch.cuda.synchronize()
-            dist_utils.barrier()
-            pel = dist_utils.allreduce_max_float(time.perf_counter() - t2_, device)
-            p_all, p_late, p_nfr = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int64 * 2)()
-            lib.check(L.tarl_prof_collect(0, p_all, p_late, p_nfr))
-            L.tarl_prof_enable(0)
-            tr_p.check_flags()
-            mlp_s = p_all[0] / max(1, p_nfr[0]) * 1e-3
-            # MPNNPolicyNet.edge_mlp per edge: 2 * (33*64 + 64*32 + 32) flop (src/agents/mpnn_agent.py:35-41); the matrix
-            # cores are the bound of this kernel: dense MFMA peaks from MI355X_MICROARCH.md (bf16 2.5 PFLOP/s, fp32 157.3 TF)
-            flops = 2.0 * (33 * 64 + 64 * 32 + 32) * Bp * E
-            # x3: the kernel ISSUES six bf16 piece products per multiply-add of the head (hi hi, hi mid, mid hi, hi lo, mid mid,
-            # lo hi; the edge_attr / bias k-step once): achieved / frac are the HEAD's flops over the bf16 peak,
-            # issued_* the piece products the matrix cores actually execute
-            peak = MFMA_PEAK_TFLOPS["f32" if prec == "fp32" else "bf16"]
-            kname = {"x3": "k_edge_mlp_fwd_x3", "fp32": "k_edge_mlp_fwd_f32", "bf16": "k_edge_mlp_fwd_bf16"}[prec]
-            mlp_roof = ({"bound": "mfma", "kernel": kname + " (per-edge MLP 33->64->32->1)",
-                         "achieved": flops / mlp_s / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flops / mlp_s / 1e12 / peak,
-                         "traffic": None, "avg_launch_us": mlp_s * 1e6, "launches_timed": int(p_nfr[0]),
-                         "flop_per_launch": flops} if mlp_s > 0 else None)
-            if mlp_roof and prec == "x3":
-                issued = 2.0 * 32 * 32 * 16 * 50 * (Bp * E / 32.0)      # 50 MFMAs of 32x32x16 per 32 edges
-                mlp_roof["issued_tflops"] = issued / mlp_s / 1e12
-                mlp_roof["issued_frac"] = issued / mlp_s / 1e12 / peak
-            policy_lines[tag] = {"value": pf * world / pel, "unit": "env-steps/s", "envs_per_gpu": Bp, "roofline": mlp_roof,
-                                 "steps": args.policy_steps, "ms_per_step": pel / args.policy_steps * 1e3,
-                                 "edge_mlp_edges_per_sec": pf * world / pel * E,
-                                 "rollout_logits": {"bf16": "bf16 MFMA (v_mfma_f32_32x32x16_bf16) on bf16 observations",
-                                                    "fp32": "fp32 MFMA (v_mfma_f32_32x32x2_f32), exact fp32 products",
-                                                    "x3": "fp32-accurate on the bf16 pipe: operands in three exact bf16 "
-                                                          "pieces, six products per multiply-add (v_mfma_f32_32x32x16_bf16)"}[prec]}
-            del tr_p
-        policy_lines["note"] = ("policy_head=edge_mlp: per-frame observation + 33->64->32->1 MLP per edge + GraphDistribution "
-                                "softmax / sample / log_prob (no table hoist), then the simulation frame; "
-                                f"GraphDistribution temperature {args.policy_temperature:g}")
+        # the bf16 per-edge MLP head at this size ("bf16 MPNN features")
+        pl, pd = policy_lines(args, net5, rank, world, device, L, T, B5, (("bf16", "bf16"),), 1, seed_off=59, agents=A5)
+        c5["edge_mlp_bf16"] = pl["bf16"]
+        c5_detail["edge_mlp_bf16"] = pd["bf16"]
+
+    # ---- the state-dependent policy at config 4 -------------------------------------------------------------------------------------
+    pol = pol_detail = None
+    if args.policy_envs > 0:
+        # "fp32": rollout logits on the fp32 matrix pipe (exact fp32 products); "fp32_x3": the same 1e-4 contract on the bf16
+        # pipe — operands split into exact bf16 pieces, k_edge_mlp_fwd_x3 (the trainer's default for an fp32 policy);
+        # "bf16": bf16 logits on bf16 observations (BASELINE config 5's "bf16 MPNN features")
+        pol, pol_detail = policy_lines(args, net, rank, world, device, L, T, args.policy_envs,
+                                       (("fp32", "fp32"), ("fp32_x3", "x3"), ("bf16", "bf16")), args.policy_steps)
 
     if rank == 0:
-        total_frames = frames * world
-        value = total_frames / elapsed
-        NB = B * n_roads
-
-        def pmc_record(window):
-            """The committed PMC record of this workload, or None: the config must match AND the record must have been taken
-            on the very frame-kernel sources this run executes (sha256 of csrc/fused.hip + fused_common.h) — a kernel edit
-            without a fresh PMC pass falls back to the compulsory bytes instead of pairing new times with old bytes."""
-            from tarl_hip.ops import frame_kernel_source_hash
-            sha = frame_kernel_source_hash()
-            want = {"edges": E, "agents": args.agents, "envs": B, "rollout_steps": T}
-            if window:
-                want["departure_window"] = window
-            for path in PMC_RECORDS:
-                try:
-                    rec = json.load(open(os.path.join(ROOT, path)))
-                    if rec["config"] == want and rec.get("source_sha16") == sha:
-                        rec["path"] = path
-                        return rec
-                except (OSError, KeyError, ValueError):
-                    pass
-            return None
-
-        def roofline(pmc, ms_late_, ms_all_, nfr_, slot, kernel, what):
-            """achieved = HBM bytes per launch (PMC counters of this script's own rollout, frames >= LATE_FRAME, corrected
-            per kernel with the factors tools/pmc_cal.hip measured for its access shapes) / the live average launch
-            duration over the same frames; without a matching PMC record: the compulsory bytes."""
-            n_late, n_all = max(1, nfr_[1]), max(1, nfr_[0])
-            late_s, all_s = ms_late_[slot] / n_late * 1e-3, ms_all_[slot] / n_all * 1e-3
-            comp = COMPULSORY[kernel]["per_node_env"] * NB
-            k = pmc["kernels"].get(kernel) if pmc else None
-            traffic = k["hbm_bytes_per_launch"] if k else None
-            byts = traffic if traffic is not None else comp
-            achieved = byts / late_s / 1e9 if late_s > 0 else 0.0
-            out = {"bound": "hbm", "kernel": f"{kernel} ({what})", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                   "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                   "traffic_source": (f"{pmc['path']}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, "
-                                      f"mean over frames >= {LATE_FRAME}; bytes = {k.get('formula', '2*FETCH_SIZE + WRITE_SIZE')}"
-                                      ) if k else None,
-                   "bytes_basis": "pmc_counters" if traffic is not None else "compulsory",
-                   "avg_launch_us": late_s * 1e6, "frames_timed": int(nfr_[1]), "first_frame": late0,
-                   "avg_launch_us_all_frames": all_s * 1e6,
-                   "compulsory_bytes_per_launch": comp,
-                   "compulsory_frac": (comp / late_s / 1e9 / HBM_PEAK_GBS) if late_s > 0 else 0.0,
-                   "traffic_over_compulsory": (traffic / comp) if (traffic is not None and comp > 0) else None}
-            if traffic is not None:
-                # frac = traffic / time / peak moves with BOTH terms: round 3 cut the row pass's traffic (1 289 -> 889 MB) by
-                # more than its time (245 -> 205 us), so the fraction fell while the kernel got faster; compulsory_frac and
-                # traffic_over_compulsory separate the two
-                out["note"] = ("frac falls when re-reads are removed faster than time: compare avg_launch_us and "
-                               "traffic_over_compulsory across rounds, not frac alone")
-            if k and "raw_frac_bracket" in k:      # the same fraction with no correction / the guide's blanket 2x on FETCH_SIZE
-                out["frac_uncorrected_to_blanket_2x"] = [b_ / late_s / 1e9 / HBM_PEAK_GBS for b_ in k["raw_frac_bracket"]]
-            if kernel in SURVEY_8D:
-                pe, pn = SURVEY_8D[kernel]
-                out["survey_8d_bytes_per_launch"] = pe * B * E + pn * NB
-            return out, late_s
-
-        pmc = pmc_record(args.departure_window)
-        rf_rows, rows_s = roofline(pmc, ms_late, ms_all, nfr, 1, "k_fused_rows",
-                                   "DirectionMPNN.update + ResponseMPNN + withdraw; the dominant kernel")
-        rf_dir, dir_s = roofline(pmc, ms_late, ms_all, nfr, 0, "k_fused_direction",
-                                 "DirectionMPNN message + aggregate on the packed hot records")
-        rf_ic, _ = roofline(pmc, ms_late, ms_all, nfr, 2, "k_fused_insert",
-                            "insert_agent_into_network + reward; a latency chain, several environments per wave")
-        if congested is not None and not args.no_kernel_timing:
-            cp = pmc_record(args.congested_window)
-            congested["roofline"], c_rows_s = roofline(cp, c_late, c_all, c_nfr, 1, "k_fused_rows",
-                                                       "the dominant kernel of the loaded network: most rows move something")
-            congested["roofline_direction"], c_dir_s = roofline(cp, c_late, c_all, c_nfr, 0, "k_fused_direction",
-                                                                "DirectionMPNN message + aggregate")
-            congested["roofline_insert"], _ = roofline(cp, c_late, c_all, c_nfr, 2, "k_fused_insert", "insert + reward")
-            congested["msgpass_pair_edges_per_sec"] = (B * E) / (c_dir_s + c_rows_s) if (c_dir_s + c_rows_s) > 0 else None
-        out = {
+        value = frames * world / elapsed
+        rl, rd, secs = rooflines({"edges": E, "agents": args.agents, "envs": B, "rollout_steps": T,
+                                  **({"departure_window": args.departure_window} if args.departure_window else {})},
+                                 NB, prof_main, T)
+        pair = secs["k_fused_direction"] + secs["k_fused_rows"]
+        head = {
             "metric": "ppo_env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
-            "value_rollout_only": ro_frames * world / ro_elapsed if ro_elapsed > 0 else None,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"mpnn+ppo train, {E}-edge synthetic torus dual graph ({n_roads} roads), "
-                                   f"{args.agents} agents per environment, rollout-steps {T}, epochs {args.epochs}, "
-                                   f"sub-batch {args.sub_batch}" +
+            "config": {"workload": f"mpnn+ppo train, {E}-edge torus dual graph, {args.agents} agents, T={T}" +
                                    (" (BASELINE config 4)" if (E, args.agents) == (10000, 16384) else ""),
-                       "envs_per_gpu": B, "env_steps_per_step": B * T, "parallelism": f"dp{world} (rollouts sharded, "
-                       "one gradient all-reduce per optimiser step)", "rollout_kernels": rollout_mode},
-            "msgpass_edges_per_sec": value * E,
+                       "envs_per_gpu": B, "parallelism": f"dp{world}", "rollout_kernels": rollout_mode},
             # Direction + Response pair alone (SURVEY 8d's second metric): B*E edges per frame / the two kernels' live time
-            "msgpass_pair_edges_per_sec": (B * E) / (dir_s + rows_s) if (dir_s + rows_s) > 0 else None,
-            "roofline": rf_rows, "roofline_direction": rf_dir, "roofline_insert": rf_ic,
-            "setup_seconds": setup_s, "timed_seconds": elapsed,
+            "msgpass_pair_edges_per_sec": (B * E) / pair if pair > 0 else None,
+            "timed_seconds": elapsed,
             "per_rank": {"setup_seconds": [r_[0] for r_ in per_rank], "timed_seconds": [r_[1] for r_ in per_rank]},
             "world_size_seen_by_backend": dist_utils.world()[1], "dist_backend": dist_utils.backend_name(),
             "replica_param_max_abs_diff": replica_diff,
-            "congested_regime": congested,
-            "state_dependent_policy": policy_lines,
         }
+        out = dict(head, **rl)
+        out["config5"], out["update_path"], out["congested_regime"], out["state_dependent_policy"] = c5, upd, congested, pol
+        out["value_rollout_only"] = ro_frames * world / ro_elapsed if ro_elapsed > 0 else None
+        details = dict(head, **rd)
+        details.update(config5=c5_detail, update_path=upd_detail, congested_regime=cong_detail, state_dependent_policy=pol_detail,
+                       value_rollout_only=out["value_rollout_only"], layout=layout_tag,
+                       env_steps_per_step=B * T, msgpass_edges_per_sec=value * E, epochs=args.epochs, sub_batch=args.sub_batch,
+                       roads=n_roads, setup_seconds=setup_s,
+                       parallelism=f"dp{world}: rollouts sharded, one gradient all-reduce per optimiser step")
         if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(args, net)
-        print(json.dumps(out), flush=True)
+            cb = cpu_baseline(args, net)
+            details["cpu_baseline"] = cb
+            out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "value_rollout_only",
+                                                      "update_seconds", "all_cores")}
+        line = json.dumps(compact(out), separators=(",", ":"))
+        if args.details:
+            try:
+                path = os.path.join(ROOT, args.details)
+                os.makedirs(os.path.dirname(path), exist_ok=True)
+                with open(path, "w") as f:
+                    json.dump(details, f, indent=1)
+                print(f"bench.py: descriptive fields in {args.details}", file=sys.stderr)
+            except OSError as exc:
+                print(f"bench.py: could not write {args.details}: {exc}", file=sys.stderr)
+        else:
+            print(json.dumps(details), file=sys.stderr)
+        print(line, flush=True)
     dist_utils.barrier()
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TARL_ABI_VERSION 4
+#define TARL_ABI_VERSION 5
 
 typedef enum {
   TARL_OK = 0,
@@ -570,6 +570,19 @@ int tarl_msa_assign(const int64_t* next_hop, int64_t num_nodes, const int64_t* o
 int tarl_select_next_hop(float* x, int64_t B, int64_t x_bstride, int64_t ldx, int32_t Nmax, int64_t num_nodes,
                          const float* agent_features, int64_t num_agents, int64_t a_bstride, const int64_t* next_hop,
                          int64_t nh_bstride, tarl_stream stream);
+
+/* ---- the device noise, written out (test hook; nothing on the product path calls it) ---------------------------------------
+ * The rollouts draw their own randomness: per frame one Gumbel value per in-edge for DirectionMPNN.aggregate's race (the
+ * reference: torch.rand_like + -log(-log(u)), src/direction_mpnn.py:136-139) and one uniform per source node for
+ * GraphDistribution.sample (src/reinforcement_learning.py:66) — Philox4x32-10 streams keyed by (seed, counter of the frame)
+ * and indexed by the environment's GLOBAL id (tarl_fused.env_base + b). tarl_noise_export evaluates the same device
+ * functions for the listed environments: kind 0 -> out [num_envs][E] fp32 Gumbel values in ORIGINAL edge order (the layout
+ * of the `gumbel` argument of tarl_direction_step / tarl_fused_frame), for frame t of a rollout seed = its `seed`, counter =
+ * its `counter0 + t`; kind 1 -> out [num_envs][G] uniforms of the action draw (seed = `policy_seed`, counter =
+ * `policy_counter0 + t`; G = nodes with out-edges, in node order). env_ids: int64 [num_envs] global environment ids
+ * (device). A CPU checker fed these values replays a device rollout bit for bit (tests/test_gpu_bench_geometry.py). */
+int tarl_noise_export(const tarl_plan* plan, int kind, uint64_t seed, uint64_t counter, const int64_t* env_ids,
+                      int64_t num_envs, float* out, tarl_stream stream);
 
 /* ---- measurement hook (bench.py roofline leg; nothing comparable in the reference) ------------------------------------
  * tarl_prof_enable(n > 0) brackets the frame kernels of the next n fused frames (Direction message+aggregate, the row

@@ -814,8 +814,10 @@ extern "C" int tarl_critic_mlp_fwd_slabs_u8(const uint8_t* counts, int64_t rows_
   // environments per workgroup: 256 when the slab divides and the launch still fills the chip several times over, else 128.
   // Measured at 16 384 environments x 257 frames x 2 500 nodes (10.5 GB of count bytes; tools/time_phases.py, whole GAE pass):
   // 5.76 ms with 128, 4.82 ms with 256, 5.22 ms with 512 (368 registers: one workgroup per CU left).
-  // (TARL_CRITIC_CT = 1 | 2 | 4: developer / test override, read at every call)
-  const int ct_env = getenv("TARL_CRITIC_CT") ? atoi(getenv("TARL_CRITIC_CT")) : 0;
+  // (TARL_CRITIC_CT = 1 | 2 | 4: test override, read per call on purpose — tests/test_gpu_fused.py compares the tile widths
+  // inside one process; one getenv per GAE pass, i.e. per ~5 ms kernel, is not a cost)
+  const char* ct_knob = getenv("TARL_CRITIC_CT");
+  const int ct_env = ct_knob ? atoi(ct_knob) : 0;
   int ct = 1;
   if (rows_per_slab % (2 * CR_BM) == 0 && M / (2 * CR_BM) >= 1024) ct = 2;
   if ((ct_env == 1 || ct_env == 2 || ct_env == 4) && rows_per_slab % (ct_env * CR_BM) == 0) ct = ct_env;

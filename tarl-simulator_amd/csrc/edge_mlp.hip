@@ -558,9 +558,14 @@ __global__ __launch_bounds__(EMR_WAVES * 64) void k_edge_mlp_fwd_bf16(const int3
 // An fp32 number is the exact sum of three bf16 numbers (8 + 8 + 8 significand bits: hi = bf16(v), mid = bf16(v - hi),
 // lo = bf16(v - hi - mid), every subtraction exact), and the product of two bf16 numbers is exact in fp32. Inputs, weights
 // AND the first hidden activation are split; of the nine piece products of x * w the six of order >= 2^-16 are
-// accumulated (hi hi, hi mid, mid hi, hi lo, mid mid, lo hi) and the three of order <= 2^-24 — below the rounding of the
-// fp32 accumulation itself — dropped: the logits equal the fp32 chain's to a few ulp of the accumulated magnitude
-// (contract: 1e-4 of the logits' scale, tests/test_gpu_edge_mlp.py), at 6 bf16 MFMAs of 8 passes per 16 k where the fp32
+// accumulated (hi hi, hi mid, mid hi, hi lo, mid mid, lo hi) and three dropped: mid lo, lo mid and lo lo. With pieces
+// taken by TRUNCATION |mid| < 2^-7 |v| and |lo| < 2^-14 |v| (not 2^-8 / 2^-16 as for round-to-nearest pieces), so a dropped
+// product is up to 2^-21 |w| |x| — a few times the 2^-24 rounding of one fp32 product, NOT below it: per multiply-add the
+// kernel carries up to ~2^-20 |w| |x| of truncation error (all of one sign per operand pair; it does not average out
+// like rounding), i.e. over the 33 + 64 terms of the head <= 1e-4 of sum |w| |x|. The contract — 1e-4 of the logits' scale
+// — therefore holds with a margin of ~100 on benign inputs and ~1 in the worst case of cancellation (large |w| |x| terms
+// of mixed sign summing to a small logit): tests/test_gpu_edge_mlp.py holds the kernel to 1e-4 of sum |w| |x| on exactly
+// such inputs (clock-time columns ~2e4 with mixed-sign weights) against an fp64 evaluation, at 6 bf16 MFMAs of 8 passes per 16 k where the fp32
 // MFMA needs 8 of 16 passes: 2.7x the matrix rate. Layout exactly as k_edge_mlp_fwd_f32 / _bf16: weights as A operands
 // in registers for the wave's life, edges as columns, layer 2 walking the hidden units in accumulator order.
 //   layer 1, k-steps of 16: [x_src 0..15] [x_dst 0..15], 6 MFMAs each per 32-row tile, then ONE k-step per tile for

@@ -2065,6 +2065,12 @@ static int launch_direction(dim3 grid, unsigned threads, hipStream_t s, const ta
     }                                                                                                                      \
   } while (0)
   const bool o32 = addr32_ok() && plan->N * B < ((int64_t)1 << 29);   // 8-byte words through 32-bit byte offsets (at32)
+  // gc8 invariant (fused_common.h: head_arrival): a rollout stores the event byte in its LAST frame only (FrameOut::write_gc) —
+  // and every frame for the metric environments, whose dtt_node reads it — while the tail word says "gc8 authoritative"
+  // (TLF_AUTH) after every event. The per-edge delta_travel_time reads gc8 of EVERY environment: it may only be requested
+  // by a caller whose frames all store the byte (the frame API does), and the per-node series only for metric environments.
+  TARL_REQUIRE(dtt == nullptr || out.write_gc != 0,
+               "per-edge delta_travel_time needs the event byte of every frame (FrameOut::write_gc): not available inside a rollout");
   // TARL_DIR_SIBLINGS=0 keeps the per-row gathers on a sibling graph (developer knob)
   static const bool sib_ok = !(getenv("TARL_DIR_SIBLINGS") && atoi(getenv("TARL_DIR_SIBLINGS")) == 0);
   // TARL_DIR_COUNT_BYTE=0 keeps the head words as the count's source (developer knob)

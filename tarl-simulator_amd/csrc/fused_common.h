@@ -203,6 +203,9 @@ __device__ __forceinline__ int phys(int hoff, int s, int Nmax) {
 // Arrival time of the row's head slot (the reference's x[i, Nmax + 0]; read by delta_travel_time only) from the packed
 // state: the head's slot record while the row holds somebody; the head slot of an EMPTY row is the pending garbage triple
 // (arrival = the last frame's clock t_last), a dead slot of a clean row (zero), or whatever the store holds (dirty rows).
+// INVARIANT: gc8 must have been stored by the frame that set TLF_AUTH on the row. Inside a rollout that holds for the last
+// frame and for the metric environments only (FrameOut::write_gc): in-call readers are restricted to those environments
+// (dtt_node, b < m_env), and launch_direction refuses the per-edge dtt of a frame whose predecessor did not store the byte.
 __device__ __forceinline__ float head_arrival(const float* __restrict__ slots, int64_t lds, const uint8_t* __restrict__ gc8,
                                               int64_t row, uint32_t hd, uint32_t tlw, int Nmax, float t_last) {
   if ((hd & HD_CNT) == 0u) {

@@ -32,10 +32,11 @@ OPTIONS = (
     ("--torch-compile", dict(action="store_true", help="accepted and ignored: the kernels are hand-written HIP")),
     ("--steps", dict(type=int, default=None, help="number of eval steps (overrides start/end time)")),
     ("--num-envs", dict(type=int, default=1, help="vectorised environments per GPU for mpnn+ppo training")),
-    ("--policy-head", dict(choices=("embedding", "edge_mlp", "edge_mlp_bf16"), default="embedding",
+    ("--policy-head", dict(choices=("embedding", "edge_mlp", "edge_mlp_fp32", "edge_mlp_bf16"), default="embedding",
                            help="mpnn / mpnn+ppo: the reference's live embedding head, or the per-edge MLP head it keeps "
                                 "as parameters (state-dependent; edge_mlp: rollout logits at fp32 accuracy on the bf16 matrix "
-                                "pipe — operands in exact bf16 pieces —, edge_mlp_bf16: bf16 logits; the PPO update runs in fp32)")),
+                                "pipe — operands in exact bf16 pieces —, edge_mlp_fp32: on the fp32 matrix pipe, exact fp32 "
+                                "products, edge_mlp_bf16: bf16 logits; the PPO update runs in fp32)")),
 )
 
 

@@ -52,8 +52,10 @@ class _EdgeMlp(torch.autograd.Function):
 class MPNNPolicyNet(MessagePassingBase, Agents):
     h = ObservationFeatureHelpers()
     # Which head produces the logits. "embedding": the reference's live forward (logit = nodes_embedding of the target
-    # road, src/agents/mpnn_agent.py:215-217). "edge_mlp" / "edge_mlp_bf16": the per-edge MLP the reference keeps as
-    # parameters and spells out in its commented lines (:227-231), on fp32 / bf16 MFMA — a state-dependent policy.
+    # road, src/agents/mpnn_agent.py:215-217). "edge_mlp" / "edge_mlp_fp32" / "edge_mlp_bf16": the per-edge MLP the reference
+    # keeps as parameters and spells out in its commented lines (:227-231), on fp32 / bf16 MFMA — a state-dependent policy
+    # (this module's forward runs the fp32 MFMA kernel for the first two; the names differ in the ROLLOUT kernel the trainer
+    # picks: fp32 accuracy on the bf16 pipe / exact fp32 products / bf16).
     policy_head = "embedding"
 
     def __init__(self, edge_index, num_nodes, free_flow_time_travel, device):

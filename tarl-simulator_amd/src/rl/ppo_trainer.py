@@ -96,7 +96,7 @@ def ppo_train(env, policy_module, value_module, *, total_frames=128, frames_per_
                             extra_params=dormant, seed=seed,
                             policy="embedding" if head == "embedding" else "edge_mlp",
                             edge_mlp_params=[m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias],
-                            policy_bf16=head == "edge_mlp_bf16")
+                            policy_precision={"edge_mlp_bf16": "bf16", "edge_mlp_fp32": "fp32"}.get(head, "x3"))
     log = writer = None
     if log_dir is not None and rank == 0:      # rank 0 alone writes
         os.makedirs(log_dir, exist_ok=True)

@@ -94,6 +94,7 @@ SIGNATURES = {
     "tarl_apsp_f64": (C.c_int, [_p, _p, _i64, _i64, _p, _i64, _p, _p, _p]),
     "tarl_msa_assign": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _p, _p, _p]),
     "tarl_select_next_hop": (C.c_int, _STATE + [_i64, _p, _i64, _i64, _p, _i64, _p]),
+    "tarl_noise_export": (C.c_int, [_p, C.c_int, _u64, _u64, _p, _i64, _p, _p]),
     "tarl_prof_enable": (C.c_int, [_i64]),
     "tarl_prof_collect": (C.c_int, [_i64, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_i64)]),
 }

@@ -1067,6 +1067,20 @@ def value_mpnn_backward(plan: Plan, node_features, agent_rows, edge_features, ti
     return grads
 
 
+def noise_export(plan: Plan, kind: str, seed: int, counter: int, env_ids):
+    """The device noise of the Philox path for the listed GLOBAL environment ids (tarl_noise_export; test hook):
+    ``kind="gumbel"`` -> (n, E) fp32 Gumbel values of DirectionMPNN.aggregate's race in ORIGINAL edge order (seed = the
+    engine's ``seed``, counter = the frame's noise counter); ``kind="uniform"`` -> (n, G) uniforms of the action draw."""
+    L = _lib.load()
+    env = torch.as_tensor(env_ids, dtype=torch.int64).to(plan.device).contiguous()
+    n = env.numel()
+    width = plan.num_edges if kind == "gumbel" else plan.num_groups
+    out = torch.empty((n, width), dtype=torch.float32, device=plan.device)
+    _lib.check(L.tarl_noise_export(plan.handle, {"gumbel": 0, "uniform": 1}[kind], int(seed), int(counter), env.data_ptr(),
+                                   n, out.data_ptr(), _lib.current_stream()))
+    return out
+
+
 def rollout_env_supported(plan: Plan) -> bool:
     return bool(_lib.load().tarl_rollout_env_supported(plan.handle))
 

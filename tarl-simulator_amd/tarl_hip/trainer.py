@@ -19,6 +19,46 @@ from . import dist_utils, ops
 from .flatparams import FlatParams
 
 
+class StageTimer:
+    """HIP-event timing of the update's stages (``bench.py``'s ``update_path`` object): a pair of events on the launch
+    stream (torch's current stream — the stream every ``ops`` call enqueues on) around each stage; ``ms()`` synchronises
+    and returns {stage: (summed ms, calls)}."""
+
+    def __init__(self):
+        self.ev = {}
+
+    class _Span:
+        def __init__(self, timer, name):
+            self.t, self.name = timer, name
+
+        def __enter__(self):
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+        def __exit__(self, *exc):
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            self.t.ev.setdefault(self.name, []).append((self.a, b))
+
+    def __call__(self, name):
+        return StageTimer._Span(self, name)
+
+    def ms(self):
+        torch.cuda.synchronize()
+        return {k: (sum(a.elapsed_time(b) for a, b in v), len(v)) for k, v in self.ev.items()}
+
+
+class NoStageTimer:
+    def __call__(self, name):
+        return self
+
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
 class VecPPOTrainer:
     def __init__(self, engine, emb_param, critic_params, *, rollout_steps, num_epochs=1, sub_batch_size=32, lr=1e-3,
                  gamma=0.99, lmbda=0.95, clip_epsilon=0.2, entropy_coef=0.01, critic_coef=1.0, temperature=1.0,
@@ -125,6 +165,7 @@ class VecPPOTrainer:
         self.done_frames = torch.zeros(self.T, dtype=torch.bool)
         self.done_mask = None
         self.obs_idx = None
+        self.stage = NoStageTimer()          # bench.py swaps in a StageTimer for its update_path object
 
     # -- views of the live parameters -----------------------------------------------------------------------------------
     def _emb(self):
@@ -159,8 +200,8 @@ class VecPPOTrainer:
         flat = torch.cat(host)      # (the frame list stays on the host: no device round trip before the rollout)
         order = torch.argsort(flat, stable=True)
         t_sorted = torch.div(flat[order], B, rounding_mode="floor").tolist()
-        keep_env = (flat[order] % B).to(torch.int32).to(eng.device)
-        keep_slot = order.to(torch.int32).to(eng.device)
+        keep_env = (flat[order] % B).to(torch.int32).pin_memory().to(eng.device, non_blocking=True)
+        keep_slot = order.to(torch.int32).pin_memory().to(eng.device, non_blocking=True)
         self.obs_mb = torch.empty((flat.numel(), N, 16), dtype=torch.float32, device=eng.device)
         w = self._edge_mlp()
         pseed = self.seed ^ 0x5DEECE66D
@@ -305,23 +346,25 @@ class VecPPOTrainer:
         eng = self.eng
         T, B, N = self.T, eng.B, eng.N
         cw = self._critic()
-        if self.env_minor and B % 128 == 0:
-            v = ops.critic_forward_slabs(cw, self.counts, self.times)           # reads [frame][node][env] bytes as is
-        elif self.env_minor and self.counts.dtype == torch.uint8:    # odd batch sizes: the count bytes as fp32 rows first
-            _, rows = ops.rollout_gather(eng.plan, T + 1, B, True, counts=self.counts)
-            v, _, _ = ops.critic_forward(cw, rows, self.times, rows_per_time=B)
-        elif self.env_minor:
-            rows = self.counts.permute(0, 2, 1).contiguous().view((T + 1) * B, N)
-            v, _, _ = ops.critic_forward(cw, rows, self.times, rows_per_time=B)
-        else:
-            v, _, _ = ops.critic_forward(cw, self.counts.view((T + 1) * B, N), self.times, rows_per_time=B)
+        with self.stage("critic_all_frames"):
+            if self.env_minor and B % 128 == 0:
+                v = ops.critic_forward_slabs(cw, self.counts, self.times)           # reads [frame][node][env] bytes as is
+            elif self.env_minor and self.counts.dtype == torch.uint8:    # odd batch sizes: the count bytes as fp32 rows first
+                _, rows = ops.rollout_gather(eng.plan, T + 1, B, True, counts=self.counts)
+                v, _, _ = ops.critic_forward(cw, rows, self.times, rows_per_time=B)
+            elif self.env_minor:
+                rows = self.counts.permute(0, 2, 1).contiguous().view((T + 1) * B, N)
+                v, _, _ = ops.critic_forward(cw, rows, self.times, rows_per_time=B)
+            else:
+                v, _, _ = ops.critic_forward(cw, self.counts.view((T + 1) * B, N), self.times, rows_per_time=B)
         self.values = v.view(T + 1, B)
         # done = terminated (src/reinforcement_learning.py:296): no bootstrap across an episode end
-        adv, target = ops.gae(self.reward, self.values[:T], self.values[1:], done=self.done_mask,
-                              terminated=self.done_mask, gamma=self.gamma, lmbda=self.lmbda)
-        stats = ops.advantage_stats(adv)
-        dist_utils.allreduce_sum_(stats)          # global mean / std over all ranks' frames
-        ops.advantage_normalize_(adv, stats)
+        with self.stage("gae"):
+            adv, target = ops.gae(self.reward, self.values[:T], self.values[1:], done=self.done_mask,
+                                  terminated=self.done_mask, gamma=self.gamma, lmbda=self.lmbda)
+            stats = ops.advantage_stats(adv)
+            dist_utils.allreduce_sum_(stats)          # global mean / std over all ranks' frames
+            ops.advantage_normalize_(adv, stats)
         return adv, target
 
     def minibatch_step(self, adv, target, idx=None):
@@ -341,56 +384,67 @@ class VecPPOTrainer:
         else:
             idx = idx.to(eng.device)
             M = idx.numel()
-        if self.policy == "edge_mlp":
-            _, counts_mb = ops.rollout_gather(eng.plan, T, B, True, idx, counts=self.counts[:T])     # env-minor bytes
-            choice_mb, _ = ops.rollout_gather(eng.plan, T, B, False, idx, choice=self.choice)        # env-major bytes
-        elif self.rollout == "unfused":
-            counts_mb = self.counts[:T].view(T * B, N).index_select(0, idx)
-            choice_mb = self.choice.view(T * B, N).index_select(0, idx)
-        else:   # one launch: the sampled frames' action bytes -> edge ids, count bytes -> fp32 rows
-            choice_mb, counts_mb = ops.rollout_gather(eng.plan, T, B, self.env_minor, idx, choice=self.choice,
-                                                      counts=self.counts[:T])
-        nf = eng.static_node_features[:1].expand(M, N, 7)
-        if eng.fs is not None and self.lazy_log_prob:   # behaviour log-prob of the sampled frames, rollout-time parameters
-            p_old = ops.graphdist_softmax(eng.plan, ops.policy_edge_logits(eng.plan, nf, self.emb_rollout),
-                                          self.temperature)
-            lp_old, _ = ops.graphdist_logprob_entropy(eng.plan, p_old, choice=choice_mb, want_entropy=False)
-        else:
-            lp_old = self.logp.view(-1).index_select(0, idx)
-        adv_mb = adv.view(-1).index_select(0, idx)
-        tgt_mb = target.view(-1).index_select(0, idx)
-        time_mb = self.times[:T].index_select(0, torch.div(idx, B, rounding_mode="floor"))
+        st = self.stage
+        with st("minibatch_gather"):
+            if self.policy == "edge_mlp":
+                _, counts_mb = ops.rollout_gather(eng.plan, T, B, True, idx, counts=self.counts[:T])     # env-minor bytes
+                choice_mb, _ = ops.rollout_gather(eng.plan, T, B, False, idx, choice=self.choice)        # env-major bytes
+            elif self.rollout == "unfused":
+                counts_mb = self.counts[:T].view(T * B, N).index_select(0, idx)
+                choice_mb = self.choice.view(T * B, N).index_select(0, idx)
+            else:   # one launch: the sampled frames' action bytes -> edge ids, count bytes -> fp32 rows
+                choice_mb, counts_mb = ops.rollout_gather(eng.plan, T, B, self.env_minor, idx, choice=self.choice,
+                                                          counts=self.counts[:T])
+            nf = eng.static_node_features[:1].expand(M, N, 7)
+            if eng.fs is not None and self.lazy_log_prob:   # behaviour log-prob of the sampled frames, rollout-time parameters
+                p_old = ops.graphdist_softmax(eng.plan, ops.policy_edge_logits(eng.plan, nf, self.emb_rollout),
+                                              self.temperature)
+                lp_old, _ = ops.graphdist_logprob_entropy(eng.plan, p_old, choice=choice_mb, want_entropy=False)
+            else:
+                lp_old = self.logp.view(-1).index_select(0, idx)
+            adv_mb = adv.view(-1).index_select(0, idx)
+            tgt_mb = target.view(-1).index_select(0, idx)
+            time_mb = self.times[:T].index_select(0, torch.div(idx, B, rounding_mode="floor"))
         # actor forward (the live policy reads only the static ROAD_INDEX column: broadcast one observation over M rows)
-        if self.policy == "edge_mlp":
-            wmlp = self._edge_mlp()
-            logits = ops.policy_edge_mlp(eng.plan, obs_mb, eng.ec, wmlp)          # fp32 MFMA
-        else:
-            logits = ops.policy_edge_logits(eng.plan, nf, self._emb())
-        proba = ops.graphdist_softmax(eng.plan, logits, self.temperature)
-        lp_new, ent = ops.graphdist_logprob_entropy(eng.plan, proba, choice=choice_mb)
+        with st("actor_logits_fwd"):
+            if self.policy == "edge_mlp":
+                wmlp = self._edge_mlp()
+                logits = ops.policy_edge_mlp(eng.plan, obs_mb, eng.ec, wmlp)          # fp32 MFMA
+            else:
+                logits = ops.policy_edge_logits(eng.plan, nf, self._emb())
+        with st("graphdist_fwd"):
+            proba = ops.graphdist_softmax(eng.plan, logits, self.temperature)
+            lp_new, ent = ops.graphdist_logprob_entropy(eng.plan, proba, choice=choice_mb)
         cw = self._critic()
-        value, h1, h2 = ops.critic_forward(cw, counts_mb, time_mb, 1, keep_hidden=True, split_k=M <= 512)
+        with st("critic_fwd"):
+            value, h1, h2 = ops.critic_forward(cw, counts_mb, time_mb, 1, keep_hidden=True, split_k=M <= 512)
         scale = 1.0 / self.world
-        out, g_lp, g_ent, g_val = ops.ppo_loss(lp_new, lp_old, adv_mb, value, tgt_mb, ent,
-                                               clip_epsilon=self.clip_epsilon, entropy_coef=self.entropy_coef,
-                                               critic_coef=self.critic_coef, grad_scale=scale)
+        with st("ppo_loss"):
+            out, g_lp, g_ent, g_val = ops.ppo_loss(lp_new, lp_old, adv_mb, value, tgt_mb, ent,
+                                                   clip_epsilon=self.clip_epsilon, entropy_coef=self.entropy_coef,
+                                                   critic_coef=self.critic_coef, grad_scale=scale)
         # backward
         self.flat.zero_grad()
-        g_logits = ops.graphdist_logprob_entropy_bwd(eng.plan, proba, self.temperature, choice=choice_mb,
-                                                     grad_log_prob=g_lp, grad_entropy=g_ent, log_prob_fwd=lp_new)
-        if self.policy == "edge_mlp":
-            gm = [self.flat.grad_view(p) for p in self.edge_mlp_params]
-            ops.policy_edge_mlp_bwd(eng.plan, obs_mb, eng.ec, wmlp, g_logits,
-                                    (gm[0], gm[1], gm[2], gm[3], gm[4].view(-1), gm[5]))
-        else:
-            g_emb = ops.policy_edge_logits_bwd(eng.plan, nf, g_logits, self.emb_param.numel())
-            self.flat.grad_view(self.emb_param).add_(g_emb.view_as(self.emb_param))
+        with st("graphdist_bwd"):
+            g_logits = ops.graphdist_logprob_entropy_bwd(eng.plan, proba, self.temperature, choice=choice_mb,
+                                                         grad_log_prob=g_lp, grad_entropy=g_ent, log_prob_fwd=lp_new)
+        with st("actor_logits_bwd"):
+            if self.policy == "edge_mlp":
+                gm = [self.flat.grad_view(p) for p in self.edge_mlp_params]
+                ops.policy_edge_mlp_bwd(eng.plan, obs_mb, eng.ec, wmlp, g_logits,
+                                        (gm[0], gm[1], gm[2], gm[3], gm[4].view(-1), gm[5]))
+            else:
+                g_emb = ops.policy_edge_logits_bwd(eng.plan, nf, g_logits, self.emb_param.numel())
+                self.flat.grad_view(self.emb_param).add_(g_emb.view_as(self.emb_param))
         gw = [self.flat.grad_view(p) for p in self.critic_params]
-        ops.critic_backward(cw, counts_mb, time_mb, 1, h1, h2, g_val,
-                            (gw[0], gw[1], gw[2], gw[3], gw[4].view(-1), gw[5]))
-        self.flat.allreduce_grads()               # ONE all-reduce of the fused gradient buffer (RCCL over xGMI)
+        with st("critic_bwd"):
+            ops.critic_backward(cw, counts_mb, time_mb, 1, h1, h2, g_val,
+                                (gw[0], gw[1], gw[2], gw[3], gw[4].view(-1), gw[5]))
+        with st("grad_allreduce"):
+            self.flat.allreduce_grads()               # ONE all-reduce of the fused gradient buffer (RCCL over xGMI)
         self.last_grad = self.flat.grad.clone() if getattr(self, "keep_grad", False) else None
-        self.flat.adam_step(lr=self.lr)
+        with st("adam"):
+            self.flat.adam_step(lr=self.lr)
         return out
 
     def update(self):

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     # the ctypes table binds exactly the declared entry points
     assert sorted(lib.SIGNATURES) == names
     L = lib.load()
-    assert L.tarl_abi_version() == 4
+    assert L.tarl_abi_version() == 5
 
 
 def test_plan_create_rejects_bad_input_without_gpu_compute():

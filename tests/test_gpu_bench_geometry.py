@@ -148,6 +148,88 @@ def test_config4_loaded_network_at_the_bench_batch_size_is_batch_independent():
         assert torch.equal(solo.x[0], xb[k]) and torch.equal(solo.agents[0], agb[k]), f"final state of environment {b}"
 
 
+def test_bench_rollout_replayed_by_the_oracle_with_the_device_noise():
+    """The path the bench times — ``tarl_fused_rollout`` with DEVICE noise (Philox Gumbel races, Philox action draws) at
+    config 4, B = 16 384, every agent departing within 600 s (the loaded network: event rows, in-place fall-back, the
+    two-environments-per-wave insert) — next to the ORACLE: for environments {0, 8 191, 16 383} the Gumbel values the
+    kernels consumed are written out by ``tarl_noise_export`` (the same ``philox_uniform`` + ``gumbel_from_u01`` device
+    functions) and ``oracle/sim.env_step`` replays all 192 frames from the reset state with those values and the device's
+    action bytes: per-node counts, reward and the leg histogram of EVERY frame, the final ``x`` (FIFO slots, clocks,
+    SELECTED_ROAD) and the agent table must be bit-exact; the stored log-probs within 1e-4 of
+    ``oracle/dist.GraphDist.log_prob``. The actions themselves are the device's (GPU ``expf`` against CPU ``exp`` can move
+    a threshold by an ulp: a flip in ~1e-7 of the draws); they are ALSO compared with ``GraphDist.sample`` fed the device's
+    uniforms, allowing two differing nodes (four one-hot entries) in the 1 440 000 draws. Reference: src/reinforcement_learning.py:62-92,222-309,
+    src/direction_mpnn.py:103-146,171-196, src/response_mpnn.py:66-127, src/agents/base.py:244-403."""
+    from oracle import dist, nets, sim
+    from tarl_hip import ops, synth
+    from tarl_hip.engine import EPISODE_START, SimEngine
+    B, A, T = 16384, 16384, 192
+    probe = [0, 8191, 16383]
+    net = synth.torus_network(25, 25)
+    N, E, Nmax = net.num_roads, net.edge_index.size(1), net.Nmax
+    pops = synth.population_batch(A, N, B, seed=9, device="cuda", t1=EPISODE_START + 600)
+    emb = torch.randn(N, generator=torch.Generator().manual_seed(4))
+    eng = SimEngine(net.x.cuda().unsqueeze(0).repeat(B, 1, 1).contiguous(), net.edge_index, net.edge_attr, Nmax,
+                    pops.clone(), congestion_constant=net.congestion_constant, seed=13)
+    eng.reset()
+    eng.prepare_policy(emb.cuda())
+    noise0, policy0 = eng.noise_counter + 1, eng.sample_counter + 1       # counters of the rollout's frame 0
+    ch, ct, lp, rw, leg = _rollout(eng, T)
+    eng.check_flags()
+    assert float(-rw[-1].mean()) > 2000 and float((ct[-1] != ct[-2]).float().mean()) > 0.05      # loaded, and moving
+    pidx = torch.tensor(probe, device="cuda")
+    ch_p, ct_p = ch[:, :, pidx].cpu(), ct[:, :, pidx].cpu()                 # (T, N, 3), (T + 1, N, 3)
+    lp_p, rw_p, leg_p = lp[:, pidx].cpu(), rw[:, pidx].cpu(), leg[:, pidx].cpu()
+    x_fin = torch.stack([eng.x[b] for b in probe]).cpu()
+    ag_fin = torch.stack([eng.agents[b] for b in probe]).cpu()
+    # CSR of the plan on the host: rank r of node i names edge out_eid[out_ptr[i] + r] (stable order of edge_index[0])
+    src = net.edge_index[0]
+    out_eid = torch.argsort(src, stable=True)
+    out_ptr = torch.zeros(N + 1, dtype=torch.long)
+    out_ptr[1:] = torch.cumsum(torch.bincount(src, minlength=N), 0)
+    adj = net.dense_adjacency()
+    c = sim.Cols(Nmax)
+    nf0 = net.x[:, 3 * Nmax:]
+    gd = dist.GraphDist(nets.policy_logits(nf0, net.edge_index, emb), net.edge_index)
+    assert gd.nb_nodes == N
+    flips = n_pops = arrivals = 0
+    for k, b in enumerate(probe):
+        x = net.x.clone()
+        x[:, :3 * Nmax] = 0
+        x[:, c.N] = 0
+        ag = pops[b].cpu().clone()
+        ag[:, sim.ON_WAY] = 0
+        ag[:, sim.DONE] = 0
+        for t in range(T):
+            clock = float(EPISODE_START + t)
+            g = ops.noise_export(eng.plan, "gumbel", eng.seed, noise0 + t, [b])[0].cpu()
+            u = ops.noise_export(eng.plan, "uniform", eng.seed ^ 0x5DEECE66D, policy0 + t, [b])[0].cpu()
+            code = ch_p[t, :, k].long()
+            drew = (code & 0x80) == 0
+            action = torch.zeros(E, dtype=torch.long)
+            action[out_eid[out_ptr[:-1][drew] + code[drew]]] = 1
+            flips += int((gd.sample(u) != action).sum())      # a node that draws another edge differs in two entries
+            lp_o = gd.log_prob(action)
+            if bool(drew.all()):
+                assert abs(float(lp_p[t, k]) - float(lp_o)) <= TOL * max(1.0, abs(float(lp_o))), (b, t, float(lp_p[t, k]), float(lp_o))
+            else:
+                assert float(lp_p[t, k]) == float("-inf") and float(lp_o) == float("-inf")
+            before = ((ag[:, sim.ON_WAY] + ag[:, sim.DONE]) > 0).sum(), (ag[:, sim.DONE] > 0).sum()
+            out = sim.env_step(x, ag, net.edge_index, net.edge_attr, adj, action, clock, Nmax, gumbel=g,
+                               congestion_constant=net.congestion_constant)
+            n_pops += int(out["popped"].sum())
+            assert torch.equal(x[:, c.N], ct_p[t + 1, :, k].float()), f"counts of environment {b} after frame {t}"
+            assert float(out["reward"]) == float(rw_p[t, k]), f"reward of environment {b}, frame {t}"
+            after = ((ag[:, sim.ON_WAY] + ag[:, sim.DONE]) > 0).sum(), (ag[:, sim.DONE] > 0).sum()
+            assert [int(after[0] - before[0]), int(after[1] - before[1])] == leg_p[t, k].tolist(), f"leg histogram, environment {b}, frame {t}"
+        assert torch.equal(x, x_fin[k]), f"final state of environment {b}"
+        assert torch.equal(ag, ag_fin[k]), f"agent table of environment {b}"
+        arrivals += int(ag[:, sim.DONE].sum())
+    # the replay exercised the whole event path: Response pops (agents moving from road to road) and withdrawals (arrivals)
+    assert n_pops > 1000 and arrivals > 0, (n_pops, arrivals)
+    assert flips <= 4, f"{flips} one-hot entries differ between the device draw and GraphDist.sample on the device's uniforms"
+
+
 def test_two_half_batches_reproduce_the_whole_batch():
     """What two data-parallel ranks simulate (each its half of the environments, env_base = rank * B / 2, one seed) is
     bit-identical to one rank simulating all of them."""

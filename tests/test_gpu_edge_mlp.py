@@ -410,3 +410,58 @@ def test_set_actions_turns_env_major_bytes_into_the_selected_road_column(W, H, B
     dst_by_rank = net.edge_index[1][src_sorted].view(N, 4).cuda()           # a torus: four out-edges per road
     assert torch.equal(sel, torch.gather(dst_by_rank.unsqueeze(0).expand(B, N, 4), 2,
                                          (want & 0x7F).long().unsqueeze(2)).squeeze(2).float())
+
+
+def test_bf16x3_forward_on_cancellation_heavy_inputs():
+    """k_edge_mlp_fwd_x3 takes its bf16 pieces by TRUNCATION and drops the mid*lo, lo*mid and lo*lo products: per multiply-add
+    up to ~2^-20 |w| |x| of one-signed error (csrc/edge_mlp.hip), i.e. the distance from the exact head is bounded by the
+    magnitude that PROPAGATES through the three layers, S(e) = |w3| . (|W2| . (|W1| |x(e)| + |b1|) + |b2|) + |b3|, not by the
+    logit. Two regimes, both against an fp64 evaluation of the head:
+      * the reference's own shape of inputs — U(-0.1, 0.1) weights of mixed sign on raw features with clock-time columns
+        around 2e4 (src/agents/mpnn_agent.py:35-41, :166-178): the north star's contract, 1e-4 of the logits' scale;
+      * weights built to cancel — +w on the source's clock column, -w on the target's, so that terms of ~2e3 sum to ~1 —:
+        4e-6 of S(e) (= 4 * 2^-20), and no more than that; the fp32 MFMA kernel (exact products, fp32 accumulation) is held
+        to 2^-19 of S(e) on the same inputs for comparison."""
+    from oracle import nets
+    from tarl_hip import ops, synth
+    net = synth.torus_network(6, 6)
+    N, E = net.num_roads, net.edge_index.size(1)
+    plan = ops.Plan(net.edge_index, N)
+    ec = ops.EdgeConst(net.edge_attr, "cuda")
+    g = torch.Generator().manual_seed(17)
+    M = 9
+    x = torch.zeros((M, N, 16))
+    x[..., 0] = 14.0
+    x[..., 1] = torch.randint(0, 14, (M, N), generator=g).float()
+    x[..., 2] = 10.0
+    x[..., 3] = 100.0
+    x[..., 5] = torch.randint(0, N, (M, N), generator=g).float()
+    x[..., 6] = torch.arange(N).float()
+    x[..., 7] = torch.randint(0, N, (M, N), generator=g).float()          # agent origin / destination
+    x[..., 8] = torch.randint(0, N, (M, N), generator=g).float()
+    x[..., 9] = 21540.0 + torch.randint(0, 3600, (M, N), generator=g).float()      # departure / arrival clock times
+    x[..., 10] = x[..., 9] + torch.rand((M, N), generator=g) * 200.0
+
+    def run(ws):
+        w = ops.EdgeMlpWeights(*(t.cuda().contiguous() for t in ws))
+        ws64 = [t.double() for t in ws]
+        ea = net.edge_attr.double().reshape(1, E, 1).expand(M, E, 1)
+        ref = nets.edge_mlp_logits(x.double(), net.edge_index, ea, *ws64)
+        a = [t.abs() for t in ws64]
+        S = nets.edge_mlp_logits(x.double().abs(), net.edge_index, ea.abs(), *a)        # all terms positive: ReLU is the identity
+        l3 = ops.policy_edge_mlp(plan, x.cuda(), ec, w, precision="x3").cpu().double()
+        l32 = ops.policy_edge_mlp(plan, x.cuda(), ec, w).cpu().double()
+        return ref, S, (l3 - ref).abs(), (l32 - ref).abs()
+
+    u = lambda *s: (torch.rand(s, generator=g) - 0.5) * 0.2
+    ref, S, e3, e32 = run([u(64, 33), u(64), u(32, 64), u(32), u(1, 32), u(1)])
+    scale = float(ref.abs().max())
+    assert scale > 1.0 and float(e3.max()) <= TOL * scale, (float(e3.max()), scale)
+    assert float((e3 / S).max()) <= 4e-6 and float((e32 / S).max()) <= 2.0 ** -19
+    w1 = u(64, 33)
+    w1[:, 16 + 9] = -w1[:, 9]                  # the target row's departure clock against the source row's
+    w1[:, 16 + 10] = -w1[:, 10]
+    ref, S, e3, e32 = run([w1, u(64), u(32, 64), u(32), u(1, 32), u(1)])
+    assert float(S.max()) > 20 * float(ref.abs().max())               # the terms do cancel
+    assert float((e3 / S).max()) <= 4e-6, float((e3 / S).max())
+    assert float((e32 / S).max()) <= 2.0 ** -19, float((e32 / S).max())

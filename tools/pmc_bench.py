@@ -9,8 +9,8 @@ MI355X_MICROARCH.md's HBM / rocprofv3 section prescribes):
       python3 bench.py --steps 1 --warmup 1 --cpu-seconds 0 --congested-window 0 --policy-envs 0 --no-kernel-timing
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_w -o run -- \
       python3 bench.py --steps 1 --warmup 1 --cpu-seconds 0 --congested-window 0 --policy-envs 0 --no-kernel-timing
-  python3 tools/pmc_bench.py gpurun_out/pmc_f gpurun_out/pmc_w [more pass dirs] --out profiles/r03_pmc_traffic.json
-  (tools/r03_pmc.sh runs the passes for the default line and for the congested regime, --departure-window 600)
+  python3 tools/pmc_bench.py gpurun_out/pmc_f gpurun_out/pmc_w [more pass dirs] --out profiles/r05_pmc_traffic.json
+  (tools/r05_pmc.sh runs the passes for the default line, the congested regime — --departure-window 600 — and config 5)
 
 Reduction: for every rollout kernel the launches of the LAST iteration's frames >= --first-frame (default 200: the
 episode has filled up; the first frames after a reset move almost nobody) are averaged. Units and the gfx950 correction
@@ -82,7 +82,10 @@ def main():
         raise SystemExit("FETCH_SIZE and WRITE_SIZE passes are required")
     T = a.rollout_steps
     cfg = {"edges": a.edges, "agents": a.agents, "envs": a.envs, "rollout_steps": T}
-    cmd = "python3 bench.py --steps 1 --warmup 1 --cpu-seconds 0 --congested-window 0 --policy-envs 0 --no-kernel-timing"
+    cmd = ("python3 bench.py --steps 1 --warmup 1 --cpu-seconds 0 --congested-window 0 --policy-envs 0 --config5-envs 0 "
+           "--update-epochs 0 --no-kernel-timing")
+    if (a.edges, a.agents, a.envs) != (10000, 16384, 16384):
+        cmd += f" --edges {a.edges} --agents {a.agents} --envs {a.envs}"
     if a.departure_window:
         cfg["departure_window"] = a.departure_window
         cmd += f" --departure-window {a.departure_window}"
