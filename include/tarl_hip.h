@@ -172,10 +172,14 @@ int tarl_graphdist_logprob_entropy_bwd(const tarl_plan* plan, const float* proba
 int tarl_policy_edge_logits_fwd(const tarl_plan* plan, const float* road_index, int64_t ri_bstride,
                                 int64_t ri_nstride, int64_t B, const float* emb, int64_t num_embeddings,
                                 float* logits, tarl_stream stream);
-/* backward: grad_emb [num_embeddings] += sum_b sum_{e: dst(e)=n} grad_logits[b][e] (one fp32 atomic per (b, n)). */
+/* backward: grad_emb [num_embeddings] += sum_b sum_{e: dst(e)=n} grad_logits[b][e], one fp32 add per (node, embedding) run
+ *   of batch rows (bit-reproducible while ROAD_INDEX is one-to-one). scratch (nullable): fp32,
+ *   tarl_policy_edge_logits_bwd_scratch_floats(plan, B) elements — with it, a broadcast observation (ri_bstride == 0) and
+ *   >= 256 rows the sum over the rows runs in parallel chunks of 64 rows whose partial sums are added in chunk order. */
+int64_t tarl_policy_edge_logits_bwd_scratch_floats(const tarl_plan* plan, int64_t B);
 int tarl_policy_edge_logits_bwd(const tarl_plan* plan, const float* road_index, int64_t ri_bstride,
                                 int64_t ri_nstride, int64_t B, const float* grad_logits, float* grad_emb,
-                                int64_t num_embeddings, tarl_stream stream);
+                                int64_t num_embeddings, float* scratch, tarl_stream stream);
 
 /* ---- the per-edge MLP head of MPNNPolicyNet (src/agents/mpnn_agent.py:35-41; evaluation spelled out at :227-231) -----
  * logits[m][e] = W3 relu(W2 relu(W1 cat(x[m][src(e)], x[m][dst(e)], edge_attr[e]) + b1) + b2) + b3, 33 -> 64 -> 32 -> 1,
@@ -216,7 +220,10 @@ int tarl_critic_mlp_fwd(const float* counts, int64_t ldc, int64_t M, int64_t N, 
                         const float* w3, const float* b3, float* value, float* h1_out, float* h2_out,
                         tarl_stream stream);
 /* backward for minibatch-sized M: ACCUMULATES (+=) into gw1 [64][N+1], gb1 [64], gw2 [64][64], gb2 [64], gw3 [64],
- *   gb3 [1]; scratch: fp32 [2][M][64]. */
+ *   gb3 [1]; scratch: fp32, tarl_critic_mlp_bwd_scratch_floats(M, N) elements ([2][M][64] for the reference's sub-batch of a
+ *   few dozen rows; from 512 rows on the reductions over the rows run in parallel row chunks that leave partial sums there,
+ *   added in chunk order: deterministic, no atomics). */
+int64_t tarl_critic_mlp_bwd_scratch_floats(int64_t M, int64_t N);
 int tarl_critic_mlp_bwd(const float* counts, int64_t ldc, int64_t M, int64_t N, const float* time_rows,
                         int64_t rows_per_time, const float* w1, const float* w2, const float* w3, const float* h1,
                         const float* h2, const float* grad_value, float* scratch, float* gw1, float* gb1, float* gw2,
@@ -377,10 +384,18 @@ typedef struct tarl_fused {
    * per environment by it (a frame of dt seconds brings ~due_rate * dt candidates). Never changes a result. */
   float due_rate;
   int32_t reserved_;
+  /* device scratch of tarl_fused_bufs_bytes() bytes, 16-byte aligned (required by the frame / rollout entry points): the
+   * library keeps a device-resident copy of this table of pointers there (written by a one-thread launch at the head of every
+   * such call, on the call's stream), and the row pass and the insert kernels read the pointers they need from it through the
+   * scalar cache instead of carrying all of them as kernel arguments — 27 pointer arguments cost those kernels a dozen
+   * scalar-register pairs each, most of them spilled (csrc/fused.hip: k_set_bufs). */
+  void* bufs_dev;
 } tarl_fused;
 
 /* floats per (node, environment) row of tarl_fused.slots for FIFOs of Nmax slots */
 int64_t tarl_fused_slot_floats(int32_t Nmax);
+/* bytes of tarl_fused.bufs_dev */
+int64_t tarl_fused_bufs_bytes(void);
 int tarl_fused_pack(const tarl_plan* plan, const tarl_fused* f, const float* x, int64_t B, int64_t x_bstride,
                     int64_t ldx, int32_t Nmax, const float* congestion_constant, const float* edge_attr,
                     const float* agent_features, int64_t num_agents, int64_t a_bstride, tarl_stream stream);

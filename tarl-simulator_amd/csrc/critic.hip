@@ -600,6 +600,145 @@ __global__ __launch_bounds__(CR_THREADS) void k_critic_bwd_w1(int64_t M, int64_t
   gw1[(int64_t)j * (N + 1) + k] += s;
 }
 
+// ---- backward for MANY rows (an optimiser minibatch of thousands of frames) ------------------------------------------------
+// The kernels above give one thread a whole column of the reduction over m: right for the reference's sub-batch of 32 rows,
+// a serial chain of M loads per thread beyond a few hundred (M = 4 096, N = 2 500: 3.7 ms, bench.py's update_path). Here the
+// reduction over m is cut into row chunks that run in parallel, each leaving partial sums, and a second launch adds the
+// partials of a weight IN CHUNK ORDER: deterministic (no atomics), the same sums in another association.
+#define CB_RC 128      // rows per chunk of the dW1 pass (dh1 tile: 32 KB of LDS)
+#define CB_RS 32       // rows per chunk of the small-matrix pass (four 8 KB tiles)
+#define CB_SMALL (CR_H * CR_H + 4 * CR_H + 1)     // gw2 | gb2 | gb1 | gw3 | gw1's time column | gb3
+
+// dW1 partial: workgroup (kt, s) = 64 input columns x all 64 hidden units x rows [128 s, 128 s + 128)
+__global__ __launch_bounds__(CR_THREADS) void k_critic_bwd_w1_part(int64_t M, int64_t N, const float* __restrict__ counts,
+                                                                   int64_t ldc, const float* __restrict__ dh1,
+                                                                   float* __restrict__ part) {
+  __shared__ float4 s_dh[CB_RC * (CR_H / 4)];     // [row][hidden unit]
+  const int tid = threadIdx.x;
+  const int64_t m0 = (int64_t)blockIdx.y * CB_RC;
+  const int rows = (int)((M - m0) < CB_RC ? (M - m0) : CB_RC);
+  const float4* src = reinterpret_cast<const float4*>(dh1 + m0 * CR_H);
+  for (int e = tid; e < rows * (CR_H / 4); e += CR_THREADS) s_dh[e] = src[e];
+  __syncthreads();
+  const int kk = tid & 63, jg = tid >> 6;         // a wave = 64 columns of one group of 16 hidden units
+  const int64_t k = (int64_t)blockIdx.x * 64 + kk;
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+  if (k < N) {
+    const float* col = counts + m0 * ldc + k;
+#pragma unroll 4
+    for (int m = 0; m < rows; ++m) {
+      const float x = col[(int64_t)m * ldc];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 d = s_dh[m * (CR_H / 4) + jg * 4 + q];      // wave-uniform address: broadcast
+        acc[4 * q + 0] = fmaf(d.x, x, acc[4 * q + 0]);
+        acc[4 * q + 1] = fmaf(d.y, x, acc[4 * q + 1]);
+        acc[4 * q + 2] = fmaf(d.z, x, acc[4 * q + 2]);
+        acc[4 * q + 3] = fmaf(d.w, x, acc[4 * q + 3]);
+      }
+    }
+    float* out = part + ((int64_t)blockIdx.y * CR_H + jg * 16) * N + k;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out[(int64_t)i * N] = acc[i];
+  }
+}
+
+__global__ __launch_bounds__(CR_THREADS) void k_critic_bwd_w1_reduce(int64_t S, int64_t N, const float* __restrict__ part,
+                                                                     float* __restrict__ gw1) {
+  const int64_t idx = (int64_t)blockIdx.x * CR_THREADS + threadIdx.x;     // (j, k) flat over [64][N]
+  if (idx >= CR_H * N) return;
+  const int64_t j = idx / N, k = idx - j * N;
+  float s = 0.0f;
+  for (int64_t c = 0; c < S; ++c) s += part[c * CR_H * N + idx];
+  gw1[j * (N + 1) + k] += s;
+}
+
+// the small gradients' partials: workgroup s = rows [32 s, 32 s + 32)
+__global__ __launch_bounds__(CR_THREADS) void k_critic_bwd_small_part(int64_t M, const float* __restrict__ dv,
+                                                                      const float* __restrict__ h1,
+                                                                      const float* __restrict__ h2,
+                                                                      const float* __restrict__ dh1,
+                                                                      const float* __restrict__ dh2,
+                                                                      const float* __restrict__ time_rows,
+                                                                      int64_t rows_per_time, float* __restrict__ part) {
+  __shared__ float s_dh2[CB_RS * CR_H], s_h1[CB_RS * CR_H], s_dh1[CB_RS * CR_H], s_h2[CB_RS * CR_H];
+  __shared__ float s_dv[CB_RS], s_tm[CB_RS];
+  const int tid = threadIdx.x;
+  const int64_t m0 = (int64_t)blockIdx.x * CB_RS;
+  const int rows = (int)((M - m0) < CB_RS ? (M - m0) : CB_RS);
+  for (int e = tid; e < CB_RS * CR_H; e += CR_THREADS) {
+    const bool in = e < rows * CR_H;
+    s_dh2[e] = in ? dh2[m0 * CR_H + e] : 0.0f;
+    s_h1[e] = in ? h1[m0 * CR_H + e] : 0.0f;
+    s_dh1[e] = in ? dh1[m0 * CR_H + e] : 0.0f;
+    s_h2[e] = in ? h2[m0 * CR_H + e] : 0.0f;
+  }
+  if (tid < CB_RS) {
+    s_dv[tid] = tid < rows ? dv[m0 + tid] : 0.0f;
+    s_tm[tid] = tid < rows ? time_rows[(m0 + tid) / rows_per_time] : 0.0f;
+  }
+  __syncthreads();
+  float* out = part + (int64_t)blockIdx.x * CB_SMALL;
+  {
+    const int j = tid >> 2, k0 = (tid & 3) * 16;       // gw2[j][k0 .. k0 + 15]
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int m = 0; m < CB_RS; ++m) {
+      const float a = s_dh2[m * CR_H + j];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = fmaf(a, s_h1[m * CR_H + k0 + i], acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out[j * CR_H + k0 + i] = acc[i];
+  }
+  if (tid < CR_H) {
+    float sb2 = 0.0f, sb1 = 0.0f, sw3 = 0.0f, swt = 0.0f;
+    for (int m = 0; m < CB_RS; ++m) {
+      sb2 += s_dh2[m * CR_H + tid];
+      sb1 += s_dh1[m * CR_H + tid];
+      sw3 = fmaf(s_dv[m], s_h2[m * CR_H + tid], sw3);
+      swt = fmaf(s_dh1[m * CR_H + tid], s_tm[m], swt);
+    }
+    out[CR_H * CR_H + tid] = sb2;
+    out[CR_H * CR_H + CR_H + tid] = sb1;
+    out[CR_H * CR_H + 2 * CR_H + tid] = sw3;
+    out[CR_H * CR_H + 3 * CR_H + tid] = swt;
+  }
+  if (tid == 0) {
+    float sd = 0.0f;
+    for (int m = 0; m < CB_RS; ++m) sd += s_dv[m];
+    out[CB_SMALL - 1] = sd;
+  }
+}
+
+__global__ __launch_bounds__(CR_THREADS) void k_critic_bwd_small_reduce(int64_t S, int64_t N, const float* __restrict__ part,
+                                                                        float* __restrict__ gw1, float* __restrict__ gb1,
+                                                                        float* __restrict__ gw2, float* __restrict__ gb2,
+                                                                        float* __restrict__ gw3, float* __restrict__ gb3) {
+  const int idx = blockIdx.x * CR_THREADS + threadIdx.x;
+  if (idx >= CB_SMALL) return;
+  float s = 0.0f;
+  for (int64_t c = 0; c < S; ++c) s += part[c * CB_SMALL + idx];
+  const int v = idx - CR_H * CR_H;
+  if (v < 0)
+    gw2[idx] += s;
+  else if (v < CR_H)
+    gb2[v] += s;
+  else if (v < 2 * CR_H)
+    gb1[v - CR_H] += s;
+  else if (v < 3 * CR_H)
+    gw3[v - 2 * CR_H] += s;
+  else if (v < 4 * CR_H)
+    gw1[(int64_t)(v - 3 * CR_H) * (N + 1) + N] += s;      // the time column of W1
+  else
+    gb3[0] += s;
+}
+
+#define CB_MANY_ROWS 512       // from this many rows on the chunked backward is used (needs tarl_critic_mlp_bwd_scratch_floats)
+
 // ---- host side -------------------------------------------------------------------------------------------------------
 template <typename XT>
 static int critic_fwd(const XT* counts, int64_t ldc, int64_t rps, int64_t M, int64_t N, const float* time_rows,
@@ -835,6 +974,13 @@ extern "C" int tarl_critic_mlp_fwd_slabs_u8(const uint8_t* counts, int64_t rows_
   return TARL_OK;
 }
 
+extern "C" int64_t tarl_critic_mlp_bwd_scratch_floats(int64_t M, int64_t N) {
+  if (M < 1 || N < 1) return -1;
+  int64_t n = 2 * M * CR_H;                                   // dh1, dh2
+  if (M >= CB_MANY_ROWS) n += ceil_div(M, CB_RC) * CR_H * N + ceil_div(M, CB_RS) * CB_SMALL;     // the chunks' partial sums
+  return n;
+}
+
 extern "C" int tarl_critic_mlp_bwd(const float* counts, int64_t ldc, int64_t M, int64_t N, const float* time_rows,
                                    int64_t rows_per_time, const float* w1, const float* w2, const float* w3,
                                    const float* h1, const float* h2, const float* grad_value, float* scratch,
@@ -850,6 +996,25 @@ extern "C" int tarl_critic_mlp_bwd(const float* counts, int64_t ldc, int64_t M, 
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_critic_bwd_rows, dim3((unsigned)M), dim3(CR_H), 0, s, M, grad_value, h1, h2, P, dh1, dh2);
   TARL_LAUNCH_CHECK();
+  if (M >= CB_MANY_ROWS) {     // chunked reductions over the rows (the caller sized scratch with tarl_critic_mlp_bwd_scratch_floats)
+    const int64_t S1 = ceil_div(M, CB_RC), S2 = ceil_div(M, CB_RS);
+    TARL_REQUIRE(S1 < 65536, "too many rows for one launch");
+    float* part_w1 = scratch + 2 * M * CR_H;
+    float* part_small = part_w1 + S1 * CR_H * N;
+    hipLaunchKernelGGL(k_critic_bwd_w1_part, dim3((unsigned)ceil_div(N, 64), (unsigned)S1), dim3(CR_THREADS), 0, s, M, N, counts,
+                       ldc, dh1, part_w1);
+    TARL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_critic_bwd_w1_reduce, dim3((unsigned)ceil_div(CR_H * N, CR_THREADS)), dim3(CR_THREADS), 0, s, S1, N,
+                       part_w1, gw1);
+    TARL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_critic_bwd_small_part, dim3((unsigned)S2), dim3(CR_THREADS), 0, s, M, grad_value, h1, h2, dh1, dh2,
+                       time_rows, rows_per_time, part_small);
+    TARL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_critic_bwd_small_reduce, dim3((unsigned)ceil_div(CB_SMALL, CR_THREADS)), dim3(CR_THREADS), 0, s, S2, N,
+                       part_small, gw1, gb1, gw2, gb2, gw3, gb3);
+    TARL_LAUNCH_CHECK();
+    return TARL_OK;
+  }
   hipLaunchKernelGGL(k_critic_bwd_small, dim3((CR_H * CR_H) / CR_THREADS), dim3(CR_THREADS), 0, s, M, grad_value, h1, h2,
                      dh1, dh2, time_rows, rows_per_time, N, gw1, gb1, gw2, gb2, gw3, gb3);
   TARL_LAUNCH_CHECK();

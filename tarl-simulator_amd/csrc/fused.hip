@@ -1150,8 +1150,13 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
                                                      const int32_t* __restrict__ out_dst,
                                                      const RowChunk* __restrict__ rchunks,
                                                      const uint32_t* __restrict__ post, int Nmax, uint32_t B, uint32_t N,
-                                                     FusedBufs fb, float* __restrict__ ag, int64_t A, int64_t a_bstride,
-                                                     float t, FrameOut out) {
+                                                     const FusedBufs* __restrict__ fbp, float* __restrict__ ag, int64_t A,
+                                                     int64_t a_bstride, float t, FrameOut out) {
+  // The table of pointers lives in device memory (tarl_fused.bufs_dev, written by k_set_bufs at the head of the call): what
+  // the pass needs of it is read where it is needed, through the scalar cache, instead of travelling as 27 kernel arguments
+  // that the register allocator keeps alive across the whole pass (round 5, static figures of tools/kernel_resources.sh for
+  // this instantiation: 45 -> 13 spilled SGPRs, 173 -> 48 v_readlane / v_writelane, 1 135 -> 1 029 vector instructions).
+  const FusedBufs& fb = *fbp;
   static_assert(!SIB || NCH == 4, "row chunks hold four rows");
   __shared__ int32_t s_cnt;
   // the event list holds EV_CAP of the TILE * NCH pairs (a filling network lists ~2 %, a loaded one ~30 %); a pair that
@@ -1353,7 +1358,7 @@ struct InsLds {
 #define s_un_k L.un_k
 #define s_un_hd L.un_hd
 #define s_un_tl L.un_tl
-__device__ __forceinline__ void fused_insert_body(InsLds& L, int64_t b, int Nmax, int64_t B, int64_t N, FusedBufs fb, PlanOut P,
+__device__ __forceinline__ void fused_insert_body(InsLds& L, int64_t b, int Nmax, int64_t B, int64_t N, const FusedBufs& fb, PlanOut P,
                                                   const uint8_t* __restrict__ sel8, float* __restrict__ ag, int64_t A,
                                                   int64_t a_bstride, int use_cong, float t,
                                                   int32_t* __restrict__ scratch, const float* __restrict__ entropy_in,
@@ -1648,7 +1653,7 @@ __device__ __forceinline__ void fused_insert_body(InsLds& L, int64_t b, int Nmax
 #undef s_un_hd
 #undef s_un_tl
 
-__global__ __launch_bounds__(INSB) void k_fused_insert(int Nmax, int64_t B, int64_t N, FusedBufs fb, PlanOut P,
+__global__ __launch_bounds__(INSB) void k_fused_insert(int Nmax, int64_t B, int64_t N, const FusedBufs* __restrict__ fbp, PlanOut P,
                                                        const uint8_t* __restrict__ sel8, float* __restrict__ ag,
                                                        int64_t A, int64_t a_bstride, int use_cong, float t,
                                                        int32_t* __restrict__ scratch,
@@ -1656,7 +1661,7 @@ __global__ __launch_bounds__(INSB) void k_fused_insert(int Nmax, int64_t B, int6
                                                        float* __restrict__ reward, FrameOut out,
                                                        float* __restrict__ log_prob, float* __restrict__ entropy) {
   __shared__ InsLds L;
-  fused_insert_body(L, blockIdx.x, Nmax, B, N, fb, P, sel8, ag, A, a_bstride, use_cong, t, scratch, entropy_in, reward,
+  fused_insert_body(L, blockIdx.x, Nmax, B, N, *fbp, P, sel8, ag, A, a_bstride, use_cong, t, scratch, entropy_in, reward,
                     out, log_prob, entropy);
 }
 
@@ -1672,7 +1677,7 @@ __global__ __launch_bounds__(INSB) void k_fused_insert(int Nmax, int64_t B, int6
 // banks itself: nothing else of that environment has been written by then). 16 384 environments: 65 us with one wave
 // each, 50 / 40 / 36 us with 2 / 4 / 8 per wave.
 template <int EPW>
-__global__ __launch_bounds__(INSB) void k_fused_insert2(int Nmax, int64_t B, int64_t N, FusedBufs fb, PlanOut P,
+__global__ __launch_bounds__(INSB) void k_fused_insert2(int Nmax, int64_t B, int64_t N, const FusedBufs* __restrict__ fbp, PlanOut P,
                                                         const uint8_t* __restrict__ sel8, float* __restrict__ ag,
                                                         int64_t A, int64_t a_bstride, int use_cong, float t,
                                                         int32_t* __restrict__ scratch,
@@ -1680,6 +1685,7 @@ __global__ __launch_bounds__(INSB) void k_fused_insert2(int Nmax, int64_t B, int
                                                         float* __restrict__ reward, FrameOut out,
                                                         float* __restrict__ log_prob, float* __restrict__ entropy) {
   __shared__ InsLds L;
+  const FusedBufs& fb = *fbp;              // the pointer table in device memory (k_set_bufs): 88 -> 38 spilled SGPRs at EPW = 8
   constexpr int LPE = 64 / EPW;            // lanes per environment
   constexpr int INS_CAP2 = INS_CAP / EPW;  // its share of the candidate list
   const int tid = threadIdx.x, h = tid / LPE, l = tid % LPE;
@@ -1853,7 +1859,8 @@ struct ChoiceArgs {
   unsigned gx;             // environment tiles (x extent of the choice grid)
   unsigned choice_blocks;  // gx * node chunks
 };
-__global__ __launch_bounds__(TILE) void k_fused_insert_choice(ChoiceArgs C, int Nmax, int64_t B, int64_t N, FusedBufs fb,
+__global__ __launch_bounds__(TILE) void k_fused_insert_choice(ChoiceArgs C, int Nmax, int64_t B, int64_t N,
+                                                              const FusedBufs* __restrict__ fbp,
                                                               PlanOut P, const uint8_t* __restrict__ sel8,
                                                               float* __restrict__ ag, int64_t A, int64_t a_bstride,
                                                               int use_cong, float t, int32_t* __restrict__ scratch,
@@ -1865,12 +1872,12 @@ __global__ __launch_bounds__(TILE) void k_fused_insert_choice(ChoiceArgs C, int 
   __shared__ InsLds L;
   if (blockIdx.x < (unsigned)B) {
     if (threadIdx.x >= INSB) return;   // whole waves leave before any barrier
-    fused_insert_body(L, (int64_t)blockIdx.x, Nmax, B, N, fb, P, sel8, ag, A, a_bstride, use_cong, t, scratch, entropy_in,
+    fused_insert_body(L, (int64_t)blockIdx.x, Nmax, B, N, *fbp, P, sel8, ag, A, a_bstride, use_cong, t, scratch, entropy_in,
                       reward, out, log_prob, entropy);
   } else {
     const unsigned cb = blockIdx.x - (unsigned)B;
-    fused_choice_body(cb % C.gx, cb / C.gx, C.out_ptr, C.out_eid, C.group_of_node, C.G, B, N, C.acc_next, fb.acc_slots,
-                      C.thr, C.lgt, nullptr, C.pseed, C.pcounter, C.sel_next, sel8, nullptr, C.nchunk, C.want_lp, fb.env_base);
+    fused_choice_body(cb % C.gx, cb / C.gx, C.out_ptr, C.out_eid, C.group_of_node, C.G, B, N, C.acc_next, fbp->acc_slots,
+                      C.thr, C.lgt, nullptr, C.pseed, C.pcounter, C.sel_next, sel8, nullptr, C.nchunk, C.want_lp, fbp->env_base);
   }
 }
 
@@ -1883,6 +1890,24 @@ FusedBufs tarl_to_bufs(const tarl_fused* f) {
                    f->a_dep,              f->a_status,      f->a_order,      f->cur_lo,          f->a_dep_sorted,
                    (const uint4*)f->a_win, f->a_ins,        f->a_rank,
                    f->acc_slots,          f->flags,         f->env_base};
+}
+
+// The device-resident copies of the pointer table (tarl_fused.bufs_dev): slot 0 = the table as the caller gave it, slot 1 =
+// the same with the second log-prob accumulator bank (the merged insert + choice launch double-buffers it by frame parity).
+// One thread, the tables by value in its kernel arguments: stream-ordered, no host copy, no synchronisation.
+__global__ void k_set_bufs(FusedBufs a, FusedBufs b, FusedBufs* __restrict__ dst) {
+  dst[0] = a;
+  dst[1] = b;
+}
+extern "C" int64_t tarl_fused_bufs_bytes(void) { return 2 * (int64_t)sizeof(FusedBufs); }
+static int upload_bufs(const tarl_fused* f, const FusedBufs& fb, long long* acc_lp_alt, hipStream_t s, const FusedBufs** dev) {
+  TARL_REQUIRE(f->bufs_dev && ((uintptr_t)f->bufs_dev) % 16 == 0, "tarl_fused.bufs_dev missing or misaligned (tarl_fused_bufs_bytes)");
+  FusedBufs alt = fb;
+  if (acc_lp_alt) alt.acc_lp = acc_lp_alt;
+  hipLaunchKernelGGL(k_set_bufs, dim3(1), dim3(1), 0, s, fb, alt, (FusedBufs*)f->bufs_dev);
+  TARL_LAUNCH_CHECK();
+  *dev = (const FusedBufs*)f->bufs_dev;
+  return TARL_OK;
 }
 
 // rows per lane of the row pass (tunable: TARL_NCHUNK = 1, 2 or 4; measured 63.7 / 57.8 / 56.0 us per launch)
@@ -2110,7 +2135,7 @@ static bool rows_sib(const tarl_plan* plan) {
 }
 static int64_t num_row_chunks(const tarl_plan* plan) { return rows_sib(plan) ? plan->num_row_chunks : num_chunks(plan); }
 static int launch_rows(dim3 grid, unsigned threads, hipStream_t s, const tarl_plan* plan, const tarl_fused* f,
-                       const FusedBufs& fb, int Nmax, int64_t B, float* agent_features, int64_t A, int64_t a_bstride,
+                       const FusedBufs* fb, int Nmax, int64_t B, float* agent_features, int64_t A, int64_t a_bstride,
                        float time, const FrameOut& out) {
 #define ROWS_LAUNCH_(NCH, SIB, FAPI, O32)                                                                                  \
   hipLaunchKernelGGL((k_fused_rows<NCH, SIB, FAPI, O32>), grid, dim3(threads), 0, s, (const NodeRec*)f->node_rec,               \
@@ -2188,6 +2213,9 @@ extern "C" int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int6
                        log_prob != nullptr ? 1 : 0, f->env_base);
     TARL_LAUNCH_CHECK();
   }
+  const FusedBufs* fbd = nullptr;
+  rc = upload_bufs(f, fb, nullptr, s, &fbd);
+  if (rc) return rc;
   const bool timed = tarl_prof_mark(s, 0) != nullptr;
   const dim3 grid_d((unsigned)ceil_div(B, threads), (unsigned)ceil_div(plan->N, nchunk_dir()));
   const FrameOut out{nullptr, counts, popped, withdrawn, nullptr, nullptr, 0, nullptr, 1};
@@ -2195,10 +2223,10 @@ extern "C" int tarl_fused_frame(const tarl_plan* plan, const tarl_fused* f, int6
                         delta_travel_time, log_eps, time, prev_time, seed, counter, B, (int)Nmax, out);
   if (rc) return rc;
   if (timed) (void)tarl_prof_mark(s, 1);
-  rc = launch_rows(grid, threads, s, plan, f, fb, (int)Nmax, B, agent_features, A, a_bstride, time, out);
+  rc = launch_rows(grid, threads, s, plan, f, fbd, (int)Nmax, B, agent_features, A, a_bstride, time, out);
   if (rc) return rc;
   if (timed) (void)tarl_prof_mark(s, 2);
-  hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(INSB), 0, s, (int)Nmax, B, plan->N, fb, P,
+  hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(INSB), 0, s, (int)Nmax, B, plan->N, fbd, P,
                      (const uint8_t*)f->sel8, agent_features, A, a_bstride, use_cong, time, ins_scratch, entropy1, reward,
                      out, log_prob, entropy);
   TARL_LAUNCH_CHECK();
@@ -2318,6 +2346,9 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
   const bool merge = !ahead && mode >= 1 && (choice || sel_scratch) && acc_scratch && T > 1;
   long long* acc_buf[2] = {(long long*)f->acc_lp, merge ? (long long*)acc_scratch : (long long*)f->acc_lp};
   if (merge) TARL_CHECK_HIP(hipMemsetAsync(acc_scratch, 0, (size_t)(f->acc_slots * B) * sizeof(int64_t), s));
+  const FusedBufs* fbd = nullptr;      // [0]: the table with acc_buf[0], [1]: with acc_buf[1]
+  rc = upload_bufs(f, fb, acc_buf[1], s, &fbd);
+  if (rc) return rc;
   ChoiceSide* side = nullptr;
   if (ahead) {
     rc = choice_side(&side);
@@ -2375,8 +2406,7 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
   for (int64_t t = 0; t < T; ++t) {
     const int cur = merge ? (int)(t & 1) : 0;
     const float time = times_host[t];
-    FusedBufs fbt = fb;
-    fbt.acc_lp = acc_buf[cur];
+    const FusedBufs* fbt = fbd + cur;
     const uint8_t* sel_t = slice(t);
     const int64_t m = metrics_envs;
     const FrameOut out{counts ? counts + t * NB : nullptr,
@@ -2444,7 +2474,7 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
       TARL_LAUNCH_CHECK();
       if (t + 1 < T) {   // unmerged: the next frame's choice as its own launch
         hipLaunchKernelGGL(k_fused_choice, grid_c, dim3(threads), 0, s, plan->out_ptr, plan->out_eid,
-                           plan->group_of_node, plan->G, B, N, fbt.acc_lp, fb.acc_slots, thresholds,
+                           plan->group_of_node, plan->G, B, N, acc_buf[cur], fb.acc_slots, thresholds,
                            (const long long*)log_probs, (const float*)nullptr, policy_seed,
                            policy_counter0 + (uint64_t)(t + 1), slice(t + 1), sel_t, (int32_t*)nullptr, nchunk_choice(),
                            want_lp, f->env_base);
@@ -2543,7 +2573,10 @@ extern "C" int tarl_fused_rollout_policy(const tarl_plan* plan, const tarl_fused
   const unsigned threads = tile_threads(B);
   const dim3 grid((unsigned)ceil_div(B, threads), (unsigned)num_chunks(plan));
   const dim3 grid_d((unsigned)ceil_div(B, threads), (unsigned)ceil_div(N, nchunk_dir()));
-  const FusedBufs fb = tarl_to_bufs(f);
+  const FusedBufs fbh = tarl_to_bufs(f);
+  const FusedBufs* fb = nullptr;
+  rc = upload_bufs(f, fbh, nullptr, s, &fb);
+  if (rc) return rc;
   const PlanOut P{plan->out_ptr, plan->out_dst};
   for (int64_t t = 0; t < T; ++t) {
     const bool keep_t = keep_ptr_host && keep_ptr_host[t + 1] > keep_ptr_host[t];

@@ -45,7 +45,8 @@ SIGNATURES = {
     "tarl_graphdist_logprob_entropy_fwd": (C.c_int, [_p, _p, _i64, _p, _p, _p, _p, _p]),
     "tarl_graphdist_logprob_entropy_bwd": (C.c_int, [_p, _p, _i64, _f32, _p, _p, _p, _p, _p, _p, _p]),
     "tarl_policy_edge_logits_fwd": (C.c_int, [_p, _p, _i64, _i64, _i64, _p, _i64, _p, _p]),
-    "tarl_policy_edge_logits_bwd": (C.c_int, [_p, _p, _i64, _i64, _i64, _p, _p, _i64, _p]),
+    "tarl_policy_edge_logits_bwd_scratch_floats": (_i64, [_p, _i64]),
+    "tarl_policy_edge_logits_bwd": (C.c_int, [_p, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _p]),
     "tarl_policy_obs16": (C.c_int, [_p, _i64, _p, _p, _i64, _i64, _i64, _i64, _p, _p]),
     "tarl_fused_obs16": (C.c_int, [_p, _p] + _STATE + [_p, _i64, _i64, _p, _p]),
     "tarl_fused_obs16_bf16": (C.c_int, [_p, _p] + _STATE + [_p, _i64, _i64, _p, _p]),
@@ -56,6 +57,7 @@ SIGNATURES = {
     "tarl_critic_mlp_fwd": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64] + [_p] * 6 + [_p, _p, _p, _p]),
     "tarl_critic_splitk_scratch_floats": (C.c_int64, [_i64, _i64]),
     "tarl_critic_mlp_fwd_splitk": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64] + [_p] * 6 + [_p, _p, _p, _p, _p]),
+    "tarl_critic_mlp_bwd_scratch_floats": (_i64, [_i64, _i64]),
     "tarl_critic_mlp_bwd": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64] + [_p] * 3 + [_p, _p, _p, _p] + [_p] * 6 + [_p]),
     "tarl_value_mpnn_fwd": (C.c_int, [_p, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p]),
     "tarl_value_mpnn_bwd": (C.c_int, [_p, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p]),
@@ -69,6 +71,7 @@ SIGNATURES = {
     "tarl_critic_mlp_fwd_slabs_u8": (C.c_int, [_p, _i64, _i64, _i64, _p, _i64] + [_p] * 6 + [_p, _p, _p]),
     "tarl_critic_split_scratch_bytes": (_i64, [_i64]),
     "tarl_fused_slot_floats": (_i64, [_i32]),
+    "tarl_fused_bufs_bytes": (_i64, []),
     "tarl_fused_pack": (C.c_int, [_p, _p] + _STATE + [_p, _p, _p, _i64, _i64, _p]),
     "tarl_fused_reset": (C.c_int, [_p, _p, _i64, _i32, _p, _i64, _i64, _p]),
     "tarl_fused_export": (C.c_int, [_p, _p] + _STATE + [_f32, _p]),
@@ -109,7 +112,7 @@ class FusedStruct(C.Structure):
                                            "a_dep", "a_status", "a_order", "cur_lo", "a_dep_sorted", "a_win", "a_ins",
                                            "a_rank")] +
                 [("acc_slots", C.c_int64), ("flags", C.c_void_p), ("env_base", C.c_int64), ("due_rate", C.c_float),
-                 ("reserved_", C.c_int32)])
+                 ("reserved_", C.c_int32), ("bufs_dev", C.c_void_p)])
 
 
 FLAG_COUNT_AT_NMAX, FLAG_AMBIGUOUS_EDGES, FLAG_PACK_RANGE, FLAG_CHOICE_OVERFLOW = 1, 2, 4, 8

@@ -419,8 +419,12 @@ def policy_edge_logits_bwd(plan: Plan, node_features, grad_logits, num_embedding
     _contig(grad_logits, torch.float32, "grad_logits")
     col, B, bs, ns = _road_index_view(node_features, plan)
     grad_emb = torch.zeros(num_embeddings, dtype=torch.float32, device=grad_logits.device)
+    scratch = None
+    if bs == 0 and B >= 256:      # one observation broadcast over many rows: the row sum in parallel chunks
+        scratch = torch.empty(int(L.tarl_policy_edge_logits_bwd_scratch_floats(plan.handle, B)), dtype=torch.float32,
+                              device=grad_logits.device)
     _lib.check(L.tarl_policy_edge_logits_bwd(plan.handle, col.data_ptr(), bs, ns, B, grad_logits.data_ptr(),
-                                             grad_emb.data_ptr(), num_embeddings, _lib.current_stream()))
+                                             grad_emb.data_ptr(), num_embeddings, _lib.ptr(scratch), _lib.current_stream()))
     return grad_emb
 
 
@@ -608,7 +612,7 @@ def critic_backward(cw: CriticWeights, counts, time_rows, rows_per_time, h1, h2,
     L = _lib.load()
     M = counts.size(0)
     _contig(grad_value, torch.float32, "grad_value")
-    scratch = torch.empty((2, M, 64), dtype=torch.float32, device=counts.device)
+    scratch = torch.empty(int(L.tarl_critic_mlp_bwd_scratch_floats(M, cw.N)), dtype=torch.float32, device=counts.device)
     gw1, gb1, gw2, gb2, gw3, gb3 = (_contig(g, torch.float32, "grad") for g in grads)
     _lib.check(L.tarl_critic_mlp_bwd(counts.data_ptr(), counts.stride(0), M, cw.N, time_rows.data_ptr(), rows_per_time,
                                      cw.w1.data_ptr(), cw.w2.data_ptr(), cw.w3.data_ptr(), h1.data_ptr(), h2.data_ptr(),
@@ -718,6 +722,8 @@ class FusedState:
         self.a_ins = torch.zeros((B, A), dtype=torch.uint8, device=device)
         self.a_rank = torch.zeros((B, A), **i32)
         self.flags = torch.zeros(1, **i32)
+        # the library's device-resident copy of the pointer table below (include/tarl_hip.h: tarl_fused.bufs_dev)
+        self.bufs_dev = torch.zeros(int(L.tarl_fused_bufs_bytes()), dtype=torch.uint8, device=device)
         self.order_valid = False
         self.struct = _lib.FusedStruct(self.hdp.data_ptr(), self.tl.data_ptr(), self.gc8.data_ptr(),
                                        self.post.data_ptr(), self.st0.data_ptr(), self.slots.data_ptr(), self.ld_slots,
@@ -726,7 +732,7 @@ class FusedState:
                                        self.acc_lp.data_ptr(), self.acc_n.data_ptr(), self.acc_w.data_ptr(),
                                        self.a_origin.data_ptr(), self.a_dest.data_ptr(), self.a_dep.data_ptr(),
                                        self.a_status.data_ptr(), None, self.cur_lo.data_ptr(), None, None, None, None,
-                                       self.acc_slots, self.flags.data_ptr(), int(env_base), 0.0, 0)
+                                       self.acc_slots, self.flags.data_ptr(), int(env_base), 0.0, 0, self.bufs_dev.data_ptr())
         self.B, self.N, self.A, self.Nmax, self.env_base = B, N, A, Nmax, int(env_base)
 
     # -- unpacked views of the dense words (tests / debugging; torch plumbing, never on a hot path) ----------------------

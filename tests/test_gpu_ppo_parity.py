@@ -34,7 +34,8 @@ def test_critic_golden(ops):
     assert torch.allclose(vb.cpu(), g["value_b"].view(-1), rtol=TOL, atol=TOL)
 
 
-@pytest.mark.parametrize("M,N,rpt", [(1, 24, 1), (37, 256, 1), (300, 2500, 4), (129, 31, 1)])
+# (the last two: the chunked backward for many rows, csrc/critic.hip CB_MANY_ROWS = 512 — whole and ragged chunks)
+@pytest.mark.parametrize("M,N,rpt", [(1, 24, 1), (37, 256, 1), (300, 2500, 4), (129, 31, 1), (1024, 333, 8), (777, 70, 1)])
 def test_critic_fwd_bwd_vs_autograd(ops, M, N, rpt):
     from oracle import nets
     gen = torch.Generator().manual_seed(M * 7 + N)
@@ -128,3 +129,31 @@ def test_adam_matches_torch_optim(ops):
         opt.step()
         ops.adam_step_(q, dev(grad), m, v, step)
         assert torch.allclose(q.cpu(), p.detach(), rtol=1e-6, atol=1e-7), f"step {step}"
+
+
+@pytest.mark.parametrize("B", [8, 300, 1000])
+def test_policy_logits_backward_many_rows_vs_autograd(ops, B):
+    """tarl_policy_edge_logits_bwd: the reference's live head (logit = embedding of the target road,
+    src/agents/mpnn_agent.py:215-217) differentiated over B batch rows that share ONE observation (the optimiser minibatch:
+    a broadcast view, stride 0) — from 256 rows on through the row-chunked kernels — against torch autograd; twice the same bits."""
+    from tarl_hip import synth
+    net = synth.torus_network(5, 4, heterogeneous=True, seed=2)
+    N, E = net.num_roads, net.edge_index.size(1)
+    plan = ops.Plan(net.edge_index, N)
+    gen = torch.Generator().manual_seed(B)
+    emb = torch.randn(N, generator=gen, requires_grad=True)
+    g = torch.randn((B, E), generator=gen)
+    nf = net.x[:, 3 * net.Nmax:].cuda()
+    nfb = nf.unsqueeze(0).expand(B, N, 7)
+    assert nfb.stride(0) == 0
+    logits = ops.policy_edge_logits(plan, nfb, emb.detach().cuda())
+    ref = emb[net.x[:, 3 * net.Nmax + 6].long()][net.edge_index[1]].unsqueeze(0).expand(B, E)
+    assert torch.equal(logits.cpu(), ref.detach())
+    (ref * g).sum().backward()
+    ge = ops.policy_edge_logits_bwd(plan, nfb, g.cuda(), N)
+    scale = max(1.0, float(emb.grad.abs().max()))
+    assert float((ge.cpu() - emb.grad).abs().max()) <= 1e-5 * scale
+    assert torch.equal(ge, ops.policy_edge_logits_bwd(plan, nfb, g.cuda(), N))
+    # the same rows as separate observations (batch stride != 0): the per-row kernel, same gradient
+    gs = ops.policy_edge_logits_bwd(plan, nfb.contiguous(), g.cuda(), N)
+    assert float((gs - ge).abs().max()) <= 1e-5 * scale

@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/.."
 REPS=2
 if [ "$1" = "-r" ]; then REPS=$2; shift 2; fi
-Q="--steps 4 --warmup 1 --cpu-seconds 0 --policy-envs 0 --congested-steps 2 $BENCH_ARGS"
+Q="--steps 4 --warmup 1 --cpu-seconds 0 --policy-envs 0 --config5-envs 0 --update-epochs 0 --congested-steps 2 --details '' $BENCH_ARGS"
 for i in $(seq $REPS); do
   for tag in "$@"; do
     if [ $tag = base ]; then L=""; else L="$PWD/tmp_ab/libtarl_hip_$tag.so"; fi
