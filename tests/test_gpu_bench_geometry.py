@@ -232,6 +232,87 @@ def test_bench_rollout_replayed_by_the_oracle_with_the_device_noise():
     assert flips <= 30, f"{flips} one-hot entries differ between the device draw and GraphDist.sample on the device's uniforms"
 
 
+@pytest.mark.parametrize("precision,lp_tol", [("x3", 1e-4), ("bf16", 1e-3)])
+def test_state_dependent_policy_rollout_replayed_by_the_oracle(precision, lp_tol):
+    """The bench's ``state_dependent_policy`` geometry — config 4, B = 2 048, the per-edge MLP head (33 -> 64 -> 32 -> 1, the
+    reference's own ``edge_mlp`` initialisation) evaluated on the matrix cores in every frame, GraphDistribution temperature
+    2 000, ``tarl_fused_rollout_policy`` — next to the ORACLE: for environments {0, 1 023, 2 047} every frame's observation is
+    rebuilt from the oracle's own state (``cat(node_features, agent_features[head])``, src/agents/mpnn_agent.py:166-178), the
+    head evaluated with ``oracle/nets.edge_mlp_logits`` (:35-41, :227-231) and ``GraphDist.log_prob`` of the device's action
+    compared with the device's stored log-prob (1e-4 of its magnitude for the fp32-accurate kernel, 1e-3 for bf16 logits:
+    a log-prob is a 2 500-term sum); then ``oracle/sim.env_step`` advances with the device's action and the Gumbel values the
+    kernels consumed: per-node counts, rewards and leg histogram of every frame, final ``x`` and agents bit-exact."""
+    from oracle import dist, nets, sim
+    from src.agents.mpnn_agent import MPNNPolicyNet
+    from tarl_hip import ops, synth
+    from tarl_hip.engine import EPISODE_START, SimEngine
+    B, A, T, TEMP = 2048, 16384, 64, 2000.0
+    probe = [0, 1023, 2047]
+    net = synth.torus_network(25, 25)
+    N, E, Nmax = net.num_roads, net.edge_index.size(1), net.Nmax
+    pops = synth.population_batch(A, N, B, seed=21, device="cuda", t1=EPISODE_START + 300)
+    eng = SimEngine(net.x.cuda().unsqueeze(0).repeat(B, 1, 1).contiguous(), net.edge_index, net.edge_attr, Nmax,
+                    pops.clone(), congestion_constant=net.congestion_constant, seed=29)
+    eng.reset()
+    torch.manual_seed(1)
+    pol = MPNNPolicyNet(net.edge_index, N, None, device="cuda")
+    ws = [pol.edge_mlp[0].weight, pol.edge_mlp[0].bias, pol.edge_mlp[2].weight, pol.edge_mlp[2].bias,
+          pol.edge_mlp[4].weight, pol.edge_mlp[4].bias]
+    w = ops.EdgeMlpWeights(*(p.data for p in ws))
+    ws_cpu = [p.detach().cpu() for p in ws]
+    z8 = lambda *shp: torch.zeros(shp, dtype=torch.uint8, device="cuda")
+    ch, ct = z8(T, B, N), z8(T + 1, N, B)
+    lp, rw = torch.zeros((T, B), device="cuda"), torch.zeros((T, B), device="cuda")
+    leg = torch.zeros((T, B, 2), dtype=torch.int32, device="cuda")
+    noise0 = eng.noise_counter + 1
+    eng.rollout_policy(T, w, precision=precision, temperature=TEMP, policy_seed=77, policy_counter0=5, choice8=ch, log_prob=lp,
+                       reward=rw, counts=ct, leg=leg)
+    eng.check_flags()
+    assert float(-rw[-1].mean()) > 500 and bool(torch.isfinite(lp).all())
+    pidx = torch.tensor(probe, device="cuda")
+    ch_p, ct_p = ch[:, pidx].cpu(), ct[:, :, pidx].cpu()                    # (T, 3, N) env-major, (T + 1, N, 3)
+    lp_p, rw_p, leg_p = lp[:, pidx].cpu(), rw[:, pidx].cpu(), leg[:, pidx].cpu()
+    x_fin = torch.stack([eng.x[b] for b in probe]).cpu()
+    ag_fin = torch.stack([eng.agents[b] for b in probe]).cpu()
+    src = net.edge_index[0]
+    out_eid = torch.argsort(src, stable=True)
+    out_ptr = torch.zeros(N + 1, dtype=torch.long)
+    out_ptr[1:] = torch.cumsum(torch.bincount(src, minlength=N), 0)
+    adj = net.dense_adjacency()
+    c = sim.Cols(Nmax)
+    n_pops = 0
+    for k, b in enumerate(probe):
+        x = net.x.clone()
+        x[:, :3 * Nmax] = 0
+        x[:, c.N] = 0
+        ag = pops[b].cpu().clone()
+        ag[:, sim.ON_WAY] = 0
+        ag[:, sim.DONE] = 0
+        for t in range(T):
+            clock = float(EPISODE_START + t)
+            nf, head = sim.observe(x, Nmax)
+            x16 = torch.cat((nf, ag[head.clamp(0, A)]), dim=-1)
+            gd = dist.GraphDist(nets.edge_mlp_logits(x16, net.edge_index, net.edge_attr, *ws_cpu), net.edge_index, TEMP)
+            code = ch_p[t, k].long()
+            assert bool((code < 4).all())                              # every road drew one of its four out-edges
+            action = torch.zeros(E, dtype=torch.long)
+            action[out_eid[out_ptr[:-1] + code]] = 1
+            lp_o = float(gd.log_prob(action))
+            assert abs(float(lp_p[t, k]) - lp_o) <= lp_tol * max(1.0, abs(lp_o)), (b, t, float(lp_p[t, k]), lp_o)
+            g = ops.noise_export(eng.plan, "gumbel", eng.seed, noise0 + t, [b])[0].cpu()
+            before = ((ag[:, sim.ON_WAY] + ag[:, sim.DONE]) > 0).sum(), (ag[:, sim.DONE] > 0).sum()
+            out = sim.env_step(x, ag, net.edge_index, net.edge_attr, adj, action, clock, Nmax, gumbel=g,
+                               congestion_constant=net.congestion_constant)
+            n_pops += int(out["popped"].sum())
+            assert torch.equal(x[:, c.N], ct_p[t + 1, :, k].float()), f"counts of environment {b} after frame {t}"
+            assert float(out["reward"]) == float(rw_p[t, k]), f"reward of environment {b}, frame {t}"
+            after = ((ag[:, sim.ON_WAY] + ag[:, sim.DONE]) > 0).sum(), (ag[:, sim.DONE] > 0).sum()
+            assert [int(after[0] - before[0]), int(after[1] - before[1])] == leg_p[t, k].tolist(), f"leg histogram, environment {b}, frame {t}"
+        assert torch.equal(x, x_fin[k]), f"final state of environment {b}"
+        assert torch.equal(ag, ag_fin[k]), f"agent table of environment {b}"
+    assert n_pops > 300, n_pops
+
+
 def test_two_half_batches_reproduce_the_whole_batch():
     """What two data-parallel ranks simulate (each its half of the environments, env_base = rank * B / 2, one seed) is
     bit-identical to one rank simulating all of them."""

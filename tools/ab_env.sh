@@ -4,10 +4,10 @@
 cd "$(dirname "$0")/.."
 REPS=2
 if [ "$1" = "-r" ]; then REPS=$2; shift 2; fi
-Q="--steps 3 --warmup 1 --cpu-seconds 0 --policy-envs 0 --congested-window 0 $BENCH_ARGS"
+Q="--steps 4 --warmup 1 --cpu-seconds 0 --policy-envs 0 --config5-envs 0 --update-epochs 0 --congested-steps 2 --details '' $BENCH_ARGS"
 for i in $(seq $REPS); do
   for kv in "$@"; do
     printf "%-28s " "$kv"
-    env $kv python bench.py $Q 2>/dev/null | python tools/bench_brief.py
+    eval env $kv python bench.py $Q 2>/dev/null | python tools/bench_brief.py
   done
 done
