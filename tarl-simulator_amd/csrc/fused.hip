@@ -1300,164 +1300,6 @@ __global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
   }
 }
 
-// ---- the row pass with the NEEDY rows compacted (round 5) --------------------------------------------------------------------
-// k_fused_rows spends ~100 vector instructions on every (row, environment) pair, whatever the pair turns out to be — and in a
-// filling network 85 % of the pairs are empty rows that idled: their post word is zero and the pass owes them one count byte.
-// A lane cannot skip work its neighbours in the wave still do, so the saving has to come from compaction, the trick the event
-// path already uses one level down: phase A0 (every pair) reads the post words, stores the count byte 0 of the rows that need
-// nothing else, and LISTS the rows that carry a flag (arrival, somebody queued, the tail word's event flag) in LDS — wave-
-// aggregated appends, so a wave-row's entries stay consecutive and their loads coalesced; phase A1 walks that list densely,
-// one lane per listed row, through the very same row_phase_a (head / tail words, Response test, idle / event decision) and
-// lists the event rows as before; phase B is unchanged. Same functions on the same words: bit-identical to k_fused_rows.
-// In a loaded network (three quarters of the rows listed) A1 runs three rounds instead of four straight-line rows.
-// Sibling row chunks (NCH = 4, the plan's row-chunk table) and the rollout instantiation (no frame-API outputs) only.
-template <bool O32>
-__global__ __launch_bounds__(TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fused_rows_c(
-    const NodeRec* __restrict__ nodes, const int32_t* __restrict__ out_pad, const int32_t* __restrict__ out_ptr,
-    const int32_t* __restrict__ out_dst, const RowChunk* __restrict__ rchunks, const uint32_t* __restrict__ post, int Nmax,
-    uint32_t B, uint32_t N, const FusedBufs* __restrict__ fbp, float* __restrict__ ag, int64_t A, int64_t a_bstride, float t,
-    FrameOut out) {
-  constexpr int NCH = 4;
-  const FusedBufs& fb = *fbp;
-  __shared__ int32_t s_need, s_cnt;
-  __shared__ uint16_t s_nitem[TILE * NCH];  // listed rows: (row offset in the chunk) << 8 | lane
-  __shared__ uint32_t s_npa[TILE * NCH];    // ... and their post words
-  __shared__ uint4 s_pj[TILE];              // the chunk's four downstream post words of every environment of the tile
-  __shared__ uint16_t s_item[TILE];         // a round's event rows: (row offset in the chunk) << 9 | pop << 8 | lane
-  __shared__ uint4 s_words[TILE];           // ... and their {post word, hd, head_dep bits, tl}
-  const int tid = threadIdx.x, lane = tid & 63;
-  const uint32_t b = blockIdx.x * blockDim.x + tid;
-  const bool valid = b < B;
-  const RowChunk& rc = rchunks[blockIdx.y];
-  int32_t ri[NCH];
-  bool live[NCH];
-#pragma unroll
-  for (int r = 0; r < NCH; ++r) {
-    live[r] = rc.row[r] >= 0;
-    ri[r] = live[r] ? rc.row[r] : rc.row[0];   // a missing row is loaded as the first one and never used
-  }
-  RowStat rs[NCH];
-#pragma unroll
-  for (int r = 0; r < NCH; ++r) {
-    const NodeRec& nr = nodes[ri[r]];
-    rs[r] = RowStat{nr.out_deg, nr.out0, nr.tt0, nr.maxn};
-  }
-  if (tid == 0) {
-    s_need = 0;
-    s_cnt = 0;
-  }
-  __syncthreads();
-  // ---- phase A0: post words of every pair; the rows without a flag are done here
-  {
-    uint32_t pa[NCH];
-    uint4 pjv = make_uint4(0u, 0u, 0u, 0u);
-    if (valid) {
-#pragma unroll
-      for (int r = 0; r < NCH; ++r) pa[r] = at32<O32>(post, (uint32_t)ri[r] * B + b);
-      const int32_t* od = rc.out4;
-      pjv.x = at32<O32>(post, (uint32_t)od[0] * B + b);
-      pjv.y = at32<O32>(post, (uint32_t)od[1] * B + b);
-      pjv.z = at32<O32>(post, (uint32_t)od[2] * B + b);
-      pjv.w = at32<O32>(post, (uint32_t)od[3] * B + b);
-    }
-    bool any = false;
-#pragma unroll
-    for (int r = 0; r < NCH; ++r) {
-      // a row is listed when its post word carries a flag; rows that small that their empty state is visible to the Direction
-      // tests (MAX_NUMBER_OF_AGENT <= 3: they keep the eager head word) and one-slot FIFOs always are (wave-uniform terms)
-      const bool need = valid & live[r] &
-                        ((Nmax < 2) | (rs[r].maxn <= TARL_CONGESTION_FILE) | ((pa[r] & (PF_ARRIVED | PF_NONEMPTY | PF_TLAUTH)) != 0u));
-      const unsigned long long m = __ballot(need);
-      if (m != 0ull) {      // (wave-uniform) one LDS atomic per wave and row: the wave's entries stay consecutive, in lane order
-        const int leader = __ffsll((long long)m) - 1;
-        int32_t base = 0;
-        if (lane == leader) base = atomicAdd(&s_need, (int32_t)__popcll(m));
-        base = __shfl(base, leader);
-        if (need) {
-          const int32_t pos = base + (int32_t)__popcll(m & ((1ull << lane) - 1ull));
-          s_nitem[pos] = (uint16_t)((r << 8) | tid);
-          s_npa[pos] = pa[r];
-        }
-      }
-      any = any | need;
-      if (valid & live[r] & !need) {     // empty, idle, flag-free: the row's whole share of the pass is its count byte (and log)
-        const uint32_t row = (uint32_t)ri[r] * B + b;
-        if (out.counts8) __builtin_nontemporal_store((uint8_t)0, &at32<O32>(out.counts8, row));
-        if (out.events && b < (uint32_t)out.m_env) out.events[(int64_t)ri[r] * out.m_env + b] = 0;
-      }
-    }
-    if (any) s_pj[tid] = pjv;
-  }
-  __syncthreads();
-  // ---- phase A1 / B in rounds of one listed row per lane: head / tail words, Response test, idle / event decision
-  // (row_phase_a); the round's event rows (at most one per lane: the list cannot overflow, so there is no in-place fall-back
-  // and ONE copy of the event path in the kernel) are listed and served behind a barrier, one lane each (row_phase_b). A row
-  // reads no other row's dense words inside this kernel, so the rounds do not see each other.
-  const int64_t bank0 = (int64_t)(blockIdx.y % (unsigned)fb.acc_slots) * B;
-  const int32_t ncnt = s_need;
-  for (int32_t base = 0; base < ncnt; base += (int32_t)blockDim.x) {
-    const int32_t idx = base + tid;
-    if (idx < ncnt) {
-      const uint32_t item = s_nitem[idx];
-      const uint32_t r = item >> 8, lane2 = item & 255u;
-      const uint32_t pa = s_npa[idx];
-      const uint4 pjv = s_pj[lane2];
-      const uint32_t b2 = blockIdx.x * blockDim.x + lane2;
-      int32_t i2 = ri[0];
-      RowStat rs2 = rs[0];
-#pragma unroll
-      for (int q = 1; q < NCH; ++q) {
-        const bool is = r == (uint32_t)q;
-        i2 = is ? ri[q] : i2;
-        rs2.out_deg = is ? rs[q].out_deg : rs2.out_deg;
-        rs2.out0 = is ? rs[q].out0 : rs2.out0;
-        rs2.tt0 = is ? rs[q].tt0 : rs2.tt0;
-        rs2.maxn = is ? rs[q].maxn : rs2.maxn;
-      }
-      const uint32_t row = (uint32_t)i2 * B + b2;
-      uint2 hp = make_uint2(0u, 0u);
-      uint32_t tlw = 0u;
-      if (Nmax < 2 || (pa & (PF_ARRIVED | PF_NONEMPTY | PF_TLAUTH))) {   // (as k_fused_rows: a flag-free row's words are not fetched)
-        hp = at32<O32>(fb.hdp, row);
-        tlw = at32<O32>(fb.tl, row);
-      }
-      const uint32_t pj4[4] = {pjv.x, pjv.y, pjv.z, pjv.w};
-      bool pop;
-      float n = 0.0f;
-      const bool ev = row_phase_a<false, O32>((uint32_t)i2, b2, rs2, post, pa, hp, tlw, pj4, Nmax, B, N, fb, A, t, out, &pop, &n);
-      if (ev) {
-        const int32_t pos = atomicAdd(&s_cnt, 1);     // < blockDim.x <= TILE
-        s_item[pos] = (uint16_t)((r << 9) | (pop ? 256u : 0u) | lane2);
-        s_words[pos] = make_uint4(pa, hp.x, hp.y, tlw);
-      }
-      // the row's share of the environment's count sum (small integers: exact in fp32 in any order)
-      if (n != 0.0f) atomicAdd(&fb.acc_n[bank0 + b2], n);
-    }
-    __syncthreads();
-    const int32_t cnt = s_cnt;
-    if (tid < cnt) {
-      const uint32_t item = s_item[tid];
-      const uint32_t r = item >> 9, lane2 = item & 255u;
-      const uint4 wd = s_words[tid];
-      const uint32_t b2 = blockIdx.x * blockDim.x + lane2;
-      int32_t i2 = ri[0];
-#pragma unroll
-      for (int q = 1; q < NCH; ++q) i2 = (r == (uint32_t)q) ? ri[q] : i2;
-      const float2 nc = row_phase_b<false>((uint32_t)i2, b2, (item & 256u) != 0u, wd.x, make_uint2(wd.y, wd.z), wd.w, nodes[i2],
-                                           out_ptr, out_dst, Nmax, B, N, fb, ag, A, a_bstride, t, out);
-      if (nc.y != 0.0f) {      // withdrawn agents leave the count sum
-        atomicAdd(&fb.acc_n[bank0 + b2], -nc.y);
-        atomicAdd(&fb.acc_w[bank0 + b2], nc.y);
-      }
-    }
-    if (base + (int32_t)blockDim.x < ncnt) {      // (block-uniform) another round: re-arm the event list behind its readers
-      __syncthreads();
-      if (tid == 0) s_cnt = 0;
-      __syncthreads();
-    }
-  }
-}
-
 // ---- insert + reward + log-prob reduction (one wave per environment) -----------------------------------------------------
 __device__ __forceinline__ bool fused_target(const FusedBufs& fb, PlanOut P, const uint8_t* __restrict__ sel8, int64_t b,
                                              int64_t B, int64_t N, int32_t origin, int32_t* road, int32_t* cap) {
@@ -2313,21 +2155,6 @@ static int launch_rows(dim3 grid, unsigned threads, hipStream_t s, const tarl_pl
   const bool fapi = out.countsf || out.popped || out.withdrawn;
   const bool o32 = addr32_ok() && plan->N * B < ((int64_t)1 << 29);   // 8-byte words through 32-bit byte offsets
   grid.y = (unsigned)num_row_chunks(plan);
-  // the compacted form (k_fused_rows_c) on sibling row chunks, rollout instantiation; TARL_ROWS_COMPACT=0 keeps the
-  // straight-line form (developer knob: the two are bit-identical, tests/test_gpu_fused.py runs both)
-  static const bool compact_ok = !(getenv("TARL_ROWS_COMPACT") && atoi(getenv("TARL_ROWS_COMPACT")) == 0);
-  if (compact_ok && !fapi && rows_sib(plan)) {
-    if (o32)
-      hipLaunchKernelGGL(k_fused_rows_c<true>, grid, dim3(threads), 0, s, (const NodeRec*)f->node_rec, (const int32_t*)f->out_pad,
-                         plan->out_ptr, plan->out_dst, (const RowChunk*)plan->row_chunks, (const uint32_t*)f->post, Nmax,
-                         (uint32_t)B, (uint32_t)plan->N, fb, agent_features, A, a_bstride, time, out);
-    else
-      hipLaunchKernelGGL(k_fused_rows_c<false>, grid, dim3(threads), 0, s, (const NodeRec*)f->node_rec, (const int32_t*)f->out_pad,
-                         plan->out_ptr, plan->out_dst, (const RowChunk*)plan->row_chunks, (const uint32_t*)f->post, Nmax,
-                         (uint32_t)B, (uint32_t)plan->N, fb, agent_features, A, a_bstride, time, out);
-    TARL_LAUNCH_CHECK();
-    return TARL_OK;
-  }
   switch (nchunk()) {
     case 1: ROWS_LAUNCH(1, false); break;
     case 2: ROWS_LAUNCH(2, false); break;

@@ -268,7 +268,9 @@ def test_state_dependent_policy_rollout_replayed_by_the_oracle(precision, lp_tol
     eng.rollout_policy(T, w, precision=precision, temperature=TEMP, policy_seed=77, policy_counter0=5, choice8=ch, log_prob=lp,
                        reward=rw, counts=ct, leg=leg)
     eng.check_flags()
-    assert float(-rw[-1].mean()) > 500 and bool(torch.isfinite(lp).all())
+    # (a node whose uniform lands beyond its last fp32 threshold draws nothing, ~1e-7 per draw: a handful of the 3e8 draws here
+    # make their frame's action infeasible, log_prob = -inf, as in the reference, src/reinforcement_learning.py:88-92)
+    assert float(-rw[-1].mean()) > 500 and float(torch.isfinite(lp).float().mean()) > 0.999
     pidx = torch.tensor(probe, device="cuda")
     ch_p, ct_p = ch[:, pidx].cpu(), ct[:, :, pidx].cpu()                    # (T, 3, N) env-major, (T + 1, N, 3)
     lp_p, rw_p, leg_p = lp[:, pidx].cpu(), rw[:, pidx].cpu(), leg[:, pidx].cpu()
@@ -294,11 +296,15 @@ def test_state_dependent_policy_rollout_replayed_by_the_oracle(precision, lp_tol
             x16 = torch.cat((nf, ag[head.clamp(0, A)]), dim=-1)
             gd = dist.GraphDist(nets.edge_mlp_logits(x16, net.edge_index, net.edge_attr, *ws_cpu), net.edge_index, TEMP)
             code = ch_p[t, k].long()
-            assert bool((code < 4).all())                              # every road drew one of its four out-edges
+            drew = (code & 0x80) == 0
+            assert bool((code[drew] < 4).all())                        # rank of one of the road's four out-edges
             action = torch.zeros(E, dtype=torch.long)
-            action[out_eid[out_ptr[:-1] + code]] = 1
+            action[out_eid[out_ptr[:-1][drew] + code[drew]]] = 1
             lp_o = float(gd.log_prob(action))
-            assert abs(float(lp_p[t, k]) - lp_o) <= lp_tol * max(1.0, abs(lp_o)), (b, t, float(lp_p[t, k]), lp_o)
+            if bool(drew.all()):
+                assert abs(float(lp_p[t, k]) - lp_o) <= lp_tol * max(1.0, abs(lp_o)), (b, t, float(lp_p[t, k]), lp_o)
+            else:
+                assert float(lp_p[t, k]) == float("-inf") and lp_o == float("-inf")
             g = ops.noise_export(eng.plan, "gumbel", eng.seed, noise0 + t, [b])[0].cpu()
             before = ((ag[:, sim.ON_WAY] + ag[:, sim.DONE]) > 0).sum(), (ag[:, sim.DONE] > 0).sum()
             out = sim.env_step(x, ag, net.edge_index, net.edge_attr, adj, action, clock, Nmax, gumbel=g,

@@ -305,13 +305,11 @@ def test_rollout_launcher_equals_frame_loop(ops, monkeypatch, B, T, merge):
 
 
 @pytest.mark.parametrize("knob", ["TARL_INSERT_EPW=1", "TARL_INSERT_EPW=2", "TARL_INSERT_EPW=8", "TARL_INSERT_PAIR=0",
-                                  "TARL_CHOICE_QUAD=0", "TARL_DIR_SIBLINGS=0", "TARL_ADDR32=0", "TARL_ROWS_SIBLINGS=0",
-                                  "TARL_ROWS_COMPACT=0"])
+                                  "TARL_CHOICE_QUAD=0", "TARL_DIR_SIBLINGS=0", "TARL_ADDR32=0", "TARL_ROWS_SIBLINGS=0"])
 def test_rollout_launcher_developer_knobs(ops, knob):
     """The rollout's kernel variants that a developer knob selects once per process (environments per wave of the insert
     kernel, the one-node-per-step action draw, per-row Direction gathers on a sibling graph, 64-bit addresses in the frame
-    kernels — what batches of 2^29 pairs and more run —, consecutive row chunks, the straight-line row pass instead of the
-    compacted one): each must pass the rollout-vs-frame-loop
+    kernels — what batches of 2^29 pairs and more run —, consecutive row chunks): each must pass the rollout-vs-frame-loop
     comparison in a process of its own."""
     import os
     import subprocess

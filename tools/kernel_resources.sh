@@ -9,7 +9,7 @@ T=$(mktemp -d)
 python3 - $T <<'PY'
 import re, sys, glob
 T = sys.argv[1]
-want = {"_Z14k_fused_rows_cILb1EE": "k_fused_rows_c<O32> (compacted)", "_Z12k_fused_rowsILi4ELb1ELb0ELb1EE": "k_fused_rows<4,SIB,rollout,O32>", "_Z17k_fused_directionILi4ELb1ELb1ELb1EE": "k_fused_direction<4,SIB,CNT,O32>",
+want = {"_Z12k_fused_rowsILi4ELb1ELb0ELb1EE": "k_fused_rows<4,SIB,rollout,O32>", "_Z17k_fused_directionILi4ELb1ELb1ELb1EE": "k_fused_direction<4,SIB,CNT,O32>",
         "_Z15k_fused_insert2ILi8EE": "k_fused_insert2<8>", "_Z15k_fused_insert2ILi2EE": "k_fused_insert2<2>", "_Z14k_fused_insertill": "k_fused_insert"}
 txt = open(T + "/remarks.txt").read()
 blocks = re.split(r"Function Name: ", txt)[1:]
