@@ -47,6 +47,20 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
   return (uint16_t)(u >> 16);
 }
 
+// One agent row (9 floats, 36 bytes at a 4-byte-aligned address) as two 16-byte loads and one dword instead of nine dwords:
+// every lane gathers from a line of its own here, so the texture-address unit pays per INSTRUCTION (64 lines each), not
+// per byte — nine scattered dword gathers per (road, environment) pair were the observation kernels' bound (round 5).
+struct __attribute__((packed, aligned(4))) AgF4 {
+  float x, y, z, w;
+};
+__device__ __forceinline__ void load_agent_row(const float* __restrict__ arow, float (&a)[9]) {
+  const AgF4 v0 = *reinterpret_cast<const AgF4*>(arow);
+  const AgF4 v1 = *reinterpret_cast<const AgF4*>(arow + 4);
+  a[0] = v0.x; a[1] = v0.y; a[2] = v0.z; a[3] = v0.w;
+  a[4] = v1.x; a[5] = v1.y; a[6] = v1.z; a[7] = v1.w;
+  a[8] = arow[8];
+}
+
 // ---- obs16: x = cat(node_features, agent_features[agent_index]) from the packed state of the fused engine ----------------
 // node_features = x[:, 3*Nmax:] = {MAX, NUMBER_OF_AGENT, FREE_FLOW, LENGTH, MAX_FLOW, SELECTED_ROAD, ROAD_INDEX}
 // (TransportationSimulator.state, src/transportation_simulator.py:360-366); agent_index = the head-of-FIFO id.
@@ -73,11 +87,13 @@ __global__ __launch_bounds__(256) void k_obs16_packed(const int32_t* __restrict_
       const float* xs = x0 + i * L.ldx;     // static columns: environment 0 speaks for all
       const long long head = (long long)(hd >> 8);
       const float* arow = ag + b * a_bstride + ((head >= 0 && head < A) ? head : 0) * AG_COLS;
+      float ar[9];
+      load_agent_row(arow, ar);
       float4* o = reinterpret_cast<float4*>(sm + bl * OB_LD + il * 16);
       o[0] = make_float4(st.x, (float)(hd & HD_CNT), st.y, xs[L.col_maxn() + 3]);
-      o[1] = make_float4(xs[L.col_maxflow()], sel_value(fb, out_ptr, out_dst, i, gid), st.z, arow[0]);
-      o[2] = make_float4(arow[1], arow[2], arow[3], arow[4]);
-      o[3] = make_float4(arow[5], arow[6], arow[7], arow[8]);
+      o[1] = make_float4(xs[L.col_maxflow()], sel_value(fb, out_ptr, out_dst, i, gid), st.z, ar[0]);
+      o[2] = make_float4(ar[1], ar[2], ar[3], ar[4]);
+      o[3] = make_float4(ar[5], ar[6], ar[7], ar[8]);
     }
   }
   __syncthreads();
@@ -114,9 +130,11 @@ __global__ __launch_bounds__(256) void k_obs16_packed_bf16(const int32_t* __rest
       const float* xs = x0 + i * L.ldx;
       const long long head = (long long)(hd >> 8);
       const float* arow = ag + b * a_bstride + ((head >= 0 && head < A) ? head : 0) * AG_COLS;
+      float ar[9];
+      load_agent_row(arow, ar);
       const float v[16] = {st.x, (float)(hd & HD_CNT), st.y, xs[L.col_maxn() + 3], xs[L.col_maxflow()],
-                           sel_value(fb, out_ptr, out_dst, i, gid), st.z, arow[0], arow[1], arow[2], arow[3], arow[4],
-                           arow[5], arow[6], arow[7], arow[8]};
+                           sel_value(fb, out_ptr, out_dst, i, gid), st.z, ar[0], ar[1], ar[2], ar[3], ar[4],
+                           ar[5], ar[6], ar[7], ar[8]};
       uint4* o = reinterpret_cast<uint4*>(sm + bl * OBB_LD + il * 8);
       uint32_t w[8];
 #pragma unroll
@@ -153,11 +171,13 @@ __global__ __launch_bounds__(FB) void k_obs16_rows(const int32_t* __restrict__ o
   const float* xs = x0 + i * L.ldx;
   const long long head = (long long)(hd >> 8);
   const float* arow = ag + b * a_bstride + ((head >= 0 && head < A) ? head : 0) * AG_COLS;
+  float ar[9];
+  load_agent_row(arow, ar);
   float4* o = reinterpret_cast<float4*>(keep + ((int64_t)slot[blockIdx.y] * N + i) * 16);
   o[0] = make_float4(st.x, (float)(hd & HD_CNT), st.y, xs[L.col_maxn() + 3]);
-  o[1] = make_float4(xs[L.col_maxflow()], sel_value(fb, out_ptr, out_dst, i, gid), st.z, arow[0]);
-  o[2] = make_float4(arow[1], arow[2], arow[3], arow[4]);
-  o[3] = make_float4(arow[5], arow[6], arow[7], arow[8]);
+  o[1] = make_float4(xs[L.col_maxflow()], sel_value(fb, out_ptr, out_dst, i, gid), st.z, ar[0]);
+  o[2] = make_float4(ar[1], ar[2], ar[3], ar[4]);
+  o[3] = make_float4(ar[5], ar[6], ar[7], ar[8]);
 }
 
 // the same from the reference's tensors: node_features (M, N, >=7 cols, row stride nf_ld) + agent rows gathered by
