@@ -417,7 +417,9 @@ class VecPPOTrainer:
             lp_new, ent = ops.graphdist_logprob_entropy(eng.plan, proba, choice=choice_mb)
         cw = self._critic()
         with st("critic_fwd"):
-            value, h1, h2 = ops.critic_forward(cw, counts_mb, time_mb, 1, keep_hidden=True, split_k=M <= 512)
+            # split-K while the minibatch is far from filling the chip with 128-row MFMA tiles (M = 4 096: 32 workgroups walking
+            # all N columns alone took 743 us, bench.py's update_path; spread over the columns: see DESIGN §4.7)
+            value, h1, h2 = ops.critic_forward(cw, counts_mb, time_mb, 1, keep_hidden=True, split_k=M <= 16384)
         scale = 1.0 / self.world
         with st("ppo_loss"):
             out, g_lp, g_ent, g_val = ops.ppo_loss(lp_new, lp_old, adv_mb, value, tgt_mb, ent,

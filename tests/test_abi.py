@@ -75,5 +75,11 @@ def test_entry_points_reject_bad_arguments_on_the_host():
     assert L.tarl_fused_apply_choice(null, null, 1, null, null) == -1
     assert L.tarl_value_mpnn_fwd(null, null, 1, null, null, 0, null, null, null, null, null, null) == -1
     assert L.tarl_select_next_hop(null, 1, 0, 52, 15, 4, null, 1, 9, null, 0, null) == -1
+    # round 5's entry points: the noise export, the scratch sizes of the chunked backward kernels, the pointer table
+    assert L.tarl_noise_export(null, 0, 1, 1, null, 1, null, null) == -1 and b"null" in L.tarl_last_error()
+    assert L.tarl_critic_mlp_bwd_scratch_floats(0, 10) == -1 and L.tarl_critic_mlp_bwd_scratch_floats(32, 10) == 2 * 32 * 64
+    assert L.tarl_critic_mlp_bwd_scratch_floats(1024, 10) > 2 * 1024 * 64          # partial sums of the row chunks
+    assert L.tarl_policy_edge_logits_bwd_scratch_floats(null, 8) == -1
+    assert L.tarl_fused_bufs_bytes() >= 2 * 27 * 8
     ms_all, ms_late, n = (C.c_double * 3)(), (C.c_double * 3)(), (C.c_int64 * 2)()
     assert L.tarl_prof_collect(0, ms_all, ms_late, n) == 0 and n[0] == 0 and n[1] == 0

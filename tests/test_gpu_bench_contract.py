@@ -36,14 +36,14 @@ def test_bench_line_contract():
     assert abs(d["value"] - 512 * 256 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-4     # env-steps of the step / its time
     r = d["roofline"]                                   # the contract's object, in full
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "k_fused_rows"
-    assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 5e-4
     assert r["avg_launch_us"] > 0 and r["bytes_basis"] in ("pmc", "compulsory")
     # the committed PMC record is for the default size: at another size the compulsory bytes stand in, and say so
     assert (r["traffic"] is None) == (r["bytes_basis"] == "compulsory")
     for holder in (d, d["congested_regime"]):          # the other kernels / workloads: the same numbers under fewer keys
         for key in ("roofline_direction", "roofline_insert") + (("roofline",) if holder is not d else ()):
             q = holder[key]
-            assert 0.0 <= q["frac"] <= 1.0 and q["avg_launch_us"] > 0 and q["us_all"] > 0 and abs(q["frac"] - q["achieved"] / 8000.0) < 1e-4
+            assert 0.0 <= q["frac"] <= 1.0 and q["avg_launch_us"] > 0 and q["us_all"] > 0 and abs(q["frac"] - q["achieved"] / 8000.0) < 5e-4
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "env-steps/s" and c["sample"]
     assert d["congested_regime"]["value"] > 0 and d["value_rollout_only"] >= d["value"] * 0.9
