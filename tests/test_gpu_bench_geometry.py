@@ -243,6 +243,15 @@ def test_bench_rollout_replayed_by_the_oracle_with_the_device_noise():
     assert st["on_way"] > 2000 and st["moved"] > 0.05, st      # loaded, and moving
 
 
+def test_headline_rollout_replayed_by_the_oracle_with_the_device_noise():
+    """The bench's HEADLINE workload itself — departures spread over the whole 61-minute episode (≈4.5 agents due per frame:
+    eight environments per wave in the insert kernel), B = 16 384, 96 frames — replayed by the oracle for environments {0, 8 191, 16 383}."""
+    from tarl_hip import synth
+    st = _replay_live_policy_rollout(synth.torus_network(25, 25), B=16384, A=16384, T=96, probe=[0, 8191, 16383], window=3660,
+                                     pop_seed=41, eng_seed=43, emb_seed=8, min_pops=300, want_arrivals=False, max_flips=30)
+    assert st["on_way"] > 200, st
+
+
 def test_config5_rollout_replayed_by_the_oracle_with_the_device_noise():
     """The same replay on BASELINE config 5's graph and population — 100 000 route edges, 25 000 roads, 262 144 agents, the
     one-wave-per-environment insert — at B = 256, every agent departing within 300 s (≈870 due per frame: more than the insert
