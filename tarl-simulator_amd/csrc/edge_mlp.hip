@@ -263,76 +263,6 @@ struct ChunkWalk {
   }
 };
 
-// fp32: v_mfma_f32_32x32x2_f32, exact fp32 products. k runs [x_src 8h..8h+7] [x_dst 8h..8h+7] for half-wave h (8 + 8
-// k-steps of 2), then one k-step {edge_attr, 1} against {W1[:, 32], b1}: the bias enters the accumulation as an exact
-// product. 34 + 32 MFMAs per 32 edges: the matrix cores are the bound (66 x 16 passes).
-__global__ __launch_bounds__(EMR_WAVES * 64) void k_edge_mlp_fwd_f32(const int32_t* __restrict__ src,
-                                                                     const int32_t* __restrict__ dst, int64_t E,
-                                                                     int64_t N, int64_t M,
-                                                                     const float* __restrict__ obs,
-                                                                     const float* __restrict__ edge_attr, EdgeMlpW W,
-                                                                     float* __restrict__ logits) {
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the chunk walker lives in SGPRs
-  const int h = lane >> 5, j = lane & 31;
-  float w1a[2][17], w2a[32];
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int u = 32 * a + j;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      w1a[a][t] = W.w1[u * EM_IN + 8 * h + t];
-      w1a[a][8 + t] = W.w1[u * EM_IN + 16 + 8 * h + t];
-    }
-    w1a[a][16] = h == 0 ? W.w1[u * EM_IN + 32] : W.b1[u];
-  }
-#pragma unroll
-  for (int t = 0; t < 32; ++t) w2a[t] = W.w2[j * EM_H1 + 32 * (t >> 4) + emr_unit(t & 15, h)];
-  f32x16 b2r;
-  float w3r[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    b2r[r] = W.b2[emr_unit(r, h)];
-    w3r[r] = W.w3[emr_unit(r, h)];
-  }
-  const float b3 = W.b3[0];
-  const f32x16 zero = {0};
-  ChunkWalk cw;
-  if (!cw.init(E, M, wave)) return;
-  EdgeIn nxt = emr_load(src, dst, edge_attr, obs, (int32_t)E, N, cw.mn, cw.cn, lane);
-  for (; cw.g < cw.g1; ++cw.g) {
-    const EdgeIn cur = nxt;
-    cw.step();
-    if (cw.g + 1 < cw.g1) nxt = emr_load(src, dst, edge_attr, obs, (int32_t)E, N, cw.mn, cw.cn, lane);
-    const float xin[17] = {cur.s0.x, cur.s0.y, cur.s0.z, cur.s0.w, cur.s1.x, cur.s1.y, cur.s1.z, cur.s1.w,
-                           cur.d0.x, cur.d0.y, cur.d0.z, cur.d0.w, cur.d1.x, cur.d1.y, cur.d1.z, cur.d1.w,
-                           h == 0 ? cur.ea : 1.0f};
-    f32x16 acc0 = zero, acc1 = zero;
-#pragma unroll
-    for (int t = 0; t < 17; ++t) {
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1a[0][t], xin[t], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1a[1][t], xin[t], acc1, 0, 0, 0);
-    }
-    f32x16 c0 = b2r;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2a[t], emr_relu(acc0[t]), c0, 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < 16; ++t) c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2a[16 + t], emr_relu(acc1[t]), c0, 0, 0, 0);
-    float part = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) part = fmaf(emr_relu(c0[r]), w3r[r], part);
-    const float tot = part + __shfl_xor(part, 32);
-    const int32_t e = cw.c * 32 + j;
-    if (h == 0 && e < (int32_t)E) logits[(int64_t)cw.m * E + e] = tot + b3;
-  }
-}
-
-// ---- bf16: v_mfma_f32_32x32x16_bf16 ----------------------------------------------------------------------------------------
-// layer 1, k-steps of 16: [x_src 0..15] [x_dst 0..15] [edge_attr, 1, 1, 1, 0 ...]: the three ones meet the bias b1 split
-// into three bf16 pieces (hi + mid + lo == b1 exactly), i.e. the fp32 bias enters the fp32 accumulation unrounded.
-// Inputs, weights and the first hidden activation are rounded to bf16 (RNE); fp32 accumulation, fp32 second activation
-// and output: BASELINE config 5's "bf16 MPNN features" (tolerance stated in tests/test_gpu_edge_mlp.py). 6 + 4 MFMAs per
-// 32 edges; the vector ALU (conversions, ReLU, the output dot product) is the bound.
 // relu on eight bf16 at once: rounding keeps the sign, and a bf16 is negative exactly when its bit pattern is a negative
 // int16 — v_pk_max_i16 does two activations per instruction
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -354,28 +284,20 @@ __device__ __forceinline__ bf16x8 emr_pack(const float4 a, const float4 b) {
   return __builtin_bit_cast(bf16x8, p);
 }
 
-// Software pipeline of the bf16 kernel: the gathers are two dependent rounds (edge -> node ids -> node rows) of ~1-2 us
-// each against ~0.2 us of arithmetic per chunk. A wave therefore keeps P chunks of rows and P chunks of node ids in
-// flight: step g consumes the rows of chunk g and the ids of chunk g + P (both requested P steps ago), then requests the
-// ids of chunk g + 2P and — with the ids it just consumed — the rows of chunk g + P into the registers it has just
-// freed. The buffers are indexed by g mod P with the loop unrolled P times (a shifting queue would have to MOVE registers
-// whose loads are still in flight, i.e. wait for them), and the ids go out before the rows because the memory counter
-// retires in order. P = 3 with bf16 observations (9 registers per chunk in flight), 1 with fp32 observations (17).
-// Past the end of its range a wave re-requests its last chunk (no divergent control flow inside the loop, which would make
-// the compiler's wait-count tracking give up and wait for everything).
-struct MC {
-  int32_t m, c;
-  uint32_t g;
-  __device__ __forceinline__ void adv(int32_t CH, uint32_t g1) {      // saturates at the last chunk of the range
-    if (g + 1 < g1) {
-      ++g;
-      if (++c == CH) {
-        c = 0;
-        ++m;
-      }
-    }
-  }
-};
+// ---- the forward kernels' walk over their chunks: a two-stage software pipeline of the gathers -----------------------------
+// The gathers are two dependent rounds (edge -> node ids -> node rows) of ~1-2 us each against ~0.2 us (bf16) to ~1 us
+// (fp32 MFMA) of arithmetic per chunk. A wave therefore keeps P chunks of rows and P chunks of node ids in flight: a step
+// consumes the rows of chunk c and the ids of chunk c + P (both requested P steps ago), then requests the ids of chunk
+// c + 2P and — with the ids it just consumed — the rows of chunk c + P into the registers it has just freed. The buffers
+// are indexed by step mod P with the loop unrolled P times (a shifting queue would have to MOVE registers whose loads are
+// still in flight, i.e. wait for them), and the ids go out before the rows because the memory counter retires in order.
+// P = 2 with bf16 observations (9 registers per chunk in flight), 1 with fp32 observations (17). Until round 5 the fp32
+// and x3 kernels fetched ids and rows of the NEXT chunk in one go — every chunk then waited a full memory round trip for
+// the ids before it could ask for the rows (a quarter of their wave-time parked at that wait, profiles/r05_mlp_counters.txt).
+// A wave's range of chunks is cut into per-sample segments (round 5): inside one the chunk walkers are plain counters
+// that saturate at the segment's last chunk (66 -> ~35 scalar instructions per chunk against three (sample, chunk) walkers
+// with carries; bf16: -4 %); past the end a wave re-requests that last chunk (no divergent control flow inside the loop,
+// which would make the compiler's wait-count tracking give up and wait for everything).
 struct EIdx {
   int32_t s, d;
   float ea;
@@ -426,8 +348,121 @@ struct ERows<true> {       // bf16 observations [M][N][16] (tarl_fused_obs16_bf1
   __device__ __forceinline__ bf16x8 xd() const { return __builtin_bit_cast(bf16x8, d); }
 };
 
+
+// chunk g = m * CH + c (host: M * CH < 2^31): wave gw of nw walks [gw * per, (gw + 1) * per), sample by sample;
+// body(rows, m, c, live) computes chunk c of sample m from its gathered rows (live = false: a pipeline step past the end
+// of a segment whose length is not a multiple of P — its rows are the last chunk's once more, nothing may be stored)
+template <int P, bool OBS_BF16, class Body>
+__device__ __forceinline__ void emr_walk(const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                                         const float* __restrict__ edge_attr, const void* __restrict__ obs, int64_t E,
+                                         int64_t N, int64_t M, int wave, int lane, Body&& body) {
+  const int32_t CH = (int32_t)((E + 31) >> 5), Ei = (int32_t)E;
+  const uint32_t total = (uint32_t)M * (uint32_t)CH, nw = gridDim.x * EMR_WAVES, gw = blockIdx.x * EMR_WAVES + wave;
+  const uint32_t per = (total + nw - 1) / nw;
+  uint32_t g = gw * per;
+  const uint32_t g1 = (g + per < total) ? g + per : total;
+  if (g >= g1) return;
+  int32_t m = (int32_t)(g / (uint32_t)CH), c0 = (int32_t)(g - (uint32_t)m * (uint32_t)CH);
+  ERows<OBS_BF16> R[P];
+  EIdx I[P];
+  while (g < g1) {
+    const int32_t left = (int32_t)(g1 - g), cend = (CH - c0 < left) ? CH : c0 + left, last = cend - 1;
+    int32_t c_cur = c0, c_idx = c0;
+#pragma unroll
+    for (int K = 0; K < P; ++K) {                  // prologue: rows of the segment's first P chunks, ids of the next P
+      R[K].load(obs, N, m, emr_ldidx(src, dst, edge_attr, Ei, c_idx, lane), lane);
+      c_idx = c_idx < last ? c_idx + 1 : last;
+    }
+#pragma unroll
+    for (int K = 0; K < P; ++K) {
+      I[K] = emr_ldidx(src, dst, edge_attr, Ei, c_idx, lane);
+      c_idx = c_idx < last ? c_idx + 1 : last;
+    }
+    for (int32_t c = c0; c < cend; c += P) {
+#pragma unroll
+      for (int K = 0; K < P; ++K) {
+        const ERows<OBS_BF16> cur = R[K];
+        const EIdx use = I[K];
+        const int32_t cc = c_cur;
+        I[K] = emr_ldidx(src, dst, edge_attr, Ei, c_idx, lane);
+        R[K].load(obs, N, m, use, lane);
+        c_cur = c_cur < last ? c_cur + 1 : last;
+        c_idx = c_idx < last ? c_idx + 1 : last;
+        body(cur, m, cc, c + K < cend);
+      }
+    }
+    g += (uint32_t)(cend - c0);
+    c0 = 0;
+    ++m;
+  }
+}
+
+// fp32: v_mfma_f32_32x32x2_f32, exact fp32 products. k runs [x_src 8h..8h+7] [x_dst 8h..8h+7] for half-wave h (8 + 8
+// k-steps of 2), then one k-step {edge_attr, 1} against {W1[:, 32], b1}: the bias enters the accumulation as an exact
+// product. 34 + 32 MFMAs per 32 edges: the matrix cores are the bound (66 x 16 passes).
+__global__ __launch_bounds__(EMR_WAVES * 64) void k_edge_mlp_fwd_f32(const int32_t* __restrict__ src,
+                                                                     const int32_t* __restrict__ dst, int64_t E,
+                                                                     int64_t N, int64_t M,
+                                                                     const float* __restrict__ obs,
+                                                                     const float* __restrict__ edge_attr, EdgeMlpW W,
+                                                                     float* __restrict__ logits) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the chunk walker lives in SGPRs
+  const int h = lane >> 5, j = lane & 31;
+  float w1a[2][17], w2a[32];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int u = 32 * a + j;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      w1a[a][t] = W.w1[u * EM_IN + 8 * h + t];
+      w1a[a][8 + t] = W.w1[u * EM_IN + 16 + 8 * h + t];
+    }
+    w1a[a][16] = h == 0 ? W.w1[u * EM_IN + 32] : W.b1[u];
+  }
+#pragma unroll
+  for (int t = 0; t < 32; ++t) w2a[t] = W.w2[j * EM_H1 + 32 * (t >> 4) + emr_unit(t & 15, h)];
+  f32x16 b2r;
+  float w3r[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    b2r[r] = W.b2[emr_unit(r, h)];
+    w3r[r] = W.w3[emr_unit(r, h)];
+  }
+  const float b3 = W.b3[0];
+  const f32x16 zero = {0};
+  emr_walk<1, false>(src, dst, edge_attr, obs, E, N, M, wave, lane, [&](const ERows<false>& cur, int32_t m, int32_t c, bool live) {
+    const float xin[17] = {cur.s0.x, cur.s0.y, cur.s0.z, cur.s0.w, cur.s1.x, cur.s1.y, cur.s1.z, cur.s1.w,
+                           cur.d0.x, cur.d0.y, cur.d0.z, cur.d0.w, cur.d1.x, cur.d1.y, cur.d1.z, cur.d1.w,
+                           h == 0 ? cur.ea : 1.0f};
+    f32x16 acc0 = zero, acc1 = zero;
+#pragma unroll
+    for (int t = 0; t < 17; ++t) {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1a[0][t], xin[t], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1a[1][t], xin[t], acc1, 0, 0, 0);
+    }
+    f32x16 c0 = b2r;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2a[t], emr_relu(acc0[t]), c0, 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w2a[16 + t], emr_relu(acc1[t]), c0, 0, 0, 0);
+    float part = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part = fmaf(emr_relu(c0[r]), w3r[r], part);
+    const float tot = part + __shfl_xor(part, 32);
+    const int32_t e = c * 32 + j;
+    if (live && h == 0 && e < (int32_t)E) logits[(int64_t)m * E + e] = tot + b3;
+  });
+}
+
+// ---- bf16: v_mfma_f32_32x32x16_bf16 ----------------------------------------------------------------------------------------
+// layer 1, k-steps of 16: [x_src 0..15] [x_dst 0..15] [edge_attr, 1, 1, 1, 0 ...]: the three ones meet the bias b1 split
+// into three bf16 pieces (hi + mid + lo == b1 exactly), i.e. the fp32 bias enters the fp32 accumulation unrounded.
+// Inputs, weights and the first hidden activation are rounded to bf16 (RNE); fp32 accumulation, fp32 second activation
+// and output: BASELINE config 5's "bf16 MPNN features" (tolerance stated in tests/test_gpu_edge_mlp.py). 6 + 4 MFMAs per
+// 32 edges; the vector ALU (conversions, ReLU, the output dot product) is the bound.
 template <bool OBS_BF16>
-__global__ __launch_bounds__(EMR_WAVES * 64) void k_edge_mlp_fwd_bf16(const int32_t* __restrict__ src,
+__global__ __launch_bounds__(EMR_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_edge_mlp_fwd_bf16(const int32_t* __restrict__ src,
                                                                       const int32_t* __restrict__ dst, int64_t E,
                                                                       int64_t N, int64_t M,
                                                                       const void* __restrict__ obs,
@@ -487,36 +522,7 @@ __global__ __launch_bounds__(EMR_WAVES * 64) void k_edge_mlp_fwd_bf16(const int3
   const float b3 = W.b3[0];
   const f32x16 zero = {0};
 
-  ChunkWalk cw;
-  if (!cw.init(E, M, wave)) return;
-  const int32_t CH = (int32_t)cw.CH, Ei = (int32_t)E;
-  const uint32_t g1 = cw.g1;
-  MC cur_mc{cw.mn, cw.cn, cw.g}, row_mc = cur_mc, idx_mc = cur_mc;
-  ERows<OBS_BF16> R[P];
-  EIdx I[P];
-#pragma unroll
-  for (int K = 0; K < P; ++K) {                  // prologue: rows of chunks g0 .. g0+P-1, ids of chunks g0+P .. g0+2P-1
-    R[K].load(obs, N, row_mc.m, emr_ldidx(src, dst, edge_attr, Ei, row_mc.c, lane), lane);
-    row_mc.adv(CH, g1);
-  }
-  idx_mc = row_mc;
-#pragma unroll
-  for (int K = 0; K < P; ++K) {
-    I[K] = emr_ldidx(src, dst, edge_attr, Ei, idx_mc.c, lane);
-    idx_mc.adv(CH, g1);
-  }
-  for (uint32_t g = cw.g; g < g1; g += P) {
-#pragma unroll
-    for (int K = 0; K < P; ++K) {
-    const bool valid = g + K < g1;
-    const ERows<OBS_BF16> cur = R[K];
-    const EIdx use = I[K];
-    const MC mc = cur_mc;
-    I[K] = emr_ldidx(src, dst, edge_attr, Ei, idx_mc.c, lane);
-    R[K].load(obs, N, row_mc.m, use, lane);
-    cur_mc.adv(CH, g1);
-    row_mc.adv(CH, g1);
-    idx_mc.adv(CH, g1);
+  emr_walk<P, OBS_BF16>(src, dst, edge_attr, obs, E, N, M, wave, lane, [&](const ERows<OBS_BF16>& cur, int32_t m, int32_t c, bool live) {
     const bf16x8 xs = cur.xs(), xd = cur.xd();
     bf16x8 xe = {0};
     if (h == 0) {
@@ -567,11 +573,10 @@ __global__ __launch_bounds__(EMR_WAVES * 64) void k_edge_mlp_fwd_bf16(const int3
       part = fmaf(emr_relu(c0[4 * q + 3]), v.w, part);
     }
     const float tot = part + __shfl_xor(part, 32);
-    const int32_t e = __builtin_amdgcn_readfirstlane(mc.c) * 32 + (lane & 31);
-    float* lrow = logits + (int64_t)__builtin_amdgcn_readfirstlane(mc.m) * E;
-    if (valid && h == 0 && e < Ei) lrow[e] = tot + b3;
-    }
-  }
+    const int32_t e = __builtin_amdgcn_readfirstlane(c) * 32 + (lane & 31);
+    float* lrow = logits + (int64_t)__builtin_amdgcn_readfirstlane(m) * E;
+    if (live && h == 0 && e < (int32_t)E) lrow[e] = tot + b3;
+  });
 }
 
 // ---- fp32 accuracy on the bf16 pipe: v_mfma_f32_32x32x16_bf16 on operands split into exact bf16 pieces -------------------
@@ -645,7 +650,7 @@ __device__ __forceinline__ f32x16 emr_mma6(const Frag3& w, const Frag3& x, f32x1
 
 #define EMX_W1 (2 * 2 * 3)     // W1 fragments: [tile][k-step][piece]
 #define EMX_W2 (4 * 3)         // W2 fragments: [k-step][piece]
-__global__ __launch_bounds__(EMR_WAVES * 64) void k_edge_mlp_fwd_x3(const int32_t* __restrict__ src,
+__global__ __launch_bounds__(EMR_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_edge_mlp_fwd_x3(const int32_t* __restrict__ src,
                                                                     const int32_t* __restrict__ dst, int64_t E,
                                                                     int64_t N, int64_t M,
                                                                     const float* __restrict__ obs,
@@ -712,13 +717,7 @@ __global__ __launch_bounds__(EMR_WAVES * 64) void k_edge_mlp_fwd_x3(const int32_
   }
   const float b3 = W.b3[0];
   const f32x16 zero = {0};
-  ChunkWalk cw;
-  if (!cw.init(E, M, wave)) return;
-  EdgeIn nxt = emr_load(src, dst, edge_attr, obs, (int32_t)E, N, cw.mn, cw.cn, lane);
-  for (; cw.g < cw.g1; ++cw.g) {
-    const EdgeIn cur = nxt;
-    cw.step();
-    if (cw.g + 1 < cw.g1) nxt = emr_load(src, dst, edge_attr, obs, (int32_t)E, N, cw.mn, cw.cn, lane);
+  emr_walk<1, false>(src, dst, edge_attr, obs, E, N, M, wave, lane, [&](const ERows<false>& cur, int32_t m, int32_t c, bool live) {
     asm volatile("" ::: "memory");      // keeps the LDS fragments out of loop-invariant registers
     const float vs[8] = {cur.s0.x, cur.s0.y, cur.s0.z, cur.s0.w, cur.s1.x, cur.s1.y, cur.s1.z, cur.s1.w};
     const float vd[8] = {cur.d0.x, cur.d0.y, cur.d0.z, cur.d0.w, cur.d1.x, cur.d1.y, cur.d1.z, cur.d1.w};
@@ -750,9 +749,9 @@ __global__ __launch_bounds__(EMR_WAVES * 64) void k_edge_mlp_fwd_x3(const int32_
 #pragma unroll
     for (int r = 0; r < 16; ++r) part = fmaf(emr_relu(c0[r]), w3r[r], part);
     const float tot = part + __shfl_xor(part, 32);
-    const int32_t e = cw.c * 32 + j;
-    if (h == 0 && e < (int32_t)E) logits[(int64_t)cw.m * E + e] = tot + b3;
-  }
+    const int32_t e = c * 32 + j;
+    if (live && h == 0 && e < (int32_t)E) logits[(int64_t)m * E + e] = tot + b3;
+  });
 }
 
 // ---- backward -------------------------------------------------------------------------------------------------------------

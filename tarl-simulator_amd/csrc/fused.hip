@@ -2288,6 +2288,50 @@ static int choice_side(ChoiceSide** out) {
   return TARL_OK;
 }
 
+// Environments per wave of the packed insert kernel (k_fused_insert2; TARL_INSERT_EPW = 1, 2, 4 or 8 forces it; 1 = one
+// workgroup per environment, k_fused_insert). A frame's window holds the agents due in it, and an environment's share of the
+// wave (64 / EPW lanes, INS_CAP / EPW list entries) should take them in one step: an environment with more candidates than
+// its share of the list sits the packed part out and is served alone afterwards, one after the other (measured with ~27 due
+// per frame and EPW = 8: 260 us per launch instead of 36). With the schedule's due rate known (tarl_fused.due_rate, from
+// pack): the largest EPW whose list share holds twice the expected candidates of a frame. Without it, by the size of the
+// population: 8 up to 20 000 agents (BASELINE config 4: ~5 due per frame) when the launch is large, 4 up to 32 768, 2 up to
+// 65 536, one wave per environment beyond (config 5: 262 144 agents, ~70 per frame).
+static int insert_envs_per_wave(const tarl_fused* f, int64_t A, int64_t B, int64_t T, const float* times_host) {
+  static const bool pair_ok = !(getenv("TARL_INSERT_PAIR") && atoi(getenv("TARL_INSERT_PAIR")) == 0);
+  static const int epw_env = getenv("TARL_INSERT_EPW") ? atoi(getenv("TARL_INSERT_EPW")) : 0;
+  int epw = A <= 20000 && B >= 12288 ? 8 : (A <= 32768 ? 4 : (A <= 65536 ? 2 : 1));
+  if (f->due_rate > 0.0f) {
+    const float dt = T > 1 ? times_host[1] - times_host[0] : 1.0f;
+    const float per_frame = f->due_rate * (dt > 0.0f ? dt : 1.0f);
+    while (epw > 1 && 2.0f * per_frame > (float)(INS_CAP / epw)) epw >>= 1;
+  }
+  if (epw_env == 1 || epw_env == 2 || epw_env == 4 || epw_env == 8) epw = epw_env;
+  return (pair_ok && f->a_order && f->a_win) ? epw : 1;
+}
+
+// the insert launch of a frame whose action is already in `sel_t` (no choice part): packed (epw > 1) or one workgroup per environment
+static int launch_insert(int epw, hipStream_t s, int Nmax, int64_t B, int64_t N, const FusedBufs* fbt, PlanOut P,
+                         const uint8_t* sel_t, float* agent_features, int64_t A, int64_t a_bstride, int use_cong, float time,
+                         int32_t* ins_scratch, const float* entropy1, float* reward_t, const FrameOut& out, float* lp_t,
+                         float* ent_t) {
+#define INS2_LAUNCH(EPW_)                                                                                                         \
+  hipLaunchKernelGGL((k_fused_insert2<EPW_>), dim3((unsigned)ceil_div(B, EPW_)), dim3(INSB), 0, s, Nmax, B, N, fbt, P, sel_t,   \
+                     agent_features, A, a_bstride, use_cong, time, ins_scratch, entropy1, reward_t, out, lp_t, ent_t)
+  if (epw == 8) {
+    INS2_LAUNCH(8);
+  } else if (epw == 4) {
+    INS2_LAUNCH(4);
+  } else if (epw == 2) {
+    INS2_LAUNCH(2);
+  } else {
+    hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(INSB), 0, s, Nmax, B, N, fbt, P, sel_t, agent_features, A,
+                       a_bstride, use_cong, time, ins_scratch, entropy1, reward_t, out, lp_t, ent_t);
+  }
+#undef INS2_LAUNCH
+  TARL_LAUNCH_CHECK();
+  return TARL_OK;
+}
+
 extern "C" int64_t tarl_fused_rollout_scratch_ints(const tarl_plan* plan, int64_t T, int64_t B) {
   // unresolved-draw list | packed policy records | per-node draw records (64-byte aligned) | per-(frame, environment)
   // log-prob accumulators (int64; last, so that every other offset is independent of T)
@@ -2403,6 +2447,7 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
                        (int32_t*)nullptr, nchunk_choice(), want_lp, f->env_base);
     TARL_LAUNCH_CHECK();
   }
+  const int epw_packed = insert_envs_per_wave(f, A, B, T, times_host);
   for (int64_t t = 0; t < T; ++t) {
     const int cur = merge ? (int)(t & 1) : 0;
     const float time = times_host[t];
@@ -2433,33 +2478,9 @@ extern "C" int tarl_fused_rollout(const tarl_plan* plan, const tarl_fused* f, in
     float* lp_t = (log_prob && !ahead) ? log_prob + t * B : nullptr;   // ahead: written by k_fused_choice_all
     float* ent_t = entropy ? entropy + t * B : nullptr;
     if (ahead) {
-      // TARL_INSERT_PAIR=0 keeps one wave per environment (developer knob)
-      static const bool pair_ok = !(getenv("TARL_INSERT_PAIR") && atoi(getenv("TARL_INSERT_PAIR")) == 0);
-      // environments per wave of the insert kernel (TARL_INSERT_EPW = 1, 2, 4 or 8). A frame's window holds the agents due
-      // in it, and an environment's share of the wave (64 / EPW lanes, INS_CAP / EPW list entries) should take them in one
-      // step: an environment with more candidates than its share of the list sits the packed part out and is served
-      // alone afterwards, one after the other (measured with ~27 due per frame and EPW = 8: 260 us per launch instead of
-      // 36). With the schedule's due rate known (tarl_fused.due_rate, from pack): the largest EPW whose list share holds
-      // twice the expected candidates of a frame. Without it, by the size of the population: 8 up to 20 000 agents
-      // (BASELINE config 4: ~5 due per frame) when the launch is large (8 at 16 384 environments: 36 us against 40 with 4;
-      // at 4 096: 21 against 18), 4 up to 32 768, 2 up to 65 536, one wave per environment beyond (config 5: 262 144
-      // agents, ~70 per frame).
-      static const int epw_env = getenv("TARL_INSERT_EPW") ? atoi(getenv("TARL_INSERT_EPW")) : 0;
-      int epw = A <= 20000 && B >= 12288 ? 8 : (A <= 32768 ? 4 : (A <= 65536 ? 2 : 1));
-      if (f->due_rate > 0.0f) {
-        const float dt = T > 1 ? times_host[1] - times_host[0] : 1.0f;
-        const float per_frame = f->due_rate * (dt > 0.0f ? dt : 1.0f);
-        while (epw > 1 && 2.0f * per_frame > (float)(INS_CAP / epw)) epw >>= 1;
-      }
-      if (epw_env == 1 || epw_env == 2 || epw_env == 4 || epw_env == 8) epw = epw_env;
-      if (pair_ok && epw > 1 && f->a_order && f->a_win) {
-        hipLaunchKernelGGL(epw == 8 ? k_fused_insert2<8> : (epw == 4 ? k_fused_insert2<4> : k_fused_insert2<2>), dim3((unsigned)ceil_div(B, epw)), dim3(INSB), 0, s, (int)Nmax, B, N, fbt, P, sel_t,
-                           agent_features, A, a_bstride, use_cong, time, ins_scratch, entropy1, reward_t, out, lp_t, ent_t);
-      } else {
-        hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(INSB), 0, s, (int)Nmax, B, N, fbt, P, sel_t,
-                           agent_features, A, a_bstride, use_cong, time, ins_scratch, entropy1, reward_t, out, lp_t, ent_t);
-      }
-      TARL_LAUNCH_CHECK();
+      rc = launch_insert(epw_packed, s, (int)Nmax, B, N, fbt, P, sel_t, agent_features, A, a_bstride, use_cong, time, ins_scratch,
+                         entropy1, reward_t, out, lp_t, ent_t);
+      if (rc) return rc;
     } else if (merge && t + 1 < T) {
       const ChoiceArgs C{plan->out_ptr, plan->out_eid, plan->group_of_node, plan->G, thresholds,
                          (const long long*)log_probs, policy_seed, policy_counter0 + (uint64_t)(t + 1), nchunk_choice(),
@@ -2578,6 +2599,7 @@ extern "C" int tarl_fused_rollout_policy(const tarl_plan* plan, const tarl_fused
   rc = upload_bufs(f, fbh, nullptr, s, &fb);
   if (rc) return rc;
   const PlanOut P{plan->out_ptr, plan->out_dst};
+  const int epw_packed = insert_envs_per_wave(f, A, B, T, times_host);
   for (int64_t t = 0; t < T; ++t) {
     const bool keep_t = keep_ptr_host && keep_ptr_host[t + 1] > keep_ptr_host[t];
     const int64_t lo = keep_t ? keep_ptr_host[t] : 0, n = keep_t ? keep_ptr_host[t + 1] - lo : 0;
@@ -2629,10 +2651,9 @@ extern "C" int tarl_fused_rollout_policy(const tarl_plan* plan, const tarl_fused
     if (rc) return rc;
     rc = launch_rows(grid, threads, s, plan, f, fb, (int)Nmax, B, agent_features, A, a_bstride, time, out);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_fused_insert, dim3((unsigned)B), dim3(INSB), 0, s, (int)Nmax, B, N, fb, P,
-                       (const uint8_t*)f->sel8, agent_features, A, a_bstride, use_cong, time, ins_scratch,
-                       (const float*)nullptr, reward ? reward + t * B : nullptr, out, (float*)nullptr, (float*)nullptr);
-    TARL_LAUNCH_CHECK();
+    rc = launch_insert(epw_packed, s, (int)Nmax, B, N, fb, P, (const uint8_t*)f->sel8, agent_features, A, a_bstride, use_cong, time,
+                       ins_scratch, (const float*)nullptr, reward ? reward + t * B : nullptr, out, (float*)nullptr, (float*)nullptr);
+    if (rc) return rc;
   }
   return TARL_OK;
 }

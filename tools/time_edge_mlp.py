@@ -27,13 +27,18 @@ ws = [torch.randn(s, generator=g) * 0.2 for s in ((64, 33), (64,), (32, 64), (32
 w = ops.EdgeMlpWeights(*[t.cuda() for t in ws])
 out = torch.empty((a.envs, E), device="cuda")
 res = {}
-for prec in ("fp32", "x3", "bf16"):
-    ops.policy_edge_mlp(plan, obs, ec, w, precision=prec, out=out)
+obs_bf = obs.to(torch.bfloat16)
+for prec in ("fp32", "x3", "bf16", "bf16 obs"):
+    if prec == "bf16 obs":      # the rollout's form: observations already bf16 (tarl_fused_obs16_bf16)
+        x, prec_kw = obs_bf, None
+    else:
+        x, prec_kw = obs, prec
+    ops.policy_edge_mlp(plan, x, ec, w, precision=prec_kw, out=out)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(a.reps):
-        ops.policy_edge_mlp(plan, obs, ec, w, precision=prec, out=out)
+        ops.policy_edge_mlp(plan, x, ec, w, precision=prec_kw, out=out)
     e1.record()
     torch.cuda.synchronize()
     res[prec] = (e0.elapsed_time(e1) / a.reps * 1e3, out[:4].clone())
@@ -43,4 +48,4 @@ ref = nets.edge_mlp_logits(obs[:4].cpu().double(), net.edge_index, net.edge_attr
 scale = float(ref.abs().max())
 for prec, (us, o) in res.items():
     err = float((o.cpu().double() - ref).abs().max())
-    print(f"{prec:5s} {us:8.1f} us per {a.envs * E / 1e6:.1f} M edges   max |err| vs fp64 {err:.3e} = {err / scale:.2e} of scale")
+    print(f"{prec:8s} {us:8.1f} us per {a.envs * E / 1e6:.1f} M edges   max |err| vs fp64 {err:.3e} = {err / scale:.2e} of scale")
