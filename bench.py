@@ -119,7 +119,7 @@ def parse():
     ap.add_argument("--config5-envs", type=int, default=2048,
                     help="environments per GPU of the config5 object (BASELINE config 5: 100k edges, 262 144 agents; 0 = skip)")
     ap.add_argument("--config5-steps", type=int, default=2)
-    ap.add_argument("--policy-envs", type=int, default=2048,
+    ap.add_argument("--policy-envs", type=int, default=4096,
                     help="environments per GPU of the state-dependent-policy lines (policy_head=edge_mlp; 0 = skip)")
     ap.add_argument("--policy-steps", type=int, default=2)
     ap.add_argument("--policy-temperature", type=float, default=2000.0,
