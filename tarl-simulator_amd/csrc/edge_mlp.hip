@@ -461,8 +461,8 @@ __global__ __launch_bounds__(EMR_WAVES * 64) void k_edge_mlp_fwd_f32(const int32
 // Inputs, weights and the first hidden activation are rounded to bf16 (RNE); fp32 accumulation, fp32 second activation
 // and output: BASELINE config 5's "bf16 MPNN features" (tolerance stated in tests/test_gpu_edge_mlp.py). 6 + 4 MFMAs per
 // 32 edges; the vector ALU (conversions, ReLU, the output dot product) is the bound.
-template <bool OBS_BF16, int WPE>
-__global__ __launch_bounds__(EMR_WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_edge_mlp_fwd_bf16(const int32_t* __restrict__ src,
+template <bool OBS_BF16>
+__global__ __launch_bounds__(EMR_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_edge_mlp_fwd_bf16(const int32_t* __restrict__ src,
                                                                       const int32_t* __restrict__ dst, int64_t E,
                                                                       int64_t N, int64_t M,
                                                                       const void* __restrict__ obs,
@@ -511,18 +511,11 @@ __global__ __launch_bounds__(EMR_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
     W3L[tid] = W.w3[emr_unit(tid & 15, tid >> 4)];
   }
   __syncthreads();
-  // WPE = 4: the ten weight fragments live in registers for the wave's life; WPE > 4: they stay in LDS and are read where
-  // they are used (a lane's 16 bytes are consecutive: conflict-free ds_read_b128) — 40 registers less, more waves per SIMD
-  constexpr bool WREG = WPE <= 4;
-  bf16x8 w1r[WREG ? 6 : 1], w2r[WREG ? 4 : 1];
-  if (WREG) {
+  bf16x8 w1f[6], w2f[4];
 #pragma unroll
-    for (int f = 0; f < 6; ++f) w1r[WREG ? f : 0] = *reinterpret_cast<const bf16x8*>(W1f + (f * 64 + lane) * 8);
+  for (int f = 0; f < 6; ++f) w1f[f] = *reinterpret_cast<const bf16x8*>(W1f + (f * 64 + lane) * 8);
 #pragma unroll
-    for (int f = 0; f < 4; ++f) w2r[WREG ? f : 0] = *reinterpret_cast<const bf16x8*>(W2f + (f * 64 + lane) * 8);
-  }
-  auto w1f = [&](int f) { return WREG ? w1r[WREG ? f : 0] : *reinterpret_cast<const bf16x8*>(W1f + (f * 64 + lane) * 8); };
-  auto w2f = [&](int f) { return WREG ? w2r[WREG ? f : 0] : *reinterpret_cast<const bf16x8*>(W2f + (f * 64 + lane) * 8); };
+  for (int f = 0; f < 4; ++f) w2f[f] = *reinterpret_cast<const bf16x8*>(W2f + (f * 64 + lane) * 8);
   const int h = lane >> 5;
   const float4* b2l = reinterpret_cast<const float4*>(B2L + 16 * h);
   const float4* w3l = reinterpret_cast<const float4*>(W3L + 16 * h);
@@ -530,7 +523,6 @@ __global__ __launch_bounds__(EMR_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
   const f32x16 zero = {0};
 
   emr_walk<P, OBS_BF16>(src, dst, edge_attr, obs, E, N, M, wave, lane, [&](const ERows<OBS_BF16>& cur, int32_t m, int32_t c, bool live) {
-    if (!WREG) asm volatile("" ::: "memory");      // keeps the LDS fragments out of loop-invariant registers
     const bf16x8 xs = cur.xs(), xd = cur.xd();
     bf16x8 xe = {0};
     if (h == 0) {
@@ -539,12 +531,12 @@ __global__ __launch_bounds__(EMR_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
       xe[2] = (__bf16)1.0f;
       xe[3] = (__bf16)1.0f;
     }
-    f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f(0), xs, zero, 0, 0, 0);
-    f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f(3), xs, zero, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f(1), xd, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f(4), xd, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f(2), xe, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f(5), xe, acc1, 0, 0, 0);
+    f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[0], xs, zero, 0, 0, 0);
+    f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[3], xs, zero, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[1], xd, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[4], xd, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[2], xe, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[5], xe, acc1, 0, 0, 0);
     bf16x8 hb[4];
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
@@ -567,10 +559,10 @@ __global__ __launch_bounds__(EMR_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
       c0[4 * q + 2] = v.z;
       c0[4 * q + 3] = v.w;
     }
-    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f(0), hb[0], c0, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f(1), hb[1], c0, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f(2), hb[2], c0, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f(3), hb[3], c0, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[0], hb[0], c0, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[1], hb[1], c0, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[2], hb[2], c0, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[3], hb[3], c0, 0, 0, 0);
     float part = 0.0f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1028,26 +1020,11 @@ extern "C" int tarl_policy_edge_mlp_fwd(const tarl_plan* plan, const float* obs1
     hipLaunchKernelGGL(k_edge_mlp_fwd_f32, dim3((unsigned)blocks), dim3(EMR_WAVES * 64), 0, (hipStream_t)stream,
                        plan->src, plan->dst, plan->E, plan->N, M, obs16, edge_attr, W, logits);
   else if (precision == 1)
-    hipLaunchKernelGGL((k_edge_mlp_fwd_bf16<false, 4>), dim3((unsigned)blocks), dim3(EMR_WAVES * 64), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_edge_mlp_fwd_bf16<false>, dim3((unsigned)blocks), dim3(EMR_WAVES * 64), 0, (hipStream_t)stream,
                        plan->src, plan->dst, plan->E, plan->N, M, (const void*)obs16, edge_attr, W, logits);
-  else {
-    // TARL_MLP_WPE = 4 | 5 | 6 (developer knob): waves per SIMD of the bf16-rows kernel (above 4: weight fragments read from LDS)
-    const char* wk = getenv("TARL_MLP_WPE");
-    const int wpe = wk ? atoi(wk) : 4;
-    if (wpe == 5 || wpe == 6) {
-      blocks = ceil_div(chunks, (int64_t)EMR_WAVES * 16);
-      if (blocks > 256 * wpe) blocks = 256 * wpe;
-    }
-    if (wpe == 6)
-      hipLaunchKernelGGL((k_edge_mlp_fwd_bf16<true, 6>), dim3((unsigned)blocks), dim3(EMR_WAVES * 64), 0, (hipStream_t)stream,
-                         plan->src, plan->dst, plan->E, plan->N, M, (const void*)obs16, edge_attr, W, logits);
-    else if (wpe == 5)
-      hipLaunchKernelGGL((k_edge_mlp_fwd_bf16<true, 5>), dim3((unsigned)blocks), dim3(EMR_WAVES * 64), 0, (hipStream_t)stream,
-                         plan->src, plan->dst, plan->E, plan->N, M, (const void*)obs16, edge_attr, W, logits);
-    else
-      hipLaunchKernelGGL((k_edge_mlp_fwd_bf16<true, 4>), dim3((unsigned)blocks), dim3(EMR_WAVES * 64), 0, (hipStream_t)stream,
-                         plan->src, plan->dst, plan->E, plan->N, M, (const void*)obs16, edge_attr, W, logits);
-  }
+  else
+    hipLaunchKernelGGL(k_edge_mlp_fwd_bf16<true>, dim3((unsigned)blocks), dim3(EMR_WAVES * 64), 0, (hipStream_t)stream,
+                       plan->src, plan->dst, plan->E, plan->N, M, (const void*)obs16, edge_attr, W, logits);
   TARL_LAUNCH_CHECK();
   return TARL_OK;
 }
