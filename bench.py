@@ -100,7 +100,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--edges", type=int, default=10000)
     ap.add_argument("--agents", type=int, default=16384)
-    ap.add_argument("--envs", type=int, default=16384, help="vectorised environments per GPU")
+    ap.add_argument("--envs", type=int, default=32768,
+                    help="vectorised environments per GPU (32 768: 150 GB of the 288; 16 384 until round 5: -6 % env-steps/s)")
     ap.add_argument("--rollout-steps", type=int, default=256)
     ap.add_argument("--epochs", type=int, default=1)
     ap.add_argument("--sub-batch", type=int, default=32)

@@ -69,7 +69,7 @@ def main():
                                             "are required; any further counters are recorded beside them)")
     ap.add_argument("--edges", type=int, default=10000)
     ap.add_argument("--agents", type=int, default=16384)
-    ap.add_argument("--envs", type=int, default=16384)
+    ap.add_argument("--envs", type=int, default=32768)
     ap.add_argument("--rollout-steps", type=int, default=256)
     ap.add_argument("--departure-window", type=int, default=0, help="the bench's --departure-window (0 = the default line)")
     ap.add_argument("--first-frame", type=int, default=200)
@@ -84,7 +84,7 @@ def main():
     cfg = {"edges": a.edges, "agents": a.agents, "envs": a.envs, "rollout_steps": T}
     cmd = ("python3 bench.py --steps 1 --warmup 1 --cpu-seconds 0 --congested-window 0 --policy-envs 0 --config5-envs 0 "
            "--update-epochs 0 --no-kernel-timing")
-    if (a.edges, a.agents, a.envs) != (10000, 16384, 16384):
+    if (a.edges, a.agents, a.envs) != (10000, 16384, 32768):
         cmd += f" --edges {a.edges} --agents {a.agents} --envs {a.envs}"
     if a.departure_window:
         cfg["departure_window"] = a.departure_window

@@ -41,7 +41,7 @@ if [[ $PARTS == *sweep* ]]; then
   # 3. other sizes (env-steps/s of the whole PPO iteration)
   for cfg in "c3_b1 --edges 1024 --agents 1024 --envs 1" "c3_b256 --edges 1024 --agents 1024 --envs 256" \
              "c3_b2048 --edges 1024 --agents 1024 --envs 2048" "c4_b1 --envs 1" "c4_b256 --envs 256" "c4_b1024 --envs 1024" \
-             "c4_b4096 --envs 4096" "c4_b8192 --envs 8192" "c4_b32768 --envs 32768" \
+             "c4_b4096 --envs 4096" "c4_b8192 --envs 8192" "c4_b16384 --envs 16384" \
              "c5_b256 --edges 100000 --agents 262144 --envs 256" "c5_b1024 --edges 100000 --agents 262144 --envs 1024" \
              "c5_b4096 --edges 100000 --agents 262144 --envs 4096"; do
     set -- $cfg; name=$1; shift
