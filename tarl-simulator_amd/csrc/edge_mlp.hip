@@ -460,7 +460,9 @@ __global__ __launch_bounds__(EMR_WAVES * 64) void k_edge_mlp_fwd_f32(const int32
 // into three bf16 pieces (hi + mid + lo == b1 exactly), i.e. the fp32 bias enters the fp32 accumulation unrounded.
 // Inputs, weights and the first hidden activation are rounded to bf16 (RNE); fp32 accumulation, fp32 second activation
 // and output: BASELINE config 5's "bf16 MPNN features" (tolerance stated in tests/test_gpu_edge_mlp.py). 6 + 4 MFMAs per
-// 32 edges; the vector ALU (conversions, ReLU, the output dot product) is the bound.
+// 32 edges. What bounds it (profiles/r05_mlp_counters.txt, round 5): neither the matrix pipe (busy 0.46 of the launch) nor
+// the vector ALU nor their sum nor the gather — a wave's in-order stream of ~190 instructions per chunk (a third of them
+// scalar) at four waves per SIMD; five or six waves with the weights left in LDS were slower.
 template <bool OBS_BF16>
 __global__ __launch_bounds__(EMR_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_edge_mlp_fwd_bf16(const int32_t* __restrict__ src,
                                                                       const int32_t* __restrict__ dst, int64_t E,
