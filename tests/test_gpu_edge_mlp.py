@@ -85,6 +85,34 @@ def test_edge_mlp_ragged_tile_and_large_batch():
     close(out.cpu(), ref, "logits")
 
 
+@pytest.mark.parametrize("drop,M", [(0, 1), (7, 5), (160, 3), (191, 2), (37, 4097)])
+def test_edge_mlp_chunk_walk_edge_cases_all_precisions(drop, M):
+    """The forwards' walk over their 32-edge chunks (``emr_walk``: a wave's range cut into per-sample segments, ids one
+    chunk ahead of the rows, the last chunk re-requested past a segment's end) on the shapes that stress it: one sample,
+    a ragged last chunk, a single (ragged) chunk per sample, ONE edge, and more samples than waves so that every wave's
+    range straddles sample boundaries — fp32, bf16 (fp32 and bf16 rows) and x3 against the fp64 evaluation of the head."""
+    from oracle import nets
+    from tarl_hip import ops, synth
+    net = synth.torus_network(3, 4, heterogeneous=True, seed=5)            # 48 roads, 192 edges
+    N = net.num_roads
+    E = net.edge_index.size(1) - drop
+    ei, ea = net.edge_index[:, :E], net.edge_attr[:E]
+    plan = ops.Plan(ei, N)
+    ec = ops.EdgeConst(ea, "cuda")
+    gen = torch.Generator().manual_seed(100 + drop)
+    ws = [torch.randn(s, generator=gen) * 0.2 for s in ((64, 33), (64,), (32, 64), (32,), (1, 32), (1,))]
+    w = ops.EdgeMlpWeights(*[t.cuda() for t in ws])
+    x16 = torch.randn((M, N, 16), generator=gen) * 2.0
+    ref = nets.edge_mlp_logits(x16.double(), ei, ea.double().expand(M, -1, -1), *[t.double() for t in ws])
+    scale = float(ref.abs().max())
+    xg = x16.cuda()
+    for prec, obs, tol in (("fp32", xg, 1e-5), ("x3", xg, 1e-4), ("bf16", xg, 2e-2), (None, xg.to(torch.bfloat16), 2e-2)):
+        out = torch.full((M, E), float("nan"), device="cuda")
+        ops.policy_edge_mlp(plan, obs, ec, w, precision=prec, out=out)
+        err = float((out.cpu().double() - ref).abs().max())
+        assert err <= tol * scale, (prec, obs.dtype, drop, M, err, scale)      # (a NaN left in `out` = a chunk nobody wrote)
+
+
 def test_fused_obs16_matches_the_exported_state():
     from tarl_hip import ops, synth
     from tarl_hip.engine import SimEngine
