@@ -252,6 +252,16 @@ def test_headline_rollout_replayed_by_the_oracle_with_the_device_noise():
     assert st["on_way"] > 200, st
 
 
+def test_default_size_rollout_replayed_by_the_oracle_with_the_device_noise():
+    """The same at the bench's DEFAULT size from the end of round 5 on — B = 32 768 environments (twice the largest launch the
+    other replays cover: 82 M (road, environment) pairs per frame kernel) —, headline schedule, 64 frames, first / middle /
+    last environment."""
+    from tarl_hip import synth
+    st = _replay_live_policy_rollout(synth.torus_network(25, 25), B=32768, A=16384, T=64, probe=[0, 16383, 32767], window=3660,
+                                     pop_seed=47, eng_seed=53, emb_seed=9, min_pops=100, want_arrivals=False, max_flips=30)
+    assert st["on_way"] > 100, st
+
+
 def test_config5_rollout_replayed_by_the_oracle_with_the_device_noise():
     """The same replay on BASELINE config 5's graph and population — 100 000 route edges, 25 000 roads, 262 144 agents, the
     one-wave-per-environment insert — at B = 256, every agent departing within 300 s (≈870 due per frame: more than the insert
