@@ -369,45 +369,76 @@ __global__ __launch_bounds__(CR_THREADS) void k_critic_fwd_slab_u8x3(const uint8
   const uint8_t* xbase = counts + (row0 / rps) * (N * rps) + (row0 % rps);   // element (env r, node k) at xbase[k * rps + r]
   const int64_t WP = CR_H * Kpad;      // one weight piece
 
-  // Two register stages: the tile of iteration i + 2 is requested while tile i is multiplied and tile i + 1 (requested one
-  // iteration earlier) is written to LDS — an iteration is 12 CT MFMAs, far less than a load's round trip, so one
-  // tile ahead left the matrix cores waiting. Loads are unconditional (a k past the end re-reads the last row: its weight
-  // pieces are zero padding; a tile past the end re-reads the last tile): no divergent control flow, exact wait counts.
-  struct Stage {
+  // Register stages. The WEIGHT pieces of tile i + 2 (L2-resident, 12 KB) are requested while tile i is multiplied and tile
+  // i + 1 is written to LDS; the COUNT bytes of tile i + 4 (HBM, 4 KB * CT) at the same moment, i.e. four tiles ahead (round 5;
+  // two until then). An iteration is 12 CT MFMAs ≈ 0.6 us and a workgroup had 16 KB of counts in flight: 8 MB on the whole
+  // chip against the ≈3 us of a loaded HBM round trip, i.e. 2.3-2.7 TB/s — the rate the pass ran at, whatever its instruction
+  // count or occupancy (profiles/r05_ab_update.txt; a plain read of the same bytes in the same 256-byte pieces reaches
+  // 6.1 TB/s, tools/dram_pattern.hip). The memory counter retires in order: inside an iteration the weights are requested
+  // BEFORE the far-ahead counts, so waiting for them leaves the younger count tiles in flight. Loads are unconditional (a k
+  // past the end re-reads the last row: its weight pieces are zero padding; a tile past the end re-reads the last tile): no
+  // divergent control flow, exact wait counts.
+  struct XStage {
     uint32_t xr[CT][4];    // per 128-environment block c: 4 environments (4 * (tid & 31) ..) of 4 consecutive k (4 * (tid >> 5) ..)
-    uint4 wr[3];           // 8 bf16 of each piece: j = tid >> 2, k = 8 * (tid & 3) ..
+  };
+  typedef uint32_t cu32x4 __attribute__((ext_vector_type(4)));      // (a native vector: HIP's uint4 is copied by memcpy, and with
+  struct WStage {                                                  // six stages in rotation those copies kept the stage in scratch)
+    cu32x4 p0, p1, p2;     // 8 bf16 of each piece: j = tid >> 2, k = 8 * (tid & 3) ..
   };
   const int64_t NIT = (N + CR_BK - 1) / CR_BK;
-  auto fetch = [&](Stage& st, int64_t it) {
+  // this thread's four count rows of a k-tile: k0 + 4 kg + i. A tile inside the matrix is addressed from one pointer and the
+  // row stride; only a tile that reaches past row N - 1 (the last one or two requests) clamps row by row (uniform branch):
+  // the clamps and 64-bit products of every row were 50 of the pass's ~150 vector instructions per k-tile
+  const uint8_t* xthread = xbase + (int64_t)(4 * (tid >> 5)) * rps + 4 * (tid & 31);
+  auto fetch_x = [&](XStage& st, int64_t it) __attribute__((always_inline)) {
     const int64_t k0 = (it < NIT ? it : NIT - 1) * CR_BK;
-    const int kg = tid >> 5, eg = tid & 31;
+    if (k0 + CR_BK <= N) {
+      const uint8_t* xk = xthread + k0 * rps;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int64_t k = k0 + 4 * kg + i;
-      const uint8_t* xk = xbase + (k < N ? k : N - 1) * rps + 4 * eg;
+      for (int i = 0; i < 4; ++i) {
 #pragma unroll
-      for (int c = 0; c < CT; ++c) st.xr[c][i] = *reinterpret_cast<const uint32_t*>(xk + CR_BM * c);
+        for (int c = 0; c < CT; ++c) st.xr[c][i] = *reinterpret_cast<const uint32_t*>(xk + CR_BM * c);
+        xk += rps;
+      }
+    } else {
+      const int kg = tid >> 5, eg = tid & 31;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t k = k0 + 4 * kg + i;
+        const uint8_t* xk = xbase + (k < N ? k : N - 1) * rps + 4 * eg;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) st.xr[c][i] = *reinterpret_cast<const uint32_t*>(xk + CR_BM * c);
+      }
     }
-    const int j = tid >> 2, q = tid & 3;
-#pragma unroll
-    for (int pc = 0; pc < 3; ++pc)
-      st.wr[pc] = *reinterpret_cast<const uint4*>(w3 + pc * WP + (int64_t)j * Kpad + k0 + 8 * q);
   };
-  auto stash = [&](const Stage& st, int buf) {
+  auto fetch_w = [&](WStage& st, int64_t it) __attribute__((always_inline)) {
+    const int64_t k0 = (it < NIT ? it : NIT - 1) * CR_BK;
+    const int j = tid >> 2, q = tid & 3;
+    const uint16_t* wp = w3 + (int64_t)j * Kpad + k0 + 8 * q;
+    st.p0 = *reinterpret_cast<const cu32x4*>(wp);
+    st.p1 = *reinterpret_cast<const cu32x4*>(wp + WP);
+    st.p2 = *reinterpret_cast<const cu32x4*>(wp + 2 * WP);
+  };
+  auto stash = [&](const XStage& sx, const WStage& sw, int buf) __attribute__((always_inline)) {
     uint8_t* Xs = lds_raw + buf * BUF;
     uint16_t* Wb = reinterpret_cast<uint16_t*>(Xs + XB);
     const int kg = tid >> 5, eg = tid & 31;
 #pragma unroll
-    for (int c = 0; c < CT; ++c)
+    for (int c = 0; c < CT; ++c) {
+      // 4 x 4 byte transposition in eight v_perm_b32 (two rounds of byte interleaves) instead of 28 shifts / masks / ors:
+      // byte e of the four k-rows -> one dword [env 128 c + 4 eg + e][k 4 kg .. 4 kg + 3]
+      const uint32_t r0 = sx.xr[c][0], r1 = sx.xr[c][1], r2 = sx.xr[c][2], r3 = sx.xr[c][3];
+      const uint32_t a_lo = __builtin_amdgcn_perm(r1, r0, 0x05010400u), a_hi = __builtin_amdgcn_perm(r1, r0, 0x07030602u);
+      const uint32_t b_lo = __builtin_amdgcn_perm(r3, r2, 0x05010400u), b_hi = __builtin_amdgcn_perm(r3, r2, 0x07030602u);
+      const uint32_t v[4] = {__builtin_amdgcn_perm(b_lo, a_lo, 0x05040100u), __builtin_amdgcn_perm(b_lo, a_lo, 0x07060302u),
+                             __builtin_amdgcn_perm(b_hi, a_hi, 0x05040100u), __builtin_amdgcn_perm(b_hi, a_hi, 0x07060302u)};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {      // byte e of the four k-rows -> one dword [env 128 c + 4 eg + e][k 4 kg .. 4 kg + 3]
-        const uint32_t v = ((st.xr[c][0] >> (8 * e)) & 0xFFu) | (((st.xr[c][1] >> (8 * e)) & 0xFFu) << 8) |
-                           (((st.xr[c][2] >> (8 * e)) & 0xFFu) << 16) | (((st.xr[c][3] >> (8 * e)) & 0xFFu) << 24);
-        *reinterpret_cast<uint32_t*>(Xs + (CR_BM * c + 4 * eg + e) * CB_XLD + 4 * kg) = v;
-      }
+      for (int e = 0; e < 4; ++e) *reinterpret_cast<uint32_t*>(Xs + (CR_BM * c + 4 * eg + e) * CB_XLD + 4 * kg) = v[e];
+    }
     const int j = tid >> 2, q = tid & 3;
-#pragma unroll
-    for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<uint4*>(Wb + (pc * CR_H + j) * CB_WLD + 8 * q) = st.wr[pc];
+    *reinterpret_cast<cu32x4*>(Wb + (0 * CR_H + j) * CB_WLD + 8 * q) = sw.p0;
+    *reinterpret_cast<cu32x4*>(Wb + (1 * CR_H + j) * CB_WLD + 8 * q) = sw.p1;
+    *reinterpret_cast<cu32x4*>(Wb + (2 * CR_H + j) * CB_WLD + 8 * q) = sw.p2;
   };
 
   // D^T: rows j (0..31 / 32..63), cols = 32 environments; the wave's tile c covers environments 128 c + 32 wave .. + 31
@@ -418,7 +449,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_critic_fwd_slab_u8x3(const uint8
     acc1[c] = (f32x16){0};
   }
   const int r32 = lane & 31, h8 = (lane >> 5) * 8;
-  auto multiply = [&](int buf) {
+  auto multiply = [&](int buf) __attribute__((always_inline)) {
     const uint8_t* Xs = lds_raw + buf * BUF;
     const uint16_t* Wb = reinterpret_cast<const uint16_t*>(Xs + XB);
 #pragma unroll
@@ -434,7 +465,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_critic_fwd_slab_u8x3(const uint8
         for (int j = 0; j < 4; ++j) {      // two counts -> two bf16 (the top halves of their fp32 images: exact below 256)
           const uint32_t xs = j < 2 ? x0 : x1;
           const float c0 = (float)((xs >> (16 * (j & 1))) & 0xFFu), c1 = (float)((xs >> (16 * (j & 1) + 8)) & 0xFFu);
-          bw[j] = (__float_as_uint(c0) >> 16) | (__float_as_uint(c1) & 0xFFFF0000u);
+          bw[j] = __builtin_amdgcn_perm(__float_as_uint(c1), __float_as_uint(c0), 0x07060302u);   // {c1.hi16, c0.hi16}: one v_perm_b32
         }
         bx[c] = __builtin_bit_cast(cbf16x8, bw);
       }
@@ -450,21 +481,33 @@ __global__ __launch_bounds__(CR_THREADS) void k_critic_fwd_slab_u8x3(const uint8
       }
     }
   };
-  Stage sa, sb;
-  fetch(sa, 0);
-  fetch(sb, 1);
-  stash(sa, 0);
+  XStage x0, x1, x2, x3;      // counts of tiles t with t % 4 == 0 .. 3
+  WStage w0, w1;              // weight pieces of tiles t with t % 2 == 0, 1
+  fetch_w(w0, 0);
+  fetch_x(x0, 0);
+  fetch_w(w1, 1);
+  fetch_x(x1, 1);
+  fetch_x(x2, 2);
+  fetch_x(x3, 3);
+  stash(x0, w0, 0);
   __syncthreads();
-  for (int64_t it = 0; it < NIT; it += 2) {
-    fetch(sa, it + 2);
-    multiply(0);                     // tile it
-    stash(sb, 1);                    // tile it + 1 (requested a whole iteration ago)
-    __syncthreads();
-    fetch(sb, it + 3);
-    if (it + 1 < NIT) multiply(1);   // tile it + 1 (uniform condition, no loads inside)
-    stash(sa, 0);                    // tile it + 2
-    __syncthreads();
+  // iteration t: request weights t + 2 and counts t + 4 (into the stages tile t's data have just left), multiply tile t
+  // (LDS buffer t % 2), write tile t + 1 into the other buffer
+#define CR_STEP(T_, XA_, XB_, WA_, WB_, BUF_)                                           \
+  {                                                                                     \
+    fetch_w(WA_, (T_) + 2);                                                             \
+    fetch_x(XA_, (T_) + 4);                                                             \
+    if ((T_) < NIT) multiply(BUF_); /* (uniform condition, no loads inside) */          \
+    stash(XB_, WB_, (BUF_) ^ 1);                                                        \
+    __syncthreads();                                                                    \
   }
+  for (int64_t it = 0; it < NIT; it += 4) {
+    CR_STEP(it, x0, x1, w0, w1, 0);
+    CR_STEP(it + 1, x1, x2, w1, w0, 1);
+    CR_STEP(it + 2, x2, x3, w0, w1, 0);
+    CR_STEP(it + 3, x3, x0, w1, w0, 1);
+  }
+#undef CR_STEP
 
   // epilogue, one 128-environment block c at a time through the same LDS: + time * W1[:, N] + b1, ReLU -> Hs [j][env]; then
   // the second and third layer exactly as k_critic_fwd_slab
