@@ -24,6 +24,8 @@ def test_library_exports_every_declared_symbol():
     assert sorted(lib.SIGNATURES) == names
     L = lib.load()
     assert L.tarl_abi_version() == 5
+    hdr = open(os.path.join(ROOT, "include", "tarl_hip.h")).read()
+    assert int(re.search(r"#define TARL_ABI_VERSION (\d+)", hdr).group(1)) == 5      # header, library and this test move together
 
 
 def test_plan_create_rejects_bad_input_without_gpu_compute():
@@ -83,3 +85,14 @@ def test_entry_points_reject_bad_arguments_on_the_host():
     assert L.tarl_fused_bufs_bytes() >= 2 * 27 * 8
     ms_all, ms_late, n = (C.c_double * 3)(), (C.c_double * 3)(), (C.c_int64 * 2)()
     assert L.tarl_prof_collect(0, ms_all, ms_late, n) == 0 and n[0] == 0 and n[1] == 0
+
+
+def test_driver_build_entry_accepts_the_built_library():
+    """__graft_entry__.build() is the driver's "does it build" check: after a build it must accept the library this tree
+    produces (round 5 shipped an entry point that still expected the previous ABI number until its last hour)."""
+    import __graft_entry__ as g
+    src = open(g.__file__).read()
+    assert "TARL_ABI_VERSION" in src and "tarl_abi_version() ==" in src      # compares against the header, not a literal
+    from tarl_hip import lib
+    hdr = open(os.path.join(ROOT, "include", "tarl_hip.h")).read()
+    assert lib.load().tarl_abi_version() == int(re.search(r"#define TARL_ABI_VERSION (\d+)", hdr).group(1))
